@@ -1,0 +1,121 @@
+/* neusky_hip.h - C ABI of libneusky_hip.so (MI355X / gfx950 HIP kernels for the NeuSky hot path).
+ *
+ * The reference (JADGardner/neusky) is 100% Python and has NO native boundary of its own
+ * (SURVEY.md F1): every native kernel it runs belongs to tiny-cuda-nn / torch / nerfacc.  This
+ * header is therefore the drop-in seam SURVEY.md 8(b) defines: each entry point replaces the
+ * external kernel (or the chain of torch ops) the reference reaches at the cited call site.
+ *
+ * Conventions (all entry points)
+ *   - extern "C", plain device pointers + sizes + scalars + a hipStream_t; no torch types.
+ *   - ownership: the caller allocates every buffer (device memory); the callee never allocates,
+ *     frees or retains a pointer.  All matrices are row-major float32 unless stated; leading
+ *     dimensions (ld*) are in elements.
+ *   - errors: return 0 on success, <0 on error (never throws); nsky_last_error() returns the text
+ *     of the calling thread's last error.
+ *   - threading: re-entrant, no global mutable state except the thread-local error string;
+ *     stream-ordered; no host synchronisation and no allocation inside (hipGraph-capturable).
+ */
+#ifndef NEUSKY_HIP_H
+#define NEUSKY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nsky_stream_t; /* hipStream_t */
+
+const char* nsky_last_error(void);
+int nsky_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense layer on the matrix cores: C[M,N] = epilogue( sum_k A(m,k) * B(n,k) + bias[n] )
+ * exact fp32 (v_mfma_f32_32x32x2_f32).  Replaces torch nn.Linear / F.linear + activation at
+ *   neusky/fields/sdf_albedo_field.py:172,199-207,233 (geo + colour nets),
+ *   neusky/utils/siren.py:114-119,138-144,207 (mapping net, FiLM sine layers, head),
+ * and the autograd-generated backward GEMMs of the same layers.
+ *   a_kcontig: 1 -> A stored [M][lda] (k contiguous); 0 -> A stored [K][lda] (m contiguous, i.e. A^T view)
+ *   b_kcontig: 1 -> B stored [N][ldb] (k contiguous, torch Linear weight); 0 -> B stored [K][ldb]
+ *   k-contiguous operands need K % 4 == 0 (zero padded); every ld % 4 == 0, bases 16-byte aligned.
+ *   k_splits > 1: split the K range over grid.z and atomically add into C (C pre-zeroed by the
+ *                 caller, epilogue must be NSKY_EPI_NONE, bias NULL) - used for weight gradients.
+ */
+enum {
+  NSKY_EPI_NONE = 0,
+  NSKY_EPI_RELU = 1,
+  NSKY_EPI_LEAKY = 2,      /* slope p0 */
+  NSKY_EPI_SIGMOID = 3,    /* C = p0 * sigmoid(v) */
+  NSKY_EPI_SOFTPLUS = 4,   /* beta p0 (threshold 20); out1 (optional) = sigmoid(beta v) = d softplus/dv */
+  NSKY_EPI_FILM = 5,       /* C = sin((p0*aux0+p1) * v + aux1); out1 (optional) = v */
+  NSKY_EPI_MUL_AUX = 6,    /* C = v * aux0[row % row_mod] */
+  NSKY_EPI_BWD_RELU = 7,   /* C = v * (aux0 > 0) */
+  NSKY_EPI_BWD_LEAKY = 8,  /* C = v * (aux0 > 0 ? 1 : p0) */
+  NSKY_EPI_BWD_FILM = 9,   /* z=aux0, F=aux1, P=aux2: u=(p0 F+p1) z+P; C=v cos(u)(p0 F+p1); out1=v cos(u) z p0; out2=v cos(u) */
+  NSKY_EPI_EXP = 10        /* C = exp(min(v, p0)) */
+};
+
+typedef struct nsky_gemm_desc {
+  const float* A; const float* B; float* C;
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc;
+  int32_t a_kcontig, b_kcontig;
+  const float* bias;
+  int32_t epi;
+  float p0, p1;
+  const float* aux0; int32_t ldaux0;
+  const float* aux1; int32_t ldaux1;
+  const float* aux2; int32_t ldaux2;
+  float* out1; int32_t ldout1;
+  float* out2; int32_t ldout2;
+  int32_t row_mod;   /* 0 = M */
+  int32_t k_splits;  /* 0/1 = none */
+  float beta;        /* C = result + beta * C_old (non-split only; 0 or 1) */
+} nsky_gemm_desc;
+
+int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream);
+
+/* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients) */
+int nsky_colsum_f32(const float* X, int32_t M, int32_t N, int32_t ldx, float* out, nsky_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multiresolution hash-grid encode (tiny-cuda-nn HashGrid semantics, fp32) fused with the rest of
+ * the MLP input row.  Replaces tcnn.Encoding + NeRFEncoding + torch.cat at
+ *   neusky/fields/sdf_albedo_field.py:119-130 (+ inherited forward_geonetwork, called :172,180,233)
+ *   neusky/fields/directional_distance_field.py:146-156, :267-268
+ * and, with `tangents`, the forward-mode input Jacobian that the reference obtains with
+ * torch.autograd.grad(sdf, inputs, create_graph=True) (sdf_albedo_field.py:235-238).
+ *
+ * Row layout written to Y (ldy >= width, pad columns are zeroed):
+ *   [ x (3, if include_x) | PE: sin(2 pi x_i 2^f) (3*pe_freqs), sin(.. + pi/2) (3*pe_freqs) | hash features (2*L) ]
+ * mode: 0 = feed x raw to the grid (DDF); 1 = (contract_Linf(x)+2)/4; 2 = (contract_L2(x)+2)/4.
+ * T (optional): three more row blocks [3][P][ldy], d(row)/d(x_k).
+ */
+typedef struct nsky_hashgrid_desc {
+  const float* table;      /* [offset[L]][2] */
+  int32_t n_levels;        /* <= 16, 2 features per level */
+  int32_t smoothstep;      /* 1: Smoothstep interpolation, 0: Linear */
+  float scale[16];
+  int32_t resolution[16];
+  uint32_t offset[17];     /* rows; level l owns rows offset[l]..offset[l+1] */
+} nsky_hashgrid_desc;
+
+int nsky_encode_fwd(const nsky_hashgrid_desc* g, const float* x, int32_t P, int32_t mode, int32_t include_x,
+                    int32_t pe_freqs, float* Y, int32_t ldy, float* T, nsky_stream_t stream);
+
+/* Backward of nsky_encode_fwd.  dY [P,lddy] = gradient w.r.t. the rows; dT (optional) [3][P][lddy] =
+ * gradient w.r.t. the tangent rows (second-order path: eikonal / normals).  Accumulates (atomic
+ * float adds) into dtable [offset[L]][2]; dx (optional, [P,3], overwritten) = dY . d(row)/dx. */
+int nsky_encode_bwd(const nsky_hashgrid_desc* g, const float* x, int32_t P, int32_t mode, int32_t include_x,
+                    int32_t pe_freqs, const float* dY, int32_t lddy, const float* dT, float* dtable, float* dx,
+                    nsky_stream_t stream);
+
+/* corner rows (uint32 [P][L][8]) exactly as the encode kernels address the table - the integer
+ * part of the hash encode, exposed for BIT-EXACT parity tests. */
+int nsky_hash_indices(const nsky_hashgrid_desc* g, const float* x, int32_t P, int32_t mode, uint32_t* idx,
+                      nsky_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEUSKY_HIP_H */

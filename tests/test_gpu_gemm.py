@@ -1,0 +1,122 @@
+"""GPU parity of the fp32-MFMA dense layer (C ABI nsky_gemm_f32) against a float64 torch reference."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(A, B, bias):
+    y = A.double() @ B.double().T
+    return y + bias.double() if bias is not None else y
+
+
+def _mk(M, N, K, dev, seed=0, ldpad=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    A = torch.randn(M, K + ldpad, generator=g)[:, :K] if ldpad == 0 else torch.randn(M, K + ldpad, generator=g)
+    return A
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 257, 72), (1000, 1, 256), (513, 3, 296), (2048, 256, 256),
+                                   (77, 40, 16), (4096, 2560, 256)])
+def test_forward_nt_bias_epilogues(M, N, K):
+    from neusky_amd import hip
+    dev = "cuda:0"
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device=dev)
+    W = torch.randn(N, K, device=dev) / K**0.5
+    b = torch.randn(N, device=dev)
+    ldc = (N + 3) // 4 * 4
+    Cbuf = torch.full((M, ldc), float("nan"), device=dev)
+    hip.gemm(A, W, Cbuf, M, N, K, bias=b)
+    ref = _ref(A, W, b)
+    err = (Cbuf[:, :N].double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+    # fused activations
+    for epi, fn in [(hip.EPI_RELU, torch.relu), (hip.EPI_LEAKY, lambda v: torch.nn.functional.leaky_relu(v, 0.2)),
+                    (hip.EPI_SIGMOID, lambda v: 2.0 * torch.sigmoid(v)),
+                    (hip.EPI_SOFTPLUS, lambda v: torch.nn.functional.softplus(v, beta=100))]:
+        p0 = {hip.EPI_LEAKY: 0.2, hip.EPI_SIGMOID: 2.0, hip.EPI_SOFTPLUS: 100.0}.get(epi, 0.0)
+        s1 = torch.empty(M, ldc, device=dev) if epi == hip.EPI_SOFTPLUS else None
+        hip.gemm(A, W, Cbuf, M, N, K, bias=b, epi=epi, p0=p0, out1=s1)
+        assert (Cbuf[:, :N].double() - fn(ref)).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+        if s1 is not None:
+            assert (s1[:, :N].double() - torch.sigmoid(100 * ref)).abs().max().item() < 2e-3  # steep: 100x amplification
+
+
+def test_film_epilogue_and_backward():
+    from neusky_amd import hip
+    dev = "cuda:0"
+    torch.manual_seed(1)
+    M, N, K = 700, 256, 256
+    X = torch.rand(M, K, device=dev) * 2 - 1
+    W = (torch.rand(N, K, device=dev) * 2 - 1) * (6 / K) ** 0.5 / 25
+    b = torch.randn(N, device=dev) * 0.01
+    F_ = torch.randn(M, N, device=dev) * 0.3
+    P_ = torch.randn(M, N, device=dev)
+    Y = torch.empty(M, N, device=dev)
+    Z = torch.empty(M, N, device=dev)
+    hip.gemm(X, W, Y, M, N, K, bias=b, epi=hip.EPI_FILM, p0=15.0, p1=30.0, aux0=F_, aux1=P_, out1=Z)
+    z = _ref(X, W, b)
+    y = torch.sin((15 * F_.double() + 30) * z + P_.double())
+    assert (Z.double() - z).abs().max().item() < 1e-6
+    assert (Y.double() - y).abs().max().item() < 5e-5
+    # backward epilogue: dZ, dF, dP from an upstream GEMM result
+    G = torch.randn(M, N, device=dev)
+    eye = torch.eye(N, device=dev)
+    dZ, dF, dP = (torch.empty(M, N, device=dev) for _ in range(3))
+    hip.gemm(G, eye, dZ, M, N, N, epi=hip.EPI_BWD_FILM, p0=15.0, p1=30.0, aux0=Z, aux1=F_, aux2=P_, out1=dF, out2=dP)
+    f = 15 * F_.double() + 30
+    c = torch.cos(f * Z.double() + P_.double()) * G.double()
+    assert (dZ.double() - c * f).abs().max().item() < 2e-3
+    assert (dF.double() - c * Z.double() * 15).abs().max().item() < 2e-4
+    assert (dP.double() - c).abs().max().item() < 2e-5
+
+
+def test_backward_layouts_and_splitk():
+    from neusky_amd import hip
+    dev = "cuda:0"
+    torch.manual_seed(2)
+    M, N, K = 5000, 257, 72
+    X = torch.randn(M, K, device=dev)
+    W = torch.randn(N, K, device=dev)
+    ldn = 260
+    dYb = torch.zeros(M, ldn, device=dev)
+    dYb[:, :N] = torch.randn(M, N, device=dev)
+    dY = dYb[:, :N]
+    # dX[M,K] = dY[M,N] @ W[N,K]      (A k-contig over N; B stored [Kred=N][K])
+    dX = torch.empty(M, K, device=dev)
+    # the reduction runs over the padded width ldn, so B carries zero rows up to ldn as well
+    Wp = torch.zeros(ldn, K, device=dev); Wp[:N] = W
+    hip.gemm(dYb, Wp, dX, M, K, ldn, a_kcontig=True, b_kcontig=False)
+    ref = dY.double() @ W.double()
+    assert (dX.double() - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
+    # dW[N,K] = dY^T[N,M] @ X[M,K]    (both reduction-major) with split-K atomics
+    dW = torch.zeros(N, K, device=dev)
+    hip.gemm(dYb, X, dW, N, K, M, a_kcontig=False, b_kcontig=False, k_splits=16)
+    refw = dY.double().T @ X.double()
+    assert (dW.double() - refw).abs().max().item() < 1e-4 * refw.abs().max().item()
+    db = torch.zeros(N, device=dev)
+    hip.colsum(dYb, M, N, db)
+    assert (db.double() - dY.double().sum(0)).abs().max().item() < 1e-3
+
+
+def test_mul_aux_tangent_rows():
+    from neusky_amd import hip
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    P, N, K = 333, 256, 72
+    Xt = torch.randn(3 * P, K, device=dev)
+    W = torch.randn(N, K, device=dev)
+    S1 = torch.rand(P, N, device=dev)
+    out = torch.empty(3 * P, N, device=dev)
+    hip.gemm(Xt, W, out, 3 * P, N, K, epi=hip.EPI_MUL_AUX, aux0=S1, row_mod=P)
+    ref = (Xt.double() @ W.double().T) * S1.double().repeat(3, 1)
+    assert (out.double() - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
+
+
+def test_errors_are_reported():
+    from neusky_amd import hip
+    dev = "cuda:0"
+    A = torch.zeros(8, 6, device=dev)
+    with pytest.raises(hip.NeuSkyHipError):
+        hip.gemm(A, A, torch.zeros(8, 8, device=dev), 8, 8, 6)  # lda % 4 != 0

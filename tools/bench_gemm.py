@@ -1,0 +1,38 @@
+"""Micro-benchmark of nsky_gemm_f32 on the DDF layer shapes (run on the GPU box)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from neusky_amd import hip
+
+dev = "cuda:0"
+def run(M, N, K, epi=hip.EPI_NONE, iters=20, **kw):
+    A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) / K**0.5; b = torch.randn(N, device=dev)
+    C = torch.empty(M, N, device=dev)
+    extra = {}
+    if epi == hip.EPI_FILM:
+        extra = dict(aux0=torch.randn(M, N, device=dev), aux1=torch.randn(M, N, device=dev), p0=15.0, p1=30.0,
+                     out1=torch.empty(M, N, device=dev))
+    if epi == hip.EPI_LEAKY: extra = dict(p0=0.2)
+    for _ in range(3): hip.gemm(A, W, C, M, N, K, bias=b, epi=epi, **extra, **kw)
+    torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): hip.gemm(A, W, C, M, N, K, bias=b, epi=epi, **extra, **kw)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print(f"M={M} N={N} K={K} epi={epi}: {ms:.3f} ms  {2*M*N*K/ms/1e9:.1f} TFLOP/s")
+    # compare to torch (rocBLAS/hipBLASLt) for context only
+    for _ in range(3): torch.addmm(b, A, W.T)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(iters): torch.addmm(b, A, W.T)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print(f"   torch.addmm: {ms:.3f} ms  {2*M*N*K/ms/1e9:.1f} TFLOP/s")
+
+run(262144, 256, 256)
+run(262144, 256, 256, epi=hip.EPI_LEAKY)
+run(262144, 256, 256, epi=hip.EPI_FILM)
+run(262144, 2560, 256)
+run(262144, 256, 36)
+run(262144, 1, 256)
+run(98304, 256, 72)
+run(4096, 4096, 4096)
