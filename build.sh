@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build libneusky_hip.so (gfx950) in-tree.  Used by __graft_entry__.build().
+set -e
+cd "$(dirname "$0")"
+SRCS="neusky_amd/csrc/api.cpp $(ls neusky_amd/csrc/*.hip)"
+mkdir -p build
+OBJS=""
+pids=""
+for f in $SRCS; do
+  o="build/$(basename $f).o"
+  OBJS="$OBJS $o"
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ include/neusky_hip.h -nt "$o" ] || [ neusky_amd/csrc/common.h -nt "$o" ]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$f" -o "$o" &
+    pids="$pids $!"
+  fi
+done
+for p in $pids; do wait $p; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o neusky_amd/libneusky_hip.so $OBJS
+echo "built neusky_amd/libneusky_hip.so"

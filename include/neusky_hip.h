@@ -87,7 +87,8 @@ int nsky_colsum_f32(const float* X, int32_t M, int32_t N, int32_t ldx, float* ou
  * torch.autograd.grad(sdf, inputs, create_graph=True) (sdf_albedo_field.py:235-238).
  *
  * Row layout written to Y (ldy >= width, pad columns are zeroed):
- *   [ x (3, if include_x) | PE: sin(2 pi x_i 2^f) (3*pe_freqs), sin(.. + pi/2) (3*pe_freqs) | hash features (2*L) ]
+ *   [ x (3, if include_x) | PE: sin(2 pi x_i 2^e_f) (3*pe_freqs), sin(.. + pi/2) (3*pe_freqs) | hash features (2*L) ]
+ *   with e_f = f * pe_max_exp / (pe_freqs - 1)  (nerfstudio NeRFEncoding, min_freq_exp = 0)
  * mode: 0 = feed x raw to the grid (DDF); 1 = (contract_Linf(x)+2)/4; 2 = (contract_L2(x)+2)/4.
  * T (optional): three more row blocks [3][P][ldy], d(row)/d(x_k).
  */
@@ -101,19 +102,77 @@ typedef struct nsky_hashgrid_desc {
 } nsky_hashgrid_desc;
 
 int nsky_encode_fwd(const nsky_hashgrid_desc* g, const float* x, int32_t P, int32_t mode, int32_t include_x,
-                    int32_t pe_freqs, float* Y, int32_t ldy, float* T, nsky_stream_t stream);
+                    int32_t pe_freqs, float pe_max_exp, float* Y, int32_t ldy, float* T, nsky_stream_t stream);
 
 /* Backward of nsky_encode_fwd.  dY [P,lddy] = gradient w.r.t. the rows; dT (optional) [3][P][lddy] =
  * gradient w.r.t. the tangent rows (second-order path: eikonal / normals).  Accumulates (atomic
  * float adds) into dtable [offset[L]][2]; dx (optional, [P,3], overwritten) = dY . d(row)/dx. */
 int nsky_encode_bwd(const nsky_hashgrid_desc* g, const float* x, int32_t P, int32_t mode, int32_t include_x,
-                    int32_t pe_freqs, const float* dY, int32_t lddy, const float* dT, float* dtable, float* dx,
-                    nsky_stream_t stream);
+                    int32_t pe_freqs, float pe_max_exp, const float* dY, int32_t lddy, const float* dT, float* dtable,
+                    float* dx, nsky_stream_t stream);
 
 /* corner rows (uint32 [P][L][8]) exactly as the encode kernels address the table - the integer
  * part of the hash encode, exposed for BIT-EXACT parity tests. */
 int nsky_hash_indices(const nsky_hashgrid_desc* g, const float* x, int32_t P, int32_t mode, uint32_t* idx,
                       nsky_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Hemisphere integral + alpha composite + sRGB on COMPACT inputs.  Replaces
+ * RGBLambertianRendererWithVisibility.render_and_combine_rgb, neusky/model_components/renderers.py:60-130
+ * (and the [R*S,D,*] broadcasts built at neusky/models/neusky_model.py:512-525, 1755-1759).
+ *   albedo, normals [R,S,3]; weights [R,S]; dirs [D,3]; cam_colours [U,D,3]; cam_of_ray [R] (row of cam_colours);
+ *   vis [R,D] or NULL; bg [R,3]  ->  rgb [R,3] (sRGB, clamped to [0,1]); lin [R,3] (optional: linear composite,
+ *   needed by the backward).  D <= 1024.
+ */
+int nsky_hemi_composite_fwd(const float* albedo, const float* normals, const float* weights, const float* dirs,
+                            const float* cam_colours, const int32_t* cam_of_ray, const float* vis, const float* bg,
+                            int32_t R, int32_t S, int32_t D, float* rgb, float* lin, nsky_stream_t stream);
+/* d_cam_colours [U,D,3] is ACCUMULATED (atomic adds; zero it first); d_vis / d_cam_colours may be NULL. */
+int nsky_hemi_composite_bwd(const float* albedo, const float* normals, const float* weights, const float* dirs,
+                            const float* cam_colours, const int32_t* cam_of_ray, const float* vis, const float* bg,
+                            const float* lin, const float* d_rgb, int32_t R, int32_t S, int32_t D, float* d_albedo,
+                            float* d_normals, float* d_weights, float* d_cam_colours, float* d_vis, float* d_bg,
+                            nsky_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * NeuS alpha -> transmittance -> weights (+ accumulation, expected depth).  Replaces nerfstudio
+ * SDFField.get_alpha (called neusky/fields/sdf_albedo_field.py:266), RaySamples.get_weights_and_
+ * transmittance_from_alphas (neusky/models/neusky_model.py:565-568) and the accumulation / expected-depth
+ * renderers (:591-595).  sdf, starts, ends [R,S]; grad [R,S,3]; ray_dirs [R,3]; variance: device scalar
+ * (LearnedVariance parameter; inv_s = clip(exp(10 v), 1e-6, 1e6)).  S <= 256.
+ * depth is sum(w mid)/(sum(w)+1e-10) WITHOUT the batch-global clip to [min mid, max mid] (host applies it).
+ */
+int nsky_neus_weights_fwd(const float* sdf, const float* grad, const float* ray_dirs, const float* starts,
+                          const float* ends, const float* variance, float cos_anneal, int32_t R, int32_t S,
+                          float* alpha, float* weights, float* trans_bg, float* accumulation, float* depth,
+                          nsky_stream_t stream);
+/* d_variance (device scalar) is ACCUMULATED. */
+int nsky_neus_weights_bwd(const float* sdf, const float* grad, const float* ray_dirs, const float* starts,
+                          const float* ends, const float* variance, float cos_anneal, int32_t R, int32_t S,
+                          const float* d_weights, const float* d_trans_bg, float* d_sdf, float* d_grad,
+                          float* d_variance, nsky_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DDF sky-visibility ray set-up and sigmoid.  Replaces the geometry of NeuSkyFactoModel.compute_visibility,
+ * neusky/models/neusky_model.py:1667-1709 (surface point incl. the outside-sphere fix-up :1674-1683,
+ * ray_sphere_intersection :1590-1622) + DDFModel.get_localised_transforms / einsum, neusky/models/ddf_model.py:158-200
+ * + the NeRF direction encoding, neusky/fields/directional_distance_field.py:188-191,270-271.
+ *   origins, ray_dirs [R,3]; depth [R]; sel_dirs [Dv,3] (the upper-hemisphere subset, :1650-1657)
+ *   -> sphere_pts [R*Dv,3]; xrow [R*Dv,ldx] = [d_loc | NeRF2(d_loc) | 0]; surf_dist [R*Dv] = min(|x-p|, 2r) (:1724-1727);
+ *      term_dist [R*Dv] (optional, :1697).
+ */
+int nsky_visibility_rays(const float* origins, const float* ray_dirs, const float* depth, const float* sel_dirs,
+                         int32_t R, int32_t Dv, float radius, float* sphere_pts, float* xrow, int32_t ldx,
+                         float* surf_dist, float* term_dist, nsky_stream_t stream);
+/* vis[r, sel_index[j]] = 1 - sigmoid(scale * (surf_dist - t_hat - threshold))  (:1730-1740); the caller pre-fills
+ * vis [R,D] with the lower-hemisphere constant (:1745-1748).  threshold: device scalar. */
+int nsky_visibility_finish_fwd(const float* t_hat, const float* surf_dist, const float* threshold, float scale,
+                               const int32_t* sel_index, int32_t R, int32_t Dv, int32_t D, float* vis,
+                               nsky_stream_t stream);
+/* d_threshold (device scalar) is ACCUMULATED. */
+int nsky_visibility_finish_bwd(const float* t_hat, const float* surf_dist, const float* threshold, float scale,
+                               const int32_t* sel_index, int32_t R, int32_t Dv, int32_t D, const float* d_vis,
+                               float* d_t_hat, float* d_threshold, nsky_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,378 @@
+// Multiresolution hash-grid encode (tiny-cuda-nn HashGrid semantics, fp32 table) fused with the rest
+// of the MLP input row (raw position, NeRF positional encoding) and, optionally, the forward-mode
+// input Jacobian (three tangent rows per point).
+//
+// Work decomposition: a workgroup = 4 waves owns 64 consecutive points; lane = point, wave w walks
+// levels w, w+4, w+8, w+12 so that a wave-instruction's 64 gathers all hit ONE level's slab of the
+// table (coarse levels live in L2, fine ones in the 256 MiB Infinity Cache; the 8 corner gathers x 4
+// levels per thread are independent loads in flight).  The finished row (up to 72 floats) is staged
+// in LDS and written back row-major, whole 128-B lines at a time, instead of 8-byte scattered stores.
+#include "common.h"
+#include "../../include/neusky_hip.h"
+
+namespace {
+
+constexpr int PB = 64;         // points per workgroup
+constexpr int MAXW = 72;       // widest row: 3 + 36 + 32 = 71 -> 72
+constexpr int LDS_LD = MAXW + 1;
+constexpr float TWO_PI = 6.283185307179586f;
+constexpr float HALF_PI = 1.5707963267948966f;
+
+struct Grid {
+  const float* table;
+  int n_levels, smoothstep;
+  float scale[16];
+  int resolution[16];
+  uint32_t offset[17];
+};
+
+__device__ __forceinline__ uint32_t grid_index(uint32_t size, uint32_t res, uint32_t px, uint32_t py, uint32_t pz) {
+  uint32_t stride = 1, index = 0;
+  if (stride <= size) { index += px * stride; stride *= res; }
+  if (stride <= size) { index += py * stride; stride *= res; }
+  if (stride <= size) { index += pz * stride; stride *= res; }
+  if (size < stride) index = (px * 1u) ^ (py * 2654435761u) ^ (pz * 805459861u);
+  return index % size;
+}
+
+// position fed to the grid + its Jacobian w.r.t. the world position (3x3, row a = d pos_a / d x_b)
+__device__ __forceinline__ void grid_position(const float x[3], int mode, float pos[3], float J[3][3]) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) J[a][b] = (a == b) ? 1.0f : 0.0f;
+  if (mode == 0) {
+    pos[0] = x[0]; pos[1] = x[1]; pos[2] = x[2];
+    return;
+  }
+  float c[3] = {x[0], x[1], x[2]};
+  if (mode == 1) {  // L-infinity contraction
+    float ax = fabsf(x[0]), ay = fabsf(x[1]), az = fabsf(x[2]);
+    float m = fmaxf(ax, fmaxf(ay, az));
+    if (!(m < 1.0f)) {
+      int im = (ax >= ay && ax >= az) ? 0 : ((ay >= az) ? 1 : 2);
+      float sgn = x[im] >= 0.0f ? 1.0f : -1.0f;
+      float inv = 1.0f / m;
+      float k = (2.0f - inv) * inv;             // f(x) = k x
+      float dk = (-2.0f + 2.0f * inv) * inv * inv;  // dk/dm
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        c[a] = k * x[a];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) J[a][b] = (a == b ? k : 0.0f) + (b == im ? x[a] * dk * sgn : 0.0f);
+      }
+    }
+  } else {  // L2 contraction
+    float m = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    if (!(m < 1.0f)) {
+      float inv = 1.0f / m;
+      float k = (2.0f - inv) * inv;
+      float dk = (-2.0f + 2.0f * inv) * inv * inv;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        c[a] = k * x[a];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) J[a][b] = (a == b ? k : 0.0f) + x[a] * dk * x[b] * inv;
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    pos[a] = (c[a] + 2.0f) * 0.25f;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) J[a][b] *= 0.25f;
+  }
+}
+
+struct Cell {
+  uint32_t idx[8];
+  float w[3], dw[3];  // interpolation weight per axis and d w / d pos (includes the level scale)
+};
+
+__device__ __forceinline__ void locate(const Grid& g, int level, const float pos[3], Cell& c) {
+  const float scale = g.scale[level];
+  const uint32_t res = (uint32_t)g.resolution[level];
+  const uint32_t size = g.offset[level + 1] - g.offset[level];
+  uint32_t pg[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float p = fmaf(scale, pos[a], 0.5f);
+    float fl = floorf(p);
+    pg[a] = (uint32_t)(int)fl;
+    float t = p - fl;
+    if (g.smoothstep) {
+      c.w[a] = t * t * (3.0f - 2.0f * t);
+      c.dw[a] = 6.0f * t * (1.0f - t) * scale;
+    } else {
+      c.w[a] = t;
+      c.dw[a] = scale;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    c.idx[k] = g.offset[level] + grid_index(size, res, pg[0] + (k & 1), pg[1] + ((k >> 1) & 1), pg[2] + ((k >> 2) & 1));
+}
+
+__host__ __device__ __forceinline__ int row_width(int include_x, int pe_freqs, int n_levels) {
+  return (include_x ? 3 : 0) + 6 * pe_freqs + 2 * n_levels;
+}
+
+template <bool TANGENTS>
+__global__ __launch_bounds__(256) void encode_fwd_kernel(Grid g, const float* __restrict__ x, int P, int mode, int include_x,
+                                                         int pe_freqs, float pe_max_exp, float* __restrict__ Y, int ldy, float* __restrict__ T) {
+  constexpr int NT = TANGENTS ? 4 : 1;
+  __shared__ float S[NT][PB][LDS_LD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = blockIdx.x * PB + lane;
+  const bool valid = p < P;
+  const int width = row_width(include_x, pe_freqs, g.n_levels);
+  const int feat0 = (include_x ? 3 : 0) + 6 * pe_freqs;
+
+  float xv[3] = {0.f, 0.f, 0.f};
+  if (valid) { xv[0] = x[(long)p * 3]; xv[1] = x[(long)p * 3 + 1]; xv[2] = x[(long)p * 3 + 2]; }
+  float pos[3], J[3][3];
+  grid_position(xv, mode, pos, J);
+
+  // zero the pad columns and (wave 0) fill x / PE
+  for (int c = width + wave; c < ldy && c < MAXW; c += 4)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) S[t][lane][c] = 0.0f;
+  if (include_x && wave == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      S[0][lane][a] = xv[a];
+      if (TANGENTS)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) S[1 + k][lane][a] = (a == k) ? 1.0f : 0.0f;
+    }
+  }
+  if (pe_freqs > 0) {
+    const int pe0 = include_x ? 3 : 0;
+    const int npe = 3 * pe_freqs;
+    // nerfstudio NeRFEncoding: column i*F+f = sin(2 pi x_i 2^f), second half + pi/2
+    for (int c = wave; c < npe; c += 4) {
+      const int i = c / pe_freqs, f = c % pe_freqs;
+      const float freq = exp2f(pe_freqs > 1 ? (float)f * pe_max_exp / (float)(pe_freqs - 1) : 0.0f);
+      const float arg = TWO_PI * xv[i] * freq;
+      const float arg2 = arg + HALF_PI;
+      S[0][lane][pe0 + c] = sinf(arg);
+      S[0][lane][pe0 + npe + c] = sinf(arg2);
+      if (TANGENTS) {
+        const float d1 = cosf(arg) * TWO_PI * freq, d2 = cosf(arg2) * TWO_PI * freq;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          S[1 + k][lane][pe0 + c] = (i == k) ? d1 : 0.0f;
+          S[1 + k][lane][pe0 + npe + c] = (i == k) ? d2 : 0.0f;
+        }
+      }
+    }
+  }
+
+  for (int level = wave; level < g.n_levels; level += 4) {
+    Cell c;
+    locate(g, level, pos, c);
+    float2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = reinterpret_cast<const float2*>(g.table)[c.idx[k]];
+    float f0 = 0.f, f1 = 0.f;
+    float d0[3] = {0.f, 0.f, 0.f}, d1[3] = {0.f, 0.f, 0.f};  // d feat / d pos_a
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float wx = (k & 1) ? c.w[0] : 1.0f - c.w[0];
+      const float wy = (k & 2) ? c.w[1] : 1.0f - c.w[1];
+      const float wz = (k & 4) ? c.w[2] : 1.0f - c.w[2];
+      const float w = wx * wy * wz;
+      f0 = fmaf(w, v[k].x, f0);
+      f1 = fmaf(w, v[k].y, f1);
+      if (TANGENTS) {
+        const float gx = ((k & 1) ? c.dw[0] : -c.dw[0]) * wy * wz;
+        const float gy = ((k & 2) ? c.dw[1] : -c.dw[1]) * wx * wz;
+        const float gz = ((k & 4) ? c.dw[2] : -c.dw[2]) * wx * wy;
+        d0[0] = fmaf(gx, v[k].x, d0[0]); d1[0] = fmaf(gx, v[k].y, d1[0]);
+        d0[1] = fmaf(gy, v[k].x, d0[1]); d1[1] = fmaf(gy, v[k].y, d1[1]);
+        d0[2] = fmaf(gz, v[k].x, d0[2]); d1[2] = fmaf(gz, v[k].y, d1[2]);
+      }
+    }
+    S[0][lane][feat0 + 2 * level] = f0;
+    S[0][lane][feat0 + 2 * level + 1] = f1;
+    if (TANGENTS) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        S[1 + k][lane][feat0 + 2 * level] = d0[0] * J[0][k] + d0[1] * J[1][k] + d0[2] * J[2][k];
+        S[1 + k][lane][feat0 + 2 * level + 1] = d1[0] * J[0][k] + d1[1] * J[1][k] + d1[2] * J[2][k];
+      }
+    }
+  }
+  __syncthreads();
+  const int wcols = min(ldy, MAXW);
+  const int p0 = blockIdx.x * PB;
+  const int nrows = min(PB, P - p0);
+  for (int idx = threadIdx.x; idx < nrows * wcols; idx += 256) {
+    const int r = idx / wcols, c = idx % wcols;
+    Y[(long)(p0 + r) * ldy + c] = S[0][r][c];
+    if (TANGENTS)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) T[((long)k * P + p0 + r) * ldy + c] = S[1 + k][r][c];
+  }
+}
+
+template <bool TANGENTS>
+__global__ __launch_bounds__(256) void encode_bwd_kernel(Grid g, const float* __restrict__ x, int P, int mode, int include_x,
+                                                         int pe_freqs, float pe_max_exp, const float* __restrict__ dY, int lddy,
+                                                         const float* __restrict__ dT, float* __restrict__ dtable,
+                                                         float* __restrict__ dx) {
+  __shared__ float red[4][PB][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = blockIdx.x * PB + lane;
+  const bool valid = p < P;
+  const int feat0 = (include_x ? 3 : 0) + 6 * pe_freqs;
+
+  float xv[3] = {0.f, 0.f, 0.f};
+  if (valid) { xv[0] = x[(long)p * 3]; xv[1] = x[(long)p * 3 + 1]; xv[2] = x[(long)p * 3 + 2]; }
+  float pos[3], J[3][3];
+  grid_position(xv, mode, pos, J);
+  float gx_acc[3] = {0.f, 0.f, 0.f};  // dL/dx through dY (first-order input gradient)
+
+  if (dx && valid) {
+    const float* row = dY + (long)p * lddy;
+    if (include_x && wave == 0)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) gx_acc[a] += row[a];
+    if (pe_freqs > 0) {
+      const int pe0 = include_x ? 3 : 0, npe = 3 * pe_freqs;
+      for (int c = wave; c < npe; c += 4) {
+        const int i = c / pe_freqs, f = c % pe_freqs;
+        const float freq = exp2f(pe_freqs > 1 ? (float)f * pe_max_exp / (float)(pe_freqs - 1) : 0.0f);
+        const float arg = TWO_PI * xv[i] * freq;
+        const float dsum = row[pe0 + c] * cosf(arg) + row[pe0 + npe + c] * cosf(arg + HALF_PI);
+        gx_acc[i] += dsum * TWO_PI * freq;
+      }
+    }
+  }
+
+  for (int level = wave; level < g.n_levels; level += 4) {
+    if (!valid) continue;
+    Cell c;
+    locate(g, level, pos, c);
+    const float2 gy = *reinterpret_cast<const float2*>(dY + (long)p * lddy + feat0 + 2 * level);
+    // gradient w.r.t. d feat / d pos_a, pulled back through J from the tangent-row gradients
+    float2 gpa[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    if (TANGENTS) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float2 gt = *reinterpret_cast<const float2*>(dT + ((long)k * P + p) * lddy + feat0 + 2 * level);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { gpa[a].x = fmaf(gt.x, J[a][k], gpa[a].x); gpa[a].y = fmaf(gt.y, J[a][k], gpa[a].y); }
+      }
+    }
+    float2 v[8];
+    if (dx)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = reinterpret_cast<const float2*>(g.table)[c.idx[k]];
+    float dpos[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float wx = (k & 1) ? c.w[0] : 1.0f - c.w[0];
+      const float wy = (k & 2) ? c.w[1] : 1.0f - c.w[1];
+      const float wz = (k & 4) ? c.w[2] : 1.0f - c.w[2];
+      const float cx = ((k & 1) ? c.dw[0] : -c.dw[0]) * wy * wz;
+      const float cy = ((k & 2) ? c.dw[1] : -c.dw[1]) * wx * wz;
+      const float cz = ((k & 4) ? c.dw[2] : -c.dw[2]) * wx * wy;
+      float a0 = wx * wy * wz * gy.x, a1 = wx * wy * wz * gy.y;
+      if (TANGENTS) {
+        a0 += cx * gpa[0].x + cy * gpa[1].x + cz * gpa[2].x;
+        a1 += cx * gpa[0].y + cy * gpa[1].y + cz * gpa[2].y;
+      }
+      atomicAdd(dtable + 2l * c.idx[k], a0);
+      atomicAdd(dtable + 2l * c.idx[k] + 1, a1);
+      if (dx) {
+        const float s = v[k].x * gy.x + v[k].y * gy.y;
+        dpos[0] = fmaf(cx, s, dpos[0]); dpos[1] = fmaf(cy, s, dpos[1]); dpos[2] = fmaf(cz, s, dpos[2]);
+      }
+    }
+    if (dx)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) gx_acc[b] += dpos[0] * J[0][b] + dpos[1] * J[1][b] + dpos[2] * J[2][b];
+  }
+  if (dx) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) red[wave][lane][a] = gx_acc[a];
+    __syncthreads();
+    if (wave == 0 && valid)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) dx[(long)p * 3 + a] = red[0][lane][a] + red[1][lane][a] + red[2][lane][a] + red[3][lane][a];
+  }
+}
+
+__global__ void hash_indices_kernel(Grid g, const float* __restrict__ x, int P, int mode, uint32_t* __restrict__ out) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)P * g.n_levels) return;
+  const int p = (int)(t / g.n_levels), level = (int)(t % g.n_levels);
+  float xv[3] = {x[(long)p * 3], x[(long)p * 3 + 1], x[(long)p * 3 + 2]};
+  float pos[3], J[3][3];
+  grid_position(xv, mode, pos, J);
+  Cell c;
+  locate(g, level, pos, c);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) out[t * 8 + k] = c.idx[k];
+}
+
+int make_grid(const nsky_hashgrid_desc* d, Grid& g, const char* who) {
+  NSKY_CHECK_ARG(d && d->table, "%s: null grid", who);
+  NSKY_CHECK_ARG(d->n_levels >= 1 && d->n_levels <= 16, "%s: n_levels=%d out of range [1,16]", who, d->n_levels);
+  g.table = d->table; g.n_levels = d->n_levels; g.smoothstep = d->smoothstep;
+  for (int i = 0; i < 16; ++i) { g.scale[i] = d->scale[i]; g.resolution[i] = d->resolution[i]; }
+  for (int i = 0; i < 17; ++i) g.offset[i] = d->offset[i];
+  for (int i = 0; i < d->n_levels; ++i)
+    NSKY_CHECK_ARG(d->offset[i + 1] > d->offset[i] && d->resolution[i] > 0, "%s: bad level %d geometry", who, i);
+  return NSKY_OK;
+}
+
+}  // namespace
+
+extern "C" int nsky_encode_fwd(const nsky_hashgrid_desc* d, const float* x, int32_t P, int32_t mode, int32_t include_x,
+                               int32_t pe_freqs, float pe_max_exp, float* Y, int32_t ldy, float* T, nsky_stream_t stream) {
+  Grid g;
+  if (int rc = make_grid(d, g, "nsky_encode_fwd")) return rc;
+  if (P == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(x && Y && P > 0, "nsky_encode_fwd: null x/Y or negative P");
+  NSKY_CHECK_ARG(mode >= 0 && mode <= 2 && pe_freqs >= 0 && pe_freqs <= 6, "nsky_encode_fwd: bad mode/pe_freqs");
+  const int width = row_width(include_x, pe_freqs, g.n_levels);
+  NSKY_CHECK_ARG(width <= MAXW && ldy >= width && ldy <= MAXW, "nsky_encode_fwd: row width %d / ldy %d unsupported (max %d)", width, ldy, MAXW);
+  dim3 grid(ceil_div(P, PB));
+  if (T)
+    hipLaunchKernelGGL(encode_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, g, x, P, mode, include_x, pe_freqs, pe_max_exp, Y, ldy, T);
+  else
+    hipLaunchKernelGGL(encode_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, g, x, P, mode, include_x, pe_freqs, pe_max_exp, Y, ldy, T);
+  NSKY_CHECK_LAUNCH("nsky_encode_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_encode_bwd(const nsky_hashgrid_desc* d, const float* x, int32_t P, int32_t mode, int32_t include_x,
+                               int32_t pe_freqs, float pe_max_exp, const float* dY, int32_t lddy, const float* dT, float* dtable,
+                               float* dx, nsky_stream_t stream) {
+  Grid g;
+  if (int rc = make_grid(d, g, "nsky_encode_bwd")) return rc;
+  if (P == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(x && dY && dtable && P > 0, "nsky_encode_bwd: null argument");
+  NSKY_CHECK_ARG(lddy % 2 == 0 && ((include_x ? 3 : 0) + 6 * pe_freqs) % 2 == (include_x ? 1 : 0), "nsky_encode_bwd: layout");
+  dim3 grid(ceil_div(P, PB));
+  if (dT)
+    hipLaunchKernelGGL(encode_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, g, x, P, mode, include_x, pe_freqs, pe_max_exp, dY, lddy, dT, dtable, dx);
+  else
+    hipLaunchKernelGGL(encode_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, g, x, P, mode, include_x, pe_freqs, pe_max_exp, dY, lddy, dT, dtable, dx);
+  NSKY_CHECK_LAUNCH("nsky_encode_bwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_hash_indices(const nsky_hashgrid_desc* d, const float* x, int32_t P, int32_t mode, uint32_t* idx,
+                                 nsky_stream_t stream) {
+  Grid g;
+  if (int rc = make_grid(d, g, "nsky_hash_indices")) return rc;
+  if (P == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(x && idx && P > 0, "nsky_hash_indices: null argument");
+  const long n = (long)P * g.n_levels;
+  hipLaunchKernelGGL(hash_indices_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, g, x, P, mode, idx);
+  NSKY_CHECK_LAUNCH("nsky_hash_indices");
+  return NSKY_OK;
+}

@@ -1,0 +1,540 @@
+// Bandwidth-shaped stages of the NeuSky step:
+//   * hemisphere integral + alpha composite + sRGB  (renderers.py:60-130)           fwd + bwd
+//   * NeuS alpha -> transmittance -> weights (+ accumulation, expected depth)        fwd + bwd
+//   * DDF visibility ray set-up (surface point, sphere hit, local frame, encoding)   fwd
+//   * visibility sigmoid + scatter into the D illumination directions                fwd + bwd
+// None of the broadcast tensors of the reference ([R*S,D,3] directions / colours, [R*S,D,1] visibility)
+// is ever materialised: directions [D,3], per-camera colours [U,D,3] and visibility [R,D] are read once
+// per ray into LDS and reduced over the hemisphere with wavefront shuffles.
+#include "common.h"
+#include "../../include/neusky_hip.h"
+
+namespace {
+
+constexpr int MAXD = 1024;  // max illumination directions
+constexpr int JPL = MAXD / 64;
+
+__device__ __forceinline__ float srgb_fwd(float x) {
+  float y = x <= 0.0031308f ? 12.92f * x : 1.055f * powf(fabsf(x), 1.0f / 2.4f) - 0.055f;
+  return fminf(fmaxf(y, 0.0f), 1.0f);
+}
+__device__ __forceinline__ float srgb_bwd(float x) {
+  float y = x <= 0.0031308f ? 12.92f * x : 1.055f * powf(fabsf(x), 1.0f / 2.4f) - 0.055f;
+  if (y < 0.0f || y > 1.0f) return 0.0f;
+  if (x <= 0.0031308f) return 12.92f;
+  return 1.055f / 2.4f * powf(fabsf(x), 1.0f / 2.4f - 1.0f);
+}
+
+// one workgroup (4 waves) per ray; wave w takes samples w, w+4, ...; lanes stride the D directions
+__global__ __launch_bounds__(256) void hemi_fwd_kernel(const float* __restrict__ albedo, const float* __restrict__ normals,
+                                                       const float* __restrict__ weights, const float* __restrict__ dirs,
+                                                       const float* __restrict__ cam_colours, const int* __restrict__ cam_of_ray,
+                                                       const float* __restrict__ vis, const float* __restrict__ bg, int R, int S,
+                                                       int D, float* __restrict__ rgb, float* __restrict__ lin) {
+  __shared__ float sdir[MAXD * 3];
+  __shared__ float svl[MAXD * 3];
+  __shared__ float red[4][4];
+  const int r = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* col = cam_colours + (long)cam_of_ray[r] * D * 3;
+  for (int i = threadIdx.x; i < D * 3; i += 256) {
+    sdir[i] = dirs[i];
+    const float v = vis ? vis[(long)r * D + i / 3] : 1.0f;
+    svl[i] = v * col[i];
+  }
+  __syncthreads();
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f, wsum = 0.f;
+  for (int s = wave; s < S; s += 4) {
+    const long o = ((long)r * S + s) * 3;
+    const float nx = normals[o], ny = normals[o + 1], nz = normals[o + 2];
+    float cnt = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int j = lane; j < D; j += 64) {
+      float d = nx * sdir[3 * j] + ny * sdir[3 * j + 1] + nz * sdir[3 * j + 2];
+      d = fminf(fmaxf(d, 0.0f), 1.0f);
+      cnt += d > 0.0f ? 1.0f : 0.0f;
+      a0 = fmaf(d, svl[3 * j], a0); a1 = fmaf(d, svl[3 * j + 1], a1); a2 = fmaf(d, svl[3 * j + 2], a2);
+    }
+    cnt = wave_sum(cnt); a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    const float inv = 1.0f / (cnt > 0.0f ? cnt : 1.0f);
+    const float w = weights[(long)r * S + s];
+    c0 = fmaf(w, albedo[o] * a0 * inv, c0);
+    c1 = fmaf(w, albedo[o + 1] * a1 * inv, c1);
+    c2 = fmaf(w, albedo[o + 2] * a2 * inv, c2);
+    wsum += w;
+  }
+  if (lane == 0) { red[wave][0] = c0; red[wave][1] = c1; red[wave][2] = c2; red[wave][3] = wsum; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int c = threadIdx.x;
+    const float acc = red[0][3] + red[1][3] + red[2][3] + red[3][3];
+    const float v = red[0][c] + red[1][c] + red[2][c] + red[3][c] + bg[(long)r * 3 + c] * (1.0f - acc);
+    if (lin) lin[(long)r * 3 + c] = v;
+    rgb[(long)r * 3 + c] = srgb_fwd(v);
+  }
+}
+
+__global__ __launch_bounds__(256) void hemi_bwd_kernel(const float* __restrict__ albedo, const float* __restrict__ normals,
+                                                       const float* __restrict__ weights, const float* __restrict__ dirs,
+                                                       const float* __restrict__ cam_colours, const int* __restrict__ cam_of_ray,
+                                                       const float* __restrict__ vis, const float* __restrict__ bg,
+                                                       const float* __restrict__ lin, const float* __restrict__ d_rgb, int R,
+                                                       int S, int D, float* __restrict__ d_albedo, float* __restrict__ d_normals,
+                                                       float* __restrict__ d_weights, float* __restrict__ d_cam_colours,
+                                                       float* __restrict__ d_vis, float* __restrict__ d_bg) {
+  __shared__ float sdir[MAXD * 3];
+  __shared__ float svl[MAXD * 3];
+  __shared__ float sA[4][MAXD * 3];  // per-wave sum_s gI_c * clamp(n.l_j)
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cam = cam_of_ray[r];
+  const float* col = cam_colours + (long)cam * D * 3;
+  for (int i = threadIdx.x; i < D * 3; i += 256) {
+    sdir[i] = dirs[i];
+    const float v = vis ? vis[(long)r * D + i / 3] : 1.0f;
+    svl[i] = v * col[i];
+  }
+  __syncthreads();
+  float gcomp[3], bgc[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    gcomp[c] = d_rgb[(long)r * 3 + c] * srgb_bwd(lin[(long)r * 3 + c]);
+    bgc[c] = bg[(long)r * 3 + c];
+  }
+  float A[JPL][3];
+#pragma unroll
+  for (int q = 0; q < JPL; ++q) A[q][0] = A[q][1] = A[q][2] = 0.0f;
+  float wsum = 0.f;
+  for (int s = wave; s < S; s += 4) {
+    const long o = ((long)r * S + s) * 3;
+    const float nx = normals[o], ny = normals[o + 1], nz = normals[o + 2];
+    float cnt = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int j = lane; j < D; j += 64) {
+      float d = nx * sdir[3 * j] + ny * sdir[3 * j + 1] + nz * sdir[3 * j + 2];
+      d = fminf(fmaxf(d, 0.0f), 1.0f);
+      cnt += d > 0.0f ? 1.0f : 0.0f;
+      a0 = fmaf(d, svl[3 * j], a0); a1 = fmaf(d, svl[3 * j + 1], a1); a2 = fmaf(d, svl[3 * j + 2], a2);
+    }
+    cnt = wave_sum(cnt); a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    const float inv = 1.0f / (cnt > 0.0f ? cnt : 1.0f);
+    const float w = weights[(long)r * S + s];
+    const float al0 = albedo[o], al1 = albedo[o + 1], al2 = albedo[o + 2];
+    const float I0 = a0 * inv, I1 = a1 * inv, I2 = a2 * inv;
+    // d comp / d w_s = rad_c - bg_c ; d comp / d albedo = w I ; d comp / d I = w albedo
+    const float gw = gcomp[0] * (al0 * I0 - bgc[0]) + gcomp[1] * (al1 * I1 - bgc[1]) + gcomp[2] * (al2 * I2 - bgc[2]);
+    const float gI0 = gcomp[0] * w * al0 * inv, gI1 = gcomp[1] * w * al1 * inv, gI2 = gcomp[2] * w * al2 * inv;
+    float gn0 = 0.f, gn1 = 0.f, gn2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < JPL; ++q) {
+      const int j = lane + 64 * q;
+      if (j < D) {
+        const float lx = sdir[3 * j], ly = sdir[3 * j + 1], lz = sdir[3 * j + 2];
+        const float draw = nx * lx + ny * ly + nz * lz;
+        const float dc = fminf(fmaxf(draw, 0.0f), 1.0f);
+        // torch.clamp_ passes gradient on the closed interval [0, 1]
+        if (draw >= 0.0f && draw <= 1.0f) {
+          const float qj = gI0 * svl[3 * j] + gI1 * svl[3 * j + 1] + gI2 * svl[3 * j + 2];
+          gn0 = fmaf(qj, lx, gn0); gn1 = fmaf(qj, ly, gn1); gn2 = fmaf(qj, lz, gn2);
+        }
+        A[q][0] = fmaf(gI0, dc, A[q][0]); A[q][1] = fmaf(gI1, dc, A[q][1]); A[q][2] = fmaf(gI2, dc, A[q][2]);
+      }
+    }
+    gn0 = wave_sum(gn0); gn1 = wave_sum(gn1); gn2 = wave_sum(gn2);
+    if (lane == 0) {
+      d_albedo[o] = gcomp[0] * w * I0; d_albedo[o + 1] = gcomp[1] * w * I1; d_albedo[o + 2] = gcomp[2] * w * I2;
+      d_normals[o] = gn0; d_normals[o + 1] = gn1; d_normals[o + 2] = gn2;
+      d_weights[(long)r * S + s] = gw;
+    }
+    wsum += w;
+  }
+#pragma unroll
+  for (int q = 0; q < JPL; ++q) {
+    const int j = lane + 64 * q;
+    if (j < D) { sA[wave][3 * j] = A[q][0]; sA[wave][3 * j + 1] = A[q][1]; sA[wave][3 * j + 2] = A[q][2]; }
+  }
+  if (lane == 0) red[wave] = wsum;
+  __syncthreads();
+  for (int j = threadIdx.x; j < D; j += 256) {
+    float gv = 0.f;
+    const float v = vis ? vis[(long)r * D + j] : 1.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float a = sA[0][3 * j + c] + sA[1][3 * j + c] + sA[2][3 * j + c] + sA[3][3 * j + c];
+      gv = fmaf(a, col[3 * j + c], gv);
+      if (d_cam_colours) atomicAdd(d_cam_colours + ((long)cam * D + j) * 3 + c, a * v);
+    }
+    if (d_vis) d_vis[(long)r * D + j] = gv;
+  }
+  if (threadIdx.x < 3) {
+    const float acc = red[0] + red[1] + red[2] + red[3];
+    d_bg[(long)r * 3 + threadIdx.x] = gcomp[threadIdx.x] * (1.0f - acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NeuS alpha / transmittance / weights.  One wave per ray, lane l owns samples [l*CH, (l+1)*CH).
+// ------------------------------------------------------------------------------------------------
+constexpr int MAXCH = 4;  // S <= 256
+
+__device__ __forceinline__ float wave_excl_prod_scan(float v, int lane) {
+  // inclusive multiplicative scan, then shift
+  float x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    float y = __shfl_up(x, off, 64);
+    if (lane >= off) x *= y;
+  }
+  float e = __shfl_up(x, 1, 64);
+  return lane == 0 ? 1.0f : e;
+}
+__device__ __forceinline__ float wave_excl_sum_scan_rev(float v, int lane) {
+  // exclusive suffix sum: result[l] = sum_{m>l} v[m]
+  float x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    float y = __shfl_down(x, off, 64);
+    if (lane + off < 64) x += y;
+  }
+  float e = __shfl_down(x, 1, 64);
+  return lane == 63 ? 0.0f : e;
+}
+
+struct AlphaTerms {
+  float alpha, prev_cdf, next_cdf, cosv, ic, inv_s;
+  bool clip_pass;
+};
+
+__device__ __forceinline__ AlphaTerms neus_alpha_terms(float sdf, const float g[3], const float d[3], float delta, float inv_s,
+                                                      float anneal) {
+  AlphaTerms t;
+  t.inv_s = inv_s;
+  t.cosv = d[0] * g[0] + d[1] * g[1] + d[2] * g[2];
+  t.ic = -(fmaxf(-t.cosv * 0.5f + 0.5f, 0.0f) * (1.0f - anneal) + fmaxf(-t.cosv, 0.0f) * anneal);
+  const float nxt = sdf + t.ic * delta * 0.5f, prv = sdf - t.ic * delta * 0.5f;
+  t.prev_cdf = sigmoidf_(prv * inv_s);
+  t.next_cdf = sigmoidf_(nxt * inv_s);
+  const float a = (t.prev_cdf - t.next_cdf + 1e-5f) / (t.prev_cdf + 1e-5f);
+  t.clip_pass = (a >= 0.0f && a <= 1.0f);
+  t.alpha = fminf(fmaxf(a, 0.0f), 1.0f);
+  return t;
+}
+
+__global__ __launch_bounds__(256) void neus_weights_fwd_kernel(const float* __restrict__ sdf, const float* __restrict__ grad,
+                                                               const float* __restrict__ ray_dirs, const float* __restrict__ starts,
+                                                               const float* __restrict__ ends, const float* __restrict__ variance,
+                                                               float anneal, int R, int S, float* __restrict__ alpha_out,
+                                                               float* __restrict__ weights, float* __restrict__ trans_bg,
+                                                               float* __restrict__ acc_out, float* __restrict__ depth_out) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int CH = (S + 63) / 64;
+  const float inv_s = fminf(fmaxf(expf(variance[0] * 10.0f), 1e-6f), 1e6f);
+  const float d[3] = {ray_dirs[(long)r * 3], ray_dirs[(long)r * 3 + 1], ray_dirs[(long)r * 3 + 2]};
+  float al[MAXCH], mid[MAXCH];
+  float prod = 1.0f;
+#pragma unroll
+  for (int q = 0; q < MAXCH; ++q) {
+    const int s = lane * CH + q;
+    al[q] = 0.0f; mid[q] = 0.0f;
+    if (q < CH && s < S) {
+      const long o = (long)r * S + s;
+      const float g[3] = {grad[o * 3], grad[o * 3 + 1], grad[o * 3 + 2]};
+      const float st = starts[o], en = ends[o];
+      AlphaTerms t = neus_alpha_terms(sdf[o], g, d, en - st, inv_s, anneal);
+      al[q] = t.alpha; mid[q] = 0.5f * (st + en);
+      if (alpha_out) alpha_out[o] = t.alpha;
+      prod *= (1.0f - t.alpha + 1e-7f);
+    }
+  }
+  float T = wave_excl_prod_scan(prod, lane);
+  float wsum = 0.f, dsum = 0.f;
+#pragma unroll
+  for (int q = 0; q < MAXCH; ++q) {
+    const int s = lane * CH + q;
+    if (q < CH && s < S) {
+      const float w = al[q] * T;
+      weights[(long)r * S + s] = w;
+      wsum += w; dsum = fmaf(w, mid[q], dsum);
+      T *= (1.0f - al[q] + 1e-7f);
+    }
+  }
+  // T of the last active lane == transmittance past the last sample
+  const int last_lane = (S - 1) / CH;
+  const float Tbg = __shfl(T, last_lane, 64);
+  wsum = wave_sum(wsum); dsum = wave_sum(dsum);
+  if (lane == 0) {
+    if (trans_bg) trans_bg[r] = Tbg;
+    if (acc_out) acc_out[r] = wsum;
+    if (depth_out) depth_out[r] = dsum / (wsum + 1e-10f);
+  }
+}
+
+__global__ __launch_bounds__(256) void neus_weights_bwd_kernel(const float* __restrict__ sdf, const float* __restrict__ grad,
+                                                               const float* __restrict__ ray_dirs, const float* __restrict__ starts,
+                                                               const float* __restrict__ ends, const float* __restrict__ variance,
+                                                               float anneal, int R, int S, const float* __restrict__ d_weights,
+                                                               const float* __restrict__ d_trans_bg, float* __restrict__ d_sdf,
+                                                               float* __restrict__ d_grad, float* __restrict__ d_variance) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int CH = (S + 63) / 64;
+  const float e10 = expf(variance[0] * 10.0f);
+  const float inv_s = fminf(fmaxf(e10, 1e-6f), 1e6f);
+  const bool invs_pass = (e10 >= 1e-6f && e10 <= 1e6f);
+  const float d[3] = {ray_dirs[(long)r * 3], ray_dirs[(long)r * 3 + 1], ray_dirs[(long)r * 3 + 2]};
+  AlphaTerms tt[MAXCH];
+  float sd[MAXCH], dl[MAXCH];
+  float prod = 1.0f;
+#pragma unroll
+  for (int q = 0; q < MAXCH; ++q) {
+    const int s = lane * CH + q;
+    tt[q].alpha = 0.f;
+    if (q < CH && s < S) {
+      const long o = (long)r * S + s;
+      const float g[3] = {grad[o * 3], grad[o * 3 + 1], grad[o * 3 + 2]};
+      sd[q] = sdf[o]; dl[q] = ends[o] - starts[o];
+      tt[q] = neus_alpha_terms(sd[q], g, d, dl[q], inv_s, anneal);
+      prod *= (1.0f - tt[q].alpha + 1e-7f);
+    }
+  }
+  float T0 = wave_excl_prod_scan(prod, lane);
+  // per-sample w and T; suffix sums of gw_i * w_i
+  float w[MAXCH], Tq[MAXCH], gw[MAXCH];
+  float local = 0.f, T = T0;
+#pragma unroll
+  for (int q = 0; q < MAXCH; ++q) {
+    const int s = lane * CH + q;
+    w[q] = 0.f; Tq[q] = T; gw[q] = 0.f;
+    if (q < CH && s < S) {
+      gw[q] = d_weights[(long)r * S + s];
+      w[q] = tt[q].alpha * T;
+      local = fmaf(gw[q], w[q], local);
+      T *= (1.0f - tt[q].alpha + 1e-7f);
+    }
+  }
+  const int last_lane = (S - 1) / CH;
+  const float Tbg = __shfl(T, last_lane, 64);
+  const float gT = d_trans_bg ? d_trans_bg[r] : 0.0f;
+  float suffix = wave_excl_sum_scan_rev(local, lane) + gT * Tbg;  // sum over later lanes (+ background term)
+  float gvar = 0.f;
+#pragma unroll
+  for (int q = MAXCH - 1; q >= 0; --q) {
+    const int s = lane * CH + q;
+    if (q < CH && s < S) {
+      const AlphaTerms& t = tt[q];
+      float galpha = gw[q] * Tq[q] - suffix / (1.0f - t.alpha + 1e-7f);
+      suffix = fmaf(gw[q], w[q], suffix);
+      float gs = 0.f, gg[3] = {0.f, 0.f, 0.f};
+      if (t.clip_pass) {
+        // a = (p + e)/(c + e), p = c - n, c = prev_cdf, n = next_cdf
+        const float den = t.prev_cdf + 1e-5f;
+        const float a = (t.prev_cdf - t.next_cdf + 1e-5f) / den;
+        const float ga_c = (1.0f - a) / den, ga_n = -1.0f / den;
+        const float gc = galpha * ga_c * t.prev_cdf * (1.0f - t.prev_cdf);  // d/d(prv*inv_s)
+        const float gn = galpha * ga_n * t.next_cdf * (1.0f - t.next_cdf);  // d/d(nxt*inv_s)
+        const float prv = sd[q] - t.ic * dl[q] * 0.5f, nxt = sd[q] + t.ic * dl[q] * 0.5f;
+        gs = (gc + gn) * t.inv_s;
+        gvar += gc * prv + gn * nxt;  // d/d inv_s
+        const float gic = (gn - gc) * t.inv_s * dl[q] * 0.5f;
+        // ic = -(relu(-cos/2+1/2)(1-an) + relu(-cos) an)
+        float dic = 0.f;
+        if (-t.cosv * 0.5f + 0.5f > 0.0f) dic += 0.5f * (1.0f - anneal);
+        if (-t.cosv > 0.0f) dic += anneal;
+        const float gcos = gic * dic;
+        gg[0] = gcos * d[0]; gg[1] = gcos * d[1]; gg[2] = gcos * d[2];
+      }
+      const long o = (long)r * S + s;
+      d_sdf[o] = gs;
+      d_grad[o * 3] = gg[0]; d_grad[o * 3 + 1] = gg[1]; d_grad[o * 3 + 2] = gg[2];
+    }
+  }
+  gvar = wave_sum(gvar);
+  if (lane == 0 && d_variance && invs_pass) atomicAdd(d_variance, gvar * inv_s * 10.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// DDF visibility ray set-up: thread per (ray, selected direction)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sphere_hit_clamped(const float p[3], const float dir[3], float radius, float out[3]) {
+  // neusky_model.py:1590-1622: normalise dir, clamp discriminant, far root
+  const float n = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+  const float d[3] = {dir[0] / n, dir[1] / n, dir[2] / n};
+  const float b = 2.0f * (d[0] * p[0] + d[1] * p[1] + d[2] * p[2]);
+  const float c = p[0] * p[0] + p[1] * p[1] + p[2] * p[2] - radius * radius;
+  const float disc = fmaxf(b * b - 4.0f * c, 0.0f);
+  const float sq = sqrtf(disc);
+  const float t = fmaxf((-b - sq) * 0.5f, (-b + sq) * 0.5f);
+  out[0] = p[0] + t * d[0]; out[1] = p[1] + t * d[1]; out[2] = p[2] + t * d[2];
+}
+
+__global__ void visibility_rays_kernel(const float* __restrict__ origins, const float* __restrict__ ray_dirs,
+                                       const float* __restrict__ depth, const float* __restrict__ sel_dirs, int R, int Dv,
+                                       float radius, float* __restrict__ sphere_pts, float* __restrict__ xrow, int ldx,
+                                       float* __restrict__ surf_dist, float* __restrict__ term_dist) {
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= (long)R * Dv) return;
+  const int r = (int)(m / Dv), j = (int)(m % Dv);
+  const float o[3] = {origins[r * 3], origins[r * 3 + 1], origins[r * 3 + 2]};
+  const float rd[3] = {ray_dirs[r * 3], ray_dirs[r * 3 + 1], ray_dirs[r * 3 + 2]};
+  const float t = depth[r];
+  float pos[3] = {o[0] + rd[0] * t, o[1] + rd[1] * t, o[2] + rd[2] * t};  // :1671
+  const float nrm = sqrtf(pos[0] * pos[0] + pos[1] * pos[1] + pos[2] * pos[2]);
+  if (!(nrm < radius)) {  // :1674-1683 (sic: elementwise product with -dir)
+    float hit[3];
+    sphere_hit_clamped(o, rd, radius, hit);
+    pos[0] = hit[0] * 0.01f * -rd[0]; pos[1] = hit[1] * 0.01f * -rd[1]; pos[2] = hit[2] * 0.01f * -rd[2];
+  }
+  const float l[3] = {sel_dirs[j * 3], sel_dirs[j * 3 + 1], sel_dirs[j * 3 + 2]};
+  float sp[3];
+  sphere_hit_clamped(pos, l, radius, sp);  // :1693
+  const float dx = sp[0] - pos[0], dy = sp[1] - pos[1], dz = sp[2] - pos[2];
+  const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+  if (term_dist) term_dist[m] = dist;                        // :1697
+  surf_dist[m] = fminf(dist, 2.0f * radius);                 // :1724-1727
+  sphere_pts[m * 3] = sp[0]; sphere_pts[m * 3 + 1] = sp[1]; sphere_pts[m * 3 + 2] = sp[2];
+  // local frame (ddf_model.py:158-181) applied to the DDF query direction -l (:1702, ddf_model.py:200)
+  const float y[3] = {-sp[0], -sp[1], -sp[2]};
+  float xl[3] = {-y[1], y[0], 0.0f};  // cross(up=(0,0,1), y)
+  const float xn = sqrtf(xl[0] * xl[0] + xl[1] * xl[1] + xl[2] * xl[2]);
+  xl[0] /= xn; xl[1] /= xn; xl[2] /= xn;
+  float zl[3] = {y[1] * xl[2] - y[2] * xl[1], y[2] * xl[0] - y[0] * xl[2], y[0] * xl[1] - y[1] * xl[0]};  // cross(y, x)
+  const float zn = sqrtf(zl[0] * zl[0] + zl[1] * zl[1] + zl[2] * zl[2]);
+  zl[0] /= zn; zl[1] /= zn; zl[2] /= zn;
+  const float q[3] = {-l[0], -l[1], -l[2]};
+  const float dl[3] = {xl[0] * q[0] + xl[1] * q[1] + xl[2] * q[2], y[0] * q[0] + y[1] * q[1] + y[2] * q[2],
+                       zl[0] * q[0] + zl[1] * q[1] + zl[2] * q[2]};
+  float* row = xrow + m * ldx;
+  // [d_loc (3) | sin(2 pi d_i {1,4}) (6) | sin(.. + pi/2) (6) | 0]   NeRFEncoding(2 freqs, 0..2) :188-191
+  row[0] = dl[0]; row[1] = dl[1]; row[2] = dl[2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const float arg = 6.283185307179586f * dl[i] * (f == 0 ? 1.0f : 4.0f);
+      row[3 + i * 2 + f] = sinf(arg);
+      row[9 + i * 2 + f] = sinf(arg + 1.5707963267948966f);
+    }
+  for (int c = 15; c < ldx; ++c) row[c] = 0.0f;
+}
+
+__global__ void visibility_finish_fwd_kernel(const float* __restrict__ t_hat, const float* __restrict__ surf_dist,
+                                             const float* __restrict__ threshold, float scale, const int* __restrict__ sel_index,
+                                             int R, int Dv, int D, float* __restrict__ vis) {
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= (long)R * Dv) return;
+  const int r = (int)(m / Dv), j = (int)(m % Dv);
+  const float u = scale * (surf_dist[m] - t_hat[m] - threshold[0]);  // :1730-1739
+  vis[(long)r * D + sel_index[j]] = 1.0f - sigmoidf_(u);
+}
+
+__global__ void visibility_finish_bwd_kernel(const float* __restrict__ t_hat, const float* __restrict__ surf_dist,
+                                             const float* __restrict__ threshold, float scale, const int* __restrict__ sel_index,
+                                             int R, int Dv, int D, const float* __restrict__ d_vis, float* __restrict__ d_t_hat,
+                                             float* __restrict__ d_threshold) {
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float gthr = 0.f;
+  if (m < (long)R * Dv) {
+    const int r = (int)(m / Dv), j = (int)(m % Dv);
+    const float s = sigmoidf_(scale * (surf_dist[m] - t_hat[m] - threshold[0]));
+    const float g = d_vis[(long)r * D + sel_index[j]] * s * (1.0f - s) * scale;  // d vis / d t_hat = + s' * scale
+    d_t_hat[m] = g;
+    gthr = g;
+  }
+  gthr = wave_sum(gthr);
+  if ((threadIdx.x & 63) == 0 && d_threshold && gthr != 0.0f) atomicAdd(d_threshold, gthr);
+}
+
+}  // namespace
+
+extern "C" int nsky_hemi_composite_fwd(const float* albedo, const float* normals, const float* weights, const float* dirs,
+                                       const float* cam_colours, const int32_t* cam_of_ray, const float* vis, const float* bg,
+                                       int32_t R, int32_t S, int32_t D, float* rgb, float* lin, nsky_stream_t stream) {
+  if (R == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(albedo && normals && weights && dirs && cam_colours && cam_of_ray && bg && rgb, "nsky_hemi_composite_fwd: null argument");
+  NSKY_CHECK_ARG(R > 0 && S > 0 && D > 0 && D <= MAXD, "nsky_hemi_composite_fwd: bad sizes R=%d S=%d D=%d (D <= %d)", R, S, D, MAXD);
+  hipLaunchKernelGGL(hemi_fwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, albedo, normals, weights, dirs, cam_colours,
+                     cam_of_ray, vis, bg, R, S, D, rgb, lin);
+  NSKY_CHECK_LAUNCH("nsky_hemi_composite_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_hemi_composite_bwd(const float* albedo, const float* normals, const float* weights, const float* dirs,
+                                       const float* cam_colours, const int32_t* cam_of_ray, const float* vis, const float* bg,
+                                       const float* lin, const float* d_rgb, int32_t R, int32_t S, int32_t D, float* d_albedo,
+                                       float* d_normals, float* d_weights, float* d_cam_colours, float* d_vis, float* d_bg,
+                                       nsky_stream_t stream) {
+  if (R == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(albedo && normals && weights && dirs && cam_colours && cam_of_ray && bg && lin && d_rgb && d_albedo && d_normals &&
+                     d_weights && d_bg, "nsky_hemi_composite_bwd: null argument");
+  NSKY_CHECK_ARG(R > 0 && S > 0 && D > 0 && D <= MAXD, "nsky_hemi_composite_bwd: bad sizes R=%d S=%d D=%d (D <= %d)", R, S, D, MAXD);
+  hipLaunchKernelGGL(hemi_bwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, albedo, normals, weights, dirs, cam_colours,
+                     cam_of_ray, vis, bg, lin, d_rgb, R, S, D, d_albedo, d_normals, d_weights, d_cam_colours, d_vis, d_bg);
+  NSKY_CHECK_LAUNCH("nsky_hemi_composite_bwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_neus_weights_fwd(const float* sdf, const float* grad, const float* ray_dirs, const float* starts,
+                                     const float* ends, const float* variance, float cos_anneal, int32_t R, int32_t S,
+                                     float* alpha, float* weights, float* trans_bg, float* accumulation, float* depth,
+                                     nsky_stream_t stream) {
+  if (R == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(sdf && grad && ray_dirs && starts && ends && variance && weights, "nsky_neus_weights_fwd: null argument");
+  NSKY_CHECK_ARG(R > 0 && S > 0 && S <= 64 * MAXCH, "nsky_neus_weights_fwd: S=%d out of range (<= %d)", S, 64 * MAXCH);
+  hipLaunchKernelGGL(neus_weights_fwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, (hipStream_t)stream, sdf, grad, ray_dirs, starts,
+                     ends, variance, cos_anneal, R, S, alpha, weights, trans_bg, accumulation, depth);
+  NSKY_CHECK_LAUNCH("nsky_neus_weights_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_neus_weights_bwd(const float* sdf, const float* grad, const float* ray_dirs, const float* starts,
+                                     const float* ends, const float* variance, float cos_anneal, int32_t R, int32_t S,
+                                     const float* d_weights, const float* d_trans_bg, float* d_sdf, float* d_grad,
+                                     float* d_variance, nsky_stream_t stream) {
+  if (R == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(sdf && grad && ray_dirs && starts && ends && variance && d_weights && d_sdf && d_grad, "nsky_neus_weights_bwd: null argument");
+  NSKY_CHECK_ARG(R > 0 && S > 0 && S <= 64 * MAXCH, "nsky_neus_weights_bwd: S=%d out of range (<= %d)", S, 64 * MAXCH);
+  hipLaunchKernelGGL(neus_weights_bwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, (hipStream_t)stream, sdf, grad, ray_dirs, starts,
+                     ends, variance, cos_anneal, R, S, d_weights, d_trans_bg, d_sdf, d_grad, d_variance);
+  NSKY_CHECK_LAUNCH("nsky_neus_weights_bwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_visibility_rays(const float* origins, const float* ray_dirs, const float* depth, const float* sel_dirs,
+                                    int32_t R, int32_t Dv, float radius, float* sphere_pts, float* xrow, int32_t ldx,
+                                    float* surf_dist, float* term_dist, nsky_stream_t stream) {
+  if ((long)R * Dv == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(origins && ray_dirs && depth && sel_dirs && sphere_pts && xrow && surf_dist, "nsky_visibility_rays: null argument");
+  NSKY_CHECK_ARG(R > 0 && Dv > 0 && ldx >= 15 && radius > 0.0f, "nsky_visibility_rays: bad sizes");
+  const long n = (long)R * Dv;
+  hipLaunchKernelGGL(visibility_rays_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, origins, ray_dirs, depth,
+                     sel_dirs, R, Dv, radius, sphere_pts, xrow, ldx, surf_dist, term_dist);
+  NSKY_CHECK_LAUNCH("nsky_visibility_rays");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_visibility_finish_fwd(const float* t_hat, const float* surf_dist, const float* threshold, float scale,
+                                          const int32_t* sel_index, int32_t R, int32_t Dv, int32_t D, float* vis,
+                                          nsky_stream_t stream) {
+  if ((long)R * Dv == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(t_hat && surf_dist && threshold && sel_index && vis && R > 0 && Dv > 0 && D >= Dv, "nsky_visibility_finish_fwd: bad argument");
+  const long n = (long)R * Dv;
+  hipLaunchKernelGGL(visibility_finish_fwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, t_hat, surf_dist,
+                     threshold, scale, sel_index, R, Dv, D, vis);
+  NSKY_CHECK_LAUNCH("nsky_visibility_finish_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_visibility_finish_bwd(const float* t_hat, const float* surf_dist, const float* threshold, float scale,
+                                          const int32_t* sel_index, int32_t R, int32_t Dv, int32_t D, const float* d_vis,
+                                          float* d_t_hat, float* d_threshold, nsky_stream_t stream) {
+  if ((long)R * Dv == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(t_hat && surf_dist && threshold && sel_index && d_vis && d_t_hat && R > 0 && Dv > 0 && D >= Dv,
+                 "nsky_visibility_finish_bwd: bad argument");
+  const long n = (long)R * Dv;
+  hipLaunchKernelGGL(visibility_finish_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, t_hat, surf_dist,
+                     threshold, scale, sel_index, R, Dv, D, d_vis, d_t_hat, d_threshold);
+  NSKY_CHECK_LAUNCH("nsky_visibility_finish_bwd");
+  return NSKY_OK;
+}

@@ -106,3 +106,122 @@ def colsum(X, M, N, out):
 
 def abi_version() -> int:
     return _lib.nsky_abi_version()
+
+
+# ------------------------------------------------------------------------------------------ hash grid
+class HashGridDesc(C.Structure):
+    _fields_ = [
+        ("table", C.c_void_p), ("n_levels", C.c_int32), ("smoothstep", C.c_int32),
+        ("scale", C.c_float * 16), ("resolution", C.c_int32 * 16), ("offset", C.c_uint32 * 17),
+    ]
+
+
+MODE_RAW, MODE_CONTRACT_LINF, MODE_CONTRACT_L2 = 0, 1, 2
+
+_encode_fwd = _sig("nsky_encode_fwd", C.POINTER(HashGridDesc), C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                   C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p)
+_encode_bwd = _sig("nsky_encode_bwd", C.POINTER(HashGridDesc), C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                   C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_hash_indices = _sig("nsky_hash_indices", C.POINTER(HashGridDesc), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p)
+
+
+def grid_desc(geom, table) -> HashGridDesc:
+    """geom: neusky_amd.encoding.HashGridGeometry; table: [n_params, 2] float32 device tensor."""
+    assert table.is_cuda and table.dtype == torch.float32 and table.is_contiguous() and table.shape == (geom.n_params, 2)
+    d = HashGridDesc(table=table.data_ptr(), n_levels=geom.n_levels, smoothstep=int(geom.smoothstep))
+    for i in range(geom.n_levels):
+        d.scale[i] = geom.scales[i]
+        d.resolution[i] = geom.resolutions[i]
+    for i in range(geom.n_levels + 1):
+        d.offset[i] = geom.offsets[i]
+    return d
+
+
+def encode_fwd(geom, table, x, mode, include_x, pe_freqs, pe_max_exp, Y, T=None):
+    P = x.shape[0]
+    assert x.shape == (P, 3) and x.is_contiguous() and Y.shape[0] == P
+    if T is not None:
+        assert T.shape == (3, P, Y.shape[1]) and T.is_contiguous() and Y.is_contiguous()
+    check(_encode_fwd(C.byref(grid_desc(geom, table)), ptr(x), P, mode, int(include_x), pe_freqs, pe_max_exp, ptr(Y), ld(Y),
+                      ptr(T), stream_ptr()), "nsky_encode_fwd")
+    return Y
+
+
+def encode_bwd(geom, table, x, mode, include_x, pe_freqs, pe_max_exp, dY, dT, dtable, dx=None):
+    P = x.shape[0]
+    if dT is not None:
+        assert dT.shape == (3, P, dY.shape[1]) and dT.is_contiguous() and dY.is_contiguous()
+    assert dtable.shape == table.shape and dtable.is_contiguous()
+    check(_encode_bwd(C.byref(grid_desc(geom, table)), ptr(x), P, mode, int(include_x), pe_freqs, pe_max_exp, ptr(dY), ld(dY),
+                      ptr(dT), ptr(dtable), ptr(dx), stream_ptr()), "nsky_encode_bwd")
+
+
+def hash_indices(geom, table, x, mode):
+    P = x.shape[0]
+    out = torch.empty(P, geom.n_levels, 8, dtype=torch.int32, device=x.device)
+    check(_hash_indices(C.byref(grid_desc(geom, table)), ptr(x), P, mode, ptr(out), stream_ptr()), "nsky_hash_indices")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ render stages
+_P = C.c_void_p
+_I = C.c_int32
+_F = C.c_float
+_hemi_fwd = _sig("nsky_hemi_composite_fwd", _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P)
+_hemi_bwd = _sig("nsky_hemi_composite_bwd", _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P)
+_neus_fwd = _sig("nsky_neus_weights_fwd", _P, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P)
+_neus_bwd = _sig("nsky_neus_weights_bwd", _P, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P)
+_vis_rays = _sig("nsky_visibility_rays", _P, _P, _P, _P, _I, _I, _F, _P, _P, _I, _P, _P, _P)
+_vis_fin_fwd = _sig("nsky_visibility_finish_fwd", _P, _P, _P, _F, _P, _I, _I, _I, _P, _P)
+_vis_fin_bwd = _sig("nsky_visibility_finish_bwd", _P, _P, _P, _F, _P, _I, _I, _I, _P, _P, _P, _P)
+
+
+def _c(t):
+    assert t is None or t.is_contiguous(), "contiguous tensor required"
+    return ptr(t)
+
+
+def hemi_composite_fwd(albedo, normals, weights, dirs, cam_colours, cam_of_ray, vis, bg, rgb, lin):
+    R, S, _ = albedo.shape
+    D = dirs.shape[0]
+    assert cam_of_ray.dtype == torch.int32
+    check(_hemi_fwd(_c(albedo), _c(normals), _c(weights), _c(dirs), _c(cam_colours), _c(cam_of_ray), _c(vis), _c(bg), R, S, D,
+                    _c(rgb), _c(lin), stream_ptr()), "nsky_hemi_composite_fwd")
+
+
+def hemi_composite_bwd(albedo, normals, weights, dirs, cam_colours, cam_of_ray, vis, bg, lin, d_rgb, d_albedo, d_normals,
+                       d_weights, d_cam_colours, d_vis, d_bg):
+    R, S, _ = albedo.shape
+    D = dirs.shape[0]
+    check(_hemi_bwd(_c(albedo), _c(normals), _c(weights), _c(dirs), _c(cam_colours), _c(cam_of_ray), _c(vis), _c(bg), _c(lin),
+                    _c(d_rgb), R, S, D, _c(d_albedo), _c(d_normals), _c(d_weights), _c(d_cam_colours), _c(d_vis), _c(d_bg),
+                    stream_ptr()), "nsky_hemi_composite_bwd")
+
+
+def neus_weights_fwd(sdf, grad, ray_dirs, starts, ends, variance, anneal, alpha, weights, trans_bg, acc, depth):
+    R, S = sdf.shape
+    check(_neus_fwd(_c(sdf), _c(grad), _c(ray_dirs), _c(starts), _c(ends), _c(variance), anneal, R, S, _c(alpha), _c(weights),
+                    _c(trans_bg), _c(acc), _c(depth), stream_ptr()), "nsky_neus_weights_fwd")
+
+
+def neus_weights_bwd(sdf, grad, ray_dirs, starts, ends, variance, anneal, d_weights, d_trans_bg, d_sdf, d_grad, d_variance):
+    R, S = sdf.shape
+    check(_neus_bwd(_c(sdf), _c(grad), _c(ray_dirs), _c(starts), _c(ends), _c(variance), anneal, R, S, _c(d_weights),
+                    _c(d_trans_bg), _c(d_sdf), _c(d_grad), _c(d_variance), stream_ptr()), "nsky_neus_weights_bwd")
+
+
+def visibility_rays(origins, ray_dirs, depth, sel_dirs, radius, sphere_pts, xrow, surf_dist, term_dist=None):
+    R, Dv = origins.shape[0], sel_dirs.shape[0]
+    check(_vis_rays(_c(origins), _c(ray_dirs), _c(depth), _c(sel_dirs), R, Dv, radius, _c(sphere_pts), _c(xrow), ld(xrow),
+                    _c(surf_dist), _c(term_dist), stream_ptr()), "nsky_visibility_rays")
+
+
+def visibility_finish_fwd(t_hat, surf_dist, threshold, scale, sel_index, R, Dv, D, vis):
+    assert sel_index.dtype == torch.int32
+    check(_vis_fin_fwd(_c(t_hat), _c(surf_dist), _c(threshold), scale, _c(sel_index), R, Dv, D, _c(vis), stream_ptr()),
+          "nsky_visibility_finish_fwd")
+
+
+def visibility_finish_bwd(t_hat, surf_dist, threshold, scale, sel_index, R, Dv, D, d_vis, d_t_hat, d_threshold):
+    check(_vis_fin_bwd(_c(t_hat), _c(surf_dist), _c(threshold), scale, _c(sel_index), R, Dv, D, _c(d_vis), _c(d_t_hat),
+                       _c(d_threshold), stream_ptr()), "nsky_visibility_finish_bwd")

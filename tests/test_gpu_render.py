@@ -1,0 +1,169 @@
+"""GPU parity of the render-stage kernels: golden vectors of the reference (G3/G4/G5) and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import inputs as gi
+from oracle import neusky_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+G = os.path.join(os.path.dirname(__file__), "golden")
+T = torch.from_numpy
+
+
+def load(name):
+    return dict(np.load(os.path.join(G, name + ".npz")))
+
+
+def _hemi_gpu(inp, want_lin=False):
+    from neusky_amd import hip
+    R, S, _ = inp["albedo"].shape
+    dv = lambda k: T(np.ascontiguousarray(inp[k])).to(DEV)
+    rgb = torch.empty(R, 3, device=DEV)
+    lin = torch.empty(R, 3, device=DEV)
+    hip.hemi_composite_fwd(dv("albedo"), dv("normals"), dv("weights"), dv("dirs"), dv("cam_colours"),
+                           T(inp["cam_of_ray"]).to(torch.int32).to(DEV), dv("vis"), dv("bg"), rgb, lin)
+    return (rgb, lin) if want_lin else rgb
+
+
+def test_hemi_composite_golden_small():
+    g = load("g3_lambertian_small")
+    rgb = _hemi_gpu(g).cpu().numpy()
+    # tolerance from the north star: 1e-4 relative on rendered radiance
+    np.testing.assert_allclose(rgb, g["rgb_train"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(rgb, g["rgb_eval"], rtol=1e-4, atol=1e-6)
+
+
+def test_hemi_composite_golden_big():
+    g = load("g3_lambertian_big")
+    R, S, D, U = [int(v) for v in g["shape"]]
+    inp = gi.lambertian_inputs(seed=int(g["seed"]), R=R, S=S, D=D, U=U)
+    rgb = _hemi_gpu(inp).cpu().numpy()
+    np.testing.assert_allclose(rgb, g["rgb_train"], rtol=1e-4, atol=2e-6)
+
+
+def test_hemi_composite_full_size_properties():
+    """BASELINE size (1024 x 96 x 512): linearity in the light colours + oracle spot check."""
+    from neusky_amd import hip
+    inp = gi.lambertian_inputs(seed=5, R=1024, S=96, D=512, U=300)
+    rgb, lin = _hemi_gpu(inp, want_lin=True)
+    inp2 = dict(inp); inp2["cam_colours"] = inp["cam_colours"] * 2.0; inp2["bg"] = inp["bg"] * 2.0
+    _, lin2 = _hemi_gpu(inp2, want_lin=True)
+    assert torch.allclose(lin2, 2.0 * lin, rtol=1e-5, atol=1e-6)  # linear composite is linear in radiance
+    sub = {k: (v[:32] if v.shape[0] == 1024 else v) for k, v in inp.items()}
+    ref = O.lambertian_render(*(T(sub[k]).double() if sub[k].dtype != np.int64 else T(sub[k]) for k in
+                                ["albedo", "normals", "dirs", "cam_colours", "cam_of_ray", "vis", "bg", "weights"]))
+    np.testing.assert_allclose(rgb[:32].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-6)
+
+
+def test_hemi_composite_backward_vs_autograd():
+    from neusky_amd import hip
+    inp = gi.lambertian_inputs(seed=8, R=24, S=10, D=100, U=5)
+    inp["normals"][0, 0] = inp["normals"][0, 1]  # no exactly-zero normal (kink of the clamp)
+    inp["bg"] *= 0.05; inp["cam_colours"] *= 0.05  # keep the composite inside the sRGB curve (< 1)
+    keys = ["albedo", "normals", "cam_colours", "vis", "bg", "weights"]
+    td = {k: T(inp[k]).double().requires_grad_(True) for k in keys}
+    ref = O.lambertian_render(td["albedo"], td["normals"], T(inp["dirs"]).double(), td["cam_colours"], T(inp["cam_of_ray"]),
+                              td["vis"], td["bg"], td["weights"])
+    gr = torch.randn(ref.shape, generator=torch.Generator().manual_seed(0), dtype=torch.float64)
+    grads = torch.autograd.grad((ref * gr).sum(), [td[k] for k in keys])
+    dv = lambda k: T(np.ascontiguousarray(inp[k])).to(DEV)
+    R, S, D, U = 24, 10, 100, 5
+    rgb, lin = torch.empty(R, 3, device=DEV), torch.empty(R, 3, device=DEV)
+    cam = T(inp["cam_of_ray"]).to(torch.int32).to(DEV)
+    hip.hemi_composite_fwd(dv("albedo"), dv("normals"), dv("weights"), dv("dirs"), dv("cam_colours"), cam, dv("vis"), dv("bg"), rgb, lin)
+    out = {"albedo": torch.empty(R, S, 3, device=DEV), "normals": torch.empty(R, S, 3, device=DEV),
+           "weights": torch.empty(R, S, device=DEV), "cam_colours": torch.zeros(U, D, 3, device=DEV),
+           "vis": torch.empty(R, D, device=DEV), "bg": torch.empty(R, 3, device=DEV)}
+    hip.hemi_composite_bwd(dv("albedo"), dv("normals"), dv("weights"), dv("dirs"), dv("cam_colours"), cam, dv("vis"), dv("bg"), lin,
+                           gr.float().to(DEV), out["albedo"], out["normals"], out["weights"], out["cam_colours"], out["vis"], out["bg"])
+    for k, gref in zip(keys, grads):
+        got = out[k].cpu().double()
+        scale = gref.abs().max().item() + 1e-12
+        assert (got - gref).abs().max().item() < 2e-4 * scale, (k, (got - gref).abs().max().item(), scale)
+
+
+def _alpha_inputs(R, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    sdf = torch.randn(R, S, generator=g) * 0.05
+    grad = torch.nn.functional.normalize(torch.randn(R, S, 3, generator=g), dim=-1) * (1 + 0.1 * torch.randn(R, S, 1, generator=g))
+    rd = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    bins = torch.sort(torch.rand(R, S + 1, generator=g) * 2 + 0.05, dim=1).values
+    return sdf, grad, rd, bins[:, :-1].contiguous(), bins[:, 1:].contiguous(), torch.tensor([0.32])
+
+
+@pytest.mark.parametrize("R,S", [(7, 5), (64, 96), (1024, 96), (33, 200)])
+def test_neus_weights_fwd_bwd(R, S):
+    from neusky_amd import hip
+    sdf, grad, rd, st, en, var = _alpha_inputs(R, S, R + S)
+    d = lambda t: t.to(DEV).contiguous()
+    alpha, w = torch.empty(R, S, device=DEV), torch.empty(R, S, device=DEV)
+    tb, acc, dep = torch.empty(R, device=DEV), torch.empty(R, device=DEV), torch.empty(R, device=DEV)
+    hip.neus_weights_fwd(d(sdf), d(grad), d(rd), d(st), d(en), d(var), 1.0, alpha, w, tb, acc, dep)
+    sd, gd, vd = sdf.double().requires_grad_(True), grad.double().requires_grad_(True), var.double().requires_grad_(True)
+    a_ref = O.neus_alpha(sd[..., None], gd, rd.double()[:, None, :].expand(R, S, 3), (en - st).double()[..., None], vd)
+    w_ref, T_ref = O.weights_from_alphas(a_ref)
+    assert (alpha.cpu().double() - a_ref[..., 0]).abs().max().item() < 2e-5
+    assert (w.cpu().double() - w_ref[..., 0]).abs().max().item() < 2e-5
+    assert (tb.cpu().double() - T_ref[:, -1, 0]).abs().max().item() < 2e-5
+    mid = ((st + en) / 2).double()
+    dref = (w_ref[..., 0] * mid).sum(1) / (w_ref[..., 0].sum(1) + 1e-10)
+    assert (dep.cpu().double() - dref).abs().max().item() < 5e-5
+    assert (acc.cpu().double() - w_ref[..., 0].sum(1)).abs().max().item() < 2e-5
+    # backward
+    g = torch.Generator().manual_seed(9)
+    gw, gT = torch.randn(R, S, generator=g), torch.randn(R, generator=g)
+    loss = (w_ref[..., 0] * gw.double()).sum() + (T_ref[:, -1, 0] * gT.double()).sum()
+    gs_ref, gg_ref, gv_ref = torch.autograd.grad(loss, [sd, gd, vd])
+    dsdf, dgrad, dvar = torch.empty(R, S, device=DEV), torch.empty(R, S, 3, device=DEV), torch.zeros(1, device=DEV)
+    hip.neus_weights_bwd(d(sdf), d(grad), d(rd), d(st), d(en), d(var), 1.0, d(gw), d(gT), dsdf, dgrad, dvar)
+    for got, ref in [(dsdf, gs_ref), (dgrad, gg_ref), (dvar, gv_ref)]:
+        sc = ref.abs().max().item() + 1e-12
+        assert (got.cpu().double() - ref).abs().max().item() < 5e-4 * sc, ((got.cpu().double() - ref).abs().max().item(), sc)
+
+
+def test_visibility_geometry_golden():
+    """nsky_visibility_rays + finish against the reference's compute_visibility (G4) and local frame (G5)."""
+    from neusky_amd import hip
+    for tag, lower in [("upper_lower1", 1.0), ("upper_lower0", 0.0)]:
+        g = load(f"g4_visibility_{tag}")
+        inp = gi.visibility_inputs(seed=4, R=16, S=3, D=42, n_outside=2)
+        R, S, D = 16, 3, 42
+        dirs = T(inp["dirs"])
+        sel = torch.nonzero(dirs[:, 2] > 0)[:, 0]
+        Dv = sel.numel()
+        M = R * Dv
+        sp = torch.empty(M, 3, device=DEV); xrow = torch.full((M, 16), float("nan"), device=DEV)
+        sdist = torch.empty(M, device=DEV); tdist = torch.empty(M, device=DEV)
+        hip.visibility_rays(T(inp["origins"][:, 0].copy()).to(DEV), T(inp["directions"][:, 0].copy()).to(DEV),
+                            T(inp["depth"][:, 0].copy()).to(DEV), dirs[sel].contiguous().to(DEV), 1.0, sp, xrow, sdist, tdist)
+        np.testing.assert_allclose(tdist.cpu().numpy(), g["termination_dist"], rtol=2e-5, atol=2e-6)
+        # stand-in DDF of the generator evaluated on OUR sphere points (world dir = -l)
+        dd = (-dirs[sel])[None].expand(R, Dv, 3).reshape(-1, 3)
+        spc = sp.cpu()
+        oz, dz = spc[:, 2], dd[:, 2]
+        t = torch.where(dz < -1e-6, (0.1 - oz) / dz.clamp(max=-1e-6), torch.full_like(oz, 2.0)).clamp(0.0, 2.0)
+        np.testing.assert_allclose(t.numpy(), g["expected_termination_dist"], rtol=1e-4, atol=1e-5)
+        vis = torch.full((R, D), lower, device=DEV)
+        hip.visibility_finish_fwd(t.to(DEV), sdist, torch.tensor([0.35], device=DEV), 25.0, sel.to(torch.int32).to(DEV), R, Dv, D, vis)
+        ref = g["visibility"].reshape(R, S, D)[:, 0]
+        np.testing.assert_allclose(vis.cpu().numpy(), ref, rtol=1e-4, atol=2e-5)
+        # local direction + encoding row against the oracle (pinned by G5)
+        dl = O.ddf_local_direction(spc.double(), dd.double())
+        row = torch.cat([dl, O.nerf_encoding(dl, 2, 0.0, 2.0, False)], -1)
+        got = xrow.cpu().double()
+        assert (got[:, :15] - row).abs().max().item() < 2e-5
+        assert (got[:, 15] == 0).all()
+        # finish backward
+        gv = torch.randn(R, D, generator=torch.Generator().manual_seed(1))
+        dth, dthr = torch.empty(M, device=DEV), torch.zeros(1, device=DEV)
+        hip.visibility_finish_bwd(t.to(DEV), sdist, torch.tensor([0.35], device=DEV), 25.0, sel.to(torch.int32).to(DEV), R, Dv, D,
+                                  gv.to(DEV), dth, dthr)
+        td = t.double().requires_grad_(True); thr = torch.tensor(0.35, dtype=torch.float64, requires_grad=True)
+        v = 1 - torch.sigmoid(25.0 * (sdist.cpu().double() - td - thr))
+        gt, gth = torch.autograd.grad((v.view(R, Dv) * gv[:, sel].double()).sum(), [td, thr])
+        assert (dth.cpu().double() - gt).abs().max().item() < 1e-4 * gt.abs().max().item()
+        assert abs(dthr.item() - gth.item()) < 1e-3 * abs(gth.item())
