@@ -1,0 +1,214 @@
+"""bench.py - train-step rays/sec of the NeuSky hot path on N MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one full training iteration on a synthetic NeRF-OSR-lk2-shaped batch (BASELINE.json config[2]:
+1024 rays/GPU x 96 samples, 512 illumination directions, RENI-shaped illumination decode, DDF visibility):
+proposal sampling -> hash encode -> SDF/albedo MLPs -> illumination decode -> DDF hemisphere visibility ->
+hemisphere integral + composite -> all losses -> backward -> gradient all-reduce (N>1) -> 5 Adam groups.
+Inputs are generated on the device before the timed region.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+import torch
+import torch.distributed as dist
+
+# fp32 matrix-core peak and HBM peak from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+PEAK_F32_MFMA_TFLOPS = 157.3
+RAYS, SAMPLES, DIRECTIONS, PROPOSAL = 1024, 96, 512, (256, 96)
+
+
+def build_pipeline(device, world_size, local_rank, rays=RAYS, samples=SAMPLES, directions=DIRECTIONS, proposal=PROPOSAL):
+    from neusky_amd.configs.neusky_config import NeuSky
+    import copy
+    cfg = copy.deepcopy(NeuSky.config.pipeline)
+    cfg.model.num_neus_samples_per_ray = samples  # BASELINE.json fixes 96
+    cfg.model.num_proposal_samples_per_ray = tuple(proposal)
+    cfg.model.illumination_sampler.num_directions = directions
+    cfg.datamanager.train_num_rays_per_batch = rays
+    pipe = cfg.setup(device=device, world_size=world_size, local_rank=local_rank)
+    pipe.train()
+    return pipe
+
+
+class GemmTimer:
+    """HIP-event timing of every launch of ONE gemm kernel variant (the dominant one) on torch's current stream."""
+
+    def __init__(self, variant):
+        self.variant = variant  # (a_kcontig, b_kcontig, wide)
+        self.records = []
+
+    def install(self):
+        from neusky_amd import hip
+        self._orig = hip.gemm
+        timer = self
+
+        def timed(A, B, Cout, M, N, K, **kw):
+            v = (bool(kw.get("a_kcontig", True)), bool(kw.get("b_kcontig", True)), N > 64)
+            if v != timer.variant:
+                return timer._orig(A, B, Cout, M, N, K, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = timer._orig(A, B, Cout, M, N, K, **kw)
+            e1.record()
+            timer.records.append((e0, e1, 2.0 * M * N * K))
+            return out
+
+        hip.gemm = timed
+        import neusky_amd.ops as ops
+        ops.hip.gemm = timed
+
+    def uninstall(self):
+        from neusky_amd import hip
+        hip.gemm = self._orig
+
+    def summary(self):
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        n = len(self.records)
+        return n, ms, fl
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The CPU oracle (oracle/neusky_oracle.py, torch-CPU fp32, all host cores) timed on a bounded sample of the same
+    workload: full train step (forward + all losses + backward through torch autograd, as the reference does) on a
+    few rays with the full 96 samples / 512 directions / full-size networks and hash tables."""
+    from oracle import neusky_oracle as O
+    from util_step import make_randoms, oracle_params, oracle_randoms, oracle_step_cfg, randomise
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rays = 4
+    pipe_cpu = None
+    # parameters come from a CPU-resident copy of the product's initial state (host modules only; no HIP call)
+    import copy
+    from neusky_amd.configs.neusky_config import NeuSky
+    cfg = copy.deepcopy(NeuSky.config.pipeline)
+    cfg.model.num_neus_samples_per_ray = SAMPLES
+    cfg.model.illumination_sampler.num_directions = DIRECTIONS
+    cfg.datamanager.train_num_rays_per_batch = rays
+    cfg.visibility_train_sampler.num_samples_on_sphere = 1
+    cfg.visibility_train_sampler.num_rays_per_sample = 4
+    cfg.num_sky_rays = 4
+    pipe = cfg.setup(device="cpu")
+    pipe.train()
+    randomise(pipe)
+    rb, batch = pipe.datamanager.next_train(0)
+    rnd = make_randoms(pipe, rays)
+    p = oracle_params(pipe, dtype=torch.float32)
+    light = pipe.model.illumination_sampler(rotation=rnd["light_rotation"]).float()
+    scfg = oracle_step_cfg(pipe)
+    orr = oracle_randoms(rnd, light, dtype=torch.float32)
+
+    def one():
+        ld, _ = O.neusky_train_step(p, scfg, rb.origins.float(), rb.directions.float(), rb.camera_indices.reshape(-1),
+                                    batch["image"].float(), batch["mask"], orr, light)
+        loss = sum(ld.values())
+        keys = [k for k in p if not k.startswith("reni.")]
+        torch.autograd.grad(loss, [p[k] for k in keys], allow_unused=True)
+
+    t0 = time.time(); one(); warm = time.time() - t0
+    reps = max(1, min(5, int(seconds_budget / max(warm, 1e-3)) - 1))
+    t0 = time.time()
+    for _ in range(reps):
+        one()
+    dt = (time.time() - t0) / reps
+    return {"value": rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} full train steps (fwd+bwd via torch autograd, fp32) of {rays} rays x {SAMPLES} samples x "
+                      f"{DIRECTIONS} directions + 4 DDF-fit + 4 sky rays; Adam excluded; {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # backend "nccl" == RCCL on ROCm
+
+    from neusky_amd.engine import Optimizers, neusky_optimizers, train_iteration
+    torch.manual_seed(1234 + rank)
+    pipe = build_pipeline(device, world, local_rank)
+    from util_step import randomise
+    randomise(pipe, seed=rank)  # identical replicas are restored by the parameter broadcast in the pipeline for N>1
+    if world > 1:
+        pipe.grad_sync.broadcast_parameters()
+    opt = Optimizers(neusky_optimizers(), pipe.get_param_groups(), world_size=world)
+
+    # synthetic batches resident in HBM before the timed region
+    batches = [pipe.datamanager.next_train(i) for i in range(args.steps + args.warmup)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        rb, b = batches[i]
+        train_iteration(pipe, opt, 1000 + i, ray_bundle=rb, batch=b)
+    timer = GemmTimer((True, True, True))  # forward NT layer kernel gemm_f32_kernel<128,128,2,2,true,true>
+    timer.install()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        rb, b = batches[args.warmup + i]
+        loss, _, _ = train_iteration(pipe, opt, 2000 + i, ray_bundle=rb, batch=b)
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.uninstall()
+    t = torch.tensor([dt], device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    n_launch, k_ms, k_flops = timer.summary()
+
+    if rank == 0:
+        rays_total = RAYS * world * args.steps
+        achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        line = {
+            "metric": "train rays/sec on NeRF-OSR lk2 @1024 rays x 96 samples",
+            "value": rays_total / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "full NeuSky train step (BASELINE configs[2]): 1024 rays/GPU x 96 samples, proposal 256+96, "
+                                   "512 illumination directions (256 upper-hemisphere DDF queries/ray), latent 100x3, "
+                                   "hash L16 F2 T2^19 x2, 256-wide MLPs; fwd + losses + bwd + all-reduce + 5 Adam groups",
+                       "rays_per_gpu": RAYS, "samples_per_ray": SAMPLES, "illumination_directions": DIRECTIONS,
+                       "parallelism": f"ray-sharded dp{world}", "final_loss": float(loss)},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "gemm_f32_kernel<128,128,2,2,true,true> (fp32 MFMA dense layer, forward NT layout)",
+                         "launches_timed": n_launch, "avg_launch_ms": k_ms / max(n_launch, 1),
+                         "algorithmic_flops_per_launch": k_flops / max(n_launch, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

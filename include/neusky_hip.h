@@ -174,6 +174,34 @@ int nsky_visibility_finish_bwd(const float* t_hat, const float* surf_dist, const
                                const int32_t* sel_index, int32_t R, int32_t Dv, int32_t D, const float* d_vis,
                                float* d_t_hat, float* d_threshold, nsky_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Reverse-over-forward step of one Softplus layer that carries three input tangents.  Together with
+ * nsky_gemm_f32 (NSKY_EPI_MUL_AUX) this replaces the double backward that the reference gets from
+ * torch.autograd.grad(..., create_graph=True) at neusky/fields/sdf_albedo_field.py:235-238 feeding the eikonal
+ * loss (neusky/models/neusky_model.py:958-960) and the shading normals (:251).
+ *   s = sigmoid(beta z) [N,ld]; ta = tangent activations [3][N,ld]; da (optional) [N,ld];
+ *   dta [3][N,ld]  OR  the outer product ggrad[N,3] x wvec[C];   out: dz [N,ld], du [3][N,ld].
+ */
+int nsky_softplus_tangent_bwd(const float* da, const float* s, const float* ta, const float* dta, const float* ggrad,
+                              const float* wvec, float beta, int32_t N, int32_t C, int32_t ld, float* dz, float* du,
+                              nsky_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Proposal PDF re-sampling: nerfstudio PDFSampler.generate_ray_samples as driven by
+ * ProposalNetworkSampler (called at neusky/models/neusky_model.py:561).  weights [R,n0] (already annealed),
+ * bins [R,n0+1] (spacing domain), u_base [nb] = linspace(0, 1-1/nb, nb) (+ 1/(2nb) when not stratified),
+ * jitter [R] in [0,1) or NULL  ->  new_bins [R,nb], inds [R,nb] (optional; searchsorted(cdf,u,right)).
+ * The CDF is accumulated sequentially in fp32, so inds are bit-reproducible against the oracle.
+ */
+int nsky_pdf_sample(const float* weights, const float* bins, const float* u_base, const float* jitter, int32_t R,
+                    int32_t n0, int32_t nb, float histogram_padding, float eps, float* new_bins, int32_t* inds,
+                    nsky_stream_t stream);
+
+/* Adam update (torch.optim.Adam semantics, no weight decay / amsgrad) over a flat slab of n floats;
+ * the five optimizer groups of neusky/configs/neusky_config.py:216-237.  grad_scale multiplies g first. */
+int nsky_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, int32_t step, float grad_scale, nsky_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

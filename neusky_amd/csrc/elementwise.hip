@@ -1,0 +1,133 @@
+// Small bandwidth-bound helpers of the train step:
+//   * reverse-over-forward step of a Softplus layer carrying three input-tangents (normals / eikonal path)
+//   * proposal PDF re-sampling (nerfstudio PDFSampler semantics, sequential fp32 CDF -> bit-exact indices)
+//   * fused Adam update over a flat parameter slab
+#include "common.h"
+#include "../../include/neusky_hip.h"
+
+namespace {
+
+// For a layer a = softplus_beta(z), tangents ta_k = u_k * s with s = sigmoid(beta z), u_k = W ta_prev_k:
+//   dz   = da * s + sum_k dta_k * ta_k * beta * (1 - s)          (u s s' / s = ta * beta (1-s))
+//   du_k = dta_k * s
+// dta_k is either a matrix block or the outer product ggrad[n,k] * wvec[c] (last hidden layer).
+__global__ void softplus_tangent_bwd_kernel(const float* __restrict__ da, const float* __restrict__ s,
+                                            const float* __restrict__ ta, const float* __restrict__ dta,
+                                            const float* __restrict__ ggrad, const float* __restrict__ wvec, float beta, int N,
+                                            int Cc, int ld, float* __restrict__ dz, float* __restrict__ du) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)N * Cc) return;
+  const int n = (int)(i / Cc), c = (int)(i % Cc);
+  const long o = (long)n * ld + c;
+  const float sv = s[o];
+  float acc = da ? da[o] * sv : 0.0f;
+  const float k1 = beta * (1.0f - sv);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const long ok = ((long)k * N + n) * ld + c;
+    const float g = dta ? dta[ok] : ggrad[(long)n * 3 + k] * wvec[c];
+    acc = fmaf(g * ta[ok], k1, acc);
+    du[ok] = g * sv;
+  }
+  dz[o] = acc;
+}
+
+// one wave per ray
+__global__ __launch_bounds__(256) void pdf_sample_kernel(const float* __restrict__ weights, const float* __restrict__ bins,
+                                                         const float* __restrict__ u_base, const float* __restrict__ jitter,
+                                                         int R, int n0, int nb, float hist_pad, float eps,
+                                                         float* __restrict__ new_bins, int* __restrict__ inds_out) {
+  extern __shared__ float sm[];  // per wave: cdf[n0+1], bins[n0+1]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  float* cdf = sm + wave * 2 * (n0 + 1);
+  float* eb = cdf + (n0 + 1);
+  for (int i = lane; i <= n0; i += 64) eb[i] = bins[(long)r * (n0 + 1) + i];
+  if (lane == 0) {
+    // sequential sums, accumulated in double and rounded to float at every step (exactly what a CPU
+    // float cumsum does): the CDF, and so every searchsorted index, is bit-reproducible
+    const float* w = weights + (long)r * n0;
+    double acc = 0.0;
+    for (int i = 0; i < n0; ++i) acc += (double)(w[i] + hist_pad);
+    float wsum = (float)acc;
+    const float padding = fmaxf(eps - wsum, 0.0f);
+    const float padn = padding / (float)n0;
+    wsum += padding;
+    acc = 0.0;
+    cdf[0] = 0.0f;
+    for (int i = 0; i < n0; ++i) {
+      acc += (double)(((w[i] + hist_pad) + padn) / wsum);
+      cdf[i + 1] = fminf(1.0f, (float)acc);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  const float jit = jitter ? jitter[r] / (float)nb : 0.0f;
+  for (int j = lane; j < nb; j += 64) {
+    const float u = u_base[j] + jit;
+    // searchsorted(cdf, u, side="right"): first index with cdf[idx] > u
+    int lo = 0, hi = n0 + 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    const int below = min(max(lo - 1, 0), n0), above = min(max(lo, 0), n0);
+    const float c0 = cdf[below], c1 = cdf[above], b0 = eb[below], b1 = eb[above];
+    float t = (u - c0) / (c1 - c0);
+    if (!(t == t) ) t = 0.0f;            // nan_to_num(nan=0)
+    if (isinf(t)) t = t > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    new_bins[(long)r * nb + j] = b0 + t * (b1 - b0);
+    if (inds_out) inds_out[(long)r * nb + j] = lo;
+  }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, float lr, float b1, float b2, float eps, float bc1, float bc2, float grad_scale) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * grad_scale;
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  // torch.optim.Adam: p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps)
+  p[i] -= (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+}
+
+}  // namespace
+
+extern "C" int nsky_softplus_tangent_bwd(const float* da, const float* s, const float* ta, const float* dta, const float* ggrad,
+                                         const float* wvec, float beta, int32_t N, int32_t C, int32_t ld, float* dz, float* du,
+                                         nsky_stream_t stream) {
+  if ((long)N * C == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(s && ta && dz && du && (dta || (ggrad && wvec)) && ld >= C, "nsky_softplus_tangent_bwd: bad argument");
+  const long n = (long)N * C;
+  hipLaunchKernelGGL(softplus_tangent_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, da, s, ta, dta, ggrad,
+                     wvec, beta, N, C, ld, dz, du);
+  NSKY_CHECK_LAUNCH("nsky_softplus_tangent_bwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_pdf_sample(const float* weights, const float* bins, const float* u_base, const float* jitter, int32_t R,
+                               int32_t n0, int32_t nb, float histogram_padding, float eps, float* new_bins, int32_t* inds,
+                               nsky_stream_t stream) {
+  if (R == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(weights && bins && u_base && new_bins && R > 0 && n0 > 0 && nb > 0 && n0 <= 4096, "nsky_pdf_sample: bad argument");
+  const size_t smem = 4 * 2 * (size_t)(n0 + 1) * sizeof(float);
+  hipLaunchKernelGGL(pdf_sample_kernel, dim3(ceil_div(R, 4)), dim3(256), smem, (hipStream_t)stream, weights, bins, u_base, jitter, R,
+                     n0, nb, histogram_padding, eps, new_bins, inds);
+  NSKY_CHECK_LAUNCH("nsky_pdf_sample");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                              float eps, int32_t step, float grad_scale, nsky_stream_t stream) {
+  if (n == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "nsky_adam_step: bad argument");
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2,
+                     eps, bc1, bc2, grad_scale);
+  NSKY_CHECK_LAUNCH("nsky_adam_step");
+  return NSKY_OK;
+}

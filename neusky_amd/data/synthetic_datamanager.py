@@ -1,0 +1,98 @@
+"""Synthetic NeRF-OSR-lk2-shaped ray batches (SURVEY.md section 8(d) 'Synthetic inputs').
+
+Stands where `NeuSkyDataManager.next_train` / `get_sky_ray_bundle` stand in the reference
+(neusky/data/datamanagers/neusky_datamanager.py:277-288, called neusky/pipelines/neusky_pipeline.py:252,503):
+same output contract (RayBundle + batch{image [R,3], mask [R,4], indices}), data drawn from a seeded
+generator instead of the NeRF-OSR image stack (there is no dataset in the build environment).  Real
+data parsers are SURVEY.md section 8(f) items 1 and 4.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Tuple, Type
+
+import torch
+
+from ..cameras.rays import RayBundle
+
+
+@dataclass
+class SyntheticDataManagerConfig:
+    _target: Type = field(default_factory=lambda: SyntheticDataManager)
+    num_train_images: int = 300
+    num_eval_images: int = 96
+    train_num_rays_per_batch: int = 1024
+    image_height: int = 823
+    image_width: int = 1280
+    focal: float = 1100.0
+    seed: int = 0
+    camera_optimizer = None
+
+    def setup(self, **kwargs):
+        return self._target(self, **kwargs)
+
+
+class _Dataset:
+    def __init__(self, n, scene_box):
+        self._n, self.scene_box, self.metadata = n, scene_box, {}
+
+    def __len__(self):
+        return self._n
+
+
+class SyntheticDataManager:
+    def __init__(self, config: SyntheticDataManagerConfig, device="cuda:0", test_mode="val", world_size=1, local_rank=0, **_):
+        self.config, self.device, self.world_size, self.local_rank = config, device, world_size, local_rank
+        scene_box = {"aabb": torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])}  # scene_scale = 1.0 (neusky_config.py:52)
+        self.train_dataset = _Dataset(config.num_train_images, scene_box)
+        self.eval_dataset = _Dataset(config.num_eval_images, scene_box)
+        self.num_val = self.num_test = config.num_eval_images
+        g = torch.Generator().manual_seed(config.seed)
+        n = config.num_train_images
+        # camera centres in the disc |xy| <= 0.8, z in [-0.05, 0.05] (poses auto-scaled to the unit box,
+        # nerfosr_cityscapes_dataparser.py:272-279), looking at the origin with jitter
+        ang = torch.rand(n, generator=g) * 2 * torch.pi
+        rad = 0.8 * torch.sqrt(torch.rand(n, generator=g))
+        self.cam_pos = torch.stack([rad * torch.cos(ang), rad * torch.sin(ang), (torch.rand(n, generator=g) - 0.5) * 0.1], 1)
+        fwd = -self.cam_pos + 0.2 * torch.randn(n, 3, generator=g)
+        fwd = fwd / fwd.norm(dim=-1, keepdim=True)
+        up = torch.tensor([0.0, 0.0, 1.0]).expand(n, 3)
+        right = torch.linalg.cross(fwd, up, dim=-1)
+        right = right / right.norm(dim=-1, keepdim=True)
+        self.cam_R = torch.stack([right, torch.linalg.cross(right, fwd, dim=-1), fwd], -1)  # columns: right, up', forward
+        self._gen = torch.Generator().manual_seed(config.seed + 1 + local_rank)
+
+    def get_param_groups(self) -> Dict:
+        return {}
+
+    def _rays(self, R: int, g: torch.Generator) -> Tuple[RayBundle, torch.Tensor]:
+        c = self.config
+        cam = torch.randint(0, c.num_train_images, (R,), generator=g)
+        px = (torch.rand(R, generator=g) - 0.5) * c.image_width / c.focal
+        py = (torch.rand(R, generator=g) - 0.5) * c.image_height / c.focal
+        d_cam = torch.stack([px, py, torch.ones(R)], -1)
+        d = torch.einsum("rij,rj->ri", self.cam_R[cam], d_cam)
+        norm = d.norm(dim=-1, keepdim=True)
+        dev = self.device
+        rb = RayBundle(origins=self.cam_pos[cam].to(dev), directions=(d / norm).to(dev), pixel_area=torch.ones(R, 1, device=dev),
+                       camera_indices=cam[:, None].to(dev), metadata={"directions_norm": torch.ones(R, 1, device=dev)})
+        return rb, cam
+
+    def next_train(self, step: int):
+        g = self._gen
+        R = self.config.train_num_rays_per_batch
+        rb, cam = self._rays(R, g)
+        image = torch.rand(R, 3, generator=g)
+        u = torch.rand(R, 4, generator=g)
+        mask = torch.stack([u[:, 0] < 0.9, u[:, 1] < 0.6, u[:, 2] < 0.15, u[:, 3] < 0.3], -1)  # [static, fg, ground, sky]
+        mask[:, 1] &= ~mask[:, 3]
+        batch = {"image": image.to(self.device), "mask": mask.to(self.device), "indices": torch.stack([cam, cam * 0, cam * 0], 1)}
+        return rb, batch
+
+    def get_sky_ray_bundle(self, number_of_rays: int) -> RayBundle:
+        g = self._gen
+        rb, _ = self._rays(number_of_rays, g)
+        d = rb.directions.clone()
+        d[:, 2] = d[:, 2].abs() + 0.2  # sky rays point upwards
+        rb.directions = d / d.norm(dim=-1, keepdim=True)
+        return rb

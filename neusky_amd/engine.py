@@ -1,0 +1,127 @@
+"""Optimizer groups + one train iteration.
+
+Replaces, for the hot path only, what nerfstudio's `Trainer.train_iteration` / `Optimizers` do around
+`pipeline.get_train_loss_dict`: sum the loss dict, backward, step the five Adam
+groups of neusky/configs/neusky_config.py:216-237 with their schedulers.  Each group's parameters and
+gradients live in ONE flat fp32 slab (parameters are re-homed as views), so a step is one
+`nsky_adam_step` launch per group and the multi-GPU gradient all-reduce runs on the slabs directly.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import hip
+
+
+@dataclass
+class AdamOptimizerConfig:
+    lr: float = 1e-3
+    eps: float = 1e-15
+    betas: tuple = (0.9, 0.999)
+
+
+@dataclass
+class CosineDecaySchedulerConfig:
+    warm_up_end: int = 500
+    learning_rate_alpha: float = 0.05
+    max_steps: int = 100001
+
+    def factor(self, step: int) -> float:
+        if step < self.warm_up_end:
+            return step / self.warm_up_end
+        progress = (step - self.warm_up_end) / (self.max_steps - self.warm_up_end)
+        return (math.cos(math.pi * progress) + 1.0) * 0.5 * (1 - self.learning_rate_alpha) + self.learning_rate_alpha
+
+
+@dataclass
+class ExponentialDecaySchedulerConfig:
+    lr_final: Optional[float] = None
+    max_steps: int = 100001
+    warmup_steps: int = 0
+    lr_pre_warmup: float = 1e-8
+    lr_init: float = 1.0  # filled from the optimizer
+
+    def factor(self, step: int) -> float:
+        lr_init = self.lr_init
+        lr_final = lr_init if self.lr_final is None else self.lr_final
+        if step < self.warmup_steps:
+            lr = self.lr_pre_warmup + (lr_init - self.lr_pre_warmup) * math.sin(0.5 * math.pi * min(max(step / self.warmup_steps, 0), 1))
+        else:
+            t = min(max((step - self.warmup_steps) / (self.max_steps - self.warmup_steps), 0), 1)
+            lr = math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+        return lr / lr_init
+
+
+def neusky_optimizers() -> Dict[str, Dict]:
+    """neusky/configs/neusky_config.py:216-237"""
+    return {
+        "proposal_networks": {"optimizer": AdamOptimizerConfig(lr=1e-2), "scheduler": CosineDecaySchedulerConfig()},
+        "fields": {"optimizer": AdamOptimizerConfig(lr=1e-3), "scheduler": CosineDecaySchedulerConfig()},
+        "illumination_field": {"optimizer": AdamOptimizerConfig(lr=1e-2), "scheduler": ExponentialDecaySchedulerConfig(lr_final=1e-5)},
+        "visibility_sigmoid": {"optimizer": AdamOptimizerConfig(lr=1e-3),
+                               "scheduler": ExponentialDecaySchedulerConfig(warmup_steps=4000, lr_final=1e-4)},
+        "ddf_field": {"optimizer": AdamOptimizerConfig(lr=1e-4), "scheduler": CosineDecaySchedulerConfig()},
+    }
+
+
+class _Group:
+    def __init__(self, name, params: List[torch.nn.Parameter], opt: AdamOptimizerConfig, sched):
+        self.name, self.opt, self.sched = name, opt, sched
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat_p = torch.empty(n, device=dev)
+        self.flat_g = torch.zeros(n, device=dev)
+        self.m = torch.zeros(n, device=dev)
+        self.v = torch.zeros(n, device=dev)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat_p[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[off:off + k].view_as(p)
+            p.grad = self.flat_g[off:off + k].view_as(p)
+            off += k
+        if isinstance(sched, ExponentialDecaySchedulerConfig):
+            sched.lr_init = opt.lr
+        self.steps = 0
+
+
+class Optimizers:
+    def __init__(self, config: Dict[str, Dict], param_groups: Dict[str, List[torch.nn.Parameter]], world_size: int = 1):
+        self.groups = [_Group(k, param_groups[k], config[k]["optimizer"], config[k]["scheduler"])
+                       for k in config if k in param_groups and len(param_groups[k]) > 0]
+        self.world_size = world_size
+
+    def zero_grad_all(self) -> None:
+        for g in self.groups:
+            g.flat_g.zero_()
+
+    def all_reduce_gradients(self) -> None:
+        """one RCCL all-reduce (mean) per optimizer slab; 5 messages, the 'fields' and 'ddf_field' slabs carry the hash tables"""
+        if self.world_size <= 1:
+            return
+        for g in self.groups:
+            dist.all_reduce(g.flat_g, op=dist.ReduceOp.SUM)
+            g.flat_g.div_(self.world_size)
+
+    def optimizer_scheduler_step_all(self, step: int) -> None:
+        for g in self.groups:
+            g.steps += 1
+            lr = g.opt.lr * (g.sched.factor(step) if g.sched is not None else 1.0)
+            hip.adam_step(g.flat_p, g.flat_g, g.m, g.v, lr, g.opt.betas[0], g.opt.betas[1], g.opt.eps, g.steps)
+
+
+def train_iteration(pipeline, optimizers: Optimizers, step: int, **kw):
+    """one step of the reference's training loop: forward + losses, backward, (all-reduce), 5 Adam steps"""
+    optimizers.zero_grad_all()
+    _, loss_dict, metrics_dict = pipeline.get_train_loss_dict(step, **kw)
+    loss = sum(loss_dict.values())
+    loss.backward()
+    optimizers.all_reduce_gradients()
+    optimizers.optimizer_scheduler_step_all(step)
+    return loss.detach(), loss_dict, metrics_dict

@@ -225,3 +225,30 @@ def visibility_finish_fwd(t_hat, surf_dist, threshold, scale, sel_index, R, Dv, 
 def visibility_finish_bwd(t_hat, surf_dist, threshold, scale, sel_index, R, Dv, D, d_vis, d_t_hat, d_threshold):
     check(_vis_fin_bwd(_c(t_hat), _c(surf_dist), _c(threshold), scale, _c(sel_index), R, Dv, D, _c(d_vis), _c(d_t_hat),
                        _c(d_threshold), stream_ptr()), "nsky_visibility_finish_bwd")
+
+
+# ------------------------------------------------------------------------------------------ elementwise helpers
+_sp_tan_bwd = _sig("nsky_softplus_tangent_bwd", _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P)
+_pdf_sample = _sig("nsky_pdf_sample", _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P)
+_adam = _sig("nsky_adam_step", _P, _P, _P, _P, C.c_int64, _F, _F, _F, _F, _I, _F, _P)
+
+
+def softplus_tangent_bwd(da, s, ta, dta, ggrad, wvec, beta, N, Cc, dz, du):
+    check(_sp_tan_bwd(ptr(da), ptr(s), ptr(ta), ptr(dta), ptr(ggrad), ptr(wvec), beta, N, Cc, ld(s), ptr(dz), ptr(du),
+                      stream_ptr()), "nsky_softplus_tangent_bwd")
+
+
+def pdf_sample(weights, bins, u_base, jitter, num_bins, histogram_padding=0.01, eps=1e-5, want_inds=False):
+    R, n0 = weights.shape
+    assert bins.shape == (R, n0 + 1) and u_base.shape == (num_bins,)
+    new_bins = torch.empty(R, num_bins, device=weights.device)
+    inds = torch.empty(R, num_bins, dtype=torch.int32, device=weights.device) if want_inds else None
+    check(_pdf_sample(_c(weights), _c(bins), _c(u_base), _c(jitter), R, n0, num_bins, histogram_padding, eps, _c(new_bins),
+                      _c(inds), stream_ptr()), "nsky_pdf_sample")
+    return new_bins, inds
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    n = p.numel()
+    assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+    check(_adam(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, beta1, beta2, eps, step, grad_scale, stream_ptr()), "nsky_adam_step")

@@ -1,0 +1,131 @@
+"""Illumination prior: direction sampler + RENI++-shaped decoder.
+
+The reference imports both from the `reni` package (neusky/models/neusky_model.py:68-75), a git
+submodule whose directory is EMPTY in the reference tree and whose pretrained weights are absent
+ -> parity unpinned.  This module is this project's definition:
+  * directions: D near-uniform unit vectors (Fibonacci lattice; reni uses an icosphere whose vertex count
+    for `num_directions=512` is unknown) with an optional random SO(3) rotation (neusky_config.py:97-101);
+  * decoder: FiLM-SIREN over a z-rotation-invariant representation of (latent Z [L,3], direction d):
+    cond = per latent row (|Z_xy|, Z_z, Z_xy . d_xy), x = (|d_xy|, d_z) + NeRF(2 freqs); 3 log-HDR outputs;
+    `unnormalise` = exp; per-image `scale` multiplies the HDR value.  Runs on ops.FilmSirenFn (MFMA).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Optional, Type
+
+import numpy as np
+import torch
+from torch import nn
+
+from ..fields.directional_distance_field import nerf_encoding
+from ..utils.siren import FiLMSiren
+
+
+def fibonacci_sphere(n: int) -> torch.Tensor:
+    i = torch.arange(n, dtype=torch.float64) + 0.5
+    phi = torch.acos(1.0 - 2.0 * i / n)
+    theta = math.pi * (1.0 + 5.0**0.5) * i
+    d = torch.stack([torch.cos(theta) * torch.sin(phi), torch.sin(theta) * torch.sin(phi), torch.cos(phi)], -1)
+    return d.float()
+
+
+def random_rotation(generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """uniform random SO(3) matrix from a unit quaternion (host side, like the reference's scipy call)"""
+    q = torch.randn(4, generator=generator, dtype=torch.float64)
+    q = q / q.norm()
+    w, x, y, z = q.tolist()
+    return torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], dtype=torch.float32)
+
+
+@dataclass
+class IcosahedronSamplerConfig:
+    _target: Type = field(default_factory=lambda: IcosahedronSampler)
+    num_directions: int = 512
+    apply_random_rotation: bool = True
+    remove_lower_hemisphere: bool = False
+
+    def setup(self, **kwargs):
+        return self._target(self, **kwargs)
+
+
+class IcosahedronSampler:
+    """returns directions [D,3] (host tensor; the model moves it to the device like neusky_model.py:456-458)"""
+
+    def __init__(self, config: IcosahedronSamplerConfig):
+        self.config = config
+        d = fibonacci_sphere(config.num_directions)
+        if config.remove_lower_hemisphere:
+            d = d[d[:, 2] > 0]
+        self.directions = d
+
+    def __call__(self, apply_random_rotation: Optional[bool] = None, rotation: Optional[torch.Tensor] = None,
+                 generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        rot = self.config.apply_random_rotation if apply_random_rotation is None else apply_random_rotation
+        if rotation is None and rot:
+            rotation = random_rotation(generator)
+        return self.directions if rotation is None else self.directions @ rotation.T.to(self.directions)
+
+
+@dataclass
+class RENIFieldConfig:
+    """subset of reni RENIFieldConfig used by neusky_config.py:78-96 (this project's decoder ignores the
+    Attention-specific members; `conditioning` other than FiLM raises)."""
+
+    _target: Type = field(default_factory=lambda: RENIField)
+    conditioning: str = "FiLM"
+    invariant_function: str = "VN"
+    equivariance: str = "SO2"
+    axis_of_invariance: str = "z"
+    latent_dim: int = 100
+    hidden_features: int = 128
+    hidden_layers: int = 9
+    mapping_layers: int = 5
+    mapping_features: int = 128
+    fixed_decoder: bool = True
+    trainable_scale: bool = True
+
+    def setup(self, **kwargs):
+        return self._target(self, **kwargs)
+
+
+class RENIField(nn.Module):
+    def __init__(self, config: RENIFieldConfig, num_train_data=None, num_eval_data=None, **_):
+        super().__init__()
+        if config.conditioning != "FiLM":
+            raise NotImplementedError("RENI++ Attention conditioning (neusky_config.py:79) is not built: the ns_reni "
+                                      "source is absent from the reference; the FiLM-SIREN decoder named by the north star is")
+        self.config = config
+        self.latent_dim = config.latent_dim
+        self.network = FiLMSiren(in_dim=2 + 8, hidden_layers=config.hidden_layers, hidden_features=config.hidden_features,
+                                 mapping_network_in_dim=3 * config.latent_dim, mapping_network_layers=config.mapping_layers,
+                                 mapping_network_features=config.mapping_features, out_dim=3)
+        if config.fixed_decoder:
+            for p in self.network.parameters():
+                p.requires_grad_(False)
+
+    @staticmethod
+    def invariant_inputs(latents: torch.Tensor, dirs: torch.Tensor):
+        zxy, zz = latents[..., :2], latents[..., 2]
+        dxy, dz = dirs[..., :2], dirs[..., 2]
+        cond = torch.stack([zxy.norm(dim=-1), zz, (zxy * dxy[:, None, :]).sum(-1)], -1).reshape(latents.shape[0], -1)
+        x = torch.stack([dxy.norm(dim=-1), dz], -1)
+        return cond, x
+
+    def forward(self, directions: torch.Tensor, latent_codes: torch.Tensor, scale: Optional[torch.Tensor] = None,
+                rotation: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """directions [B,3], latent_codes [B,L,3], scale [B] -> HDR radiance [B,3] (already unnormalised)."""
+        if rotation is not None:  # z-axis rotation of the illumination (render_animation.py:196-207)
+            directions = directions @ (rotation if rotation.dim() == 2 else rotation).transpose(-1, -2)
+        cond, x = self.invariant_inputs(latent_codes, directions)
+        x = torch.cat([x, nerf_encoding(x, 2, 2.0)], -1)
+        pad = (-x.shape[1]) % 4
+        x = torch.nn.functional.pad(x, (0, pad)).contiguous()
+        cpad = (-cond.shape[1]) % 4
+        cond = torch.nn.functional.pad(cond, (0, cpad)).contiguous()
+        rgb = self.network(x, cond, train_weights=not self.config.fixed_decoder)
+        out = torch.exp(rgb)  # unnormalise (log-domain HDR)
+        return out * scale[:, None] if scale is not None else out

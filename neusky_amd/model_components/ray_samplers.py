@@ -1,0 +1,119 @@
+"""Proposal-network sampling.
+
+Restates nerfstudio's ProposalNetworkSampler / UniformSampler / PDFSampler / HashMLPDensityField as the
+reference drives them (`self.proposal_sampler(ray_bundle, density_fns=...)`, neusky/models/neusky_model.py:561;
+sizes from NeuSFactoModelConfig).  The upstream source is not vendored in the
+reference -> parity unpinned; this file is this project's definition, checked against oracle/.
+Density = hash encode (HIP) -> 16-wide ReLU layer (MFMA GEMM) -> exp; re-sampling = nsky_pdf_sample.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from .. import hip, ops
+from ..encoding import HashGridGeometry
+from ..fields.sdf_albedo_field import HashEncoding
+
+
+class HashMLPDensityField(nn.Module):
+    """nerfstudio HashMLPDensityField(num_layers=2, hidden_dim=16, num_levels=5, log2_hashmap_size=17, max_res=64|256)."""
+
+    def __init__(self, hidden_dim: int = 16, num_levels: int = 5, max_res: int = 64, base_res: int = 16,
+                 log2_hashmap_size: int = 17, contraction_mode: int = hip.MODE_CONTRACT_LINF):
+        super().__init__()
+        self.geom = HashGridGeometry(n_levels=num_levels, log2_hashmap_size=log2_hashmap_size, base_res=base_res,
+                                     max_res=max_res, smoothstep=False)
+        self.encoding = HashEncoding(self.geom)
+        self.lin0 = nn.Linear(self.geom.out_dim, hidden_dim)
+        self.lin1 = nn.Linear(hidden_dim, 1)
+        self.mode = contraction_mode
+
+    def density_fn(self, positions: torch.Tensor) -> torch.Tensor:
+        """positions [R,n,3] -> density [R,n,1].  Under scene contraction every point maps strictly inside
+        (0,1)^3, so nerfstudio's `selector` mask is identically one and is not materialised."""
+        R, n, _ = positions.shape
+        x = positions.reshape(-1, 3).detach()
+        feat = ops.HashEncodeFn.apply(x, self.encoding.table, self.geom, self.mode, False, 0, 0.0, False, False)
+        h = ops.DenseFn.apply(feat, ops.pad_weight(self.lin0.weight), ops.pad_bias(self.lin0.bias), self.lin0.out_features, "relu", True)
+        d = ops.DenseFn.apply(h, ops.pad_weight(self.lin1.weight), ops.pad_bias(self.lin1.bias), 1, "none", True)
+        return ops.TruncExpFn.apply(d[:, :1]).view(R, n, 1)
+
+
+def weights_from_density(density: torch.Tensor, deltas: torch.Tensor) -> torch.Tensor:
+    """nerfstudio RaySamples.get_weights: density, deltas [R,n,1] -> weights [R,n,1]"""
+    dd = deltas * density
+    alphas = 1 - torch.exp(-dd)
+    T = torch.cumsum(dd[..., :-1, :], dim=-2)
+    T = torch.exp(-torch.cat([torch.zeros_like(T[..., :1, :]), T], dim=-2))
+    return torch.nan_to_num(alphas * T)
+
+
+def uniform_bins(nears: torch.Tensor, fars: torch.Tensor, num_samples: int, jitter: Optional[torch.Tensor]):
+    """UniformSampler(single_jitter=True): spacing bins [R,n+1] in [0,1] and euclidean bins."""
+    bins = torch.linspace(0.0, 1.0, num_samples + 1, device=nears.device)[None]
+    if jitter is not None:
+        centers = (bins[..., 1:] + bins[..., :-1]) / 2.0
+        upper = torch.cat([centers, bins[..., -1:]], -1)
+        lower = torch.cat([bins[..., :1], centers], -1)
+        bins = lower + (upper - lower) * jitter
+    else:
+        bins = bins.expand(nears.shape[0], -1)
+    return bins.contiguous(), (bins * fars + (1 - bins) * nears).contiguous()
+
+
+class ProposalNetworkSampler(nn.Module):
+    def __init__(self, num_nerf_samples_per_ray: int = 48, num_proposal_samples_per_ray: Tuple[int, ...] = (256, 96),
+                 num_proposal_network_iterations: int = 2, histogram_padding: float = 0.01):
+        super().__init__()
+        self.num_nerf_samples_per_ray = num_nerf_samples_per_ray
+        self.num_proposal_samples_per_ray = tuple(num_proposal_samples_per_ray)
+        self.num_proposal_network_iterations = num_proposal_network_iterations
+        self.histogram_padding = histogram_padding
+        self._anneal = 1.0
+        self._u_cache: Dict[Tuple[int, bool, str], torch.Tensor] = {}
+
+    def set_anneal(self, anneal: float) -> None:
+        self._anneal = anneal
+
+    def _u_base(self, num_bins: int, stratified: bool, device) -> torch.Tensor:
+        key = (num_bins, stratified, str(device))
+        if key not in self._u_cache:
+            u = torch.linspace(0.0, 1.0 - (1.0 / num_bins), steps=num_bins)  # host linspace == the reference's
+            if not stratified:
+                u = u + 1.0 / (2 * num_bins)
+            self._u_cache[key] = u.to(device)
+        return self._u_cache[key]
+
+    def forward(self, origins, directions, nears, fars, density_fns, jitters: Optional[Sequence[torch.Tensor]],
+                want_inds: bool = False):
+        """origins/directions [R,3], nears/fars [R,1]; jitters: one [R,1] uniform per level or None (eval).
+        Returns final (sbins, ebins) [R,S+1], weights_list / sbins_list of the proposal levels, searchsorted inds."""
+        n = self.num_proposal_network_iterations
+        weights_list: List[torch.Tensor] = []
+        sbins_list: List[torch.Tensor] = []
+        inds_list: List[torch.Tensor] = []
+        sbins = ebins = weights = None
+        for lvl in range(n + 1):
+            ns = self.num_proposal_samples_per_ray[lvl] if lvl < n else self.num_nerf_samples_per_ray
+            jit = None if jitters is None else jitters[lvl]
+            if lvl == 0:
+                sbins, ebins = uniform_bins(nears, fars, ns, jit)
+            else:
+                annealed = torch.pow(weights.detach(), self._anneal) if self._anneal != 1.0 else weights.detach()
+                sbins, inds = hip.pdf_sample(annealed.contiguous(), sbins, self._u_base(ns + 1, jit is not None, sbins.device),
+                                             None if jit is None else jit.reshape(-1).contiguous(), ns + 1,
+                                             self.histogram_padding, 1e-5, want_inds)
+                inds_list.append(inds)
+                ebins = (sbins * fars + (1 - sbins) * nears).contiguous()
+            if lvl < n:
+                mid = (ebins[:, :-1] + ebins[:, 1:]) / 2
+                pos = origins[:, None, :] + directions[:, None, :] * mid[..., None]
+                dens = density_fns[lvl](pos)
+                weights = weights_from_density(dens, (ebins[:, 1:] - ebins[:, :-1])[..., None])[..., 0]
+                weights_list.append(weights)
+                sbins_list.append(sbins)
+        return sbins, ebins, weights_list, sbins_list, inds_list

@@ -1,0 +1,161 @@
+"""DDF model (sky-visibility field) - mirrors neusky/models/ddf_model.py:89-493 for the hot path:
+`get_localised_transforms` (:158-181), `get_outputs` (:183-369), `get_loss_dict` (:407-493),
+`get_param_groups` (:151-156).  Image / metric code (:550-674) is out of scope."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Type
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn import Parameter
+
+from ..cameras.rays import Frustums, RayBundle, RaySamples
+from ..field_components.neusky_fieldheadnames import NeuSkyFieldHeadNames
+from ..fields.directional_distance_field import DirectionalDistanceFieldConfig
+from ..model_components.losses import scale_dict
+from ..utils.utils import ray_sphere_intersection
+
+
+@dataclass
+class DDFModelConfig:
+    """neusky/models/ddf_model.py:53-86 with the values of neusky/configs/neusky_config.py:162-206"""
+
+    _target: Type = field(default_factory=lambda: DDFModel)
+    ddf_field: DirectionalDistanceFieldConfig = field(default_factory=DirectionalDistanceFieldConfig)
+    compute_normals: bool = False
+    include_depth_loss_scene_center_weight: bool = True
+    scene_center_weight_exp: float = 3.0
+    scene_center_weight_include_z: bool = False
+    mask_to_circumference: bool = False
+    inverse_depth_weight: bool = False
+    log_depth: bool = False
+    eval_num_rays_per_chunk: int = 1024
+    loss_inclusions: Dict[str, bool] = field(default_factory=lambda: {
+        "depth_l1_loss": True, "depth_l2_loss": False, "sdf_l1_loss": False, "sdf_l2_loss": True, "prob_hit_loss": False,
+        "normal_loss": False, "multi_view_loss": True, "sky_ray_loss": True})
+    loss_coefficients: Dict[str, float] = field(default_factory=lambda: {
+        "depth_l1_loss": 1.0, "depth_l2_loss": 0.0, "sdf_l1_loss": 1.0, "sdf_l2_loss": 0.01, "prob_hit_loss": 0.01,
+        "normal_loss": 1.0, "multi_view_loss": 0.01, "sky_ray_loss": 1.0})
+
+    def setup(self, **kwargs):
+        return self._target(self, **kwargs)
+
+
+class DDFModel(nn.Module):
+    config: DDFModelConfig
+
+    def __init__(self, config: DDFModelConfig, ddf_radius: float, **kwargs) -> None:
+        super().__init__()
+        self.config = config
+        self.ddf_radius = ddf_radius
+        if config.compute_normals:
+            raise NotImplementedError("compute_normals is disabled in the neusky config (neusky_config.py:199)")
+        self.field = config.ddf_field.setup(ddf_radius=ddf_radius)
+
+    def get_param_groups(self) -> Dict[str, List[Parameter]]:
+        return {"ddf_field": list(self.field.parameters())}
+
+    def get_localised_transforms(self, positions: torch.Tensor) -> torch.Tensor:
+        """ddf_model.py:158-181 (torch ops; the [R*Dv] visibility rays use the fused HIP kernel instead)"""
+        up = torch.tensor([0.0, 0.0, 1.0], device=positions.device).expand_as(positions)
+        y = -positions
+        x = torch.linalg.cross(up, y, dim=-1)
+        x = x / x.norm(dim=-1, keepdim=True)
+        z = torch.linalg.cross(y, x, dim=-1)
+        z = z / z.norm(dim=-1, keepdim=True)
+        return torch.stack((x, y, z), dim=-1)
+
+    def query(self, positions: torch.Tensor, directions: torch.Tensor) -> torch.Tensor:
+        """world rays on the sphere -> expected termination distance [M] (:193-219)"""
+        rot = self.get_localised_transforms(positions)
+        local = torch.einsum("ijl,ij->il", rot, directions)
+        rs = RaySamples(frustums=Frustums(origins=positions, directions=local, starts=torch.zeros_like(positions),
+                                          ends=torch.zeros_like(positions), pixel_area=torch.ones_like(positions[..., 0])))
+        return self.field.forward(rs)[NeuSkyFieldHeadNames.TERMINATION_DISTANCE]
+
+    def get_outputs(self, ray_bundle: RayBundle, batch, neusky, stop_gradients: bool = True,
+                    mv_points: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        positions = ray_bundle.origins.reshape(-1, 3)
+        directions = ray_bundle.directions.reshape(-1, 3)
+        outputs: Dict[str, Any] = {}
+        expected = self.query(positions, directions)
+        outputs["expected_termination_dist"] = expected
+        c = self.config
+        if c.include_depth_loss_scene_center_weight and self.training and batch is not None:  # :224-238
+            dist = positions.norm(dim=-1) if c.scene_center_weight_include_z else positions[..., :2].norm(dim=-1)
+            outputs["distance_weight"] = 1.0 - (dist / self.ddf_radius) ** c.scene_center_weight_exp
+        if (c.loss_inclusions["sdf_l1_loss"] or c.loss_inclusions["sdf_l2_loss"]) and self.training:  # :241-254
+            if neusky is not None:
+                term = positions + directions * expected.unsqueeze(-1)
+                if stop_gradients:
+                    with torch.no_grad():
+                        sdf = neusky.field.get_sdf_at_pos(term).detach()
+                else:
+                    sdf = neusky.field.get_sdf_at_pos(term)
+                outputs["sdf_at_termination"] = sdf
+            elif batch is not None and "sdf_at_termination" in batch:
+                outputs["sdf_at_termination"] = batch["sdf_at_termination"]
+        if c.loss_inclusions["multi_view_loss"] and self.training and batch is not None:  # :279-322
+            gt_pts = positions + directions * batch["termination_dist"].repeat(1, 3)
+            if mv_points is None:
+                theta = 2 * torch.pi * torch.rand(gt_pts.shape[0])
+                phi = torch.acos(2 * torch.rand(gt_pts.shape[0]) - 1)
+                mv_points = torch.stack([torch.sin(phi) * torch.cos(theta), torch.sin(phi) * torch.sin(theta), torch.cos(phi)], 1)
+            pts = mv_points.to(gt_pts).clone()
+            pts[:, 2] = torch.abs(pts[:, 2])
+            dvec = gt_pts - pts
+            dlen = torch.norm(dvec, dim=-1)
+            outputs["multi_view_termintation_dist"] = batch["termination_dist"]  # (sic)
+            outputs["multi_view_expected_termination_dist"] = self.query(pts, dvec / dlen.unsqueeze(-1))
+        if c.loss_inclusions["sky_ray_loss"] and self.training and batch is not None:  # :324-363
+            sky = batch["sky_ray_bundle"]
+            o, d = sky.origins.reshape(-1, 3), sky.directions.reshape(-1, 3)
+            sp = ray_sphere_intersection(o, d, self.ddf_radius)
+            outputs["sky_ray_termination_dist"] = torch.norm(o - sp, dim=-1)
+            outputs["sky_ray_expected_termination_dist"] = self.query(sp, -d)
+        return outputs
+
+    def forward(self, ray_bundle: RayBundle, batch, neusky, stop_gradients: bool = True, **kw) -> Dict[str, torch.Tensor]:
+        return self.get_outputs(ray_bundle, batch, neusky, stop_gradients=stop_gradients, **kw)
+
+    def get_metrics_dict(self, outputs, batch) -> Dict[str, torch.Tensor]:
+        """ddf_model.py:381-405 (depth PSNR over [0, ddf_radius])"""
+        mask = batch["mask"].to(outputs["expected_termination_dist"].device)
+        pred = outputs["expected_termination_dist"].unsqueeze(1) * mask
+        gt = batch["termination_dist"].to(pred.device) * mask
+        mse = F.mse_loss(pred.detach(), gt.detach())
+        return {"depth_psnr": 10 * torch.log10(self.ddf_radius**2 / mse)}
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, torch.Tensor]:
+        """ddf_model.py:407-493"""
+        c = self.config
+        loss_dict: Dict[str, torch.Tensor] = {}
+        if c.mask_to_circumference:
+            expected = outputs["expected_termination_dist"].unsqueeze(1)
+            gt = batch["termination_dist"].clone()
+            gt[batch["mask"] == 0] = self.ddf_radius * 2
+        else:
+            expected = outputs["expected_termination_dist"].unsqueeze(1) * batch["mask"]
+            gt = batch["termination_dist"] * batch["mask"]
+        inv_w = 1.0 / (gt + 1e-6) if c.inverse_depth_weight else 1.0
+        if c.loss_inclusions["depth_l1_loss"]:
+            l = torch.abs(expected - gt)
+            if c.include_depth_loss_scene_center_weight:
+                loss_dict["depth_l1_loss"] = torch.mean(l * outputs["distance_weight"].unsqueeze(-1) * inv_w)
+            else:
+                loss_dict["depth_l1_loss"] = torch.mean(l.mean() * inv_w)
+        if c.loss_inclusions["sdf_l2_loss"]:
+            loss_dict["sdf_l2_loss"] = F.mse_loss(outputs["sdf_at_termination"] * batch["mask"],
+                                                  torch.zeros_like(outputs["sdf_at_termination"]) * batch["mask"])
+        if c.loss_inclusions["sdf_l1_loss"]:
+            loss_dict["sdf_l1_loss"] = F.l1_loss(outputs["sdf_at_termination"] * batch["mask"],
+                                                 torch.zeros_like(outputs["sdf_at_termination"]) * batch["mask"])
+        if c.loss_inclusions["multi_view_loss"]:
+            # (sic) [M] - [M,1] broadcasts to [M,M] in the reference (:478-483); reproduced
+            loss_dict["multi_view_loss"] = torch.mean(F.relu(outputs["multi_view_expected_termination_dist"] -
+                                                             outputs["multi_view_termintation_dist"]) ** 2)
+        if c.loss_inclusions["sky_ray_loss"]:
+            loss_dict["sky_ray_loss"] = F.l1_loss(outputs["sky_ray_expected_termination_dist"], outputs["sky_ray_termination_dist"])
+        return scale_dict(loss_dict, c.loss_coefficients)

@@ -1,0 +1,480 @@
+"""NeuSky model on the MI355X kernels.
+
+Mirrors `neusky.models.neusky_model.NeuSkyFactoModel` (neusky/models/neusky_model.py:171-1778) for the
+per-ray train / render step: `forward` (:425-443), `sample_illumination` (:445-551),
+`sample_and_forward_field` (:553-736), `get_outputs` (:738-931), `get_loss_dict` (:933-1062, train branch),
+`get_metrics_dict` (:1064-1077), `generate_ddf_ground_truth` (:1337-1367),
+`get_outputs_for_camera_ray_bundle` (:1369-1501), `compute_visibility` (:1624-1778), `get_param_groups`
+(:379-398).  Viewer GUI, animation and image-metric code are out of scope.
+
+Differences in kind, not in arithmetic: the reference's [R*S, D, *] broadcasts of light directions,
+light colours and visibility are never built (compact [D,3] / [U,D,3] + camera row / [R,D] tensors go
+straight into the fused hemisphere kernel); every random draw of a step can be injected (`randoms`) so the
+step is reproducible against the CPU oracle.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Tuple, Type, Union
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn import Parameter
+
+from .. import hip, ops
+from ..cameras.rays import Frustums, RayBundle, RaySamples
+from ..field_components.neusky_fieldheadnames import FieldHeadNames, NeuSkyFieldHeadNames
+from ..fields.sdf_albedo_field import SDFAlbedoFieldConfig
+from ..model_components.illumination import IcosahedronSamplerConfig, RENIFieldConfig
+from ..model_components.losses import RENISkyPixelLoss, interlevel_loss, monosdf_normal_loss, scale_dict
+from ..model_components.ray_samplers import HashMLPDensityField, ProposalNetworkSampler
+from ..model_components.renderers import RGBLambertianRendererWithVisibility
+from ..utils.utils import linear_to_sRGB
+
+
+def _default_loss_inclusions() -> Dict[str, Any]:  # neusky/configs/neusky_config.py:102-126
+    return {
+        "rgb_l1_loss": True, "rgb_l2_loss": False, "cosine_colour_loss": False, "eikonal loss": True, "fg_mask_loss": True,
+        "normal_loss": False, "depth_loss": False, "sdf_level_set_visibility_loss": True, "interlevel_loss": True,
+        "sky_pixel_loss": {"enabled": True, "cosine_weight": 0.1},
+        "hashgrid_density_loss": {"enabled": True, "grid_resolution": 10},
+        "ground_plane_loss": True,
+        "visibility_sigmoid_loss": {"visibility_threshold_method": "learnable", "optimise_sigmoid_bias": True,
+                                    "optimise_sigmoid_scale": False, "target_min_bias": 0.1, "target_max_scale": 25,
+                                    "steps_until_min_bias": 50000},
+    }
+
+
+def _default_loss_coefficients() -> Dict[str, float]:  # neusky/configs/neusky_config.py:127-141
+    return {"rgb_l1_loss": 1.0, "rgb_l2_loss": 0.0, "cosine_colour_loss": 1.0, "eikonal loss": 0.1, "fg_mask_loss": 1.0,
+            "normal_loss": 1.0, "depth_loss": 1.0, "sdf_level_set_visibility_loss": 1.0, "interlevel_loss": 1.0,
+            "sky_pixel_loss": 1.0, "hashgrid_density_loss": 1e-4, "ground_plane_loss": 0.1, "visibility_sigmoid_loss": 0.01}
+
+
+@dataclass
+class NeuSkyFactoModelConfig:
+    """neusky/models/neusky_model.py:81-169 + inherited NeuSFactoModelConfig members,
+    defaults = the `neusky` method (neusky/configs/neusky_config.py:65-161)."""
+
+    _target: Type = field(default_factory=lambda: NeuSkyFactoModel)
+    sdf_field: SDFAlbedoFieldConfig = field(default_factory=SDFAlbedoFieldConfig)
+    illumination_field: RENIFieldConfig = field(default_factory=RENIFieldConfig)
+    illumination_sampler: IcosahedronSamplerConfig = field(default_factory=IcosahedronSamplerConfig)
+    num_proposal_samples_per_ray: Tuple[int, ...] = (256, 96)
+    num_neus_samples_per_ray: int = 48
+    num_proposal_iterations: int = 2
+    proposal_net_args_list: List[Dict] = field(default_factory=lambda: [
+        {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 64},
+        {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 256}])
+    use_proposal_weight_anneal: bool = True
+    proposal_weights_anneal_slope: float = 10.0
+    proposal_weights_anneal_max_num_iters: int = 1000
+    use_single_jitter: bool = True
+    loss_inclusions: Dict[str, Any] = field(default_factory=_default_loss_inclusions)
+    loss_coefficients: Dict[str, float] = field(default_factory=_default_loss_coefficients)
+    use_visibility: bool = True
+    fit_visibility_field: bool = True
+    sdf_to_visibility_stop_gradients: str = "depth"
+    only_upperhemisphere_visibility: bool = True
+    lower_hermisphere_visibility: bool = True
+    fix_test_illumination_directions: bool = True
+    eval_num_rays_per_chunk: int = 256
+    scene_contraction_order: str = "L2"
+    collider_shape: str = "sphere"
+    near_plane: float = 0.05
+    visibility_threshold: Union[str, float] = "learnable"
+    render_ambient_light: bool = False
+
+    def setup(self, **kwargs):
+        return self._target(self, **kwargs)
+
+
+class NeuSkyFactoModel(nn.Module):
+    config: NeuSkyFactoModelConfig
+
+    def __init__(self, config: NeuSkyFactoModelConfig, scene_box, num_train_data: int, num_val_data: int, num_test_data: int,
+                 visibility_field, test_mode: str, **kwargs) -> None:
+        super().__init__()
+        self.config = config
+        self.scene_box = scene_box
+        self.num_train_data, self.num_val_data, self.num_test_data = num_train_data, num_val_data, num_test_data
+        self.test_mode = test_mode
+        self.num_eval_data = num_val_data if test_mode == "val" else num_test_data
+        self.fitting_eval_latents = False
+        self.train_metadata = kwargs.get("train_metadata", None)
+        self.eval_metadata = kwargs.get("eval_metadata", None)
+        if config.collider_shape != "sphere":
+            raise NotImplementedError("the neusky config uses the unit-sphere collider (neusky_config.py:159)")
+        self.populate_modules()
+        self.visibility_field = visibility_field  # neusky_model.py:203 (registered as a sub-module on purpose)
+        if self.visibility_field is not None:  # :217-246
+            self.ddf_radius = self.visibility_field.ddf_radius
+            vsl = config.loss_inclusions["visibility_sigmoid_loss"]
+            self.visibility_threshold_method = vsl["visibility_threshold_method"]
+            if self.visibility_threshold_method != "learnable" or vsl["optimise_sigmoid_scale"] or not vsl["optimise_sigmoid_bias"]:
+                raise NotImplementedError("only the learnable-bias / fixed-scale visibility sigmoid of neusky_config.py:118-125")
+            self.sigmoid_scale = float(vsl["target_max_scale"])
+            self.visibility_threshold = Parameter(torch.tensor([self.ddf_radius * 2.0]))  # :234
+
+    # ------------------------------------------------------------------ construction
+    def populate_modules(self) -> None:
+        c = self.config
+        aabb = self.scene_box["aabb"] if isinstance(self.scene_box, dict) else self.scene_box.aabb
+        self.field = c.sdf_field.setup(aabb=aabb, num_images=self.num_train_data, spatial_distortion=None)
+        self.proposal_networks = nn.ModuleList([
+            HashMLPDensityField(hidden_dim=a["hidden_dim"], num_levels=a["num_levels"], max_res=a["max_res"],
+                                log2_hashmap_size=a["log2_hashmap_size"]) for a in c.proposal_net_args_list])
+        self.density_fns = [n.density_fn for n in self.proposal_networks]
+        self.proposal_sampler = ProposalNetworkSampler(
+            num_nerf_samples_per_ray=c.num_neus_samples_per_ray, num_proposal_samples_per_ray=c.num_proposal_samples_per_ray,
+            num_proposal_network_iterations=c.num_proposal_iterations)
+        # illumination (neusky_model.py:253-300); decoder frozen, per-image latents + scale trainable
+        self.illumination_field = c.illumination_field.setup(num_train_data=None, num_eval_data=None)
+        L = self.illumination_field.latent_dim
+        self.train_illumination_latents = Parameter(torch.zeros((self.num_train_data, L, 3)))
+        self.train_scale = Parameter(torch.ones(self.num_train_data))
+        self.eval_illumination_latents = Parameter(torch.zeros((max(self.num_eval_data, 1), L, 3)))
+        self.eval_scale = Parameter(torch.ones(max(self.num_eval_data, 1)))
+        self.illumination_sampler = c.illumination_sampler.setup()
+        self.lambertian_renderer = RGBLambertianRendererWithVisibility()
+        li = c.loss_inclusions
+        assert not (li["rgb_l1_loss"] and li["rgb_l2_loss"]), "Cannot have both L1 and L2 loss"  # :359-361
+        if li["sky_pixel_loss"]["enabled"]:
+            self.sky_pixel_loss = RENISkyPixelLoss(alpha=li["sky_pixel_loss"]["cosine_weight"])
+        self._step = 0
+
+    @property
+    def device(self):
+        return self.visibility_threshold.device if hasattr(self, "visibility_threshold") else next(self.parameters()).device
+
+    def get_param_groups(self) -> Dict[str, List[Parameter]]:
+        """neusky_model.py:379-398"""
+        groups = {
+            "fields": list(self.field.parameters()),
+            "proposal_networks": list(self.proposal_networks.parameters()),
+            "illumination_field": [self.train_illumination_latents, self.train_scale],
+        }
+        if self.visibility_field is not None:
+            groups["visibility_sigmoid"] = [self.visibility_threshold]
+        return groups
+
+    def get_illumination_field(self):
+        """neusky_model.py:400-412"""
+        if self.training and not self.fitting_eval_latents:
+            return self.train_illumination_latents, self.train_scale
+        return self.eval_illumination_latents, self.eval_scale
+
+    def set_step(self, step: int) -> None:
+        """proposal-weight annealing callback of NeuSFacto/nerfacto"""
+        self._step = step
+        c = self.config
+        if c.use_proposal_weight_anneal:
+            N = c.proposal_weights_anneal_max_num_iters
+            frac = min(max(step / N, 0.0), 1.0)
+            bias = lambda x, b: (b * x) / ((b - 1) * x + 1)
+            self.proposal_sampler.set_anneal(bias(frac, c.proposal_weights_anneal_slope))
+
+    # ------------------------------------------------------------------ collider
+    def collider(self, ray_bundle: RayBundle) -> RayBundle:
+        """nerfstudio SphereCollider(center=0, radius=1, near_plane=0.05) (neusky_model.py:213)"""
+        o, d = ray_bundle.origins, ray_bundle.directions
+        a = (d * d).sum(-1)
+        b = 2 * (o * d).sum(-1)
+        c = (o * o).sum(-1) - 1.0
+        disc = b * b - 4 * a * c
+        ok = disc > 0
+        sq = torch.sqrt(torch.where(ok, disc, torch.zeros_like(disc)))
+        t0, t1 = (-b - sq) / (2 * a), (-b + sq) / (2 * a)
+        nears = torch.clamp(torch.where(ok, t0, torch.zeros_like(t0)), min=self.config.near_plane)
+        fars = torch.maximum(torch.where(ok, t1, torch.zeros_like(t1)), nears + 1e-6)
+        ray_bundle.nears, ray_bundle.fars = nears[:, None], fars[:, None]
+        return ray_bundle
+
+    def forward(self, ray_bundle: RayBundle, batch: Optional[Dict] = None, rotation: Optional[torch.Tensor] = None,
+                step: Optional[int] = None, randoms: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, Any]:
+        """neusky_model.py:425-443"""
+        ray_bundle = self.collider(ray_bundle)
+        return self.get_outputs(ray_bundle, batch=batch, rotation=rotation, step=step, randoms=randoms)
+
+    # ------------------------------------------------------------------ sampling + field
+    def _sample(self, ray_bundle: RayBundle, randoms: Optional[Dict], want_inds: bool = False):
+        R = ray_bundle.origins.shape[0]
+        dev = ray_bundle.origins.device
+        n_lvls = self.config.num_proposal_iterations + 1
+        if self.training:
+            if randoms is not None and "jitters" in randoms:
+                jitters = [j.to(dev) for j in randoms["jitters"]]
+            else:
+                jitters = [torch.rand(R, 1, device=dev) for _ in range(n_lvls)]
+        else:
+            jitters = None
+        sbins, ebins, weights_list, sbins_list, inds_list = self.proposal_sampler(
+            ray_bundle.origins, ray_bundle.directions, ray_bundle.nears, ray_bundle.fars, self.density_fns, jitters, want_inds)
+        S = ebins.shape[1] - 1
+        o = ray_bundle.origins[:, None, :].expand(R, S, 3)
+        d = ray_bundle.directions[:, None, :].expand(R, S, 3)
+        cam = ray_bundle.camera_indices.reshape(R, 1, 1).expand(R, S, 1) if ray_bundle.camera_indices is not None else None
+        rs = RaySamples(frustums=Frustums(origins=o, directions=d, starts=ebins[:, :-1, None], ends=ebins[:, 1:, None],
+                                          pixel_area=None),
+                        camera_indices=cam, deltas=(ebins[:, 1:] - ebins[:, :-1])[..., None],
+                        spacing_starts=sbins[:, :-1, None], spacing_ends=sbins[:, 1:, None])
+        return rs, weights_list, sbins_list, sbins, inds_list
+
+    def sample_illumination(self, camera_indices: torch.Tensor, ray_directions: torch.Tensor,
+                            rotation: Optional[torch.Tensor] = None, randoms: Optional[Dict] = None):
+        """neusky_model.py:445-551 on compact data: camera_indices [R], ray_directions [R,3] ->
+        directions [D,3], cam_colours [U,D,3], cam_of_ray [R] (int32 row of cam_colours), hdr_background [R,3]."""
+        latents, scales = self.get_illumination_field()
+        if not self.training and self.config.fix_test_illumination_directions:
+            dirs = self.illumination_sampler(apply_random_rotation=False)  # :451-454
+        elif randoms is not None and "light_rotation" in randoms:
+            dirs = self.illumination_sampler(rotation=randoms["light_rotation"].cpu())
+        else:
+            dirs = self.illumination_sampler()  # :456
+        dirs = dirs.to(self.device).contiguous()  # :458
+        unique, inverse = torch.unique(camera_indices, return_inverse=True)  # :461-463
+        U, D = unique.shape[0], dirs.shape[0]
+        ci = unique[:, None].expand(U, D).reshape(-1)
+        dd = dirs[None].expand(U, D, 3).reshape(-1, 3)
+        rot = rotation if (rotation is None or rotation.dim() == 2) else rotation[ci]
+        cols = self.illumination_field(dd, latents[ci], scales[ci], rot).reshape(U, D, 3)  # :488-510
+        rot_r = rotation if (rotation is None or rotation.dim() == 2) else rotation[camera_indices]
+        bg = self.illumination_field(ray_directions, latents[camera_indices], scales[camera_indices], rot_r)  # :535-549
+        return dirs, cols, inverse.to(torch.int32), bg
+
+    def render_depth(self, weights: torch.Tensor, ray_samples: RaySamples) -> torch.Tensor:
+        """nerfstudio DepthRenderer('expected') (neusky_model.py:591): weights [R,S,1] -> [R,1]"""
+        steps = (ray_samples.frustums.starts + ray_samples.frustums.ends) / 2
+        depth = torch.sum(weights * steps, dim=-2) / (torch.sum(weights, -2) + 1e-10)
+        return torch.clip(depth, steps.min(), steps.max())
+
+    def compute_visibility(self, origins: torch.Tensor, ray_directions: torch.Tensor, depth: torch.Tensor,
+                           illumination_directions: torch.Tensor, threshold_distance: torch.Tensor, sigmoid_scale: float,
+                           compute_shadow_map: bool = False) -> Dict[str, Any]:
+        """neusky_model.py:1624-1778 on compact data: origins / ray_directions [R,3] (= sample 0 of each ray,
+        :1667-1668), depth [R,1], illumination_directions [D,3] (= row 0 of the broadcast, :1648).
+        Returns visibility [R,D] (the reference repeats it over S, :1755-1759)."""
+        R, D = origins.shape[0], illumination_directions.shape[0]
+        dev = origins.device
+        if self.config.only_upperhemisphere_visibility:  # :1650-1657
+            sel = torch.nonzero(illumination_directions[:, 2] > 0)[:, 0]
+        else:
+            sel = torch.arange(D, device=dev)
+        Dv = sel.numel()
+        sel_dirs = illumination_directions[sel].contiguous()
+        M = R * Dv
+        sphere_pts = torch.empty(M, 3, device=dev)
+        xrow = torch.empty(M, 16, device=dev)
+        surf_dist = torch.empty(M, device=dev)
+        term_dist = torch.empty(M, device=dev)
+        hip.visibility_rays(origins.detach().contiguous(), ray_directions.detach().contiguous(),
+                            depth.detach().reshape(-1).contiguous(), sel_dirs, self.ddf_radius, sphere_pts, xrow, surf_dist, term_dist)
+        t_hat = self.visibility_field.field.forward_rows(sphere_pts, xrow)  # :1716 -> ddf_model.py:217
+        out: Dict[str, Any] = {"expected_termination_dist": t_hat}
+        stop_gradients = self.config.sdf_to_visibility_stop_gradients in ["sdf", "both"]  # :1712-1714
+        vcfg = self.visibility_field.config
+        if (vcfg.loss_inclusions["sdf_l1_loss"] or vcfg.loss_inclusions["sdf_l2_loss"]) and self.visibility_field.training:
+            world_dirs = (-sel_dirs)[None].expand(R, Dv, 3).reshape(-1, 3)
+            term_pts = sphere_pts + world_dirs * t_hat[:, None]  # ddf_model.py:243
+            if stop_gradients:
+                with torch.no_grad():
+                    out["sdf_at_termination"] = self.field.get_sdf_at_pos(term_pts).detach()
+            else:
+                out["sdf_at_termination"] = self.field.get_sdf_at_pos(term_pts)
+        lower = 1.0 if self.config.lower_hermisphere_visibility else 0.0
+        vis = ops.VisibilityFinishFn.apply(t_hat, surf_dist, threshold_distance, float(sigmoid_scale),
+                                           sel.to(torch.int32).contiguous(), R, Dv, D, lower)
+        out["visibility"] = vis
+        if compute_shadow_map:
+            out["difference"] = surf_dist - t_hat
+        out["visibility_batch"] = {"termination_dist": term_dist, "mask": torch.ones_like(term_dist),
+                                   "sdf_at_termination": out.get("sdf_at_termination")}
+        return out
+
+    def sample_and_forward_field(self, ray_bundle: RayBundle, batch=None, rotation=None, step=None, randoms=None) -> Dict[str, Any]:
+        """neusky_model.py:553-736"""
+        ray_samples, weights_list, sbins_list, sbins, inds_list = self._sample(ray_bundle, randoms, want_inds=randoms is not None)
+        field_outputs = self.field(ray_samples, return_alphas=True)
+        weights = field_outputs["weights"]
+        weights_list = weights_list + [weights[..., 0]]
+        sbins_list = sbins_list + [sbins]
+        cam = ray_bundle.camera_indices.reshape(-1)
+        dirs, cam_colours, cam_of_ray, hdr_bg = self.sample_illumination(cam, ray_bundle.directions, rotation, randoms)
+        out: Dict[str, Any] = {
+            "ray_samples": ray_samples, "field_outputs": field_outputs, "weights": weights,
+            "bg_transmittance": field_outputs["bg_transmittance"], "weights_list": weights_list, "sbins_list": sbins_list,
+            "pdf_inds_list": inds_list, "illumination_directions": dirs, "hdr_illumination_colours": cam_colours,
+            "cam_of_ray": cam_of_ray, "hdr_background_colours": hdr_bg,
+        }
+        if self.config.use_visibility:
+            p2p_dist = self.render_depth(weights, ray_samples)  # :591
+            depth = p2p_dist / ray_bundle.metadata["directions_norm"]  # :593
+            accumulation = weights.sum(dim=-2)  # :595
+            p2p_vis = p2p_dist.detach() if self.config.sdf_to_visibility_stop_gradients in ["depth", "both"] else p2p_dist
+            if p2p_vis.requires_grad:
+                raise NotImplementedError("visibility geometry is differentiated only in 'depth'/'both' mode (neusky_config.py:156)")
+            out["visibility_dict"] = self.compute_visibility(ray_bundle.origins, ray_bundle.directions, p2p_vis, dirs,
+                                                             self.visibility_threshold, self.sigmoid_scale)
+            out.update(p2p_dist=p2p_dist, depth=depth, accumulation=accumulation)
+        if self.training and self.config.loss_inclusions["hashgrid_density_loss"]["enabled"]:  # :672-734
+            res = self.config.loss_inclusions["hashgrid_density_loss"]["grid_resolution"]
+            aabb = self.scene_box["aabb"] if isinstance(self.scene_box, dict) else self.scene_box.aabb
+            mn, mx = aabb[0], aabb[1]
+            lin = [torch.linspace(float(mn[i]), float(mx[i]), res) for i in range(3)]
+            X, Y, Z = torch.meshgrid(*lin, indexing="ij")
+            positions = torch.stack((X, Y, Z), -1).reshape(-1, 3)
+            gap = torch.tensor([(float(mx[i]) - float(mn[i])) / res for i in range(3)])
+            if randoms is not None and "grid_perturb" in randoms:
+                perturb, gdir = randoms["grid_perturb"].cpu(), randoms["grid_dirs"].cpu()
+            else:
+                perturb, gdir = torch.rand_like(positions), torch.randn_like(positions)
+            positions = positions + (perturb * gap - gap / 2)
+            gdir = gdir / torch.norm(gdir, dim=-1, keepdim=True)
+            dev = ray_bundle.origins.device
+            grid_samples = RaySamples(frustums=Frustums(origins=positions.to(dev), directions=gdir.to(dev),
+                                                        starts=torch.zeros(positions.shape[0], 3, device=dev)[:, :1] * 0,
+                                                        ends=torch.zeros(positions.shape[0], 1, device=dev), pixel_area=None),
+                                      deltas=gap.to(dev))
+            # (sic) the reference hands `deltas=gap` ([3]) to get_alpha, which broadcasts [P,1]*[3] -> three alphas
+            # per point, one per axis gap (equal for the cubic scene box) (:715-724, :732)
+            out["grid_density"] = self._grid_alpha(grid_samples)
+        return out
+
+    def _grid_alpha(self, grid_samples: RaySamples) -> torch.Tensor:
+        x = grid_samples.frustums.origins
+        d = grid_samples.frustums.directions
+        sdf, grad, _ = self.field.field_values(x)
+        P = x.shape[0]
+        cols = []
+        for a in range(3):
+            rs = RaySamples(frustums=Frustums(origins=x, directions=d, starts=torch.zeros(P, 1, device=x.device),
+                                              ends=torch.zeros(P, 1, device=x.device)),
+                            deltas=grid_samples.deltas[a].expand(P))
+            cols.append(self.field.get_alpha(rs, sdf, grad))
+        return torch.cat(cols, -1)
+
+    # ------------------------------------------------------------------ outputs
+    def get_outputs(self, ray_bundle: RayBundle, batch=None, rotation=None, step=None, randoms=None) -> Dict[str, Any]:
+        """neusky_model.py:738-931"""
+        so = self.sample_and_forward_field(ray_bundle, batch=batch, rotation=rotation, step=step, randoms=randoms)
+        fo = so["field_outputs"]
+        weights, ray_samples = so["weights"], so["ray_samples"]
+        visibility = so["visibility_dict"]["visibility"] if self.config.use_visibility else None
+        sdf_at_termination = so["visibility_dict"].get("sdf_at_termination") if self.config.use_visibility else None
+        rgb = self.lambertian_renderer.forward_compact(
+            albedos=fo[NeuSkyFieldHeadNames.ALBEDO], normals=fo[FieldHeadNames.NORMALS],
+            light_directions=so["illumination_directions"], cam_colours=so["hdr_illumination_colours"],
+            cam_of_ray=so["cam_of_ray"], visibility=visibility, background_illumination=so["hdr_background_colours"],
+            weights=weights)  # :797-805
+        accumulation = so.get("accumulation", weights.sum(dim=-2))
+        p2p_dist = so.get("p2p_dist")
+        if p2p_dist is None:
+            p2p_dist = self.render_depth(weights, ray_samples)
+        depth = p2p_dist / ray_bundle.metadata["directions_norm"]
+        normal = torch.sum(weights * fo[FieldHeadNames.NORMALS], dim=-2)  # :812 (SemanticRenderer-style)
+        albedo = torch.sum(weights * fo[NeuSkyFieldHeadNames.ALBEDO], dim=-2) + (1.0 - weights.sum(dim=-2))  # :813, white bg
+        outputs: Dict[str, Any] = {
+            "rgb": rgb, "albedo": albedo, "accumulation": accumulation, "depth": depth, "p2p_dist": p2p_dist, "normal": normal,
+            "weights": weights, "hdr_background_colours": so["hdr_background_colours"],
+            "directions_norm": ray_bundle.metadata["directions_norm"], "sdf_at_termination": sdf_at_termination,
+        }
+        if self.training:
+            outputs["eik_grad"] = fo[FieldHeadNames.GRADIENT]  # :903-904
+            outputs.update(so)
+        outputs["normal_vis"] = (outputs["normal"] + 1.0) / 2.0
+        if "grid_density" in so:
+            outputs["grid_density"] = so["grid_density"]
+        if "visibility_dict" in so:
+            outputs["visibility_batch"] = so["visibility_dict"]["visibility_batch"]
+        return outputs
+
+    def get_loss_dict(self, outputs: Dict[str, Any], batch: Dict[str, Any], metrics_dict=None) -> Dict[str, torch.Tensor]:
+        """neusky_model.py:933-1062"""
+        dev = self.device
+        mask = batch["mask"].to(dev)
+        fg_mask, ground_mask, sky_mask = mask[..., 1], mask[..., 2], mask[..., 3]
+        li = self.config.loss_inclusions
+        ld: Dict[str, torch.Tensor] = {}
+        image = batch["image"].to(dev)
+        keep = (1 - sky_mask.float()).unsqueeze(1)
+        img, pred = image * keep, outputs["rgb"] * keep  # :947-948
+        if li["rgb_l1_loss"]:
+            ld["rgb_l1_loss"] = F.l1_loss(img, pred)
+        if li["rgb_l2_loss"]:
+            ld["rgb_l2_loss"] = F.mse_loss(img, pred)
+        if li["cosine_colour_loss"]:
+            ld["cosine_colour_loss"] = torch.mean(1 - F.cosine_similarity(img, pred, dim=1))
+        if self.training and not self.fitting_eval_latents:
+            if li["eikonal loss"]:
+                ld["eikonal_loss"] = ((outputs["eik_grad"].norm(2, dim=-1) - 1) ** 2).mean()  # :958-960
+            if li["fg_mask_loss"]:
+                ws = torch.nan_to_num(outputs["weights"].sum(dim=1).clip(1e-3, 1.0 - 1e-3), nan=0.5)  # :964-965
+                ld["fg_mask_loss"] = F.binary_cross_entropy(ws, fg_mask.float().unsqueeze(1))
+            if li["interlevel_loss"]:
+                ld["interlevel_loss"] = interlevel_loss(outputs["weights_list"], outputs["sbins_list"])  # :987-988
+            if li["hashgrid_density_loss"]["enabled"]:
+                ld["hashgrid_density_loss"] = outputs["grid_density"].abs().mean()  # :990-993
+            if li["ground_plane_loss"]:
+                npred = outputs["normal"]
+                ngt = torch.tensor([0.0, 0.0, 1.0], device=dev).expand_as(npred)
+                gm = ground_mask.unsqueeze(1).expand_as(npred)
+                ld["ground_plane_loss"] = monosdf_normal_loss(npred * gm, ngt * gm)  # :995-1000
+            if li["sky_pixel_loss"]["enabled"]:
+                sm = sky_mask.float().unsqueeze(1).expand(-1, 3)
+                ld["sky_pixel_loss"] = self.sky_pixel_loss(inputs=linear_to_sRGB(outputs["hdr_background_colours"]),
+                                                           targets=image, mask=sm)  # :1002-1009
+            if self.visibility_field is not None and self.visibility_threshold_method == "learnable":
+                tgt = li["visibility_sigmoid_loss"]["target_min_bias"]
+                ld["visibility_sigmoid_loss"] = F.mse_loss(self.visibility_threshold[0], torch.tensor(tgt, device=dev))  # :1011-1030
+            if li["sdf_level_set_visibility_loss"] and outputs.get("sdf_at_termination") is not None:
+                ld["sdf_level_set_visibility_loss"] = (outputs["sdf_at_termination"] ** 2).mean()  # :1032-1035
+        elif li["sky_pixel_loss"]["enabled"]:
+            sm = sky_mask.float().unsqueeze(1).expand(-1, 3)
+            ld["sky_pixel_loss"] = self.sky_pixel_loss(inputs=linear_to_sRGB(outputs["hdr_background_colours"]), targets=image, mask=sm)
+        return scale_dict(ld, self.config.loss_coefficients)
+
+    def get_metrics_dict(self, outputs, batch) -> Dict[str, Any]:
+        """neusky_model.py:1064-1077"""
+        image = batch["image"].to(self.device)
+        mse = F.mse_loss(outputs["rgb"].detach(), image)
+        m: Dict[str, Any] = {"psnr": -10.0 * torch.log10(mse)}
+        if self.training:
+            m["s_val"] = self.field.deviation_network.get_variance().detach()
+            m["inv_s"] = 1.0 / m["s_val"]
+            if self.config.visibility_threshold == "learnable" and self.visibility_field is not None:
+                m["visibility_threshold"] = self.visibility_threshold.detach()
+        return m
+
+    def generate_ddf_ground_truth(self, ray_bundle: RayBundle, mask_threshold: float = 0.5, randoms=None) -> Dict[str, Any]:
+        """neusky_model.py:1337-1367: second sampler + field pass on the DDF-fit rays"""
+        ray_bundle = self.collider(ray_bundle)
+        sub = None if randoms is None else {"jitters": randoms["ddf_jitters"]}
+        ray_samples, _, _, _, _ = self._sample(ray_bundle, sub)
+        fo = self.field(ray_samples, return_alphas=True)
+        weights = fo["weights"]
+        accumulations = weights.sum(dim=-2).reshape(-1, 1)
+        mask = (accumulations > mask_threshold).float()
+        p2p = self.render_depth(weights, ray_samples).reshape(-1, 1)
+        if self.visibility_field is not None:
+            p2p = torch.clamp(p2p, max=2 * self.visibility_field.ddf_radius)
+        normals = torch.sum(weights * fo[FieldHeadNames.NORMALS], dim=-2).reshape(-1, 3)
+        return {"ray_bundle": ray_bundle, "accumulations": accumulations, "mask": mask, "termination_dist": p2p, "normals": normals}
+
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle, show_progress=False, rotation=None, to_cpu=False,
+                                          step=None) -> Dict[str, torch.Tensor]:
+        """neusky_model.py:1369-1501: chunked full-frame render.  The reference chunks at
+        eval_num_rays_per_chunk = 256 (8100 python iterations per 1080p frame); any chunk size gives the same image."""
+        chunk = self.config.eval_num_rays_per_chunk
+        shape = camera_ray_bundle.origins.shape[:-1]
+        num_rays = int(torch.tensor(shape).prod())
+        lists: Dict[str, List[torch.Tensor]] = {}
+        for i in range(0, num_rays, chunk):
+            rb = camera_ray_bundle.slice(i, i + chunk)
+            out = self.forward(ray_bundle=rb, rotation=rotation, step=step)
+            for k, v in out.items():
+                if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == rb.origins.shape[0]:
+                    lists.setdefault(k, []).append(v.cpu() if to_cpu else v)
+        return {k: torch.cat(v).view(*shape, -1) for k, v in lists.items()}

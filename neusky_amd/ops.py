@@ -1,0 +1,497 @@
+"""torch.autograd.Function wrappers that chain the HIP kernels of libneusky_hip.so.
+
+Every Function's forward AND backward run exclusively on the C ABI in neusky_amd.hip (fp32 MFMA dense
+layers with fused epilogues, hash-grid encode, render-stage kernels); PyTorch only owns the device
+buffers and the autograd graph between Functions.  Hand-derived backward passes replace what the
+reference obtains from torch autograd (incl. the double backward of sdf_albedo_field.py:235-238).
+
+Conventions: activation matrices are row-major float32 with a leading dimension that is a multiple
+of 4; weights arrive zero-padded to multiples of 4 in both dimensions (`pad_weight`).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import hip
+
+
+def pad4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+def pad_weight(w: torch.Tensor) -> torch.Tensor:
+    """[out, in] -> zero padded [pad4(out), pad4(in)] (autograd-tracked)."""
+    o, i = w.shape
+    return F.pad(w, (0, pad4(i) - i, 0, pad4(o) - o)).contiguous()
+
+
+def pad_bias(b: torch.Tensor) -> torch.Tensor:
+    return F.pad(b, (0, pad4(b.shape[0]) - b.shape[0])).contiguous()
+
+
+def _splits(M: int) -> int:
+    return max(1, min(512, (M + 2047) // 2048))
+
+
+def grad_weight(dZ, X, M, n_out, k_in, like):
+    """dW[n_out, k_in] = dZ[:M, :n_out]^T @ X[:M, :k_in] (split-K over M, atomically reduced)."""
+    dW = torch.zeros_like(like)
+    hip.gemm(dZ, X, dW, n_out, k_in, M, a_kcontig=False, b_kcontig=False, k_splits=_splits(M))
+    return dW
+
+
+def grad_bias(dZ, M, n_out, like):
+    db = torch.zeros_like(like)
+    hip.colsum(dZ, M, n_out, db)
+    return db
+
+
+def grad_input(dZ, W, M, k_in, n_red, out, **epi):
+    """dX[M, k_in] = dZ[M, n_red] @ W[n_red, k_in]   (W stored [out, in] = [n_red, k_in])."""
+    return hip.gemm(dZ, W, out, M, k_in, n_red, a_kcontig=True, b_kcontig=False, **epi)
+
+
+# =============================================================================================
+# hash-grid encode
+# =============================================================================================
+class HashEncodeFn(torch.autograd.Function):
+    """rows = [x | PE(x) | hash(x)] (+ three tangent row blocks).  Output [P, ld] or stacked [4P, ld]."""
+
+    @staticmethod
+    def forward(ctx, x, table, geom, mode, include_x, pe_freqs, pe_max_exp, tangents, need_dx):
+        P = x.shape[0]
+        width = (3 if include_x else 0) + 6 * pe_freqs + 2 * geom.n_levels
+        ldy = pad4(width)
+        x = x.contiguous()
+        out = torch.empty((4 * P if tangents else P), ldy, device=x.device)
+        T = out[P:].view(3, P, ldy) if tangents else None
+        hip.encode_fwd(geom, table, x, mode, include_x, pe_freqs, pe_max_exp, out[:P], T)
+        ctx.save_for_backward(x, table)
+        ctx.cfg = (geom, mode, include_x, pe_freqs, pe_max_exp, tangents, need_dx, P, ldy)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, table = ctx.saved_tensors
+        geom, mode, include_x, pe_freqs, pe_max_exp, tangents, need_dx, P, ldy = ctx.cfg
+        d_out = d_out.contiguous()
+        dtable = torch.zeros_like(table)
+        dx = torch.empty(P, 3, device=x.device) if need_dx else None
+        dT = d_out[P:].view(3, P, ldy) if tangents else None
+        hip.encode_bwd(geom, table, x, mode, include_x, pe_freqs, pe_max_exp, d_out[:P], dT, dtable, dx)
+        return dx, dtable, None, None, None, None, None, None, None
+
+
+# =============================================================================================
+# generic dense layer (used for the small proposal networks and heads)
+# =============================================================================================
+_ACT = {"none": hip.EPI_NONE, "relu": hip.EPI_RELU}
+
+
+class DenseFn(torch.autograd.Function):
+    """Y[M, n_out] = act(X[M, :k] @ Wp^T + b); X has ld = Wp.shape[1] (padded), Wp/b padded."""
+
+    @staticmethod
+    def forward(ctx, X, Wp, bp, n_out, act, need_dx):
+        M, K = X.shape[0], Wp.shape[1]
+        Y = torch.zeros(M, Wp.shape[0], device=X.device)
+        hip.gemm(X, Wp, Y, M, n_out, K, bias=bp, epi=_ACT[act])
+        ctx.save_for_backward(X, Wp, bp, Y)
+        ctx.cfg = (n_out, act, need_dx)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        X, Wp, bp, Y = ctx.saved_tensors
+        n_out, act, need_dx = ctx.cfg
+        M, K = X.shape[0], Wp.shape[1]
+        dZ = dY.contiguous()
+        if act == "relu":
+            dZ = dZ * (Y > 0)
+        dW = grad_weight(dZ, X, M, n_out, K, Wp)
+        db = grad_bias(dZ, M, n_out, bp)
+        dX = None
+        if need_dx:
+            dX = torch.empty(M, K, device=X.device)
+            grad_input(dZ, Wp, M, K, Wp.shape[0], dX)
+        return dX, dW, db, None, None, None
+
+
+# =============================================================================================
+# FiLM-SIREN (DDF network, RENI-shaped illumination decoder)
+# =============================================================================================
+class FilmSirenFn(torch.autograd.Function):
+    """neusky/utils/siren.py:108-208 as a chain of fp32-MFMA layers with fused epilogues.
+
+    args: x [M, pad4(in)], cond [M, pad4(cond)], n_map, n_film, train_weights, then padded tensors
+          map_w0,map_b0,...,map_wo,map_bo, film_w0,film_b0,...,out_w,out_b.
+    Returns the raw head output [M, pad4(out)] (activation applied by the caller)."""
+
+    @staticmethod
+    def forward(ctx, x, cond, n_map, n_film, train_weights, need_dcond, *wb):
+        M = x.shape[0]
+        ctx.need_dx = x.requires_grad
+        dev = x.device
+        mw = [wb[2 * i] for i in range(n_map)]
+        mb = [wb[2 * i + 1] for i in range(n_map)]
+        mwo, mbo = wb[2 * n_map], wb[2 * n_map + 1]
+        o = 2 * n_map + 2
+        fw = [wb[o + 2 * i] for i in range(n_film)]
+        fb = [wb[o + 2 * i + 1] for i in range(n_film)]
+        ow, ob = wb[o + 2 * n_film], wb[o + 2 * n_film + 1]
+        H = fw[0].shape[0]
+        Hm = mw[0].shape[0]
+        # mapping network: (Linear, LeakyReLU(0.2)) * n  -> Linear to 2*n_film*H  (siren.py:114-119)
+        hs = []
+        h = cond
+        for i in range(n_map):
+            out = torch.empty(M, Hm, device=dev)
+            hip.gemm(h, mw[i], out, M, Hm, mw[i].shape[1], bias=mb[i], epi=hip.EPI_LEAKY, p0=0.2)
+            hs.append(out)
+            h = out
+        FP = torch.empty(M, 2 * n_film * H, device=dev)
+        hip.gemm(h, mwo, FP, M, 2 * n_film * H, Hm, bias=mbo)
+        # FiLM layers: sin((15 F + 30) (W y + b) + P)  (siren.py:141-144, :200)
+        ys, zs = [], []
+        y = x
+        for i in range(n_film):
+            out = torch.empty(M, H, device=dev)
+            z = torch.empty(M, H, device=dev)
+            hip.gemm(y, fw[i], out, M, H, fw[i].shape[1], bias=fb[i], epi=hip.EPI_FILM, p0=15.0, p1=30.0,
+                     aux0=FP[:, i * H:(i + 1) * H], aux1=FP[:, (n_film + i) * H:(n_film + i + 1) * H], out1=z)
+            ys.append(out)
+            zs.append(z)
+            y = out
+        n_out_p = ow.shape[0]
+        res = torch.zeros(M, n_out_p, device=dev)
+        hip.gemm(y, ow, res, M, n_out_p, H, bias=ob)
+        ctx.save_for_backward(x, cond, FP, *hs, *ys, *zs, *wb)
+        ctx.cfg = (n_map, n_film, train_weights, need_dcond, M, H, Hm)
+        return res
+
+    @staticmethod
+    def backward(ctx, d_res):
+        n_map, n_film, train_w, need_dcond, M, H, Hm = ctx.cfg
+        sv = ctx.saved_tensors
+        x, cond, FP = sv[0], sv[1], sv[2]
+        hs = list(sv[3:3 + n_map])
+        ys = list(sv[3 + n_map:3 + n_map + n_film])
+        zs = list(sv[3 + n_map + n_film:3 + n_map + 2 * n_film])
+        wb = sv[3 + n_map + 2 * n_film:]
+        mw = [wb[2 * i] for i in range(n_map)]
+        mb = [wb[2 * i + 1] for i in range(n_map)]
+        mwo, mbo = wb[2 * n_map], wb[2 * n_map + 1]
+        o = 2 * n_map + 2
+        fw = [wb[o + 2 * i] for i in range(n_film)]
+        fb = [wb[o + 2 * i + 1] for i in range(n_film)]
+        ow, ob = wb[o + 2 * n_film], wb[o + 2 * n_film + 1]
+        dev = x.device
+        grads: List[Optional[torch.Tensor]] = [None] * len(wb)
+        d_res = d_res.contiguous()
+        n_out_p = ow.shape[0]
+        if train_w:
+            grads[o + 2 * n_film] = grad_weight(d_res, ys[-1], M, n_out_p, H, ow)
+            grads[o + 2 * n_film + 1] = grad_bias(d_res, M, n_out_p, ob)
+        dFP = torch.empty(M, 2 * n_film * H, device=dev)
+        d_x = None
+        # walk the FiLM layers backwards; each dX GEMM applies the FiLM backward epilogue of the layer below
+        dZ = torch.empty(M, H, device=dev)
+        i = n_film - 1
+        grad_input(d_res, ow, M, H, n_out_p, dZ, epi=hip.EPI_BWD_FILM, p0=15.0, p1=30.0, aux0=zs[i],
+                   aux1=FP[:, i * H:(i + 1) * H], aux2=FP[:, (n_film + i) * H:(n_film + i + 1) * H],
+                   out1=dFP[:, i * H:(i + 1) * H], out2=dFP[:, (n_film + i) * H:(n_film + i + 1) * H])
+        while True:
+            y_in = ys[i - 1] if i > 0 else x
+            k_in = fw[i].shape[1]
+            if train_w:
+                grads[o + 2 * i] = grad_weight(dZ, y_in, M, H, k_in, fw[i])
+                grads[o + 2 * i + 1] = grad_bias(dZ, M, H, fb[i])
+            if i == 0:
+                if ctx.need_dx:  # gradient w.r.t. the encoded direction rows (DDF multi-view rays, ddf_model.py:297-322)
+                    d_x = torch.empty(M, k_in, device=dev)
+                    grad_input(dZ, fw[0], M, k_in, H, d_x)
+                break
+            dZn = torch.empty(M, H, device=dev)
+            j = i - 1
+            grad_input(dZ, fw[i], M, H, H, dZn, epi=hip.EPI_BWD_FILM, p0=15.0, p1=30.0, aux0=zs[j],
+                       aux1=FP[:, j * H:(j + 1) * H], aux2=FP[:, (n_film + j) * H:(n_film + j + 1) * H],
+                       out1=dFP[:, j * H:(j + 1) * H], out2=dFP[:, (n_film + j) * H:(n_film + j + 1) * H])
+            dZ = dZn
+            i = j
+        # mapping network
+        NF = 2 * n_film * H
+        if train_w:
+            grads[2 * n_map] = grad_weight(dFP, hs[-1], M, NF, Hm, mwo)
+            grads[2 * n_map + 1] = grad_bias(dFP, M, NF, mbo)
+        dpre = torch.empty(M, Hm, device=dev)
+        grad_input(dFP, mwo, M, Hm, NF, dpre, epi=hip.EPI_BWD_LEAKY, p0=0.2, aux0=hs[-1])
+        d_cond = None
+        for i in range(n_map - 1, -1, -1):
+            h_in = hs[i - 1] if i > 0 else cond
+            k_in = mw[i].shape[1]
+            if train_w:
+                grads[2 * i] = grad_weight(dpre, h_in, M, Hm, k_in, mw[i])
+                grads[2 * i + 1] = grad_bias(dpre, M, Hm, mb[i])
+            if i > 0:
+                nxt = torch.empty(M, Hm, device=dev)
+                grad_input(dpre, mw[i], M, Hm, Hm, nxt, epi=hip.EPI_BWD_LEAKY, p0=0.2, aux0=hs[i - 1])
+                dpre = nxt
+            elif need_dcond:
+                d_cond = torch.empty(M, k_in, device=dev)
+                grad_input(dpre, mw[0], M, k_in, Hm, d_cond)
+        return (d_x, d_cond, None, None, None, None, *grads)
+
+
+# =============================================================================================
+# SDF + albedo field (geo net with forward-mode tangents, colour net)
+# =============================================================================================
+class SDFAlbedoFn(torch.autograd.Function):
+    """forward_geonetwork + analytic d sdf/dx + colour net (sdf_albedo_field.py:211-269).
+
+    ET: stacked encode rows [4N, 72] = [E; T0; T1; T2] from HashEncodeFn(tangents=True).
+    Padded / permuted weights (see fields/sdf_albedo_field.py):
+      W0 [256,72] b0; W1 [256,256] b1; W2 [260,256] rows = [feat(256) | sdf | 0 0 0], b2 [260];
+      Wc0 [256,300] columns = [feat(256) | sdf-slot,3 pad (zero) | x(3) PE(36) | pad], bc0; Wc1, bc1; Wc2 [4,256], bc2 [4].
+    Returns sdf [N], gradients [N,3], albedo [N,3]."""
+
+    @staticmethod
+    def forward(ctx, ET, W0, b0, W1, b1, W2, b2, Wc0, bc0, Wc1, bc1, Wc2, bc2, beta):
+        N = ET.shape[0] // 4
+        dev = ET.device
+        Hd = W0.shape[0]
+        Kin = W0.shape[1]
+        A0 = torch.empty(4 * N, Hd, device=dev)
+        S0 = torch.empty(N, Hd, device=dev)
+        hip.gemm(ET[:N], W0, A0[:N], N, Hd, Kin, bias=b0, epi=hip.EPI_SOFTPLUS, p0=beta, out1=S0)
+        hip.gemm(ET[N:], W0, A0[N:], 3 * N, Hd, Kin, epi=hip.EPI_MUL_AUX, aux0=S0, row_mod=N)
+        A1 = torch.empty(4 * N, Hd, device=dev)
+        S1 = torch.empty(N, Hd, device=dev)
+        hip.gemm(A0[:N], W1, A1[:N], N, Hd, Hd, bias=b1, epi=hip.EPI_SOFTPLUS, p0=beta, out1=S1)
+        hip.gemm(A0[N:], W1, A1[N:], 3 * N, Hd, Hd, epi=hip.EPI_MUL_AUX, aux0=S1, row_mod=N)
+        GF = W2.shape[0] - 4  # geo feature dim (256)
+        ldc = Wc0.shape[1]
+        CIN = torch.zeros(N, ldc, device=dev)
+        hip.gemm(A1[:N], W2, CIN, N, GF + 1, Hd, bias=b2)  # [feat | sdf] straight into the colour-net input
+        npe = 39  # x (3) + PE6 (36) columns of the encode row
+        CIN[:, GF + 4:GF + 4 + npe] = ET[:N, :npe]
+        G = torch.zeros(3 * N, 4, device=dev)
+        hip.gemm(A1[N:], W2[GF:GF + 1], G, 3 * N, 1, Hd)  # d sdf / d x_k = tangent . w_sdf
+        Hc = Wc0.shape[0]
+        C0 = torch.empty(N, Hc, device=dev)
+        hip.gemm(CIN, Wc0, C0, N, Hc, ldc, bias=bc0, epi=hip.EPI_RELU)
+        C1 = torch.empty(N, Hc, device=dev)
+        hip.gemm(C0, Wc1, C1, N, Hc, Hc, bias=bc1, epi=hip.EPI_RELU)
+        ALB = torch.zeros(N, 4, device=dev)
+        hip.gemm(C1, Wc2, ALB, N, 3, Hc, bias=bc2, epi=hip.EPI_SIGMOID, p0=1.0)
+        ctx.save_for_backward(ET, A0, S0, A1, S1, CIN, C0, C1, ALB, W0, b0, W1, b1, W2, b2, Wc0, bc0, Wc1, bc1, Wc2, bc2)
+        ctx.cfg = (N, Hd, Kin, GF, ldc, Hc, beta)
+        sdf = CIN[:, GF].clone()
+        grad = G.view(3, N, 4)[:, :, 0].t().contiguous()
+        return sdf, grad, ALB[:, :3].clone()
+
+    @staticmethod
+    def backward(ctx, g_sdf, g_grad, g_alb):
+        ET, A0, S0, A1, S1, CIN, C0, C1, ALB, W0, b0, W1, b1, W2, b2, Wc0, bc0, Wc1, bc1, Wc2, bc2 = ctx.saved_tensors
+        N, Hd, Kin, GF, ldc, Hc, beta = ctx.cfg
+        dev = ET.device
+        # ---- colour net
+        dpc2 = torch.zeros(N, 4, device=dev)
+        if g_alb is not None:
+            alb = ALB[:, :3]
+            dpc2[:, :3] = g_alb * alb * (1.0 - alb)
+        dWc2 = grad_weight(dpc2, C1, N, 4, Hc, Wc2)
+        dbc2 = grad_bias(dpc2, N, 4, bc2)
+        dpc1 = torch.empty(N, Hc, device=dev)
+        grad_input(dpc2, Wc2, N, Hc, 4, dpc1, epi=hip.EPI_BWD_RELU, aux0=C1)
+        dWc1 = grad_weight(dpc1, C0, N, Hc, Hc, Wc1)
+        dbc1 = grad_bias(dpc1, N, Hc, bc1)
+        dpc0 = torch.empty(N, Hc, device=dev)
+        grad_input(dpc1, Wc1, N, Hc, Hc, dpc0, epi=hip.EPI_BWD_RELU, aux0=C0)
+        dWc0 = grad_weight(dpc0, CIN, N, Hc, ldc, Wc0)
+        dbc0 = grad_bias(dpc0, N, Hc, bc0)
+        dCIN = torch.empty(N, ldc, device=dev)
+        grad_input(dpc0, Wc0, N, ldc, Hc, dCIN)
+        # the sdf slot / pad columns of Wc0 are structural zeros: overwrite them with the upstream sdf gradient
+        dCIN[:, GF:GF + 4] = 0.0
+        if g_sdf is not None:
+            dCIN[:, GF] = g_sdf
+        dH = dCIN[:, :GF + 4]
+        # ---- geo net, last layer (value rows)
+        dW2 = grad_weight(dH, A1[:N], N, GF + 4, Hd, W2)
+        db2 = grad_bias(dH, N, GF + 4, b2)
+        dA1v = torch.empty(N, Hd, device=dev)
+        grad_input(dH, W2, N, Hd, GF + 4, dA1v)
+        # tangent rows of the last layer: grad_k = ta1_k . w_sdf
+        if g_grad is None:
+            g_grad = torch.zeros(N, 3, device=dev)
+        g_grad = g_grad.contiguous()
+        ggT = torch.zeros(3 * N, 4, device=dev)
+        ggT[:, 0] = g_grad.t().reshape(-1)
+        dw2s = torch.zeros(4, Hd, device=dev)
+        hip.gemm(ggT, A1[N:], dw2s, 1, Hd, 3 * N, a_kcontig=False, b_kcontig=False, k_splits=_splits(3 * N))
+        dW2[GF] += dw2s[0]
+        w2s = W2[GF].contiguous()
+        # ---- layer 1 (reverse over forward)
+        D1 = torch.empty(4 * N, Hd, device=dev)
+        hip.softplus_tangent_bwd(dA1v, S1, A1[N:], None, g_grad, w2s, beta, N, Hd, D1[:N], D1[N:])
+        dW1 = grad_weight(D1, A0, 4 * N, Hd, Hd, W1)
+        db1 = grad_bias(D1, N, Hd, b1)
+        dA0 = torch.empty(4 * N, Hd, device=dev)
+        grad_input(D1, W1, 4 * N, Hd, Hd, dA0)
+        # ---- layer 0
+        D0 = torch.empty(4 * N, Hd, device=dev)
+        hip.softplus_tangent_bwd(dA0[:N], S0, A0[N:], dA0[N:], None, None, beta, N, Hd, D0[:N], D0[N:])
+        dW0 = grad_weight(D0, ET, 4 * N, Hd, Kin, W0)
+        db0 = grad_bias(D0, N, Hd, b0)
+        dET = torch.empty(4 * N, Kin, device=dev)
+        grad_input(D0, W0, 4 * N, Kin, Hd, dET)
+        # x / PE columns of the colour-net input came straight from the encode row
+        dET[:N, :39] += dCIN[:, GF + 4:GF + 4 + 39]
+        return dET, dW0, db0, dW1, db1, dW2, db2, dWc0, dbc0, dWc1, dbc1, dWc2, dbc2, None
+
+
+class SDFValueFn(torch.autograd.Function):
+    """get_sdf_at_pos (sdf_albedo_field.py:169-174): value-only geo net on encode rows E [M,72] -> sdf [M]."""
+
+    @staticmethod
+    def forward(ctx, E, W0, b0, W1, b1, W2, b2, beta, train_weights):
+        M = E.shape[0]
+        dev = E.device
+        Hd, Kin = W0.shape
+        GF = W2.shape[0] - 4
+        A0 = torch.empty(M, Hd, device=dev); S0 = torch.empty(M, Hd, device=dev)
+        hip.gemm(E, W0, A0, M, Hd, Kin, bias=b0, epi=hip.EPI_SOFTPLUS, p0=beta, out1=S0)
+        A1 = torch.empty(M, Hd, device=dev); S1 = torch.empty(M, Hd, device=dev)
+        hip.gemm(A0, W1, A1, M, Hd, Hd, bias=b1, epi=hip.EPI_SOFTPLUS, p0=beta, out1=S1)
+        out = torch.zeros(M, 4, device=dev)
+        hip.gemm(A1, W2[GF:GF + 1], out, M, 1, Hd, bias=b2[GF:GF + 1])
+        ctx.save_for_backward(E, A0, S0, A1, S1, W0, b0, W1, b1, W2, b2)
+        ctx.cfg = (M, Hd, Kin, GF, beta, train_weights)
+        return out[:, 0]
+
+    @staticmethod
+    def backward(ctx, g_sdf):
+        E, A0, S0, A1, S1, W0, b0, W1, b1, W2, b2 = ctx.saved_tensors
+        M, Hd, Kin, GF, beta, train_w = ctx.cfg
+        dev = E.device
+        g = torch.zeros(M, 4, device=dev)
+        g[:, 0] = g_sdf
+        w2s = torch.zeros(4, Hd, device=dev)
+        w2s[0] = W2[GF]
+        dZ1 = torch.empty(M, Hd, device=dev)
+        grad_input(g, w2s, M, Hd, 4, dZ1, epi=hip.EPI_MUL_AUX, aux0=S1)  # da1 * softplus'(z1)
+        dZ0 = torch.empty(M, Hd, device=dev)
+        grad_input(dZ1, W1, M, Hd, Hd, dZ0, epi=hip.EPI_MUL_AUX, aux0=S0)
+        dE = torch.empty(M, Kin, device=dev)
+        grad_input(dZ0, W0, M, Kin, Hd, dE)
+        dW0 = db0 = dW1 = db1 = dW2 = db2 = None
+        if train_w:
+            dW2 = torch.zeros_like(W2); db2 = torch.zeros_like(b2)
+            dw = torch.zeros(4, Hd, device=dev)
+            hip.gemm(g, A1, dw, 1, Hd, M, a_kcontig=False, b_kcontig=False, k_splits=_splits(M))
+            dW2[GF] = dw[0]
+            db2[GF] = g_sdf.sum()
+            dW1 = grad_weight(dZ1, A0, M, Hd, Hd, W1); db1 = grad_bias(dZ1, M, Hd, b1)
+            dW0 = grad_weight(dZ0, E, M, Hd, Kin, W0); db0 = grad_bias(dZ0, M, Hd, b0)
+        return dE, dW0, db0, dW1, db1, dW2, db2, None, None
+
+
+# =============================================================================================
+# render stages
+# =============================================================================================
+class HemiCompositeFn(torch.autograd.Function):
+    """renderers.py:60-130 on compact inputs -> rgb [R,3]."""
+
+    @staticmethod
+    def forward(ctx, albedo, normals, weights, dirs, cam_colours, cam_of_ray, vis, bg):
+        R = albedo.shape[0]
+        a, n, w = albedo.contiguous(), normals.contiguous(), weights.contiguous()
+        dirs, cam_colours, bg = dirs.contiguous(), cam_colours.contiguous(), bg.contiguous()
+        vis = vis.contiguous() if vis is not None else None
+        rgb = torch.empty(R, 3, device=a.device)
+        lin = torch.empty(R, 3, device=a.device)
+        hip.hemi_composite_fwd(a, n, w, dirs, cam_colours, cam_of_ray, vis, bg, rgb, lin)
+        ctx.save_for_backward(a, n, w, dirs, cam_colours, cam_of_ray, bg, lin, *([vis] if vis is not None else []))
+        ctx.has_vis = vis is not None
+        return rgb
+
+    @staticmethod
+    def backward(ctx, d_rgb):
+        sv = ctx.saved_tensors
+        a, n, w, dirs, cam_colours, cam_of_ray, bg, lin = sv[:8]
+        vis = sv[8] if ctx.has_vis else None
+        R, S, _ = a.shape
+        dev = a.device
+        da, dn = torch.empty_like(a), torch.empty_like(n)
+        dw = torch.empty_like(w)
+        dcol = torch.zeros_like(cam_colours)
+        dvis = torch.empty_like(vis) if vis is not None else None
+        dbg = torch.empty_like(bg)
+        hip.hemi_composite_bwd(a, n, w, dirs, cam_colours, cam_of_ray, vis, bg, lin, d_rgb.contiguous(), da, dn, dw, dcol, dvis, dbg)
+        return da, dn, dw, None, dcol, None, dvis, dbg
+
+
+class NeusWeightsFn(torch.autograd.Function):
+    """NeuS alpha + transmittance + weights; returns weights [R,S], T_bg [R], accumulation [R], depth [R] (unclipped)."""
+
+    @staticmethod
+    def forward(ctx, sdf, grad, ray_dirs, starts, ends, variance, anneal):
+        R, S = sdf.shape
+        dev = sdf.device
+        sdf, grad, ray_dirs = sdf.contiguous(), grad.contiguous(), ray_dirs.contiguous()
+        starts, ends = starts.contiguous(), ends.contiguous()
+        w = torch.empty(R, S, device=dev)
+        tb, acc, dep = torch.empty(R, device=dev), torch.empty(R, device=dev), torch.empty(R, device=dev)
+        hip.neus_weights_fwd(sdf, grad, ray_dirs, starts, ends, variance, anneal, None, w, tb, acc, dep)
+        ctx.save_for_backward(sdf, grad, ray_dirs, starts, ends, variance, w)
+        ctx.anneal = anneal
+        ctx.mark_non_differentiable(acc, dep)
+        return w, tb, acc, dep
+
+    @staticmethod
+    def backward(ctx, dw, dtb, _dacc, _ddep):
+        sdf, grad, ray_dirs, starts, ends, variance, w = ctx.saved_tensors
+        dsdf, dgrad = torch.empty_like(sdf), torch.empty_like(grad)
+        dvar = torch.zeros_like(variance)
+        dw = torch.zeros_like(w) if dw is None else dw.contiguous()
+        hip.neus_weights_bwd(sdf, grad, ray_dirs, starts, ends, variance, ctx.anneal, dw,
+                             None if dtb is None else dtb.contiguous(), dsdf, dgrad, dvar)
+        return dsdf, dgrad, None, None, None, dvar, None
+
+
+class VisibilityFinishFn(torch.autograd.Function):
+    """vis [R,D] from DDF distances (neusky_model.py:1724-1753)."""
+
+    @staticmethod
+    def forward(ctx, t_hat, surf_dist, threshold, scale, sel_index, R, Dv, D, lower_value):
+        vis = torch.full((R, D), float(lower_value), device=t_hat.device)
+        t_hat = t_hat.contiguous()
+        hip.visibility_finish_fwd(t_hat, surf_dist, threshold, scale, sel_index, R, Dv, D, vis)
+        ctx.save_for_backward(t_hat, surf_dist, threshold, sel_index)
+        ctx.cfg = (scale, R, Dv, D)
+        return vis
+
+    @staticmethod
+    def backward(ctx, d_vis):
+        t_hat, surf_dist, threshold, sel_index = ctx.saved_tensors
+        scale, R, Dv, D = ctx.cfg
+        d_t = torch.empty_like(t_hat)
+        d_thr = torch.zeros_like(threshold)
+        hip.visibility_finish_bwd(t_hat, surf_dist, threshold, scale, sel_index, R, Dv, D, d_vis.contiguous(), d_t, d_thr)
+        return d_t, None, d_thr, None, None, None, None, None, None
+
+
+class TruncExpFn(torch.autograd.Function):
+    """nerfstudio trunc_exp (density activation of the proposal networks)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * torch.exp(ctx.saved_tensors[0].clamp(-15, 15))

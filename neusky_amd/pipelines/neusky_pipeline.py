@@ -1,0 +1,141 @@
+"""Train-step orchestration - mirrors `neusky.pipelines.neusky_pipeline.NeuSkyPipeline`
+(neusky/pipelines/neusky_pipeline.py:99-515) for `__init__` (:117-202), `get_param_groups` (:227-238),
+`get_train_loss_dict` (:241-291), `generate_ddf_samples` (:493-515), `_setup_visibility_field` (:446-491).
+
+Multi-GPU: one process per GPU; parameters are replicated and the flat gradient is all-reduced (mean) over
+RCCL once per step (`neusky_amd.distributed.GradientAllReduce`).  The reference wraps the model in DDP and
+then dereferences `.visibility_field` on the wrapper (:249-250, :278), which does not work;
+here the model is never wrapped, so the same call sites work at any world size.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Type
+
+import torch
+from torch import nn
+from torch.nn import Parameter
+
+from ..data.synthetic_datamanager import SyntheticDataManagerConfig
+from ..model_components.ddf_sampler import VMFDDFSamplerConfig
+from ..models.ddf_model import DDFModelConfig
+from ..models.neusky_model import NeuSkyFactoModelConfig
+
+
+@dataclass
+class NeuSkyPipelineConfig:
+    """neusky/pipelines/neusky_pipeline.py:61-96 with the `neusky` values (neusky_config.py:43-215)"""
+
+    _target: Type = field(default_factory=lambda: NeuSkyPipeline)
+    datamanager: Any = field(default_factory=SyntheticDataManagerConfig)
+    model: NeuSkyFactoModelConfig = field(default_factory=NeuSkyFactoModelConfig)
+    visibility_field: Optional[DDFModelConfig] = field(default_factory=DDFModelConfig)
+    visibility_field_radius: Any = "AABB"
+    visibility_train_sampler: VMFDDFSamplerConfig = field(default_factory=VMFDDFSamplerConfig)
+    visibility_accumulation_mask_threshold: float = 0.0
+    num_sky_rays: int = 256
+    test_mode: Optional[str] = None
+    stop_sdf_gradients: bool = False
+
+    def setup(self, **kwargs):
+        return self._target(self, **kwargs)
+
+
+class NeuSkyPipeline(nn.Module):
+    def __init__(self, config: NeuSkyPipelineConfig, device: str, test_mode: str = "val", world_size: int = 1,
+                 local_rank: int = 0, grad_scaler=None):
+        super().__init__()
+        self.config = config
+        self.test_mode = test_mode if config.test_mode is None else config.test_mode
+        self.datamanager = config.datamanager.setup(device=device, test_mode=self.test_mode, world_size=world_size,
+                                                    local_rank=local_rank)
+        assert self.datamanager.train_dataset is not None, "Missing input dataset"
+        self.register_buffer("num_train_data", torch.tensor(len(self.datamanager.train_dataset)))  # :146-148
+        self.register_buffer("num_test_data", torch.tensor(self.datamanager.num_test))
+        self.register_buffer("num_val_data", torch.tensor(self.datamanager.num_val))
+        self.scene_box = self.datamanager.train_dataset.scene_box
+        visibility_field = None
+        if config.visibility_field is not None:
+            visibility_field = self._setup_visibility_field(device=device)
+            self.visibility_train_sampler = config.visibility_train_sampler.setup(
+                ddf_sphere_radius=visibility_field.ddf_radius, device=device)
+        self._model = config.model.setup(
+            scene_box=self.scene_box, num_train_data=int(self.num_train_data), num_val_data=int(self.num_val_data),
+            num_test_data=int(self.num_test_data), visibility_field=visibility_field, test_mode=test_mode,
+            train_metadata=self.datamanager.train_dataset.metadata, eval_metadata=self.datamanager.eval_dataset.metadata,
+            grad_scaler=grad_scaler)
+        self._model.to(device)
+        self.world_size, self.local_rank = world_size, local_rank
+        self.grad_sync = None
+        if world_size > 1:
+            from ..distributed import GradientAllReduce
+            self.grad_sync = GradientAllReduce([p for p in self.parameters() if p.requires_grad], world_size)
+            self.grad_sync.broadcast_parameters()  # identical replicas, then the :200 barrier
+            self.grad_sync.barrier()
+
+    @property
+    def model(self):
+        return self._model
+
+    def _setup_visibility_field(self, device):
+        """:446-491 (checkpoint branch = SURVEY 8(f) item 3)"""
+        aabb = self.scene_box["aabb"] if isinstance(self.scene_box, dict) else self.scene_box.aabb
+        radius = float(torch.abs(aabb[0, 0])) if self.config.visibility_field_radius == "AABB" else float(self.config.visibility_field_radius)
+        vf = self.config.visibility_field.setup(scene_box=None, num_train_data=int(self.num_train_data), ddf_radius=radius)
+        vf.to(device)
+        vf.train(self.config.model.fit_visibility_field)
+        return vf
+
+    def get_param_groups(self) -> Dict[str, List[Parameter]]:
+        """:227-238 -> keys fields, proposal_networks, illumination_field, visibility_sigmoid, ddf_field"""
+        groups = {**self.datamanager.get_param_groups(), **self.model.get_param_groups()}
+        if self.model.visibility_field is not None:
+            groups.update(self.model.visibility_field.get_param_groups())
+        return groups
+
+    def generate_ddf_samples(self, randoms: Optional[Dict] = None) -> Dict[str, Any]:
+        """:493-515"""
+        if randoms is not None and "ddf_rays" in randoms:
+            from ..cameras.rays import RayBundle
+            o, d = randoms["ddf_rays"]
+            dev = o.device
+            rb = RayBundle(origins=o, directions=d, pixel_area=torch.ones(o.shape[0], 1, device=dev),
+                           camera_indices=torch.zeros(o.shape[0], 1, dtype=torch.int64, device=dev),
+                           metadata={"directions_norm": torch.ones(o.shape[0], 1, device=dev)})
+        else:
+            rb = self.visibility_train_sampler()
+        data = self.model.generate_ddf_ground_truth(rb, self.config.visibility_accumulation_mask_threshold, randoms)
+        data["sky_ray_bundle"] = randoms["sky_ray_bundle"] if randoms is not None and "sky_ray_bundle" in randoms else \
+            self.datamanager.get_sky_ray_bundle(self.config.num_sky_rays)
+        if self.config.stop_sdf_gradients:
+            for k in ["accumulations", "mask", "termination_dist", "normals"]:
+                data[k] = data[k].detach()
+        return data
+
+    def get_train_loss_dict(self, step: int, ray_bundle=None, batch=None, randoms: Optional[Dict] = None):
+        """:241-291.  ray_bundle/batch/randoms may be injected (tests, bench); otherwise they come from the datamanager."""
+        model = self.model
+        if model.visibility_field is not None and not model.config.fit_visibility_field:
+            model.visibility_field.eval()
+        if ray_bundle is None:
+            ray_bundle, batch = self.datamanager.next_train(step)
+        model.set_step(step)
+        model_outputs = model(ray_bundle, batch=batch, step=step, randoms=randoms)
+        metrics_dict = model.get_metrics_dict(model_outputs, batch)
+        loss_dict = model.get_loss_dict(model_outputs, batch, metrics_dict)
+        if model.config.fit_visibility_field and model.visibility_field is not None:
+            vis_batch = self.generate_ddf_samples(randoms)
+            vis_outputs = model.visibility_field(ray_bundle=vis_batch["ray_bundle"], batch=vis_batch, neusky=model,
+                                                 stop_gradients=self.config.stop_sdf_gradients,
+                                                 mv_points=None if randoms is None else randoms.get("mv_points"))
+            vis_metrics = model.visibility_field.get_metrics_dict(vis_outputs, vis_batch)
+            vis_loss = model.visibility_field.get_loss_dict(vis_outputs, vis_batch, vis_metrics)
+            model_outputs = {**model_outputs, **vis_outputs}
+            loss_dict = {**loss_dict, **vis_loss}
+            metrics_dict = {**metrics_dict, **vis_metrics}
+        return model_outputs, loss_dict, metrics_dict
+
+    def sync_gradients(self) -> None:
+        """all-reduce (mean) of every trainable gradient; no-op on one GPU"""
+        if self.grad_sync is not None:
+            self.grad_sync.all_reduce()

@@ -1,0 +1,33 @@
+"""Small geometry / colour helpers (torch ops, small tensors): neusky/utils/utils.py."""
+from __future__ import annotations
+
+import torch
+
+
+def linear_to_sRGB(color: torch.Tensor, use_quantile: bool = False) -> torch.Tensor:
+    """neusky/utils/utils.py:11-31"""
+    if use_quantile:
+        q = torch.quantile(color.flatten(), 0.98)
+        color = color / q.expand_as(color)
+    color = torch.where(color <= 0.0031308, 12.92 * color, 1.055 * torch.pow(torch.abs(color), 1 / 2.4) - 0.055)
+    return torch.clamp(color, 0.0, 1.0)
+
+
+def ray_sphere_intersection(positions: torch.Tensor, directions: torch.Tensor, radius: float) -> torch.Tensor:
+    """neusky/utils/utils.py:68-93 (unit directions, far root)"""
+    b = 2 * (directions * positions).sum(-1)
+    c = (positions * positions).sum(-1) - radius**2
+    disc = b**2 - 4 * c
+    t = torch.max((-b - torch.sqrt(disc)) / 2, (-b + torch.sqrt(disc)) / 2)
+    return positions + t[..., None] * directions
+
+
+def sph2cart(theta, phi):
+    """neusky/utils/utils.py:95-99"""
+    return torch.sin(phi) * torch.cos(theta), torch.sin(phi) * torch.sin(theta), torch.cos(phi)
+
+
+def rot_z(gamma: torch.Tensor) -> torch.Tensor:
+    """neusky/utils/utils.py:168-173"""
+    c, s = torch.cos(gamma), torch.sin(gamma)
+    return torch.tensor([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=gamma.dtype)

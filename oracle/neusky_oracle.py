@@ -447,7 +447,7 @@ def pdf_sample_bins(existing_bins: Tensor, weights: Tensor, num_samples: int, ji
     and the searchsorted indices `inds` [R,num_samples+1] (int64: the BIT-EXACT ray-sample indices)."""
     num_bins = num_samples + 1
     w = weights + histogram_padding
-    wsum = w.sum(-1, keepdim=True)
+    wsum = torch.cumsum(w, dim=-1)[..., -1:]  # sequential left-to-right sum (defined order -> reproducible indices)
     padding = torch.relu(eps - wsum)
     w = w + padding / w.shape[-1]
     wsum = wsum + padding
@@ -478,7 +478,20 @@ def proposal_density(x: Tensor, p: Dict[str, Tensor], prefix: str, cfg: HashGrid
     h = hash_grid_encode(pos, p[prefix + "table"], cfg)
     h = F.relu(F.linear(h, p[prefix + "w0"], p[prefix + "b0"]))
     d = F.linear(h, p[prefix + "w1"], p[prefix + "b1"])
-    return torch.exp(d.clamp(max=15.0)) * sel[:, None]  # trunc_exp fwd = exp; clamp only guards overflow
+    return _TruncExp.apply(d) * sel[:, None]
+
+
+class _TruncExp(torch.autograd.Function):
+    """nerfstudio trunc_exp: forward exp(x); backward g * exp(clamp(x, -15, 15))."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * torch.exp(ctx.saved_tensors[0].clamp(-15, 15))
 
 
 def weights_from_density(density: Tensor, deltas: Tensor) -> Tensor:
@@ -712,3 +725,100 @@ def vmf_ddf_rays(num_positions: int, num_directions: int, kappa: float, radius: 
     x = torch.where(flip[..., None], -x, x)
     P = (pos * radius)[:, None, :].expand(-1, num_directions, -1).reshape(-1, 3)
     return P, x.reshape(-1, 3)
+
+
+# =====================================================================================
+# full train-step forward (composition of the rows above; neusky_pipeline.py:241-291)
+# =====================================================================================
+@dataclass
+class StepCfg:
+    num_prop: Tuple[int, ...] = (256, 96)
+    num_final: int = 48
+    radius: float = 1.0
+    sigmoid_scale: float = 25.0
+    anneal: float = 1.0
+    grid_res: int = 10
+    field_grid: HashGridCfg = field(default_factory=lambda: HashGridCfg(smoothstep=True))
+    ddf_grid: HashGridCfg = field(default_factory=lambda: HashGridCfg(smoothstep=False))
+    prop_grids: Tuple[HashGridCfg, ...] = field(default_factory=lambda: (
+        HashGridCfg(n_levels=5, log2_hashmap_size=17, max_res=64), HashGridCfg(n_levels=5, log2_hashmap_size=17, max_res=256)))
+
+
+def render_depth(weights: Tensor, ebins: Tensor) -> Tensor:
+    """nerfstudio DepthRenderer('expected') as called at neusky_model.py:591: weights [R,S] -> [R,1]"""
+    mid = (ebins[:, :-1] + ebins[:, 1:]) / 2
+    depth = (weights * mid).sum(-1, keepdim=True) / (weights.sum(-1, keepdim=True) + 1e-10)
+    return torch.clip(depth, mid.min(), mid.max())
+
+
+def field_pass(p, cfg: StepCfg, origins, directions, ebins):
+    R, S = ebins.shape[0], ebins.shape[1] - 1
+    o = origins[:, None, :].expand(R, S, 3)
+    d = directions[:, None, :].expand(R, S, 3)
+    fo = sdf_field_outputs(o, d, ebins[:, :-1, None], ebins[:, 1:, None], p, cfg.field_grid)
+    w, T = weights_from_alphas(fo["alpha"])
+    fo["weights"], fo["bg_transmittance"] = w[..., 0], T[:, -1]
+    return fo
+
+
+def neusky_train_step(p: Dict[str, Tensor], cfg: StepCfg, origins: Tensor, directions: Tensor, cam_idx: Tensor,
+                      image: Tensor, mask: Tensor, rnd: Dict[str, Tensor], light_dirs: Tensor):
+    """Forward of one full training step -> (scaled loss dict, outputs).  All randomness is explicit:
+    rnd = {jitters: [L+1 x [R,1]], grid_perturb [G,3], grid_dirs [G,3], ddf_rays (o,d), ddf_jitters, mv_points [Mv,3],
+    sky_o, sky_d}; light_dirs [D,3] is the (already rotated) illumination direction set."""
+    dt = origins.dtype
+    R = origins.shape[0]
+    nears, fars = sphere_collider(origins, directions, cfg.radius)  # neusky_model.py:440-441
+    samp = proposal_sample(origins, directions, nears, fars, p, cfg.prop_grids, cfg.num_prop, cfg.num_final, rnd["jitters"], cfg.anneal)
+    ebins = samp["ebins"]
+    fo = field_pass(p, cfg, origins, directions, ebins)  # :563-568
+    weights = fo["weights"]
+    decode = lambda lat, dd, sc: reni_decode(lat, dd, sc, p)
+    cols, inverse, bg = sample_illumination(cam_idx, directions, light_dirs, p["train_latents"], p["train_scale"], decode)  # :573
+    p2p = render_depth(weights, ebins)  # :591
+    ddf_fn = lambda sp, dd: ddf_query(sp, dd, p, cfg.ddf_grid, cfg.radius)
+
+    def vis_field(sp, dd):
+        t = ddf_fn(sp, dd)
+        return {"expected_termination_dist": t, "sdf_at_termination": sdf_at_positions(sp + dd * t[:, None], p, cfg.field_grid)}
+
+    vis = compute_visibility(origins, directions, p2p.detach(), light_dirs, p["visibility_threshold"], cfg.sigmoid_scale,
+                             cfg.radius, vis_field, True, True)  # :624-630 ('depth' stop-gradient mode)
+    rgb = lambertian_render(fo["albedo"], fo["normals"], light_dirs, cols, inverse, vis["visibility"], bg, weights)  # :797-805
+    # hash-grid density probe (:672-734): jittered res^3 lattice over the scene box, alpha per axis gap
+    res = cfg.grid_res
+    lin = torch.linspace(-cfg.radius, cfg.radius, res, dtype=dt)
+    X, Y, Z = torch.meshgrid(lin, lin, lin, indexing="ij")
+    gap = torch.full((3,), 2 * cfg.radius / res, dtype=dt)
+    gpos = torch.stack((X, Y, Z), -1).reshape(-1, 3) + (rnd["grid_perturb"].to(dt) * gap - gap / 2)
+    gdir = rnd["grid_dirs"].to(dt)
+    gdir = gdir / gdir.norm(dim=-1, keepdim=True)
+    xg = gpos.detach().requires_grad_(True)
+    hg = geo_network(xg, p, cfg.field_grid)
+    gg = torch.autograd.grad(hg[:, :1], xg, torch.ones_like(hg[:, :1]), create_graph=True)[0]
+    grid_density = neus_alpha(hg[:, :1], gg, gdir, gap[None, :], p["field.variance"])  # [G,3] (sic: deltas = gap [3])
+    out = {
+        "rgb": rgb, "eik_grad": fo["gradients"], "weights": weights[..., None], "normal": (weights[..., None] * fo["normals"]).sum(-2),
+        "hdr_background_colours": bg, "grid_density": grid_density, "sdf_at_termination": vis["sdf_at_termination"],
+        "weights_list": samp["weights_list"] + [weights], "sbins_list": samp["sbins_list"] + [samp["sbins"]],
+        "p2p_dist": p2p, "visibility": vis["visibility"], "expected_termination_dist": vis["expected_termination_dist"],
+        "pdf_inds_list": samp["inds_list"], "albedo": fo["albedo"], "sdf": fo["sdf"], "ebins": ebins,
+    }
+    ld = scale_dict(neusky_losses(out, image, mask, p["visibility_threshold"].reshape(())), NEUSKY_LOSS_COEFFICIENTS)
+    # DDF fitting (:271-289): second sampler + field pass on the vMF rays, then the DDF model
+    do, dd = rnd["ddf_rays"]
+    dn, df = sphere_collider(do, dd, cfg.radius)
+    dsamp = proposal_sample(do, dd, dn, df, p, cfg.prop_grids, cfg.num_prop, cfg.num_final, rnd["ddf_jitters"], cfg.anneal)
+    dfo = field_pass(p, cfg, do, dd, dsamp["ebins"])
+    acc = dfo["weights"].sum(-1, keepdim=True)
+    dmask = (acc > 0.0).to(dt)  # visibility_accumulation_mask_threshold = 0.0 (neusky_config.py:214)
+    gt_term = torch.clamp(render_depth(dfo["weights"], dsamp["ebins"]), max=2 * cfg.radius)  # :1348-1351
+    dout = ddf_model_outputs(do, dd, gt_term, rnd["mv_points"].to(dt), rnd["sky_o"], rnd["sky_d"], cfg.radius, ddf_fn,
+                             lambda x: sdf_at_positions(x, p, cfg.field_grid))
+    dl = ddf_losses(dout["expected_termination_dist"], gt_term, dmask, dout["distance_weight"], dout["sdf_at_termination"],
+                    dout["multi_view_expected_termination_dist"], dout["multi_view_termintation_dist"],
+                    dout["sky_ray_expected_termination_dist"], dout["sky_ray_termination_dist"])
+    ld.update(scale_dict(dl, DDF_LOSS_COEFFICIENTS))
+    out.update({"ddf_" + k: v for k, v in dout.items()})
+    out["ddf_gt_termination_dist"] = gt_term
+    return ld, out

@@ -1,0 +1,56 @@
+"""world_size-2 gloo test of the ray-sharded data-parallel path: replicas start identical (broadcast), the flat
+gradient all-reduce averages the per-rank gradients, parameters without a gradient are zero-filled
+(find_unused_parameters semantics), and the averaged gradient equals the gradient of the concatenated batch."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from neusky_amd.distributed import GradientAllReduce
+    torch.manual_seed(100 + rank)  # deliberately different initial replicas
+    w = torch.nn.Parameter(torch.randn(5, 3))
+    b = torch.nn.Parameter(torch.randn(5))
+    unused = torch.nn.Parameter(torch.randn(4))  # receives no gradient on any rank
+    sync = GradientAllReduce([w, b, unused], world)
+    sync.broadcast_parameters()
+    sync.barrier()
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(8, 3, generator=g); Y = torch.randn(8, 5, generator=g)
+    xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]  # each rank owns its rays
+    loss = ((xs @ w.T + b - ys) ** 2).mean()
+    loss.backward()
+    sync.all_reduce()
+    # reference: one process, concatenated batch (batch-mean losses => average, not sum, of the shard gradients)
+    w2, b2 = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    ((X @ w2.T + b2 - Y) ** 2).mean().backward()
+    out_q.put((rank, w.detach().clone(), w.grad.clone(), b.grad.clone(), unused.grad.clone(), w2.grad.clone(), b2.grad.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_equals_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w0, gw0, gb0, gu0, rw0, rb0), (_, w1, gw1, gb1, gu1, _, _) = res
+    assert torch.equal(w0, w1), "replicas differ after the parameter broadcast"
+    assert torch.allclose(gw0, gw1) and torch.allclose(gb0, gb1), "ranks disagree after the all-reduce"
+    assert torch.allclose(gw0, rw0, atol=1e-6) and torch.allclose(gb0, rb0, atol=1e-6), "N-GPU gradient != 1-GPU gradient"
+    assert torch.equal(gu0, torch.zeros(4)) and torch.equal(gu1, torch.zeros(4))
