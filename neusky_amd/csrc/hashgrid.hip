@@ -283,8 +283,10 @@ __global__ __launch_bounds__(256) void encode_bwd_kernel(Grid g, const float* __
         a0 += cx * gpa[0].x + cy * gpa[1].x + cz * gpa[2].x;
         a1 += cx * gpa[0].y + cy * gpa[1].y + cz * gpa[2].y;
       }
-      atomicAdd(dtable + 2l * c.idx[k], a0);
-      atomicAdd(dtable + 2l * c.idx[k] + 1, a1);
+      if (dtable) {
+        atomicAdd(dtable + 2l * c.idx[k], a0);
+        atomicAdd(dtable + 2l * c.idx[k] + 1, a1);
+      }
       if (dx) {
         const float s = v[k].x * gy.x + v[k].y * gy.y;
         dpos[0] = fmaf(cx, s, dpos[0]); dpos[1] = fmaf(cy, s, dpos[1]); dpos[2] = fmaf(cz, s, dpos[2]);
@@ -301,6 +303,101 @@ __global__ __launch_bounds__(256) void encode_bwd_kernel(Grid g, const float* __
     if (wave == 0 && valid)
 #pragma unroll
       for (int a = 0; a < 3; ++a) dx[(long)p * 3 + a] = red[0][lane][a] + red[1][lane][a] + red[2][lane][a] + red[3][lane][a];
+  }
+}
+
+// ---- table-gradient scatter --------------------------------------------------------------------
+// Float atomics leave L2 as one request per touched 64-B line per wave-instruction, and the chip-wide rate
+// for lines-scattered requests is ~17x below the contiguous rate.  So the scatter is laid out to (a) put
+// the two features of a corner on adjacent lanes (one line, one request), and (b) keep the small dense
+// levels, where thousands of points collide on a few KB, in LDS and flush them once per workgroup.
+struct CornerTerm {
+  uint32_t idx;
+  float a;  // value to add to table[idx][f]
+};
+
+template <bool TANGENTS>
+__device__ __forceinline__ CornerTerm corner_term(const Grid& g, int level, int k, int f, const float pos[3], const float J[3][3],
+                                                  const float* __restrict__ dY, const float* __restrict__ dT, int P, int p,
+                                                  int lddy, int feat0) {
+  const float scale = g.scale[level];
+  const uint32_t res = (uint32_t)g.resolution[level];
+  const uint32_t size = g.offset[level + 1] - g.offset[level];
+  uint32_t pg[3];
+  float w[3], dw[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float q = fmaf(scale, pos[a], 0.5f);
+    const float fl = floorf(q);
+    pg[a] = (uint32_t)(int)fl;
+    const float t = q - fl;
+    if (g.smoothstep) { w[a] = t * t * (3.0f - 2.0f * t); dw[a] = 6.0f * t * (1.0f - t) * scale; }
+    else { w[a] = t; dw[a] = scale; }
+  }
+  CornerTerm ct;
+  ct.idx = g.offset[level] + grid_index(size, res, pg[0] + (k & 1), pg[1] + ((k >> 1) & 1), pg[2] + ((k >> 2) & 1));
+  const float wx = (k & 1) ? w[0] : 1.0f - w[0];
+  const float wy = (k & 2) ? w[1] : 1.0f - w[1];
+  const float wz = (k & 4) ? w[2] : 1.0f - w[2];
+  const int col = feat0 + 2 * level + f;
+  float a = wx * wy * wz * dY[(long)p * lddy + col];
+  if (TANGENTS) {
+    const float cx = ((k & 1) ? dw[0] : -dw[0]) * wy * wz;
+    const float cy = ((k & 2) ? dw[1] : -dw[1]) * wx * wz;
+    const float cz = ((k & 4) ? dw[2] : -dw[2]) * wx * wy;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const float gt = dT[((long)t * P + p) * lddy + col];
+      a = fmaf(gt, cx * J[0][t] + cy * J[1][t] + cz * J[2][t], a);
+    }
+  }
+  ct.a = a;
+  return ct;
+}
+
+// fine / hashed levels: block = 16 points x (8 corners x 2 features), blockIdx.y = level - level0
+template <bool TANGENTS>
+__global__ __launch_bounds__(256) void encode_bwd_scatter_kernel(Grid g, const float* __restrict__ x, int P, int mode, int feat0,
+                                                                 const float* __restrict__ dY, int lddy,
+                                                                 const float* __restrict__ dT, float* __restrict__ dtable,
+                                                                 int level0) {
+  const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (p >= P) return;
+  const int k = (threadIdx.x >> 1) & 7, f = threadIdx.x & 1;
+  const int level = level0 + blockIdx.y;
+  const float xv[3] = {x[(long)p * 3], x[(long)p * 3 + 1], x[(long)p * 3 + 2]};
+  float pos[3], J[3][3];
+  grid_position(xv, mode, pos, J);
+  const CornerTerm ct = corner_term<TANGENTS>(g, level, k, f, pos, J, dY, dT, P, p, lddy, feat0);
+  atomicAdd(dtable + 2l * ct.idx + f, ct.a);
+}
+
+// coarse dense levels [0, n_coarse): accumulated in LDS over a long run of points, flushed with contiguous atomics
+template <bool TANGENTS>
+__global__ __launch_bounds__(256) void encode_bwd_coarse_kernel(Grid g, const float* __restrict__ x, int P, int mode, int feat0,
+                                                                const float* __restrict__ dY, int lddy,
+                                                                const float* __restrict__ dT, float* __restrict__ dtable,
+                                                                int n_coarse, int points_per_block) {
+  extern __shared__ float acc[];  // 2 * offset[n_coarse] floats
+  const int nflt = 2 * (int)g.offset[n_coarse];
+  for (int i = threadIdx.x; i < nflt; i += 256) acc[i] = 0.0f;
+  __syncthreads();
+  const int k = (threadIdx.x >> 1) & 7, f = threadIdx.x & 1;
+  const int p_beg = blockIdx.x * points_per_block;
+  const int p_end = min(P, p_beg + points_per_block);
+  for (int p = p_beg + (threadIdx.x >> 4); p < p_end; p += 16) {
+    const float xv[3] = {x[(long)p * 3], x[(long)p * 3 + 1], x[(long)p * 3 + 2]};
+    float pos[3], J[3][3];
+    grid_position(xv, mode, pos, J);
+    for (int level = 0; level < n_coarse; ++level) {
+      const CornerTerm ct = corner_term<TANGENTS>(g, level, k, f, pos, J, dY, dT, P, p, lddy, feat0);
+      atomicAdd(acc + 2 * ct.idx + f, ct.a);  // ds_add_f32
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nflt; i += 256) {
+    const float v = acc[i];
+    if (v != 0.0f) atomicAdd(dtable + i, v);
   }
 }
 
@@ -355,13 +452,40 @@ extern "C" int nsky_encode_bwd(const nsky_hashgrid_desc* d, const float* x, int3
   if (int rc = make_grid(d, g, "nsky_encode_bwd")) return rc;
   if (P == 0) return NSKY_OK;
   NSKY_CHECK_ARG(x && dY && dtable && P > 0, "nsky_encode_bwd: null argument");
-  NSKY_CHECK_ARG(lddy % 2 == 0 && ((include_x ? 3 : 0) + 6 * pe_freqs) % 2 == (include_x ? 1 : 0), "nsky_encode_bwd: layout");
-  dim3 grid(ceil_div(P, PB));
-  if (dT)
-    hipLaunchKernelGGL(encode_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, g, x, P, mode, include_x, pe_freqs, pe_max_exp, dY, lddy, dT, dtable, dx);
-  else
-    hipLaunchKernelGGL(encode_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, g, x, P, mode, include_x, pe_freqs, pe_max_exp, dY, lddy, dT, dtable, dx);
-  NSKY_CHECK_LAUNCH("nsky_encode_bwd");
+  NSKY_CHECK_ARG(mode >= 0 && mode <= 2 && pe_freqs >= 0 && pe_freqs <= 6, "nsky_encode_bwd: bad mode/pe_freqs");
+  hipStream_t s = (hipStream_t)stream;
+  const int feat0 = (include_x ? 3 : 0) + 6 * pe_freqs;
+  // coarse levels whose slabs fit together in LDS (<= 144 KiB) are privatised per workgroup
+  int n_coarse = 0;
+  while (n_coarse < g.n_levels && (size_t)g.offset[n_coarse + 1] * 2 * sizeof(float) <= 144 * 1024) ++n_coarse;
+  if (n_coarse > 0) {
+    const int blocks = 256;
+    const int ppb = ((P + blocks - 1) / blocks + 15) / 16 * 16;
+    const size_t smem = (size_t)g.offset[n_coarse] * 2 * sizeof(float);
+    dim3 grid(ceil_div(P, ppb));
+    if (dT) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_coarse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL(encode_bwd_coarse_kernel<true>, grid, dim3(256), smem, s, g, x, P, mode, feat0, dY, lddy, dT, dtable, n_coarse, ppb);
+    } else {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_coarse_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL(encode_bwd_coarse_kernel<false>, grid, dim3(256), smem, s, g, x, P, mode, feat0, dY, lddy, dT, dtable, n_coarse, ppb);
+    }
+    NSKY_CHECK_LAUNCH("nsky_encode_bwd(coarse)");
+  }
+  if (n_coarse < g.n_levels) {
+    dim3 grid(ceil_div(P, 16), g.n_levels - n_coarse);
+    if (dT)
+      hipLaunchKernelGGL(encode_bwd_scatter_kernel<true>, grid, dim3(256), 0, s, g, x, P, mode, feat0, dY, lddy, dT, dtable, n_coarse);
+    else
+      hipLaunchKernelGGL(encode_bwd_scatter_kernel<false>, grid, dim3(256), 0, s, g, x, P, mode, feat0, dY, lddy, dT, dtable, n_coarse);
+    NSKY_CHECK_LAUNCH("nsky_encode_bwd(scatter)");
+  }
+  if (dx) {  // first-order input gradient (lane = point kernel, no table traffic)
+    dim3 grid(ceil_div(P, PB));
+    hipLaunchKernelGGL(encode_bwd_kernel<false>, grid, dim3(256), 0, s, g, x, P, mode, include_x, pe_freqs, pe_max_exp, dY, lddy,
+                       (const float*)nullptr, (float*)nullptr, dx);
+    NSKY_CHECK_LAUNCH("nsky_encode_bwd(dx)");
+  }
   return NSKY_OK;
 }
 
