@@ -71,6 +71,7 @@ typedef struct nsky_gemm_desc {
   int32_t row_mod;   /* 0 = M */
   int32_t k_splits;  /* 0/1 = none */
   float beta;        /* C = result + beta * C_old (non-split only; 0 or 1) */
+  float* a_rowsum;   /* optional [M]: ACCUMULATES sum_k A(m,k) (bias gradient when A = dZ^T); atomics */
 } nsky_gemm_desc;
 
 int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream);

@@ -238,7 +238,7 @@ struct TileLoader {
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool AK, bool BKC>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                        float* __restrict__ C, int M, int N, int K, int lda, int ldb,
-                                                       int ldc, int k_split_len, int vec4, EpiCtx e) {
+                                                       int ldc, int k_split_len, int vec4, float* __restrict__ a_rowsum, EpiCtx e) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -273,11 +273,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
   __syncthreads();
 
   int cur = 0;
+  float rs_acc = 0.0f;
   for (int t = 0; t < ntiles; ++t) {
     const bool more = (t + 1 < ntiles);
     if (more) {
       la.load(A, lda, m0, M, kbeg + (t + 1) * BK, kend, tid);
       lb.load(B, ldb, n0, N, kbeg + (t + 1) * BK, kend, tid);
+    }
+    if (a_rowsum != nullptr && blockIdx.y == 0 && tid < BM) {
+      // bias gradient for free: sum_k A(m,k) of this K tile (A = dZ^T in the weight-gradient GEMM)
+      const float* col = As + cur * BK * LDA_S + tid;
+      float sacc = 0.0f;
+#pragma unroll
+      for (int kk = 0; kk < BK; ++kk) sacc += col[kk * LDA_S];
+      rs_acc += sacc;
     }
     const float* as = As + cur * BK * LDA_S + (lane >> 5) * LDA_S + wm * WM + (lane & 31);
     const float* bs = Bs + cur * BK * LDB_S + (lane >> 5) * LDB_S + wn * WN + (lane & 31);
@@ -300,6 +309,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
     __syncthreads();
     cur ^= 1;
   }
+
+  if (a_rowsum != nullptr && blockIdx.y == 0 && tid < BM && m0 + tid < M) atomicAdd(a_rowsum + m0 + tid, rs_acc);
 
   // Epilogue: park the accumulators in LDS (the operand buffers are dead after the last barrier),
   // then sweep the tile row-major so C, the aux operands and the side outputs move as whole rows.
@@ -343,7 +354,7 @@ void launch(const nsky_gemm_desc* d, const EpiCtx& e, int splits, int k_split_le
   dim3 grid(ceil_div(d->M, BM), ceil_div(d->N, BN), splits);
 #define NSKY_GEMM_LAUNCH(AK, BKC)                                                                              \
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, AK, BKC>), grid, dim3(256), 0, s, d->A, d->B, \
-                     d->C, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, k_split_len, vec4, e)
+                     d->C, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, k_split_len, vec4, d->a_rowsum, e)
   if (d->a_kcontig && d->b_kcontig) NSKY_GEMM_LAUNCH(true, true);
   else if (d->a_kcontig && !d->b_kcontig) NSKY_GEMM_LAUNCH(true, false);
   else if (!d->a_kcontig && d->b_kcontig) NSKY_GEMM_LAUNCH(false, true);

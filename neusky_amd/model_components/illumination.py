@@ -115,17 +115,30 @@ class RENIField(nn.Module):
         x = torch.stack([dxy.norm(dim=-1), dz], -1)
         return cond, x
 
+    def _decode(self, cond: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        x = torch.cat([x, nerf_encoding(x, 2, 2.0)], -1)
+        x = torch.nn.functional.pad(x, (0, (-x.shape[1]) % 4)).contiguous()
+        cond = torch.nn.functional.pad(cond, (0, (-cond.shape[1]) % 4)).contiguous()
+        return torch.exp(self.network(x, cond, train_weights=not self.config.fixed_decoder))  # unnormalise (log-domain HDR)
+
+    def forward_grid(self, directions: torch.Tensor, latent_codes: torch.Tensor, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """every latent code against every direction: directions [D,3], latent_codes [U,L,3], scale [U] -> [U,D,3].
+        Same arithmetic as forward() on the U*D pairs, built by broadcasting instead of gathering latents per pair."""
+        U, L, _ = latent_codes.shape
+        D = directions.shape[0]
+        zxy, zz = latent_codes[..., :2], latent_codes[..., 2]
+        dxy, dz = directions[:, :2], directions[:, 2]
+        dot = torch.einsum("uln,dn->udl", zxy, dxy)
+        cond = torch.stack([zxy.norm(dim=-1)[:, None, :].expand(U, D, L), zz[:, None, :].expand(U, D, L), dot], -1).reshape(U * D, 3 * L)
+        x = torch.stack([dxy.norm(dim=-1), dz], -1)[None].expand(U, D, 2).reshape(U * D, 2)
+        out = self._decode(cond, x).reshape(U, D, 3)
+        return out * scale[:, None, None] if scale is not None else out
+
     def forward(self, directions: torch.Tensor, latent_codes: torch.Tensor, scale: Optional[torch.Tensor] = None,
                 rotation: Optional[torch.Tensor] = None) -> torch.Tensor:
         """directions [B,3], latent_codes [B,L,3], scale [B] -> HDR radiance [B,3] (already unnormalised)."""
         if rotation is not None:  # z-axis rotation of the illumination (render_animation.py:196-207)
             directions = directions @ (rotation if rotation.dim() == 2 else rotation).transpose(-1, -2)
         cond, x = self.invariant_inputs(latent_codes, directions)
-        x = torch.cat([x, nerf_encoding(x, 2, 2.0)], -1)
-        pad = (-x.shape[1]) % 4
-        x = torch.nn.functional.pad(x, (0, pad)).contiguous()
-        cpad = (-cond.shape[1]) % 4
-        cond = torch.nn.functional.pad(cond, (0, cpad)).contiguous()
-        rgb = self.network(x, cond, train_weights=not self.config.fixed_decoder)
-        out = torch.exp(rgb)  # unnormalise (log-domain HDR)
+        out = self._decode(cond, x)
         return out * scale[:, None] if scale is not None else out

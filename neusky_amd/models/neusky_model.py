@@ -236,10 +236,13 @@ class NeuSkyFactoModel(nn.Module):
         dirs = dirs.to(self.device).contiguous()  # :458
         unique, inverse = torch.unique(camera_indices, return_inverse=True)  # :461-463
         U, D = unique.shape[0], dirs.shape[0]
-        ci = unique[:, None].expand(U, D).reshape(-1)
-        dd = dirs[None].expand(U, D, 3).reshape(-1, 3)
-        rot = rotation if (rotation is None or rotation.dim() == 2) else rotation[ci]
-        cols = self.illumination_field(dd, latents[ci], scales[ci], rot).reshape(U, D, 3)  # :488-510
+        if rotation is None:
+            cols = self.illumination_field.forward_grid(dirs, latents[unique], scales[unique])  # :488-510, no per-pair gather
+        else:
+            ci = unique[:, None].expand(U, D).reshape(-1)
+            dd = dirs[None].expand(U, D, 3).reshape(-1, 3)
+            rot = rotation if rotation.dim() == 2 else rotation[ci]
+            cols = self.illumination_field(dd, latents[ci], scales[ci], rot).reshape(U, D, 3)
         rot_r = rotation if (rotation is None or rotation.dim() == 2) else rotation[camera_indices]
         bg = self.illumination_field(ray_directions, latents[camera_indices], scales[camera_indices], rot_r)  # :535-549
         return dirs, cols, inverse.to(torch.int32), bg

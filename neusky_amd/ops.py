@@ -36,11 +36,21 @@ def _splits(M: int) -> int:
     return max(1, min(512, (M + 2047) // 2048))
 
 
-def grad_weight(dZ, X, M, n_out, k_in, like):
-    """dW[n_out, k_in] = dZ[:M, :n_out]^T @ X[:M, :k_in] (split-K over M, atomically reduced)."""
+def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None):
+    """dW[n_out, k_in] = dZ[:M, :n_out]^T @ X[:M, :k_in] (split-K over M, atomically reduced).
+    With bias_like, also returns db[n_out] = column sums of dZ (over the first `bias_rows` rows when the tail rows are
+    tangent rows that carry no bias) from the same pass over dZ."""
     dW = torch.zeros_like(like)
-    hip.gemm(dZ, X, dW, n_out, k_in, M, a_kcontig=False, b_kcontig=False, k_splits=_splits(M))
-    return dW
+    if bias_like is None:
+        hip.gemm(dZ, X, dW, n_out, k_in, M, a_kcontig=False, b_kcontig=False, k_splits=_splits(M))
+        return dW
+    db = torch.zeros_like(bias_like)
+    if bias_rows is None or bias_rows == M:
+        hip.gemm(dZ, X, dW, n_out, k_in, M, a_kcontig=False, b_kcontig=False, k_splits=_splits(M), a_rowsum=db)
+    else:
+        hip.gemm(dZ, X, dW, n_out, k_in, M, a_kcontig=False, b_kcontig=False, k_splits=_splits(M))
+        hip.colsum(dZ, bias_rows, n_out, db)
+    return dW, db
 
 
 def grad_bias(dZ, M, n_out, like):
@@ -111,8 +121,7 @@ class DenseFn(torch.autograd.Function):
         dZ = dY.contiguous()
         if act == "relu":
             dZ = dZ * (Y > 0)
-        dW = grad_weight(dZ, X, M, n_out, K, Wp)
-        db = grad_bias(dZ, M, n_out, bp)
+        dW, db = grad_weight(dZ, X, M, n_out, K, Wp, bp)
         dX = None
         if need_dx:
             dX = torch.empty(M, K, device=X.device)
@@ -193,8 +202,7 @@ class FilmSirenFn(torch.autograd.Function):
         d_res = d_res.contiguous()
         n_out_p = ow.shape[0]
         if train_w:
-            grads[o + 2 * n_film] = grad_weight(d_res, ys[-1], M, n_out_p, H, ow)
-            grads[o + 2 * n_film + 1] = grad_bias(d_res, M, n_out_p, ob)
+            grads[o + 2 * n_film], grads[o + 2 * n_film + 1] = grad_weight(d_res, ys[-1], M, n_out_p, H, ow, ob)
         dFP = torch.empty(M, 2 * n_film * H, device=dev)
         d_x = None
         # walk the FiLM layers backwards; each dX GEMM applies the FiLM backward epilogue of the layer below
@@ -207,8 +215,7 @@ class FilmSirenFn(torch.autograd.Function):
             y_in = ys[i - 1] if i > 0 else x
             k_in = fw[i].shape[1]
             if train_w:
-                grads[o + 2 * i] = grad_weight(dZ, y_in, M, H, k_in, fw[i])
-                grads[o + 2 * i + 1] = grad_bias(dZ, M, H, fb[i])
+                grads[o + 2 * i], grads[o + 2 * i + 1] = grad_weight(dZ, y_in, M, H, k_in, fw[i], fb[i])
             if i == 0:
                 if ctx.need_dx:  # gradient w.r.t. the encoded direction rows (DDF multi-view rays, ddf_model.py:297-322)
                     d_x = torch.empty(M, k_in, device=dev)
@@ -224,8 +231,7 @@ class FilmSirenFn(torch.autograd.Function):
         # mapping network
         NF = 2 * n_film * H
         if train_w:
-            grads[2 * n_map] = grad_weight(dFP, hs[-1], M, NF, Hm, mwo)
-            grads[2 * n_map + 1] = grad_bias(dFP, M, NF, mbo)
+            grads[2 * n_map], grads[2 * n_map + 1] = grad_weight(dFP, hs[-1], M, NF, Hm, mwo, mbo)
         dpre = torch.empty(M, Hm, device=dev)
         grad_input(dFP, mwo, M, Hm, NF, dpre, epi=hip.EPI_BWD_LEAKY, p0=0.2, aux0=hs[-1])
         d_cond = None
@@ -233,8 +239,7 @@ class FilmSirenFn(torch.autograd.Function):
             h_in = hs[i - 1] if i > 0 else cond
             k_in = mw[i].shape[1]
             if train_w:
-                grads[2 * i] = grad_weight(dpre, h_in, M, Hm, k_in, mw[i])
-                grads[2 * i + 1] = grad_bias(dpre, M, Hm, mb[i])
+                grads[2 * i], grads[2 * i + 1] = grad_weight(dpre, h_in, M, Hm, k_in, mw[i], mb[i])
             if i > 0:
                 nxt = torch.empty(M, Hm, device=dev)
                 grad_input(dpre, mw[i], M, Hm, Hm, nxt, epi=hip.EPI_BWD_LEAKY, p0=0.2, aux0=hs[i - 1])
@@ -302,16 +307,13 @@ class SDFAlbedoFn(torch.autograd.Function):
         if g_alb is not None:
             alb = ALB[:, :3]
             dpc2[:, :3] = g_alb * alb * (1.0 - alb)
-        dWc2 = grad_weight(dpc2, C1, N, 4, Hc, Wc2)
-        dbc2 = grad_bias(dpc2, N, 4, bc2)
+        dWc2, dbc2 = grad_weight(dpc2, C1, N, 4, Hc, Wc2, bc2)
         dpc1 = torch.empty(N, Hc, device=dev)
         grad_input(dpc2, Wc2, N, Hc, 4, dpc1, epi=hip.EPI_BWD_RELU, aux0=C1)
-        dWc1 = grad_weight(dpc1, C0, N, Hc, Hc, Wc1)
-        dbc1 = grad_bias(dpc1, N, Hc, bc1)
+        dWc1, dbc1 = grad_weight(dpc1, C0, N, Hc, Hc, Wc1, bc1)
         dpc0 = torch.empty(N, Hc, device=dev)
         grad_input(dpc1, Wc1, N, Hc, Hc, dpc0, epi=hip.EPI_BWD_RELU, aux0=C0)
-        dWc0 = grad_weight(dpc0, CIN, N, Hc, ldc, Wc0)
-        dbc0 = grad_bias(dpc0, N, Hc, bc0)
+        dWc0, dbc0 = grad_weight(dpc0, CIN, N, Hc, ldc, Wc0, bc0)
         dCIN = torch.empty(N, ldc, device=dev)
         grad_input(dpc0, Wc0, N, ldc, Hc, dCIN)
         # the sdf slot / pad columns of Wc0 are structural zeros: overwrite them with the upstream sdf gradient
@@ -320,8 +322,7 @@ class SDFAlbedoFn(torch.autograd.Function):
             dCIN[:, GF] = g_sdf
         dH = dCIN[:, :GF + 4]
         # ---- geo net, last layer (value rows)
-        dW2 = grad_weight(dH, A1[:N], N, GF + 4, Hd, W2)
-        db2 = grad_bias(dH, N, GF + 4, b2)
+        dW2, db2 = grad_weight(dH, A1[:N], N, GF + 4, Hd, W2, b2)
         dA1v = torch.empty(N, Hd, device=dev)
         grad_input(dH, W2, N, Hd, GF + 4, dA1v)
         # tangent rows of the last layer: grad_k = ta1_k . w_sdf
@@ -337,15 +338,13 @@ class SDFAlbedoFn(torch.autograd.Function):
         # ---- layer 1 (reverse over forward)
         D1 = torch.empty(4 * N, Hd, device=dev)
         hip.softplus_tangent_bwd(dA1v, S1, A1[N:], None, g_grad, w2s, beta, N, Hd, D1[:N], D1[N:])
-        dW1 = grad_weight(D1, A0, 4 * N, Hd, Hd, W1)
-        db1 = grad_bias(D1, N, Hd, b1)
+        dW1, db1 = grad_weight(D1, A0, 4 * N, Hd, Hd, W1, b1, bias_rows=N)
         dA0 = torch.empty(4 * N, Hd, device=dev)
         grad_input(D1, W1, 4 * N, Hd, Hd, dA0)
         # ---- layer 0
         D0 = torch.empty(4 * N, Hd, device=dev)
         hip.softplus_tangent_bwd(dA0[:N], S0, A0[N:], dA0[N:], None, None, beta, N, Hd, D0[:N], D0[N:])
-        dW0 = grad_weight(D0, ET, 4 * N, Hd, Kin, W0)
-        db0 = grad_bias(D0, N, Hd, b0)
+        dW0, db0 = grad_weight(D0, ET, 4 * N, Hd, Kin, W0, b0, bias_rows=N)
         dET = torch.empty(4 * N, Kin, device=dev)
         grad_input(D0, W0, 4 * N, Kin, Hd, dET)
         # x / PE columns of the colour-net input came straight from the encode row
@@ -394,8 +393,8 @@ class SDFValueFn(torch.autograd.Function):
             hip.gemm(g, A1, dw, 1, Hd, M, a_kcontig=False, b_kcontig=False, k_splits=_splits(M))
             dW2[GF] = dw[0]
             db2[GF] = g_sdf.sum()
-            dW1 = grad_weight(dZ1, A0, M, Hd, Hd, W1); db1 = grad_bias(dZ1, M, Hd, b1)
-            dW0 = grad_weight(dZ0, E, M, Hd, Kin, W0); db0 = grad_bias(dZ0, M, Hd, b0)
+            dW1, db1 = grad_weight(dZ1, A0, M, Hd, Hd, W1, b1)
+            dW0, db0 = grad_weight(dZ0, E, M, Hd, Kin, W0, b0)
         return dE, dW0, db0, dW1, db1, dW2, db2, None, None
 
 

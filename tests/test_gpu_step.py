@@ -109,18 +109,21 @@ def _module_grads(pipe):
 
 
 def test_parameter_gradients(step):
-    """bar per tensor: 2e-3 of its max + 3x the fp32-conditioning of its network, where the conditioning is the
-    largest relative distance between the float32 and float64 oracle gradients among that network's tensors
-    (SIREN chains with frequencies ~30 and hash grids at scale 2047 are ill-conditioned in fp32 for ANY evaluator)."""
+    """bar per tensor: 2e-3 of its max + the fp32 conditioning of that gradient, measured as the distance of the
+    float32 oracle from the float64 oracle (own tensor x3, or the median of its network x5 - a single fp32 sample can
+    sit atypically close to exact math).  SIREN chains with frequencies ~30 and hash grids at scale 2047 make some
+    gradients ill-conditioned in fp32 for ANY evaluator; the bar lets the HIP path be as far from exact math as the
+    reference's own fp32 arithmetic, not further."""
+    import statistics
     got = _module_grads(step["pipe"])
-    rel_gap = {}
+    rel_gap, per_net = {}, {}
     for k, ref in step["grads"].items():
         if ref is None or k.startswith("reni."):
             continue
         b = ref.reshape(-1)
-        gap = (step["grads32"][k].double().reshape(-1) - b).abs().max().item() / (b.abs().max().item() + 1e-30)
-        net = k.split(".")[0]
-        rel_gap[net] = max(rel_gap.get(net, 0.0), gap)
+        rel_gap[k] = (step["grads32"][k].double().reshape(-1) - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+        per_net.setdefault(k.split(".")[0], []).append(rel_gap[k])
+    med = {n: statistics.median(v) for n, v in per_net.items()}
     bad = []
     for k, ref in step["grads"].items():
         if k.startswith("reni.") or ref is None:
@@ -130,8 +133,8 @@ def test_parameter_gradients(step):
         a, b = gg.detach().cpu().double().reshape(-1), ref.reshape(-1)
         scale = b.abs().max().item()
         err = (a - b).abs().max().item()
-        bar = (2e-3 + 3.0 * rel_gap[k.split(".")[0]]) * scale + 1e-12
+        bar = (2e-3 + max(3.0 * rel_gap[k], 5.0 * med[k.split(".")[0]])) * scale + 1e-12
         if err > bar:
             bad.append((k, err, scale, bar))
     assert not bad, bad
-    assert max(rel_gap.values()) < 0.1, rel_gap  # the fp32 oracle itself must stay meaningful
+    assert max(med.values()) < 0.05, med  # the fp32 oracle itself must stay meaningful
