@@ -27,6 +27,7 @@ import torch.distributed as dist
 
 # fp32 matrix-core peak and HBM peak from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0
 RAYS, SAMPLES, DIRECTIONS, PROPOSAL = 1024, 96, 512, (256, 96)
 
 
@@ -47,7 +48,7 @@ class GemmTimer:
     """HIP-event timing of every launch of ONE gemm kernel variant (the dominant one) on torch's current stream."""
 
     def __init__(self, variant):
-        self.variant = variant  # (a_kcontig, b_kcontig, wide)
+        self.variant = variant  # (a_kcontig, b_kcontig, wide, precision)
         self.records = []
 
     def install(self):
@@ -56,7 +57,7 @@ class GemmTimer:
         timer = self
 
         def timed(A, B, Cout, M, N, K, **kw):
-            v = (bool(kw.get("a_kcontig", True)), bool(kw.get("b_kcontig", True)), N > 64)
+            v = (bool(kw.get("a_kcontig", True)), bool(kw.get("b_kcontig", True)), N > 64, int(kw.get("precision", 0)))
             if v != timer.variant:
                 return timer._orig(A, B, Cout, M, N, K, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -168,7 +169,10 @@ def main():
     for i in range(args.warmup):
         rb, b = batches[i]
         train_iteration(pipe, opt, 1000 + i, ray_bundle=rb, batch=b)
-    timer = GemmTimer((True, True, True))  # forward NT layer kernel gemm_f32_kernel<128,128,2,2,true,true>
+    import neusky_amd.ops as ops
+    from neusky_amd import hip as _hip
+    # dominant kernel of the step = the forward (NT layout) dense-layer kernel of the active precision policy
+    timer = GemmTimer((True, True, True, ops.FWD_PRECISION))
     timer.install()
     barrier()
     t0 = time.perf_counter()
@@ -187,19 +191,27 @@ def main():
     if rank == 0:
         rays_total = RAYS * world * args.steps
         achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        if ops.FWD_PRECISION == _hip.PREC_F32:
+            kernel = "gemm_f32_kernel<128,128,2,2,true,true,32,2> (exact fp32 MFMA v_mfma_f32_32x32x2_f32, forward NT layout)"
+            peak, dtype = PEAK_F32_MFMA_TFLOPS, "f32"
+            peak_note = "fp32 matrix peak 157.3 TFLOP/s (MI355X_MICROARCH.md)"
+        else:
+            kernel = "gemm_bf16s_kernel<3,true,true> (fp32 operands split on the fly into 3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate)"
+            peak, dtype = PEAK_BF16_MFMA_TFLOPS / 6.0, "f32 (3-term bf16 split on the matrix cores)"
+            peak_note = "bf16 dense MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32-equivalent product = 416.7 TFLOP/s of algorithmic FLOPs"
         line = {
             "metric": "train rays/sec on NeRF-OSR lk2 @1024 rays x 96 samples",
             "value": rays_total / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": dtype, "data": "synthetic",
             "config": {"workload": "full NeuSky train step (BASELINE configs[2]): 1024 rays/GPU x 96 samples, proposal 256+96, "
                                    "512 illumination directions (256 upper-hemisphere DDF queries/ray), latent 100x3, "
                                    "hash L16 F2 T2^19 x2, 256-wide MLPs; fwd + losses + bwd + all-reduce + 5 Adam groups",
                        "rays_per_gpu": RAYS, "samples_per_ray": SAMPLES, "illumination_directions": DIRECTIONS,
                        "parallelism": f"ray-sharded dp{world}", "final_loss": float(loss)},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "gemm_f32_kernel<128,128,2,2,true,true> (fp32 MFMA dense layer, forward NT layout)",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None, "kernel": kernel, "peak_note": peak_note,
+                         "precision_policy": ops._POLICY,
                          "launches_timed": n_launch, "avg_launch_ms": k_ms / max(n_launch, 1),
                          "algorithmic_flops_per_launch": k_flops / max(n_launch, 1)},
         }

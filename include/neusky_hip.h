@@ -55,6 +55,11 @@ enum {
   NSKY_EPI_EXP = 10        /* C = exp(min(v, p0)) */
 };
 
+/* contraction arithmetic: exact fp32 MFMA (default); or operands split on the fly into 2 / 3 bf16 terms and
+ * rebuilt from 3 / 6 bf16 MFMAs with fp32 accumulation (relative product error ~2^-16 / ~2^-22).  N <= 64 always
+ * runs the fp32 kernel. */
+enum { NSKY_PREC_F32 = 0, NSKY_PREC_BF16X2 = 2, NSKY_PREC_BF16X3 = 3 };
+
 typedef struct nsky_gemm_desc {
   const float* A; const float* B; float* C;
   int32_t M, N, K;
@@ -72,6 +77,7 @@ typedef struct nsky_gemm_desc {
   int32_t k_splits;  /* 0/1 = none */
   float beta;        /* C = result + beta * C_old (non-split only; 0 or 1) */
   float* a_rowsum;   /* optional [M]: ACCUMULATES sum_k A(m,k) (bias gradient when A = dZ^T); atomics */
+  int32_t precision; /* NSKY_PREC_*: arithmetic of the contraction (operands and result stay fp32 in memory) */
 } nsky_gemm_desc;
 
 int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream);

@@ -10,6 +10,8 @@
 // segment, the (BM+2) stride keeps the scattered ds_write_b32 at 2-way = free).  Global->LDS is
 // register staged and software pipelined: tile t+1 is fetched to VGPRs before the 64 MFMAs of tile
 // t and written to the other LDS buffer after them, one barrier per tile.
+#include <stdlib.h>
+
 #include "common.h"
 #include "../../include/neusky_hip.h"
 
@@ -17,7 +19,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BK = 32;
+constexpr int BK_DEFAULT = 32;
 
 struct EpiCtx {
   const float* bias;
@@ -192,10 +194,11 @@ __device__ __forceinline__ void epilogue_store4(const EpiCtx& e, float* C, int l
   st4(dst, make_float4(r[0], r[1], r[2], r[3]));
 }
 
-template <int BT, bool KCONTIG>
+template <int BT, bool KCONTIG, int BK>
 struct TileLoader {
   // BT x BK tile; F4 float4 per thread
   static constexpr int F4 = BT * BK / 4 / 256;
+  static constexpr int KQ = BK / 4;  // float4 per row (k-contiguous layout)
   float4 v[F4];
 
   __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int t0, int T, int k0, int kend, int tid) {
@@ -204,7 +207,7 @@ struct TileLoader {
       int f = it * 256 + tid;
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
       if (KCONTIG) {
-        int row = f >> 3, kq = f & 7;
+        int row = f / KQ, kq = f % KQ;
         int t = t0 + row, k = k0 + kq * 4;
         if (t < T && k < kend) x = *reinterpret_cast<const float4*>(P + (long)t * ld + k);
       } else {
@@ -222,7 +225,7 @@ struct TileLoader {
     for (int it = 0; it < F4; ++it) {
       int f = it * 256 + tid;
       if (KCONTIG) {
-        int row = f >> 3, kq = f & 7;
+        int row = f / KQ, kq = f % KQ;
         float* s = S + (kq * 4) * LD + row;
         s[0] = v[it].x; s[LD] = v[it].y; s[2 * LD] = v[it].z; s[3 * LD] = v[it].w;
       } else {
@@ -235,15 +238,16 @@ struct TileLoader {
   }
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool AK, bool BKC>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool AK, bool BKC, int BK, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                        float* __restrict__ C, int M, int N, int K, int lda, int ldb,
                                                        int ldc, int k_split_len, int vec4, float* __restrict__ a_rowsum, EpiCtx e) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int LDA_S = BM + 2, LDB_S = BN + 2;
-  __shared__ float smem[2 * BK * (LDA_S + LDB_S)];
+  constexpr int SMEM_MAIN = 2 * BK * (LDA_S + LDB_S), SMEM_EPI = WM * BN;
+  __shared__ float smem[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
   float* As = smem;
   float* Bs = smem + 2 * BK * LDA_S;
 
@@ -262,8 +266,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  TileLoader<BM, AK> la;
-  TileLoader<BN, BKC> lb;
+  TileLoader<BM, AK, BK> la;
+  TileLoader<BN, BKC, BK> lb;
   if (ntiles > 0) {
     la.load(A, lda, m0, M, kbeg, kend, tid);
     lb.load(B, ldb, n0, N, kbeg, kend, tid);
@@ -290,17 +294,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
     }
     const float* as = As + cur * BK * LDA_S + (lane >> 5) * LDA_S + wm * WM + (lane & 31);
     const float* bs = Bs + cur * BK * LDB_S + (lane >> 5) * LDB_S + wn * WN + (lane & 31);
+    // fragment reads run one k-step ahead of the MFMAs that consume them (LDS latency hidden behind the
+    // 4 x 64-cycle MFMAs of the current step)
+    float a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[0][i] = as[i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[0][j] = bs[j * 32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      float a[TM], b[TN];
+      if (kk + 1 < BK / 2) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = as[kk * 2 * LDA_S + i * 32];
+        for (int i = 0; i < TM; ++i) a[(kk + 1) & 1][i] = as[(kk + 1) * 2 * LDA_S + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = bs[kk * 2 * LDB_S + j * 32];
+        for (int j = 0; j < TN; ++j) b[(kk + 1) & 1][j] = bs[(kk + 1) * 2 * LDB_S + j * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (hipcc otherwise re-serialises them)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) {
       la.store(As + (cur ^ 1) * BK * LDA_S, tid);
@@ -312,48 +327,277 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
 
   if (a_rowsum != nullptr && blockIdx.y == 0 && tid < BM && m0 + tid < M) atomicAdd(a_rowsum + m0 + tid, rs_acc);
 
-  // Epilogue: park the accumulators in LDS (the operand buffers are dead after the last barrier),
-  // then sweep the tile row-major so C, the aux operands and the side outputs move as whole rows.
-  float* Cs = smem;  // BM*BN floats <= 2*BK*(LDA_S+LDB_S)
+  // Epilogue: park the accumulators in LDS (the operand buffers are dead after the last barrier), one
+  // wave-row (WM rows) at a time, and sweep them row-major so C, the aux operands and the side outputs move
+  // as whole rows.
+  float* Cs = smem;
+  const bool atomic = gridDim.z > 1;
+#pragma unroll
+  for (int pass = 0; pass < WAVES_M; ++pass) {
+    if (pass > 0) __syncthreads();
+    if (wm == pass) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int cl = wn * WN + j * 32 + (lane & 31);
+            Cs[rl * BN + cl] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+    const int mrow0 = m0 + pass * WM;
+    if (vec4 && !atomic) {
+      constexpr int C4 = BN / 4;
+      for (int c = tid; c < WM * C4; c += 256) {
+        const int rl = c / C4, cl = (c % C4) * 4;
+        const int row = mrow0 + rl, col = n0 + cl;
+        if (row < M && col < N) epilogue_store4(e, C, ldc, row, col, *reinterpret_cast<const float4*>(Cs + rl * BN + cl));
+      }
+    } else {
+      for (int idx = tid; idx < WM * BN; idx += 256) {
+        const int rl = idx / BN, cl = idx % BN;
+        const int row = mrow0 + rl, col = n0 + cl;
+        if (row < M && col < N) {
+          const float v = Cs[idx];
+          if (atomic)
+            atomicAdd(C + (long)row * ldc + col, v);
+          else
+            epilogue_store(e, C, ldc, row, col, v);
+        }
+      }
+    }
+  }
+}
+
+// =================================================================================================
+// Split-bf16 variant: every fp32 operand element is split into NS bf16 terms (hi, [mid,] lo) while it is
+// staged into LDS, and the product is rebuilt from 3 (NS=2: hh + hl + lh, ~2^-16 relative) or 6 (NS=3:
+// + mm + hl' + l'h, ~fp32) v_mfma_f32_32x32x16_bf16 per output tile and 16-deep k-step, accumulated in fp32.
+// One bf16 MFMA does 16x the MACs of v_mfma_f32_32x32x2_f32 in half the cycles, so the rebuilt product runs at
+// 32/3 (NS=2) or 32/6 (NS=3) times the fp32 matrix rate.  Used for the backward GEMMs (gradients tolerate 1e-5).
+// LDS image per operand and term: [128 rows][32 k] bf16, 80-byte rows (64 B + 16 B pad): the 16-byte operand
+// fragments (8 consecutive k of one row) of any 16-lane group fall on 16 distinct 16-byte bank slots.
+// =================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SROW = 40;  // bf16 elements per LDS row (32 + 8 pad)
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  f32x2 v = {a, b};
+  bf16x2 r = __builtin_convertvector(v, bf16x2);
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ float bf16_hi_as_f32(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_lo_as_f32(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// split 4 floats into NS terms of 4 bf16 each (8 bytes per term)
+template <int NS>
+__device__ __forceinline__ void split4(const float x[4], uint2 out[NS]) {
+  float r[4] = {x[0], x[1], x[2], x[3]};
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    const uint32_t p01 = pack2(r[0], r[1]), p23 = pack2(r[2], r[3]);
+    out[t] = make_uint2(p01, p23);
+    if (t + 1 < NS) {
+      r[0] -= bf16_hi_as_f32(p01); r[1] -= bf16_lo_as_f32(p01);
+      r[2] -= bf16_hi_as_f32(p23); r[3] -= bf16_lo_as_f32(p23);
+    }
+  }
+}
+
+template <int NS, bool KCONTIG>
+struct SplitLoader {  // 128 x 32 fp32 tile -> NS bf16 images [128][SROW]
+  float4 v[4];
+  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int t0, int T, int k0, int kend, int tid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (KCONTIG) {
+        const int f = it * 256 + tid;
+        const int row = f >> 3, kq = f & 7;
+        const int t = t0 + row, k = k0 + kq * 4;
+        if (t < T && k < kend) x = *reinterpret_cast<const float4*>(P + (long)t * ld + k);
+      } else {  // 4(k) x 4(t) block per thread: kb = tid % 8, mb = tid / 8; load row k0 + 4 kb + it
+        const int kb = tid & 7, mb = tid >> 3;
+        const int k = k0 + 4 * kb + it, t = t0 + 4 * mb;
+        if (k < kend && t < T) x = *reinterpret_cast<const float4*>(P + (long)k * ld + t);
+      }
+      v[it] = x;
+    }
+  }
+  // images: S + term * (128 * SROW) bf16 ; rowsum (optional, LDS float[128]) accumulates sum_k of the tile rows
+  __device__ __forceinline__ void store(__bf16* S, int tid, float* rowsum) const {
+    if (KCONTIG) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int f = it * 256 + tid;
+        const int row = f >> 3, kq = f & 7;
+        const float x[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+        uint2 o[NS];
+        split4<NS>(x, o);
+#pragma unroll
+        for (int t = 0; t < NS; ++t) *reinterpret_cast<uint2*>(S + t * 128 * SROW + row * SROW + kq * 4) = o[t];
+        if (rowsum) atomicAdd(rowsum + row, (x[0] + x[1]) + (x[2] + x[3]));
+      }
+    } else {
+      const int kb = tid & 7, mb = tid >> 3;
+      const float m[4][4] = {{v[0].x, v[1].x, v[2].x, v[3].x}, {v[0].y, v[1].y, v[2].y, v[3].y},
+                             {v[0].z, v[1].z, v[2].z, v[3].z}, {v[0].w, v[1].w, v[2].w, v[3].w}};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint2 o[NS];
+        split4<NS>(m[i], o);
+#pragma unroll
+        for (int t = 0; t < NS; ++t) *reinterpret_cast<uint2*>(S + t * 128 * SROW + (4 * mb + i) * SROW + 4 * kb) = o[t];
+        if (rowsum) atomicAdd(rowsum + 4 * mb + i, (m[i][0] + m[i][1]) + (m[i][2] + m[i][3]));
+      }
+    }
+  }
+};
+
+template <int NS, bool AK, bool BKC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                           float* __restrict__ C, int M, int N, int K, int lda, int ldb,
+                                                           int ldc, int k_split_len, int vec4, float* __restrict__ a_rowsum,
+                                                           EpiCtx e) {
+  constexpr int BM = 128, BN = 128, BKT = 32, WM = 64, WN = 64, TM = 2, TN = 2;
+  constexpr int IMG = 128 * SROW;  // bf16 elements per image
+  constexpr int SMEM_MAIN = 2 * NS * IMG * 2 + 128 * 4, SMEM_EPI = WM * BN * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
+  __bf16* As = reinterpret_cast<__bf16*>(smem_raw);
+  __bf16* Bs = As + NS * IMG;
+  float* rsum = reinterpret_cast<float*>(smem_raw + 2 * NS * IMG * 2);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kbeg = blockIdx.z * k_split_len;
+  const int kend = min(K, kbeg + k_split_len);
+  const int ntiles = (kend - kbeg + BKT - 1) / BKT;
+  const bool want_rs = (a_rowsum != nullptr) && blockIdx.y == 0;
+  if (want_rs && tid < 128) rsum[tid] = 0.0f;
+
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rl = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int cl = wn * WN + j * 32 + (lane & 31);
-        Cs[rl * BN + cl] = acc[i][j][r];
-      }
-  __syncthreads();
-  const bool atomic = gridDim.z > 1;
-  if (vec4 && !atomic) {
-    constexpr int C4 = BN / 4;
-    for (int c = tid; c < BM * C4; c += 256) {
-      const int rl = c / C4, cl = (c % C4) * 4;
-      const int row = m0 + rl, col = n0 + cl;
-      if (row < M && col < N) epilogue_store4(e, C, ldc, row, col, *reinterpret_cast<const float4*>(Cs + rl * BN + cl));
-    }
-    return;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  SplitLoader<NS, AK> la;
+  SplitLoader<NS, BKC> lb;
+  if (ntiles > 0) {
+    la.load(A, lda, m0, M, kbeg, kend, tid);
+    lb.load(B, ldb, n0, N, kbeg, kend, tid);
   }
-  for (int idx = tid; idx < BM * BN; idx += 256) {
-    const int rl = idx / BN, cl = idx % BN;
-    const int row = m0 + rl, col = n0 + cl;
-    if (row < M && col < N) {
-      const float v = Cs[idx];
-      if (atomic)
-        atomicAdd(C + (long)row * ldc + col, v);
-      else
-        epilogue_store(e, C, ldc, row, col, v);
+  const int frow = lane & 31, fh = lane >> 5;
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();  // previous tile's fragment reads are done
+    la.store(As, tid, want_rs ? rsum : nullptr);
+    lb.store(Bs, tid, nullptr);
+    __syncthreads();
+    if (t + 1 < ntiles) {
+      la.load(A, lda, m0, M, kbeg + (t + 1) * BKT, kend, tid);
+      lb.load(B, ldb, n0, N, kbeg + (t + 1) * BKT, kend, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[NS][TM], bfr[NS][TN];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[s][i] = *reinterpret_cast<const bf16x8*>(As + s * IMG + (wm * WM + i * 32 + frow) * SROW + ks * 16 + fh * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bfr[s][j] = *reinterpret_cast<const bf16x8*>(Bs + s * IMG + (wn * WN + j * 32 + frow) * SROW + ks * 16 + fh * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          // smallest cross terms first
+          if (NS == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  __syncthreads();
+  if (want_rs && tid < 128 && m0 + tid < M) atomicAdd(a_rowsum + m0 + tid, rsum[tid]);
+  __syncthreads();
+
+  float* Cs = reinterpret_cast<float*>(smem_raw);
+  const bool atomic = gridDim.z > 1;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass > 0) __syncthreads();
+    if (wm == pass) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int cl = wn * WN + j * 32 + (lane & 31);
+            Cs[rl * BN + cl] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+    const int mrow0 = m0 + pass * WM;
+    if (vec4 && !atomic) {
+      constexpr int C4 = BN / 4;
+      for (int c = tid; c < WM * C4; c += 256) {
+        const int rl = c / C4, cl = (c % C4) * 4;
+        const int row = mrow0 + rl, col = n0 + cl;
+        if (row < M && col < N) epilogue_store4(e, C, ldc, row, col, *reinterpret_cast<const float4*>(Cs + rl * BN + cl));
+      }
+    } else {
+      for (int idx = tid; idx < WM * BN; idx += 256) {
+        const int rl = idx / BN, cl = idx % BN;
+        const int row = mrow0 + rl, col = n0 + cl;
+        if (row < M && col < N) {
+          const float v = Cs[idx];
+          if (atomic)
+            atomicAdd(C + (long)row * ldc + col, v);
+          else
+            epilogue_store(e, C, ldc, row, col, v);
+        }
+      }
     }
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int NS>
+void launch_split(const nsky_gemm_desc* d, const EpiCtx& e, int splits, int k_split_len, int vec4, hipStream_t s) {
+  dim3 grid(ceil_div(d->M, 128), ceil_div(d->N, 128), splits);
+#define NSKY_SGEMM_LAUNCH(AK, BKC)                                                                          \
+  hipLaunchKernelGGL((gemm_bf16s_kernel<NS, AK, BKC>), grid, dim3(256), 0, s, d->A, d->B, d->C, d->M, d->N, \
+                     d->K, d->lda, d->ldb, d->ldc, k_split_len, vec4, d->a_rowsum, e)
+  if (d->a_kcontig && d->b_kcontig) NSKY_SGEMM_LAUNCH(true, true);
+  else if (d->a_kcontig && !d->b_kcontig) NSKY_SGEMM_LAUNCH(true, false);
+  else if (!d->a_kcontig && d->b_kcontig) NSKY_SGEMM_LAUNCH(false, true);
+  else NSKY_SGEMM_LAUNCH(false, false);
+#undef NSKY_SGEMM_LAUNCH
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int OCC>
 void launch(const nsky_gemm_desc* d, const EpiCtx& e, int splits, int k_split_len, int vec4, hipStream_t s) {
   dim3 grid(ceil_div(d->M, BM), ceil_div(d->N, BN), splits);
 #define NSKY_GEMM_LAUNCH(AK, BKC)                                                                              \
-  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, AK, BKC>), grid, dim3(256), 0, s, d->A, d->B, \
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, AK, BKC, BK, OCC>), grid, dim3(256), 0, s, d->A, d->B, \
                      d->C, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, k_split_len, vec4, d->a_rowsum, e)
   if (d->a_kcontig && d->b_kcontig) NSKY_GEMM_LAUNCH(true, true);
   else if (d->a_kcontig && !d->b_kcontig) NSKY_GEMM_LAUNCH(true, false);
@@ -392,7 +636,7 @@ extern "C" int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream) {
   int k_split_len = d->K;
   if (splits > 1) {
     NSKY_CHECK_ARG(d->epi == NSKY_EPI_NONE && !d->bias && d->beta == 0.0f, "nsky_gemm_f32: split-K needs a plain epilogue");
-    k_split_len = ((d->K + splits - 1) / splits + BK - 1) / BK * BK;
+    k_split_len = ((d->K + splits - 1) / splits + 31) / 32 * 32;
     splits = (d->K + k_split_len - 1) / k_split_len;
   }
   switch (d->epi) {
@@ -412,12 +656,26 @@ extern "C" int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream) {
   auto ok = [](const void* p, int ld) { return p == nullptr || ((((uintptr_t)p) % 16 == 0) && (ld % 4 == 0)); };
   const int vec4 = (d->N % 4 == 0) && ok(d->C, d->ldc) && ok(d->bias, 4) && ok(d->aux0, d->ldaux0) && ok(d->aux1, d->ldaux1) &&
                    ok(d->aux2, d->ldaux2) && ok(d->out1, d->ldout1) && ok(d->out2, d->ldout2);
+  static const int variant = getenv("NSKY_GEMM_VARIANT") ? atoi(getenv("NSKY_GEMM_VARIANT")) : 0;
+  if (d->precision != NSKY_PREC_F32 && d->N > 64) {
+    NSKY_CHECK_ARG(d->precision == NSKY_PREC_BF16X2 || d->precision == NSKY_PREC_BF16X3, "nsky_gemm_f32: unknown precision %d", d->precision);
+    if (d->precision == NSKY_PREC_BF16X2) launch_split<2>(d, e, splits, k_split_len, vec4, s);
+    else launch_split<3>(d, e, splits, k_split_len, vec4, s);
+    NSKY_CHECK_LAUNCH("nsky_gemm_f32(split-bf16)");
+    return NSKY_OK;
+  }
   if (d->N <= 32)
-    launch<128, 32, 4, 1>(d, e, splits, k_split_len, vec4, s);
+    launch<128, 32, 4, 1, 32, 2>(d, e, splits, k_split_len, vec4, s);
   else if (d->N <= 64)
-    launch<128, 64, 2, 2>(d, e, splits, k_split_len, vec4, s);
+    launch<128, 64, 2, 2, 32, 2>(d, e, splits, k_split_len, vec4, s);
+  else if (variant == 1)
+    launch<128, 128, 2, 2, 16, 3>(d, e, splits, k_split_len, vec4, s);
+  else if (variant == 2)
+    launch<128, 128, 2, 2, 16, 4>(d, e, splits, k_split_len, vec4, s);
+  else if (variant == 3)
+    launch<128, 128, 2, 2, 32, 1>(d, e, splits, k_split_len, vec4, s);
   else
-    launch<128, 128, 2, 2>(d, e, splits, k_split_len, vec4, s);
+    launch<128, 128, 2, 2, 32, 2>(d, e, splits, k_split_len, vec4, s);
   NSKY_CHECK_LAUNCH("nsky_gemm_f32");
   return NSKY_OK;
 }

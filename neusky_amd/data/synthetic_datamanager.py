@@ -14,6 +14,7 @@ from typing import Dict, Tuple, Type
 import torch
 
 from ..cameras.rays import RayBundle
+from ..utils.utils import to_device_async
 
 
 @dataclass
@@ -74,8 +75,8 @@ class SyntheticDataManager:
         d = torch.einsum("rij,rj->ri", self.cam_R[cam], d_cam)
         norm = d.norm(dim=-1, keepdim=True)
         dev = self.device
-        rb = RayBundle(origins=self.cam_pos[cam].to(dev), directions=(d / norm).to(dev), pixel_area=torch.ones(R, 1, device=dev),
-                       camera_indices=cam[:, None].to(dev), metadata={"directions_norm": torch.ones(R, 1, device=dev)})
+        rb = RayBundle(origins=to_device_async(self.cam_pos[cam], dev), directions=to_device_async(d / norm, dev),
+                       pixel_area=torch.ones(R, 1, device=dev), camera_indices=to_device_async(cam[:, None], dev), metadata={"directions_norm": torch.ones(R, 1, device=dev)})
         return rb, cam
 
     def next_train(self, step: int):
@@ -86,13 +87,13 @@ class SyntheticDataManager:
         u = torch.rand(R, 4, generator=g)
         mask = torch.stack([u[:, 0] < 0.9, u[:, 1] < 0.6, u[:, 2] < 0.15, u[:, 3] < 0.3], -1)  # [static, fg, ground, sky]
         mask[:, 1] &= ~mask[:, 3]
-        batch = {"image": image.to(self.device), "mask": mask.to(self.device), "indices": torch.stack([cam, cam * 0, cam * 0], 1)}
+        batch = {"image": to_device_async(image, self.device), "mask": to_device_async(mask, self.device), "indices": torch.stack([cam, cam * 0, cam * 0], 1)}
         return rb, batch
 
     def get_sky_ray_bundle(self, number_of_rays: int) -> RayBundle:
         g = self._gen
         rb, _ = self._rays(number_of_rays, g)
         d = rb.directions.clone()
-        d[:, 2] = d[:, 2].abs() + 0.2  # sky rays point upwards
+        d[:, 2] = d[:, 2].abs() + 0.2  # sky rays point upwards (device-side ops, no host round trip)
         rb.directions = d / d.norm(dim=-1, keepdim=True)
         return rb

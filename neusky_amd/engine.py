@@ -73,9 +73,10 @@ class _Group:
     def __init__(self, name, params: List[torch.nn.Parameter], opt: AdamOptimizerConfig, sched):
         self.name, self.opt, self.sched = name, opt, sched
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        # every parameter starts on a 16-byte boundary of the slab (the GEMM operands are read with float4 loads)
+        n = sum((p.numel() + 3) // 4 * 4 for p in self.params)
         dev = self.params[0].device
-        self.flat_p = torch.empty(n, device=dev)
+        self.flat_p = torch.zeros(n, device=dev)
         self.flat_g = torch.zeros(n, device=dev)
         self.m = torch.zeros(n, device=dev)
         self.v = torch.zeros(n, device=dev)
@@ -85,7 +86,7 @@ class _Group:
             self.flat_p[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat_p[off:off + k].view_as(p)
             p.grad = self.flat_g[off:off + k].view_as(p)
-            off += k
+            off += (k + 3) // 4 * 4
         if isinstance(sched, ExponentialDecaySchedulerConfig):
             sched.lr_init = opt.lr
         self.steps = 0

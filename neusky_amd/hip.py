@@ -28,6 +28,7 @@ _lib = C.CDLL(LIB_PATH)
 # ---- epilogues (keep in sync with include/neusky_hip.h)
 EPI_NONE, EPI_RELU, EPI_LEAKY, EPI_SIGMOID, EPI_SOFTPLUS, EPI_FILM, EPI_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 EPI_BWD_RELU, EPI_BWD_LEAKY, EPI_BWD_FILM, EPI_EXP = 7, 8, 9, 10
+PREC_F32, PREC_BF16X2, PREC_BF16X3 = 0, 2, 3
 
 
 class GemmDesc(C.Structure):
@@ -43,7 +44,7 @@ class GemmDesc(C.Structure):
         ("aux2", C.c_void_p), ("ldaux2", C.c_int32),
         ("out1", C.c_void_p), ("ldout1", C.c_int32),
         ("out2", C.c_void_p), ("ldout2", C.c_int32),
-        ("row_mod", C.c_int32), ("k_splits", C.c_int32), ("beta", C.c_float), ("a_rowsum", C.c_void_p),
+        ("row_mod", C.c_int32), ("k_splits", C.c_int32), ("beta", C.c_float), ("a_rowsum", C.c_void_p), ("precision", C.c_int32),
     ]
 
 
@@ -68,18 +69,17 @@ def stream_ptr() -> int:
 
 
 def ptr(t):
-    if t is None:
-        return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.int64, torch.uint8), (t.device, t.dtype)
-    return t.data_ptr()
+    return None if t is None else t.data_ptr()
 
 
 def ld(t):
     """leading dimension (elements) of a 2-D row-major view whose rows are contiguous"""
     if t is None:
         return 0
-    assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
-    return t.stride(0)
+    st = t.stride()
+    if len(st) != 2 or st[1] != 1:
+        raise ValueError(f"expected a 2-D view with contiguous rows, got shape {tuple(t.shape)} stride {st}")
+    return st[0]
 
 
 _gemm = _sig("nsky_gemm_f32", C.POINTER(GemmDesc), C.c_void_p)
@@ -87,14 +87,14 @@ _colsum = _sig("nsky_colsum_f32", C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C
 
 
 def gemm(A, B, Cout, M, N, K, *, a_kcontig=True, b_kcontig=True, bias=None, epi=EPI_NONE, p0=0.0, p1=0.0,
-         aux0=None, aux1=None, aux2=None, out1=None, out2=None, row_mod=0, k_splits=0, beta=0.0, a_rowsum=None):
+         aux0=None, aux1=None, aux2=None, out1=None, out2=None, row_mod=0, k_splits=0, beta=0.0, a_rowsum=None, precision=0):
     """C[M,N] = epi(sum_k A(m,k) B(n,k) + bias).  A/B/C are 2-D row-major views (rows contiguous)."""
     d = GemmDesc(
         A=ptr(A), B=ptr(B), C=ptr(Cout), M=M, N=N, K=K, lda=ld(A), ldb=ld(B), ldc=ld(Cout),
         a_kcontig=int(a_kcontig), b_kcontig=int(b_kcontig), bias=ptr(bias), epi=epi, p0=p0, p1=p1,
         aux0=ptr(aux0), ldaux0=ld(aux0), aux1=ptr(aux1), ldaux1=ld(aux1), aux2=ptr(aux2), ldaux2=ld(aux2),
         out1=ptr(out1), ldout1=ld(out1), out2=ptr(out2), ldout2=ld(out2), row_mod=row_mod, k_splits=k_splits, beta=beta,
-        a_rowsum=ptr(a_rowsum),
+        a_rowsum=ptr(a_rowsum), precision=precision,
     )
     check(_gemm(C.byref(d), stream_ptr()), "nsky_gemm_f32")
     return Cout

@@ -9,6 +9,7 @@ from typing import Optional, Type
 import torch
 
 from ..cameras.rays import RayBundle
+from ..utils.utils import to_device_async
 
 
 @dataclass
@@ -73,8 +74,8 @@ class VMFDDFSampler:
         flip = torch.einsum("nij,nj->ni", directions, -positions) < 0
         directions = torch.where(flip[..., None], -directions, directions)
         positions = positions * self.ddf_sphere_radius
-        positions = positions.unsqueeze(1).repeat(1, num_directions, 1).reshape(-1, 3).to(self.device)
-        directions = directions.reshape(-1, 3).to(self.device)
+        positions = to_device_async(positions.unsqueeze(1).repeat(1, num_directions, 1).reshape(-1, 3), self.device)
+        directions = to_device_async(directions.reshape(-1, 3), self.device)
         n = positions.shape[0]
         return RayBundle(origins=positions, directions=directions, pixel_area=torch.ones(n, 1, device=self.device),
                          camera_indices=torch.zeros(n, 1, device=self.device, dtype=torch.int64),

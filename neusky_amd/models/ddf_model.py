@@ -59,7 +59,8 @@ class DDFModel(nn.Module):
 
     def get_localised_transforms(self, positions: torch.Tensor) -> torch.Tensor:
         """ddf_model.py:158-181 (torch ops; the [R*Dv] visibility rays use the fused HIP kernel instead)"""
-        up = torch.tensor([0.0, 0.0, 1.0], device=positions.device).expand_as(positions)
+        up = torch.zeros_like(positions)
+        up[:, 2] = 1.0
         y = -positions
         x = torch.linalg.cross(up, y, dim=-1)
         x = x / x.norm(dim=-1, keepdim=True)
@@ -80,9 +81,34 @@ class DDFModel(nn.Module):
         positions = ray_bundle.origins.reshape(-1, 3)
         directions = ray_bundle.directions.reshape(-1, 3)
         outputs: Dict[str, Any] = {}
-        expected = self.query(positions, directions)
-        outputs["expected_termination_dist"] = expected
         c = self.config
+        # The reference issues up to three separate DDF evaluations here (the rays themselves :217, the multi-view
+        # rays :319, the sky rays :360).  Their inputs do not depend on each other's outputs, so they are gathered
+        # first and evaluated as ONE batch (one chain of GEMM launches instead of three).
+        q_pos, q_dir, spans = [positions], [directions], {"main": (0, positions.shape[0])}
+        want_mv = c.loss_inclusions["multi_view_loss"] and self.training and batch is not None
+        want_sky = c.loss_inclusions["sky_ray_loss"] and self.training and batch is not None
+        if want_mv:  # :279-317
+            gt_pts = positions + directions * batch["termination_dist"].repeat(1, 3)
+            if mv_points is None:
+                theta = 2 * torch.pi * torch.rand(gt_pts.shape[0], device=gt_pts.device)  # drawn on the device (no host round trip)
+                phi = torch.acos(2 * torch.rand(gt_pts.shape[0], device=gt_pts.device) - 1)
+                mv_points = torch.stack([torch.sin(phi) * torch.cos(theta), torch.sin(phi) * torch.sin(theta), torch.cos(phi)], 1)
+            pts = mv_points.to(gt_pts).clone()
+            pts[:, 2] = torch.abs(pts[:, 2])
+            dvec = gt_pts - pts
+            dlen = torch.norm(dvec, dim=-1)
+            n0 = sum(t.shape[0] for t in q_pos)
+            q_pos.append(pts); q_dir.append(dvec / dlen.unsqueeze(-1)); spans["mv"] = (n0, n0 + pts.shape[0])
+        if want_sky:  # :324-358
+            sky = batch["sky_ray_bundle"]
+            o, d = sky.origins.reshape(-1, 3), sky.directions.reshape(-1, 3)
+            sp = ray_sphere_intersection(o, d, self.ddf_radius)
+            n0 = sum(t.shape[0] for t in q_pos)
+            q_pos.append(sp); q_dir.append(-d); spans["sky"] = (n0, n0 + sp.shape[0])
+        t_all = self.query(torch.cat(q_pos, 0), torch.cat(q_dir, 0))
+        expected = t_all[spans["main"][0]:spans["main"][1]]
+        outputs["expected_termination_dist"] = expected
         if c.include_depth_loss_scene_center_weight and self.training and batch is not None:  # :224-238
             dist = positions.norm(dim=-1) if c.scene_center_weight_include_z else positions[..., :2].norm(dim=-1)
             outputs["distance_weight"] = 1.0 - (dist / self.ddf_radius) ** c.scene_center_weight_exp
@@ -97,24 +123,12 @@ class DDFModel(nn.Module):
                 outputs["sdf_at_termination"] = sdf
             elif batch is not None and "sdf_at_termination" in batch:
                 outputs["sdf_at_termination"] = batch["sdf_at_termination"]
-        if c.loss_inclusions["multi_view_loss"] and self.training and batch is not None:  # :279-322
-            gt_pts = positions + directions * batch["termination_dist"].repeat(1, 3)
-            if mv_points is None:
-                theta = 2 * torch.pi * torch.rand(gt_pts.shape[0])
-                phi = torch.acos(2 * torch.rand(gt_pts.shape[0]) - 1)
-                mv_points = torch.stack([torch.sin(phi) * torch.cos(theta), torch.sin(phi) * torch.sin(theta), torch.cos(phi)], 1)
-            pts = mv_points.to(gt_pts).clone()
-            pts[:, 2] = torch.abs(pts[:, 2])
-            dvec = gt_pts - pts
-            dlen = torch.norm(dvec, dim=-1)
-            outputs["multi_view_termintation_dist"] = batch["termination_dist"]  # (sic)
-            outputs["multi_view_expected_termination_dist"] = self.query(pts, dvec / dlen.unsqueeze(-1))
-        if c.loss_inclusions["sky_ray_loss"] and self.training and batch is not None:  # :324-363
-            sky = batch["sky_ray_bundle"]
-            o, d = sky.origins.reshape(-1, 3), sky.directions.reshape(-1, 3)
-            sp = ray_sphere_intersection(o, d, self.ddf_radius)
-            outputs["sky_ray_termination_dist"] = torch.norm(o - sp, dim=-1)
-            outputs["sky_ray_expected_termination_dist"] = self.query(sp, -d)
+        if want_mv:
+            outputs["multi_view_termintation_dist"] = batch["termination_dist"]  # (sic) :321
+            outputs["multi_view_expected_termination_dist"] = t_all[spans["mv"][0]:spans["mv"][1]]
+        if want_sky:
+            outputs["sky_ray_termination_dist"] = torch.norm(o - sp, dim=-1)  # :343
+            outputs["sky_ray_expected_termination_dist"] = t_all[spans["sky"][0]:spans["sky"][1]]
         return outputs
 
     def forward(self, ray_bundle: RayBundle, batch, neusky, stop_gradients: bool = True, **kw) -> Dict[str, torch.Tensor]:

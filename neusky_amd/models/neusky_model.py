@@ -31,7 +31,7 @@ from ..model_components.illumination import IcosahedronSamplerConfig, RENIFieldC
 from ..model_components.losses import RENISkyPixelLoss, interlevel_loss, monosdf_normal_loss, scale_dict
 from ..model_components.ray_samplers import HashMLPDensityField, ProposalNetworkSampler
 from ..model_components.renderers import RGBLambertianRendererWithVisibility
-from ..utils.utils import linear_to_sRGB
+from ..utils.utils import linear_to_sRGB, to_device_async
 
 
 def _default_loss_inclusions() -> Dict[str, Any]:  # neusky/configs/neusky_config.py:102-126
@@ -233,10 +233,23 @@ class NeuSkyFactoModel(nn.Module):
             dirs = self.illumination_sampler(rotation=randoms["light_rotation"].cpu())
         else:
             dirs = self.illumination_sampler()  # :456
-        dirs = dirs.to(self.device).contiguous()  # :458
-        unique, inverse = torch.unique(camera_indices, return_inverse=True)  # :461-463
-        U, D = unique.shape[0], dirs.shape[0]
-        if rotation is None:
+        # upper-hemisphere subset (:1650-1657) selected on the host, where the directions were generated: no device sync
+        self._upper_sel = to_device_async(torch.nonzero(dirs[:, 2] > 0)[:, 0].to(torch.int32), self.device)
+        dirs = to_device_async(dirs, self.device).contiguous()  # :458
+        D = dirs.shape[0]
+        if self.training and not self.fitting_eval_latents and self.num_train_data <= max(1024, camera_indices.shape[0]):
+            # every training camera is decoded (U = num_train_data, static shape, no torch.unique host sync); rows of
+            # cameras absent from the batch are never read by the renderer and receive zero gradient
+            inverse = camera_indices
+            cols = self.illumination_field.forward_grid(dirs, latents, scales) if rotation is None else None
+            unique = torch.arange(latents.shape[0], device=dirs.device)
+        else:
+            unique, inverse = torch.unique(camera_indices, return_inverse=True)  # :461-463
+            cols = None
+        U = unique.shape[0]
+        if cols is not None:
+            pass
+        elif rotation is None:
             cols = self.illumination_field.forward_grid(dirs, latents[unique], scales[unique])  # :488-510, no per-pair gather
         else:
             ci = unique[:, None].expand(U, D).reshape(-1)
@@ -255,18 +268,20 @@ class NeuSkyFactoModel(nn.Module):
 
     def compute_visibility(self, origins: torch.Tensor, ray_directions: torch.Tensor, depth: torch.Tensor,
                            illumination_directions: torch.Tensor, threshold_distance: torch.Tensor, sigmoid_scale: float,
-                           compute_shadow_map: bool = False) -> Dict[str, Any]:
+                           compute_shadow_map: bool = False, sel: Optional[torch.Tensor] = None) -> Dict[str, Any]:
         """neusky_model.py:1624-1778 on compact data: origins / ray_directions [R,3] (= sample 0 of each ray,
         :1667-1668), depth [R,1], illumination_directions [D,3] (= row 0 of the broadcast, :1648).
         Returns visibility [R,D] (the reference repeats it over S, :1755-1759)."""
         R, D = origins.shape[0], illumination_directions.shape[0]
         dev = origins.device
-        if self.config.only_upperhemisphere_visibility:  # :1650-1657
-            sel = torch.nonzero(illumination_directions[:, 2] > 0)[:, 0]
-        else:
-            sel = torch.arange(D, device=dev)
+        if not self.config.only_upperhemisphere_visibility:
+            sel = torch.arange(D, device=dev, dtype=torch.int32)
+        elif sel is not None:
+            pass  # chosen on the host by sample_illumination
+        else:  # :1650-1657
+            sel = torch.nonzero(illumination_directions[:, 2] > 0)[:, 0].to(torch.int32)
         Dv = sel.numel()
-        sel_dirs = illumination_directions[sel].contiguous()
+        sel_dirs = illumination_directions[sel.long()].contiguous()
         M = R * Dv
         sphere_pts = torch.empty(M, 3, device=dev)
         xrow = torch.empty(M, 16, device=dev)
@@ -288,7 +303,7 @@ class NeuSkyFactoModel(nn.Module):
                 out["sdf_at_termination"] = self.field.get_sdf_at_pos(term_pts)
         lower = 1.0 if self.config.lower_hermisphere_visibility else 0.0
         vis = ops.VisibilityFinishFn.apply(t_hat, surf_dist, threshold_distance, float(sigmoid_scale),
-                                           sel.to(torch.int32).contiguous(), R, Dv, D, lower)
+                                           sel.contiguous(), R, Dv, D, lower)
         out["visibility"] = vis
         if compute_shadow_map:
             out["difference"] = surf_dist - t_hat
@@ -319,27 +334,32 @@ class NeuSkyFactoModel(nn.Module):
             if p2p_vis.requires_grad:
                 raise NotImplementedError("visibility geometry is differentiated only in 'depth'/'both' mode (neusky_config.py:156)")
             out["visibility_dict"] = self.compute_visibility(ray_bundle.origins, ray_bundle.directions, p2p_vis, dirs,
-                                                             self.visibility_threshold, self.sigmoid_scale)
+                                                             self.visibility_threshold, self.sigmoid_scale,
+                                                             sel=getattr(self, "_upper_sel", None))
             out.update(p2p_dist=p2p_dist, depth=depth, accumulation=accumulation)
         if self.training and self.config.loss_inclusions["hashgrid_density_loss"]["enabled"]:  # :672-734
             res = self.config.loss_inclusions["hashgrid_density_loss"]["grid_resolution"]
             aabb = self.scene_box["aabb"] if isinstance(self.scene_box, dict) else self.scene_box.aabb
             mn, mx = aabb[0], aabb[1]
-            lin = [torch.linspace(float(mn[i]), float(mx[i]), res) for i in range(3)]
-            X, Y, Z = torch.meshgrid(*lin, indexing="ij")
-            positions = torch.stack((X, Y, Z), -1).reshape(-1, 3)
-            gap = torch.tensor([(float(mx[i]) - float(mn[i])) / res for i in range(3)])
-            if randoms is not None and "grid_perturb" in randoms:
-                perturb, gdir = randoms["grid_perturb"].cpu(), randoms["grid_dirs"].cpu()
-            else:
-                perturb, gdir = torch.rand_like(positions), torch.randn_like(positions)
-            positions = positions + (perturb * gap - gap / 2)
-            gdir = gdir / torch.norm(gdir, dim=-1, keepdim=True)
             dev = ray_bundle.origins.device
-            grid_samples = RaySamples(frustums=Frustums(origins=positions.to(dev), directions=gdir.to(dev),
-                                                        starts=torch.zeros(positions.shape[0], 3, device=dev)[:, :1] * 0,
-                                                        ends=torch.zeros(positions.shape[0], 1, device=dev), pixel_area=None),
-                                      deltas=gap.to(dev))
+            key = (res, str(dev))
+            if getattr(self, "_grid_cache_key", None) != key:  # lattice + gaps built once, kept on the device
+                lin = [torch.linspace(float(mn[i]), float(mx[i]), res) for i in range(3)]
+                X, Y, Z = torch.meshgrid(*lin, indexing="ij")
+                self._grid_lattice = torch.stack((X, Y, Z), -1).reshape(-1, 3).to(dev)
+                self._grid_gap = torch.tensor([(float(mx[i]) - float(mn[i])) / res for i in range(3)]).to(dev)
+                self._grid_cache_key = key
+            gap = self._grid_gap
+            if randoms is not None and "grid_perturb" in randoms:
+                perturb, gdir = randoms["grid_perturb"].to(dev), randoms["grid_dirs"].to(dev)
+            else:  # the reference draws these on the CPU every step (:704-712); drawn on the device here
+                perturb = torch.rand(self._grid_lattice.shape, device=dev)
+                gdir = torch.randn(self._grid_lattice.shape, device=dev)
+            positions = self._grid_lattice + (perturb * gap - gap / 2)
+            gdir = gdir / torch.norm(gdir, dim=-1, keepdim=True)
+            P = positions.shape[0]
+            grid_samples = RaySamples(frustums=Frustums(origins=positions, directions=gdir, starts=torch.zeros(P, 1, device=dev),
+                                                        ends=torch.zeros(P, 1, device=dev), pixel_area=None), deltas=gap)
             # (sic) the reference hands `deltas=gap` ([3]) to get_alpha, which broadcasts [P,1]*[3] -> three alphas
             # per point, one per axis gap (equal for the cubic scene box) (:715-724, :732)
             out["grid_density"] = self._grid_alpha(grid_samples)
@@ -421,7 +441,8 @@ class NeuSkyFactoModel(nn.Module):
                 ld["hashgrid_density_loss"] = outputs["grid_density"].abs().mean()  # :990-993
             if li["ground_plane_loss"]:
                 npred = outputs["normal"]
-                ngt = torch.tensor([0.0, 0.0, 1.0], device=dev).expand_as(npred)
+                ngt = torch.zeros_like(npred)
+                ngt[:, 2] = 1.0
                 gm = ground_mask.unsqueeze(1).expand_as(npred)
                 ld["ground_plane_loss"] = monosdf_normal_loss(npred * gm, ngt * gm)  # :995-1000
             if li["sky_pixel_loss"]["enabled"]:
@@ -430,7 +451,7 @@ class NeuSkyFactoModel(nn.Module):
                                                            targets=image, mask=sm)  # :1002-1009
             if self.visibility_field is not None and self.visibility_threshold_method == "learnable":
                 tgt = li["visibility_sigmoid_loss"]["target_min_bias"]
-                ld["visibility_sigmoid_loss"] = F.mse_loss(self.visibility_threshold[0], torch.tensor(tgt, device=dev))  # :1011-1030
+                ld["visibility_sigmoid_loss"] = (self.visibility_threshold[0] - tgt) ** 2  # MSE of two scalars, :1011-1030
             if li["sdf_level_set_visibility_loss"] and outputs.get("sdf_at_termination") is not None:
                 ld["sdf_level_set_visibility_loss"] = (outputs["sdf_at_termination"] ** 2).mean()  # :1032-1035
         elif li["sky_pixel_loss"]["enabled"]:

@@ -18,6 +18,32 @@ import torch.nn.functional as F
 from . import hip
 
 
+# Arithmetic of the dense contractions (operands and results are fp32 in memory either way; see include/neusky_hip.h):
+#   forward GEMMs  : exact fp32 MFMA, or 3-term bf16 split (6 bf16 MFMAs, ~2^-22 per product) when NSKY_PRECISION=split
+#   backward GEMMs : 2-term bf16 split (3 bf16 MFMAs, ~2^-16 per product) unless NSKY_PRECISION=f32
+import os as _os
+
+_POLICY = _os.environ.get("NSKY_PRECISION", "split")
+if _POLICY not in ("f32", "mixed", "split"):
+    raise ValueError(f"NSKY_PRECISION={_POLICY!r}: expected f32 | mixed | split")
+FWD_PRECISION = hip.PREC_BF16X3 if _POLICY == "split" else hip.PREC_F32
+BWD_PRECISION = hip.PREC_F32 if _POLICY == "f32" else hip.PREC_BF16X2
+
+
+def set_precision_policy(policy: str) -> None:
+    global FWD_PRECISION, BWD_PRECISION, _POLICY
+    if policy not in ("f32", "mixed", "split"):
+        raise ValueError(policy)
+    _POLICY = policy
+    FWD_PRECISION = hip.PREC_BF16X3 if policy == "split" else hip.PREC_F32
+    BWD_PRECISION = hip.PREC_F32 if policy == "f32" else hip.PREC_BF16X2
+
+
+def fgemm(*a, **k):
+    """forward-pass dense layer"""
+    return hip.gemm(*a, precision=FWD_PRECISION, **k)
+
+
 def pad4(n: int) -> int:
     return (n + 3) // 4 * 4
 
@@ -25,15 +51,23 @@ def pad4(n: int) -> int:
 def pad_weight(w: torch.Tensor) -> torch.Tensor:
     """[out, in] -> zero padded [pad4(out), pad4(in)] (autograd-tracked)."""
     o, i = w.shape
+    if o % 4 == 0 and i % 4 == 0:
+        return w if w.is_contiguous() else w.contiguous()
     return F.pad(w, (0, pad4(i) - i, 0, pad4(o) - o)).contiguous()
 
 
 def pad_bias(b: torch.Tensor) -> torch.Tensor:
+    if b.shape[0] % 4 == 0:
+        return b if b.is_contiguous() else b.contiguous()
     return F.pad(b, (0, pad4(b.shape[0]) - b.shape[0])).contiguous()
 
 
-def _splits(M: int) -> int:
-    return max(1, min(512, (M + 2047) // 2048))
+def _splits(M: int, n_out: int = 256, k_in: int = 256) -> int:
+    """split-K factor of a weight-gradient GEMM (reduction over M rows): enough workgroups to fill 256 CUs twice,
+    at least 128 rows and at most 2048 rows per split"""
+    tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
+    want = max(1, (512 + tiles - 1) // tiles)
+    return max((M + 2047) // 2048, min(want, max(1, M // 128)))
 
 
 def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None):
@@ -42,13 +76,13 @@ def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None):
     tangent rows that carry no bias) from the same pass over dZ."""
     dW = torch.zeros_like(like)
     if bias_like is None:
-        hip.gemm(dZ, X, dW, n_out, k_in, M, a_kcontig=False, b_kcontig=False, k_splits=_splits(M))
+        hip.gemm(dZ, X, dW, n_out, k_in, M, a_kcontig=False, b_kcontig=False, k_splits=_splits(M, n_out, k_in), precision=BWD_PRECISION)
         return dW
     db = torch.zeros_like(bias_like)
     if bias_rows is None or bias_rows == M:
-        hip.gemm(dZ, X, dW, n_out, k_in, M, a_kcontig=False, b_kcontig=False, k_splits=_splits(M), a_rowsum=db)
+        hip.gemm(dZ, X, dW, n_out, k_in, M, a_kcontig=False, b_kcontig=False, k_splits=_splits(M, n_out, k_in), a_rowsum=db, precision=BWD_PRECISION)
     else:
-        hip.gemm(dZ, X, dW, n_out, k_in, M, a_kcontig=False, b_kcontig=False, k_splits=_splits(M))
+        hip.gemm(dZ, X, dW, n_out, k_in, M, a_kcontig=False, b_kcontig=False, k_splits=_splits(M, n_out, k_in), precision=BWD_PRECISION)
         hip.colsum(dZ, bias_rows, n_out, db)
     return dW, db
 
@@ -61,7 +95,7 @@ def grad_bias(dZ, M, n_out, like):
 
 def grad_input(dZ, W, M, k_in, n_red, out, **epi):
     """dX[M, k_in] = dZ[M, n_red] @ W[n_red, k_in]   (W stored [out, in] = [n_red, k_in])."""
-    return hip.gemm(dZ, W, out, M, k_in, n_red, a_kcontig=True, b_kcontig=False, **epi)
+    return hip.gemm(dZ, W, out, M, k_in, n_red, a_kcontig=True, b_kcontig=False, precision=BWD_PRECISION, **epi)
 
 
 # =============================================================================================
@@ -108,7 +142,7 @@ class DenseFn(torch.autograd.Function):
     def forward(ctx, X, Wp, bp, n_out, act, need_dx):
         M, K = X.shape[0], Wp.shape[1]
         Y = torch.zeros(M, Wp.shape[0], device=X.device)
-        hip.gemm(X, Wp, Y, M, n_out, K, bias=bp, epi=_ACT[act])
+        fgemm(X, Wp, Y, M, n_out, K, bias=bp, epi=_ACT[act])
         ctx.save_for_backward(X, Wp, bp, Y)
         ctx.cfg = (n_out, act, need_dx)
         return Y
@@ -158,25 +192,25 @@ class FilmSirenFn(torch.autograd.Function):
         h = cond
         for i in range(n_map):
             out = torch.empty(M, Hm, device=dev)
-            hip.gemm(h, mw[i], out, M, Hm, mw[i].shape[1], bias=mb[i], epi=hip.EPI_LEAKY, p0=0.2)
+            fgemm(h, mw[i], out, M, Hm, mw[i].shape[1], bias=mb[i], epi=hip.EPI_LEAKY, p0=0.2)
             hs.append(out)
             h = out
         FP = torch.empty(M, 2 * n_film * H, device=dev)
-        hip.gemm(h, mwo, FP, M, 2 * n_film * H, Hm, bias=mbo)
+        fgemm(h, mwo, FP, M, 2 * n_film * H, Hm, bias=mbo)
         # FiLM layers: sin((15 F + 30) (W y + b) + P)  (siren.py:141-144, :200)
         ys, zs = [], []
         y = x
         for i in range(n_film):
             out = torch.empty(M, H, device=dev)
             z = torch.empty(M, H, device=dev)
-            hip.gemm(y, fw[i], out, M, H, fw[i].shape[1], bias=fb[i], epi=hip.EPI_FILM, p0=15.0, p1=30.0,
+            fgemm(y, fw[i], out, M, H, fw[i].shape[1], bias=fb[i], epi=hip.EPI_FILM, p0=15.0, p1=30.0,
                      aux0=FP[:, i * H:(i + 1) * H], aux1=FP[:, (n_film + i) * H:(n_film + i + 1) * H], out1=z)
             ys.append(out)
             zs.append(z)
             y = out
         n_out_p = ow.shape[0]
         res = torch.zeros(M, n_out_p, device=dev)
-        hip.gemm(y, ow, res, M, n_out_p, H, bias=ob)
+        fgemm(y, ow, res, M, n_out_p, H, bias=ob)
         ctx.save_for_backward(x, cond, FP, *hs, *ys, *zs, *wb)
         ctx.cfg = (n_map, n_film, train_weights, need_dcond, M, H, Hm)
         return res
@@ -270,27 +304,27 @@ class SDFAlbedoFn(torch.autograd.Function):
         Kin = W0.shape[1]
         A0 = torch.empty(4 * N, Hd, device=dev)
         S0 = torch.empty(N, Hd, device=dev)
-        hip.gemm(ET[:N], W0, A0[:N], N, Hd, Kin, bias=b0, epi=hip.EPI_SOFTPLUS, p0=beta, out1=S0)
-        hip.gemm(ET[N:], W0, A0[N:], 3 * N, Hd, Kin, epi=hip.EPI_MUL_AUX, aux0=S0, row_mod=N)
+        fgemm(ET[:N], W0, A0[:N], N, Hd, Kin, bias=b0, epi=hip.EPI_SOFTPLUS, p0=beta, out1=S0)
+        fgemm(ET[N:], W0, A0[N:], 3 * N, Hd, Kin, epi=hip.EPI_MUL_AUX, aux0=S0, row_mod=N)
         A1 = torch.empty(4 * N, Hd, device=dev)
         S1 = torch.empty(N, Hd, device=dev)
-        hip.gemm(A0[:N], W1, A1[:N], N, Hd, Hd, bias=b1, epi=hip.EPI_SOFTPLUS, p0=beta, out1=S1)
-        hip.gemm(A0[N:], W1, A1[N:], 3 * N, Hd, Hd, epi=hip.EPI_MUL_AUX, aux0=S1, row_mod=N)
+        fgemm(A0[:N], W1, A1[:N], N, Hd, Hd, bias=b1, epi=hip.EPI_SOFTPLUS, p0=beta, out1=S1)
+        fgemm(A0[N:], W1, A1[N:], 3 * N, Hd, Hd, epi=hip.EPI_MUL_AUX, aux0=S1, row_mod=N)
         GF = W2.shape[0] - 4  # geo feature dim (256)
         ldc = Wc0.shape[1]
         CIN = torch.zeros(N, ldc, device=dev)
-        hip.gemm(A1[:N], W2, CIN, N, GF + 1, Hd, bias=b2)  # [feat | sdf] straight into the colour-net input
+        fgemm(A1[:N], W2, CIN, N, GF + 1, Hd, bias=b2)  # [feat | sdf] straight into the colour-net input
         npe = 39  # x (3) + PE6 (36) columns of the encode row
         CIN[:, GF + 4:GF + 4 + npe] = ET[:N, :npe]
         G = torch.zeros(3 * N, 4, device=dev)
-        hip.gemm(A1[N:], W2[GF:GF + 1], G, 3 * N, 1, Hd)  # d sdf / d x_k = tangent . w_sdf
+        fgemm(A1[N:], W2[GF:GF + 1], G, 3 * N, 1, Hd)  # d sdf / d x_k = tangent . w_sdf
         Hc = Wc0.shape[0]
         C0 = torch.empty(N, Hc, device=dev)
-        hip.gemm(CIN, Wc0, C0, N, Hc, ldc, bias=bc0, epi=hip.EPI_RELU)
+        fgemm(CIN, Wc0, C0, N, Hc, ldc, bias=bc0, epi=hip.EPI_RELU)
         C1 = torch.empty(N, Hc, device=dev)
-        hip.gemm(C0, Wc1, C1, N, Hc, Hc, bias=bc1, epi=hip.EPI_RELU)
+        fgemm(C0, Wc1, C1, N, Hc, Hc, bias=bc1, epi=hip.EPI_RELU)
         ALB = torch.zeros(N, 4, device=dev)
-        hip.gemm(C1, Wc2, ALB, N, 3, Hc, bias=bc2, epi=hip.EPI_SIGMOID, p0=1.0)
+        fgemm(C1, Wc2, ALB, N, 3, Hc, bias=bc2, epi=hip.EPI_SIGMOID, p0=1.0)
         ctx.save_for_backward(ET, A0, S0, A1, S1, CIN, C0, C1, ALB, W0, b0, W1, b1, W2, b2, Wc0, bc0, Wc1, bc1, Wc2, bc2)
         ctx.cfg = (N, Hd, Kin, GF, ldc, Hc, beta)
         sdf = CIN[:, GF].clone()
@@ -362,11 +396,11 @@ class SDFValueFn(torch.autograd.Function):
         Hd, Kin = W0.shape
         GF = W2.shape[0] - 4
         A0 = torch.empty(M, Hd, device=dev); S0 = torch.empty(M, Hd, device=dev)
-        hip.gemm(E, W0, A0, M, Hd, Kin, bias=b0, epi=hip.EPI_SOFTPLUS, p0=beta, out1=S0)
+        fgemm(E, W0, A0, M, Hd, Kin, bias=b0, epi=hip.EPI_SOFTPLUS, p0=beta, out1=S0)
         A1 = torch.empty(M, Hd, device=dev); S1 = torch.empty(M, Hd, device=dev)
-        hip.gemm(A0, W1, A1, M, Hd, Hd, bias=b1, epi=hip.EPI_SOFTPLUS, p0=beta, out1=S1)
+        fgemm(A0, W1, A1, M, Hd, Hd, bias=b1, epi=hip.EPI_SOFTPLUS, p0=beta, out1=S1)
         out = torch.zeros(M, 4, device=dev)
-        hip.gemm(A1, W2[GF:GF + 1], out, M, 1, Hd, bias=b2[GF:GF + 1])
+        fgemm(A1, W2[GF:GF + 1], out, M, 1, Hd, bias=b2[GF:GF + 1])
         ctx.save_for_backward(E, A0, S0, A1, S1, W0, b0, W1, b1, W2, b2)
         ctx.cfg = (M, Hd, Kin, GF, beta, train_weights)
         return out[:, 0]

@@ -31,3 +31,11 @@ def rot_z(gamma: torch.Tensor) -> torch.Tensor:
     """neusky/utils/utils.py:168-173"""
     c, s = torch.cos(gamma), torch.sin(gamma)
     return torch.tensor([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=gamma.dtype)
+
+
+def to_device_async(t: torch.Tensor, device) -> torch.Tensor:
+    """host tensor -> device through pinned memory with a non-blocking copy (a pageable .to(device) blocks the host
+    until the stream drains, which serialises the CPU-side generators of a step with the GPU work)"""
+    if t.device.type != "cpu" or str(device) == "cpu":
+        return t.to(device)
+    return t.contiguous().pin_memory().to(device, non_blocking=True)

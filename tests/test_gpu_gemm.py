@@ -120,3 +120,37 @@ def test_errors_are_reported():
     A = torch.zeros(8, 6, device=dev)
     with pytest.raises(hip.NeuSkyHipError):
         hip.gemm(A, A, torch.zeros(8, 8, device=dev), 8, 8, 6)  # lda % 4 != 0
+
+
+@pytest.mark.parametrize("prec,tol", [(2, 6e-5), (3, 2e-6)])
+def test_split_bf16_precision_all_layouts(prec, tol):
+    """operands split into 2 / 3 bf16 terms, rebuilt from 3 / 6 bf16 MFMAs: every layout, ragged sizes, split-K + bias sums"""
+    from neusky_amd import hip
+    dev = "cuda:0"
+    torch.manual_seed(5)
+    M, N, K = 1000, 260, 296
+    A = torch.randn(M, K, device=dev)
+    W = torch.randn(N, K, device=dev)
+    b = torch.randn(N, device=dev)
+    ref = _ref(A, W, b)
+    sc = ref.abs().max().item()
+    C = torch.full((M, N), float("nan"), device=dev)
+    hip.gemm(A, W, C, M, N, K, bias=b, precision=prec)  # NT
+    assert (C.double() - ref).abs().max().item() < tol * sc
+    At = A.t().contiguous()  # [K, M]
+    Wt = W.t().contiguous()  # [K, N]
+    hip.gemm(A, Wt, C, M, N, K, bias=b, b_kcontig=False, precision=prec)  # NN
+    assert (C.double() - ref).abs().max().item() < tol * sc
+    hip.gemm(At, W, C, M, N, K, bias=b, a_kcontig=False, precision=prec)  # TN-ish (A reduction-major)
+    assert (C.double() - ref).abs().max().item() < tol * sc
+    C0 = torch.zeros(M, N, device=dev)
+    rs = torch.zeros(M, device=dev)
+    hip.gemm(At, Wt, C0, M, N, K, a_kcontig=False, b_kcontig=False, k_splits=4, a_rowsum=rs, precision=prec)
+    assert (C0.double() - _ref(A, W, None)).abs().max().item() < tol * sc
+    assert (rs.double() - A.double().sum(1)).abs().max().item() < 1e-3
+    # fused backward epilogue rides on the same kernel
+    aux = torch.randn(M, N, device=dev)
+    hip.gemm(A, W, C, M, N, K, epi=hip.EPI_BWD_LEAKY, p0=0.2, aux0=aux, precision=prec)
+    r2 = _ref(A, W, None)
+    r2 = torch.where(aux.double() > 0, r2, 0.2 * r2)
+    assert (C.double() - r2).abs().max().item() < tol * sc
