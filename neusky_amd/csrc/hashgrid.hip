@@ -463,11 +463,16 @@ extern "C" int nsky_encode_bwd(const nsky_hashgrid_desc* d, const float* x, int3
     const int ppb = ((P + blocks - 1) / blocks + 15) / 16 * 16;
     const size_t smem = (size_t)g.offset[n_coarse] * 2 * sizeof(float);
     dim3 grid(ceil_div(P, ppb));
+    // raise the dynamic-LDS ceiling once per process (not a stream operation; kept out of captured regions)
+    static bool attr_set = [] {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_coarse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_coarse_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      return true;
+    }();
+    (void)attr_set;
     if (dT) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_coarse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       hipLaunchKernelGGL(encode_bwd_coarse_kernel<true>, grid, dim3(256), smem, s, g, x, P, mode, feat0, dY, lddy, dT, dtable, n_coarse, ppb);
     } else {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_coarse_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       hipLaunchKernelGGL(encode_bwd_coarse_kernel<false>, grid, dim3(256), smem, s, g, x, P, mode, feat0, dY, lddy, dT, dtable, n_coarse, ppb);
     }
     NSKY_CHECK_LAUNCH("nsky_encode_bwd(coarse)");

@@ -126,3 +126,68 @@ def train_iteration(pipeline, optimizers: Optimizers, step: int, **kw):
     optimizers.all_reduce_gradients()
     optimizers.optimizer_scheduler_step_all(step)
     return loss.detach(), loss_dict, metrics_dict
+
+
+class GraphedTrainStep:
+    """One training iteration captured in a HIP graph (torch.cuda.graph): zero-grad, forward, every loss and the whole
+    backward replay as ONE graph launch, so the ~2300 kernel launches of a step cost no host time; the gradient
+    all-reduce and the five Adam launches stay outside (the learning rates change every step).
+
+    Everything inside the graph has static shapes and no host dependency: the step's inputs live in fixed device
+    buffers (`load`), the illumination-direction rotation, sample jitter, hash-grid probe, vMF DDF rays and multi-view
+    points are drawn on the device, every training camera's illumination is decoded (no torch.unique), and the
+    upper-hemisphere direction subset has the static size D/2 (antipodal direction set)."""
+
+    def __init__(self, pipeline, optimizers: Optimizers, ray_bundle, batch, warmup: int = 3, start_step: int = 0):
+        import copy
+        from .cameras.rays import RayBundle
+        self.pipeline, self.opt = pipeline, optimizers
+        dev = ray_bundle.origins.device
+        c = lambda t: t.detach().clone()
+        self.rb = RayBundle(origins=c(ray_bundle.origins), directions=c(ray_bundle.directions), pixel_area=c(ray_bundle.pixel_area),
+                            camera_indices=c(ray_bundle.camera_indices), metadata={k: c(v) for k, v in ray_bundle.metadata.items()})
+        self.batch = {"image": c(batch["image"]), "mask": c(batch["mask"])}
+        sky = pipeline.datamanager.get_sky_ray_bundle(pipeline.config.num_sky_rays)
+        self.sky = RayBundle(origins=c(sky.origins), directions=c(sky.directions))
+        self.randoms = {"sky_ray_bundle": self.sky}
+        self.step_idx = start_step
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # eager warm-up on the side stream: caches, autotuned paths, allocator pools
+            for i in range(warmup):
+                self._body(start_step + i)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.loss_dict, self.metrics = self._body(start_step + warmup)
+        torch.cuda.synchronize()
+
+    def _body(self, step):
+        self.opt.zero_grad_all()
+        _, loss_dict, metrics = self.pipeline.get_train_loss_dict(step, ray_bundle=self.rb, batch=self.batch, randoms=self.randoms)
+        loss = sum(loss_dict.values())
+        loss.backward()
+        return loss.detach(), {k: v.detach() for k, v in loss_dict.items()}, metrics
+
+    def load(self, ray_bundle, batch, sky=None) -> None:
+        """device-to-device copies of the next step's inputs into the graph's static buffers"""
+        self.rb.origins.copy_(ray_bundle.origins, non_blocking=True)
+        self.rb.directions.copy_(ray_bundle.directions, non_blocking=True)
+        self.rb.camera_indices.copy_(ray_bundle.camera_indices, non_blocking=True)
+        for k, v in ray_bundle.metadata.items():
+            self.rb.metadata[k].copy_(v, non_blocking=True)
+        self.batch["image"].copy_(batch["image"], non_blocking=True)
+        self.batch["mask"].copy_(batch["mask"], non_blocking=True)
+        if sky is not None:
+            self.sky.origins.copy_(sky.origins, non_blocking=True)
+            self.sky.directions.copy_(sky.directions, non_blocking=True)
+
+    def step(self, step: int, ray_bundle=None, batch=None, sky=None):
+        if ray_bundle is not None:
+            self.load(ray_bundle, batch, sky)
+        self.pipeline.model.set_step(step)  # proposal-weight anneal: a device scalar the graph reads
+        self.graph.replay()
+        self.opt.all_reduce_gradients()
+        self.opt.optimizer_scheduler_step_all(step)
+        return self.loss, self.loss_dict, self.metrics

@@ -31,6 +31,29 @@ def fibonacci_sphere(n: int) -> torch.Tensor:
     return d.float()
 
 
+def antipodal_sphere(n: int) -> torch.Tensor:
+    """n (even) near-uniform unit directions that come in antipodal pairs {d, -d}, like the vertices of an
+    icosphere (which is centrally symmetric).  Under ANY rotation exactly n/2 of them have z > 0, so the
+    upper-hemisphere subset used for the DDF visibility (neusky_model.py:1650-1657) has a static size."""
+    assert n % 2 == 0
+    i = torch.arange(n // 2, dtype=torch.float64) + 0.5
+    z = 1.0 - i / (n // 2)  # upper hemisphere, uniform in z
+    r = torch.sqrt(1.0 - z * z)
+    theta = math.pi * (1.0 + 5.0**0.5) * i
+    up = torch.stack([r * torch.cos(theta), r * torch.sin(theta), z], -1)
+    return torch.cat([up, -up], 0).float()
+
+
+def random_rotation_device(device, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """uniform random SO(3) matrix from a unit quaternion, drawn and built on the device (no host round trip)"""
+    q = torch.randn(4, device=device, generator=generator)
+    q = q / q.norm()
+    w, x, y, z = q[0], q[1], q[2], q[3]
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                        2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                        2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]).view(3, 3)
+
+
 def random_rotation(generator: Optional[torch.Generator] = None) -> torch.Tensor:
     """uniform random SO(3) matrix from a unit quaternion (host side, like the reference's scipy call)"""
     q = torch.randn(4, generator=generator, dtype=torch.float64)
@@ -57,10 +80,28 @@ class IcosahedronSampler:
 
     def __init__(self, config: IcosahedronSamplerConfig):
         self.config = config
-        d = fibonacci_sphere(config.num_directions)
+        d = antipodal_sphere(config.num_directions)
         if config.remove_lower_hemisphere:
             d = d[d[:, 2] > 0]
         self.directions = d
+        self._dev_cache = {}
+
+    def on_device(self, device, apply_random_rotation: Optional[bool] = None, rotation: Optional[torch.Tensor] = None):
+        """directions [D,3] on `device` (+ the indices of the D/2 with the largest z, ascending: for the antipodal set
+        this IS the z > 0 subset).  Rotation drawn on the device; everything has static shapes (hipGraph-safe)."""
+        key = str(device)
+        if key not in self._dev_cache:
+            self._dev_cache[key] = self.directions.to(device)
+        base = self._dev_cache[key]
+        rot = self.config.apply_random_rotation if apply_random_rotation is None else apply_random_rotation
+        if rotation is not None:
+            rotation = rotation.to(device)
+        elif rot:
+            rotation = random_rotation_device(device)
+        dirs = base if rotation is None else base @ rotation.T
+        half = dirs.shape[0] // 2
+        sel = torch.sort(torch.topk(dirs[:, 2], half).indices).values.to(torch.int32)
+        return dirs.contiguous(), sel
 
     def __call__(self, apply_random_rotation: Optional[bool] = None, rotation: Optional[torch.Tensor] = None,
                  generator: Optional[torch.Generator] = None) -> torch.Tensor:

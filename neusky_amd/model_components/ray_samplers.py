@@ -74,10 +74,13 @@ class ProposalNetworkSampler(nn.Module):
         self.num_proposal_network_iterations = num_proposal_network_iterations
         self.histogram_padding = histogram_padding
         self._anneal = 1.0
+        self._anneal_t: Optional[torch.Tensor] = None  # device scalar mirror of _anneal (a captured graph reads it)
         self._u_cache: Dict[Tuple[int, bool, str], torch.Tensor] = {}
 
     def set_anneal(self, anneal: float) -> None:
         self._anneal = anneal
+        if self._anneal_t is not None:
+            self._anneal_t.fill_(anneal)
 
     def _u_base(self, num_bins: int, stratified: bool, device) -> torch.Tensor:
         key = (num_bins, stratified, str(device))
@@ -103,7 +106,9 @@ class ProposalNetworkSampler(nn.Module):
             if lvl == 0:
                 sbins, ebins = uniform_bins(nears, fars, ns, jit)
             else:
-                annealed = torch.pow(weights.detach(), self._anneal) if self._anneal != 1.0 else weights.detach()
+                if self._anneal_t is None:
+                    self._anneal_t = torch.full((1,), float(self._anneal), device=weights.device)
+                annealed = torch.pow(weights.detach(), self._anneal_t)  # tensor exponent: the value can change under a captured graph
                 sbins, inds = hip.pdf_sample(annealed.contiguous(), sbins, self._u_base(ns + 1, jit is not None, sbins.device),
                                              None if jit is None else jit.reshape(-1).contiguous(), ns + 1,
                                              self.histogram_padding, 1e-5, want_inds)

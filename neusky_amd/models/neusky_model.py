@@ -228,14 +228,12 @@ class NeuSkyFactoModel(nn.Module):
         directions [D,3], cam_colours [U,D,3], cam_of_ray [R] (int32 row of cam_colours), hdr_background [R,3]."""
         latents, scales = self.get_illumination_field()
         if not self.training and self.config.fix_test_illumination_directions:
-            dirs = self.illumination_sampler(apply_random_rotation=False)  # :451-454
+            dirs, sel = self.illumination_sampler.on_device(self.device, apply_random_rotation=False)  # :451-454
         elif randoms is not None and "light_rotation" in randoms:
-            dirs = self.illumination_sampler(rotation=randoms["light_rotation"].cpu())
+            dirs, sel = self.illumination_sampler.on_device(self.device, rotation=randoms["light_rotation"])
         else:
-            dirs = self.illumination_sampler()  # :456
-        # upper-hemisphere subset (:1650-1657) selected on the host, where the directions were generated: no device sync
-        self._upper_sel = to_device_async(torch.nonzero(dirs[:, 2] > 0)[:, 0].to(torch.int32), self.device)
-        dirs = to_device_async(dirs, self.device).contiguous()  # :458
+            dirs, sel = self.illumination_sampler.on_device(self.device)  # :456-458, drawn on the device
+        self._upper_sel = sel  # upper-hemisphere subset (:1650-1657): static size D/2 for the antipodal direction set
         D = dirs.shape[0]
         if self.training and not self.fitting_eval_latents and self.num_train_data <= max(1024, camera_indices.shape[0]):
             # every training camera is decoded (U = num_train_data, static shape, no torch.unique host sync); rows of
@@ -474,7 +472,7 @@ class NeuSkyFactoModel(nn.Module):
     def generate_ddf_ground_truth(self, ray_bundle: RayBundle, mask_threshold: float = 0.5, randoms=None) -> Dict[str, Any]:
         """neusky_model.py:1337-1367: second sampler + field pass on the DDF-fit rays"""
         ray_bundle = self.collider(ray_bundle)
-        sub = None if randoms is None else {"jitters": randoms["ddf_jitters"]}
+        sub = None if randoms is None or "ddf_jitters" not in randoms else {"jitters": randoms["ddf_jitters"]}
         ray_samples, _, _, _, _ = self._sample(ray_bundle, sub)
         fo = self.field(ray_samples, return_alphas=True)
         weights = fo["weights"]

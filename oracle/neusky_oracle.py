@@ -227,6 +227,8 @@ def hash_grid_encode(x: Tensor, table: Tensor, cfg: HashGridCfg) -> Tensor:
     Differentiable w.r.t. table and x (torch autograd), so the reference's
     autograd.grad(create_graph=True) flow (sdf_albedo_field.py:231-238) can be followed literally."""
     idx, fl = hash_grid_indices(x, cfg)
+    P = x.shape[0]
+    vals = table[idx.reshape(-1)].view(P, cfg.n_levels, 8, table.shape[1])  # one gather (one dense grad) per call
     outs = []
     for lvl in range(cfg.n_levels):
         t = x * float(np.float32(cfg.scales[lvl])) + 0.5 - fl[:, lvl].to(x.dtype)
@@ -236,7 +238,7 @@ def hash_grid_encode(x: Tensor, table: Tensor, cfg: HashGridCfg) -> Tensor:
             wc = 1.0
             for d in range(3):
                 wc = wc * (w[:, d] if (c >> d) & 1 else (1.0 - w[:, d]))
-            acc = acc + wc[:, None] * table[idx[:, lvl, c]]
+            acc = acc + wc[:, None] * vals[:, lvl, c]
         outs.append(acc)
     return torch.cat(outs, -1)
 
