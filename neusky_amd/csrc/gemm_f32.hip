@@ -460,18 +460,18 @@ struct SplitLoader {  // 128 x 32 fp32 tile -> NS bf16 images [128][SROW]
   }
 };
 
-template <int NS, bool AK, bool BKC>
-__global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                           float* __restrict__ C, int M, int N, int K, int lda, int ldb,
-                                                           int ldc, int k_split_len, int vec4, float* __restrict__ a_rowsum,
-                                                           EpiCtx e) {
+template <int NS, bool AK, bool BKC, bool DBUF>
+__global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : 2) void gemm_bf16s_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K, int lda, int ldb,
+    int ldc, int k_split_len, int vec4, float* __restrict__ a_rowsum, EpiCtx e) {
   constexpr int BM = 128, BN = 128, BKT = 32, WM = 64, WN = 64, TM = 2, TN = 2;
   constexpr int IMG = 128 * SROW;  // bf16 elements per image
-  constexpr int SMEM_MAIN = 2 * NS * IMG * 2 + 128 * 4, SMEM_EPI = WM * BN * 4;
+  constexpr int NBUF = DBUF ? 2 : 1;
+  constexpr int STAGE = 2 * NS * IMG;  // bf16 elements per pipeline stage (A images then B images)
+  constexpr int SMEM_MAIN = NBUF * STAGE * 2 + 128 * 4, SMEM_EPI = WM * BN * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
-  __bf16* As = reinterpret_cast<__bf16*>(smem_raw);
-  __bf16* Bs = As + NS * IMG;
-  float* rsum = reinterpret_cast<float*>(smem_raw + 2 * NS * IMG * 2);
+  __bf16* S0 = reinterpret_cast<__bf16*>(smem_raw);
+  float* rsum = reinterpret_cast<float*>(smem_raw + NBUF * STAGE * 2);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -492,20 +492,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const float* __restr
 
   SplitLoader<NS, AK> la;
   SplitLoader<NS, BKC> lb;
-  if (ntiles > 0) {
-    la.load(A, lda, m0, M, kbeg, kend, tid);
-    lb.load(B, ldb, n0, N, kbeg, kend, tid);
-  }
   const int frow = lane & 31, fh = lane >> 5;
-  for (int t = 0; t < ntiles; ++t) {
-    __syncthreads();  // previous tile's fragment reads are done
-    la.store(As, tid, want_rs ? rsum : nullptr);
-    lb.store(Bs, tid, nullptr);
-    __syncthreads();
-    if (t + 1 < ntiles) {
-      la.load(A, lda, m0, M, kbeg + (t + 1) * BKT, kend, tid);
-      lb.load(B, ldb, n0, N, kbeg + (t + 1) * BKT, kend, tid);
-    }
+
+  auto compute = [&](const __bf16* As, const __bf16* Bs) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[NS][TM], bfr[NS][TN];
@@ -522,8 +511,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const float* __restr
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          // smallest cross terms first
-          if (NS == 3) {
+          if (NS == 3) {  // smallest cross terms first
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], acc[i][j], 0, 0, 0);
@@ -532,6 +520,51 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const float* __restr
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
         }
+    }
+  };
+
+  if (ntiles > 0) {
+    la.load(A, lda, m0, M, kbeg, kend, tid);
+    lb.load(B, ldb, n0, N, kbeg, kend, tid);
+  }
+  if (DBUF) {
+    // two LDS stages: tile t+1 is split and written (VALU + LDS pipes) in the same instruction stream as the bf16
+    // MFMAs of tile t (matrix pipe); tile t+2's global loads are issued right after and land during the next tile
+    if (ntiles > 0) {
+      __syncthreads();
+      la.store(S0, tid, want_rs ? rsum : nullptr);
+      lb.store(S0 + NS * IMG, tid, nullptr);
+      if (ntiles > 1) {
+        la.load(A, lda, m0, M, kbeg + BKT, kend, tid);
+        lb.load(B, ldb, n0, N, kbeg + BKT, kend, tid);
+      }
+    }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+      const __bf16* cur = S0 + (t & 1) * STAGE;
+      __bf16* nxt = S0 + ((t + 1) & 1) * STAGE;
+      compute(cur, cur + NS * IMG);
+      if (t + 1 < ntiles) {
+        la.store(nxt, tid, want_rs ? rsum : nullptr);
+        lb.store(nxt + NS * IMG, tid, nullptr);
+        if (t + 2 < ntiles) {
+          la.load(A, lda, m0, M, kbeg + (t + 2) * BKT, kend, tid);
+          lb.load(B, ldb, n0, N, kbeg + (t + 2) * BKT, kend, tid);
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int t = 0; t < ntiles; ++t) {
+      __syncthreads();  // previous tile's fragment reads are done
+      la.store(S0, tid, want_rs ? rsum : nullptr);
+      lb.store(S0 + NS * IMG, tid, nullptr);
+      __syncthreads();
+      if (t + 1 < ntiles) {
+        la.load(A, lda, m0, M, kbeg + (t + 1) * BKT, kend, tid);
+        lb.load(B, ldb, n0, N, kbeg + (t + 1) * BKT, kend, tid);
+      }
+      compute(S0, S0 + NS * IMG);
     }
   }
   __syncthreads();
@@ -580,11 +613,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(const float* __restr
   }
 }
 
-template <int NS>
+template <int NS, bool DBUF>
 void launch_split(const nsky_gemm_desc* d, const EpiCtx& e, int splits, int k_split_len, int vec4, hipStream_t s) {
   dim3 grid(ceil_div(d->M, 128), ceil_div(d->N, 128), splits);
 #define NSKY_SGEMM_LAUNCH(AK, BKC)                                                                          \
-  hipLaunchKernelGGL((gemm_bf16s_kernel<NS, AK, BKC>), grid, dim3(256), 0, s, d->A, d->B, d->C, d->M, d->N, \
+  hipLaunchKernelGGL((gemm_bf16s_kernel<NS, AK, BKC, DBUF>), grid, dim3(256), 0, s, d->A, d->B, d->C, d->M, d->N, \
                      d->K, d->lda, d->ldb, d->ldc, k_split_len, vec4, d->a_rowsum, e)
   if (d->a_kcontig && d->b_kcontig) NSKY_SGEMM_LAUNCH(true, true);
   else if (d->a_kcontig && !d->b_kcontig) NSKY_SGEMM_LAUNCH(true, false);
@@ -659,8 +692,11 @@ extern "C" int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream) {
   static const int variant = getenv("NSKY_GEMM_VARIANT") ? atoi(getenv("NSKY_GEMM_VARIANT")) : 0;
   if (d->precision != NSKY_PREC_F32 && d->N > 64) {
     NSKY_CHECK_ARG(d->precision == NSKY_PREC_BF16X2 || d->precision == NSKY_PREC_BF16X3, "nsky_gemm_f32: unknown precision %d", d->precision);
-    if (d->precision == NSKY_PREC_BF16X2) launch_split<2>(d, e, splits, k_split_len, vec4, s);
-    else launch_split<3>(d, e, splits, k_split_len, vec4, s);
+    // the two-stage LDS variant needs 80-120 KB per workgroup (one workgroup per CU) and measured 1.4-2.5x SLOWER than
+    // the single-stage kernel at 2 workgroups per CU; kept selectable (NSKY_GEMM_VARIANT=4) for experiments only
+    const bool dbuf = (variant & 4) != 0;
+    if (d->precision == NSKY_PREC_BF16X2) { if (dbuf) launch_split<2, true>(d, e, splits, k_split_len, vec4, s); else launch_split<2, false>(d, e, splits, k_split_len, vec4, s); }
+    else { if (dbuf) launch_split<3, true>(d, e, splits, k_split_len, vec4, s); else launch_split<3, false>(d, e, splits, k_split_len, vec4, s); }
     NSKY_CHECK_LAUNCH("nsky_gemm_f32(split-bf16)");
     return NSKY_OK;
   }

@@ -24,18 +24,18 @@ from . import hip
 import os as _os
 
 _POLICY = _os.environ.get("NSKY_PRECISION", "split")
-if _POLICY not in ("f32", "mixed", "split"):
+if _POLICY not in ("f32", "mixed", "split", "split2"):
     raise ValueError(f"NSKY_PRECISION={_POLICY!r}: expected f32 | mixed | split")
-FWD_PRECISION = hip.PREC_BF16X3 if _POLICY == "split" else hip.PREC_F32
+FWD_PRECISION = {"split": hip.PREC_BF16X3, "split2": hip.PREC_BF16X2}.get(_POLICY, hip.PREC_F32)
 BWD_PRECISION = hip.PREC_F32 if _POLICY == "f32" else hip.PREC_BF16X2
 
 
 def set_precision_policy(policy: str) -> None:
     global FWD_PRECISION, BWD_PRECISION, _POLICY
-    if policy not in ("f32", "mixed", "split"):
+    if policy not in ("f32", "mixed", "split", "split2"):
         raise ValueError(policy)
     _POLICY = policy
-    FWD_PRECISION = hip.PREC_BF16X3 if policy == "split" else hip.PREC_F32
+    FWD_PRECISION = {"split": hip.PREC_BF16X3, "split2": hip.PREC_BF16X2}.get(policy, hip.PREC_F32)
     BWD_PRECISION = hip.PREC_F32 if policy == "f32" else hip.PREC_BF16X2
 
 
