@@ -227,6 +227,14 @@ class NeuSkyFactoModel(nn.Module):
         """neusky_model.py:445-551 on compact data: camera_indices [R], ray_directions [R,3] ->
         directions [D,3], cam_colours [U,D,3], cam_of_ray [R] (int32 row of cam_colours), hdr_background [R,3]."""
         latents, scales = self.get_illumination_field()
+        frame = getattr(self, "_frame_illumination", None)
+        if frame is not None and not self.training:
+            # chunked full-frame render: directions and the frame camera's colours were decoded once per frame
+            dirs, cols, sel, cam, rot_f = frame
+            self._upper_sel = sel
+            R = camera_indices.shape[0]
+            bg = self.illumination_field(ray_directions, latents[cam][None].expand(R, -1, -1), scales[cam].expand(R), rot_f)
+            return dirs, cols, torch.zeros(R, dtype=torch.int32, device=dirs.device), bg
         if not self.training and self.config.fix_test_illumination_directions:
             dirs, sel = self.illumination_sampler.on_device(self.device, apply_random_rotation=False)  # :451-454
         elif randoms is not None and "light_rotation" in randoms:
@@ -484,19 +492,89 @@ class NeuSkyFactoModel(nn.Module):
         normals = torch.sum(weights * fo[FieldHeadNames.NORMALS], dim=-2).reshape(-1, 3)
         return {"ray_bundle": ray_bundle, "accumulations": accumulations, "mask": mask, "termination_dist": p2p, "normals": normals}
 
+    def begin_frame(self, camera_index: int, rotation: Optional[torch.Tensor] = None) -> None:
+        """decode the illumination of ONE camera for a whole frame (the reference re-decodes it in each of the
+        8100 chunks of a 1080p frame, neusky_model.py:1413-1432; the result is the same)"""
+        latents, scales = self.get_illumination_field()
+        fixed = self.config.fix_test_illumination_directions
+        dirs, sel = self.illumination_sampler.on_device(self.device, apply_random_rotation=False if fixed else None)
+        cam = int(camera_index)
+        D = dirs.shape[0]
+        if rotation is None:
+            cols = self.illumination_field.forward_grid(dirs, latents[cam][None], scales[cam][None])
+        else:
+            cols = self.illumination_field(dirs, latents[cam][None].expand(D, -1, -1), scales[cam].expand(D), rotation)[None]
+        self._frame_illumination = (dirs, cols.contiguous(), sel, cam, rotation)
+
+    def end_frame(self) -> None:
+        self._frame_illumination = None
+
     @torch.no_grad()
     def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle, show_progress=False, rotation=None, to_cpu=False,
-                                          step=None) -> Dict[str, torch.Tensor]:
-        """neusky_model.py:1369-1501: chunked full-frame render.  The reference chunks at
-        eval_num_rays_per_chunk = 256 (8100 python iterations per 1080p frame); any chunk size gives the same image."""
-        chunk = self.config.eval_num_rays_per_chunk
+                                          step=None, camera_index: Optional[int] = None, chunk: Optional[int] = None,
+                                          use_graph: bool = True) -> Dict[str, torch.Tensor]:
+        """neusky_model.py:1369-1501: chunked full-frame render.  The reference chunks at eval_num_rays_per_chunk = 256
+        (8100 python iterations per 1080p frame); any chunk size gives the same image, so a larger static chunk is used
+        and its forward is captured once in a HIP graph and replayed per chunk (BASELINE config 5)."""
+        assert not self.training, "call model.eval() first"
+        chunk = chunk or max(self.config.eval_num_rays_per_chunk, 4096)
         shape = camera_ray_bundle.origins.shape[:-1]
-        num_rays = int(torch.tensor(shape).prod())
-        lists: Dict[str, List[torch.Tensor]] = {}
-        for i in range(0, num_rays, chunk):
-            rb = camera_ray_bundle.slice(i, i + chunk)
-            out = self.forward(ray_bundle=rb, rotation=rotation, step=step)
-            for k, v in out.items():
-                if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == rb.origins.shape[0]:
-                    lists.setdefault(k, []).append(v.cpu() if to_cpu else v)
-        return {k: torch.cat(v).view(*shape, -1) for k, v in lists.items()}
+        flat = camera_ray_bundle.slice(0, 1 << 62)
+        num_rays = flat.origins.shape[0]
+        if camera_index is None:
+            camera_index = int(flat.camera_indices.reshape(-1)[0]) if flat.camera_indices is not None else 0
+        self.begin_frame(camera_index, rotation)
+        keys = ["rgb", "albedo", "accumulation", "depth", "p2p_dist", "normal"]
+        out = {k: [] for k in keys}
+        try:
+            runner = _ChunkRunner(self, chunk, flat, use_graph)
+            for i in range(0, num_rays, chunk):
+                res = runner.run(flat, i, min(i + chunk, num_rays))
+                for k in keys:
+                    out[k].append(res[k].cpu() if to_cpu else res[k])
+        finally:
+            self.end_frame()
+        return {k: torch.cat(v).view(*shape, -1) for k, v in out.items()}
+
+
+class _ChunkRunner:
+    """static-shape forward of one render chunk, optionally captured in a HIP graph and replayed"""
+
+    def __init__(self, model: "NeuSkyFactoModel", chunk: int, flat: RayBundle, use_graph: bool):
+        self.model, self.chunk, self.graph = model, chunk, None
+        dev = flat.origins.device
+        self.rb = RayBundle(origins=torch.zeros(chunk, 3, device=dev), directions=torch.zeros(chunk, 3, device=dev),
+                            pixel_area=torch.ones(chunk, 1, device=dev), camera_indices=torch.zeros(chunk, 1, dtype=torch.long, device=dev),
+                            metadata={"directions_norm": torch.ones(chunk, 1, device=dev)})
+        self.rb.directions[:, 2] = 1.0
+        if use_graph:
+            self._load(flat, 0, min(chunk, flat.origins.shape[0]))
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.out = model.forward(self.rb)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = model.forward(self.rb)
+
+    def _load(self, flat: RayBundle, a: int, b: int) -> None:
+        n = b - a
+        self.rb.origins[:n].copy_(flat.origins[a:b])
+        self.rb.directions[:n].copy_(flat.directions[a:b])
+        if "directions_norm" in flat.metadata:
+            self.rb.metadata["directions_norm"][:n].copy_(flat.metadata["directions_norm"][a:b])
+        if n < self.chunk:  # pad the last chunk with copies of its first ray (results discarded)
+            self.rb.origins[n:].copy_(self.rb.origins[:1].expand(self.chunk - n, 3))
+            self.rb.directions[n:].copy_(self.rb.directions[:1].expand(self.chunk - n, 3))
+
+    def run(self, flat: RayBundle, a: int, b: int) -> Dict[str, torch.Tensor]:
+        self._load(flat, a, b)
+        if self.graph is not None:
+            self.graph.replay()
+            out = self.out
+        else:
+            out = self.model.forward(self.rb)
+        return {k: v[:b - a].clone() for k, v in out.items() if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == self.chunk}

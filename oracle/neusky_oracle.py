@@ -824,3 +824,30 @@ def neusky_train_step(p: Dict[str, Tensor], cfg: StepCfg, origins: Tensor, direc
     out.update({"ddf_" + k: v for k, v in dout.items()})
     out["ddf_gt_termination_dist"] = gt_term
     return ld, out
+
+
+def neusky_render(p: Dict[str, Tensor], cfg: StepCfg, origins: Tensor, directions: Tensor, latent: Tensor, scale: Tensor,
+                  light_dirs: Tensor, rotation: Optional[Tensor] = None):
+    """Eval-mode forward of a camera ray bundle with ONE illumination latent (relighting render,
+    neusky_model.py:1369-1501 -> forward -> get_outputs eval branch :814-879): deterministic samplers (no jitter,
+    fixed directions :451-454), optional z-rotation of the illumination (:483-493, render_animation.py:196-207),
+    visibility without the sdf probe, Lambertian render with the eval clamp."""
+    R = origins.shape[0]
+    nears, fars = sphere_collider(origins, directions, cfg.radius)
+    samp = proposal_sample(origins, directions, nears, fars, p, cfg.prop_grids, cfg.num_prop, cfg.num_final, None, 1.0)
+    fo = field_pass(p, cfg, origins, directions, samp["ebins"])
+    weights = fo["weights"]
+    ldir = light_dirs if rotation is None else light_dirs @ rotation.T
+    rdir = directions if rotation is None else directions @ rotation.T
+    D = light_dirs.shape[0]
+    cols = reni_decode(latent[None].expand(D, -1, -1), ldir, scale.expand(D), p)[None]  # [1,D,3]
+    bg = reni_decode(latent[None].expand(R, -1, -1), rdir, scale.expand(R), p)
+    p2p = render_depth(weights, samp["ebins"])
+    ddf_fn = lambda sp, dd: {"expected_termination_dist": ddf_query(sp, dd, p, cfg.ddf_grid, cfg.radius)}
+    vis = compute_visibility(origins, directions, p2p, light_dirs, p["visibility_threshold"], cfg.sigmoid_scale, cfg.radius,
+                             ddf_fn, True, True)
+    rgb = lambertian_render(fo["albedo"], fo["normals"], light_dirs, cols, torch.zeros(R, dtype=torch.long), vis["visibility"], bg,
+                            weights, training=False)
+    return {"rgb": rgb, "p2p_dist": p2p, "accumulation": weights.sum(-1, keepdim=True),
+            "normal": (weights[..., None] * fo["normals"]).sum(-2), "albedo": (weights[..., None] * fo["albedo"]).sum(-2) + (1 - weights.sum(-1, keepdim=True)),
+            "visibility": vis["visibility"]}
