@@ -39,6 +39,11 @@ def set_precision_policy(policy: str) -> None:
     BWD_PRECISION = hip.PREC_F32 if policy == "f32" else hip.PREC_BF16X2
 
 
+# row-chunking of the FiLM-SIREN chain (keeps layer hand-offs inside the Infinity Cache): measured no gain on MI355X
+# (50.8 ms/step un-chunked, 51.1 @65536, 54.2 @32768, 65.2 @16384 rows) -> off by default
+FILM_ROW_CHUNK = int(_os.environ.get("NSKY_FILM_ROW_CHUNK", "0"))
+
+
 def fgemm(*a, **k):
     """forward-pass dense layer"""
     return hip.gemm(*a, precision=FWD_PRECISION, **k)
@@ -70,19 +75,27 @@ def _splits(M: int, n_out: int = 256, k_in: int = 256) -> int:
     return max((M + 2047) // 2048, min(want, max(1, M // 128)))
 
 
-def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None):
+def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None, acc=None):
     """dW[n_out, k_in] = dZ[:M, :n_out]^T @ X[:M, :k_in] (split-K over M, atomically reduced).
     With bias_like, also returns db[n_out] = column sums of dZ (over the first `bias_rows` rows when the tail rows are
-    tangent rows that carry no bias) from the same pass over dZ."""
-    dW = torch.zeros_like(like)
-    if bias_like is None:
-        hip.gemm(dZ, X, dW, n_out, k_in, M, a_kcontig=False, b_kcontig=False, k_splits=_splits(M, n_out, k_in), precision=BWD_PRECISION)
-        return dW
-    db = torch.zeros_like(bias_like)
-    if bias_rows is None or bias_rows == M:
-        hip.gemm(dZ, X, dW, n_out, k_in, M, a_kcontig=False, b_kcontig=False, k_splits=_splits(M, n_out, k_in), a_rowsum=db, precision=BWD_PRECISION)
+    tangent rows that carry no bias) from the same pass over dZ.  acc=(dW, db): accumulate into existing buffers
+    (row-chunked callers)."""
+    if acc is not None:
+        dW, db = acc
     else:
-        hip.gemm(dZ, X, dW, n_out, k_in, M, a_kcontig=False, b_kcontig=False, k_splits=_splits(M, n_out, k_in), precision=BWD_PRECISION)
+        dW = torch.zeros_like(like)
+        db = torch.zeros_like(bias_like) if bias_like is not None else None
+    splits = _splits(M, n_out, k_in)
+    kw = dict(a_kcontig=False, b_kcontig=False, k_splits=splits, precision=BWD_PRECISION)
+    if acc is not None and splits <= 1:
+        kw["beta"] = 1.0  # single-pass epilogue: add to what the previous chunks left
+    if db is None:
+        hip.gemm(dZ, X, dW, n_out, k_in, M, **kw)
+        return dW
+    if bias_rows is None or bias_rows == M:
+        hip.gemm(dZ, X, dW, n_out, k_in, M, a_rowsum=db, **kw)
+    else:
+        hip.gemm(dZ, X, dW, n_out, k_in, M, **kw)
         hip.colsum(dZ, bias_rows, n_out, db)
     return dW, db
 
@@ -174,43 +187,54 @@ class FilmSirenFn(torch.autograd.Function):
     Returns the raw head output [M, pad4(out)] (activation applied by the caller)."""
 
     @staticmethod
-    def forward(ctx, x, cond, n_map, n_film, train_weights, need_dcond, *wb):
-        M = x.shape[0]
-        ctx.need_dx = x.requires_grad
-        dev = x.device
+    def _unpack(wb, n_map, n_film):
         mw = [wb[2 * i] for i in range(n_map)]
         mb = [wb[2 * i + 1] for i in range(n_map)]
         mwo, mbo = wb[2 * n_map], wb[2 * n_map + 1]
         o = 2 * n_map + 2
         fw = [wb[o + 2 * i] for i in range(n_film)]
         fb = [wb[o + 2 * i + 1] for i in range(n_film)]
-        ow, ob = wb[o + 2 * n_film], wb[o + 2 * n_film + 1]
-        H = fw[0].shape[0]
-        Hm = mw[0].shape[0]
-        # mapping network: (Linear, LeakyReLU(0.2)) * n  -> Linear to 2*n_film*H  (siren.py:114-119)
-        hs = []
-        h = cond
-        for i in range(n_map):
-            out = torch.empty(M, Hm, device=dev)
-            fgemm(h, mw[i], out, M, Hm, mw[i].shape[1], bias=mb[i], epi=hip.EPI_LEAKY, p0=0.2)
-            hs.append(out)
-            h = out
-        FP = torch.empty(M, 2 * n_film * H, device=dev)
-        fgemm(h, mwo, FP, M, 2 * n_film * H, Hm, bias=mbo)
-        # FiLM layers: sin((15 F + 30) (W y + b) + P)  (siren.py:141-144, :200)
-        ys, zs = [], []
-        y = x
-        for i in range(n_film):
-            out = torch.empty(M, H, device=dev)
-            z = torch.empty(M, H, device=dev)
-            fgemm(y, fw[i], out, M, H, fw[i].shape[1], bias=fb[i], epi=hip.EPI_FILM, p0=15.0, p1=30.0,
-                     aux0=FP[:, i * H:(i + 1) * H], aux1=FP[:, (n_film + i) * H:(n_film + i + 1) * H], out1=z)
-            ys.append(out)
-            zs.append(z)
-            y = out
+        return mw, mb, mwo, mbo, fw, fb, wb[o + 2 * n_film], wb[o + 2 * n_film + 1], o
+
+    @staticmethod
+    def _chunks(M):
+        """Row chunks.  A chunk of 32768 rows keeps every producer -> consumer hand-off of the layer chain (33.5 MB per
+        [chunk, 256] matrix) inside the 256 MiB Infinity Cache, so the next layer's operand and aux reads are served
+        on-die instead of from HBM; the un-chunked chain streams 268 MB matrices through HBM between launches."""
+        ch = FILM_ROW_CHUNK
+        if ch <= 0 or M < 2 * ch:
+            return [(0, M)]
+        return [(r, min(M, r + ch)) for r in range(0, M, ch)]
+
+    @staticmethod
+    def forward(ctx, x, cond, n_map, n_film, train_weights, need_dcond, *wb):
+        M = x.shape[0]
+        ctx.need_dx = x.requires_grad
+        dev = x.device
+        mw, mb, mwo, mbo, fw, fb, ow, ob, o = FilmSirenFn._unpack(wb, n_map, n_film)
+        H, Hm = fw[0].shape[0], mw[0].shape[0]
         n_out_p = ow.shape[0]
+        hs = [torch.empty(M, Hm, device=dev) for _ in range(n_map)]
+        FP = torch.empty(M, 2 * n_film * H, device=dev)
+        ys = [torch.empty(M, H, device=dev) for _ in range(n_film)]
+        zs = [torch.empty(M, H, device=dev) for _ in range(n_film)]
         res = torch.zeros(M, n_out_p, device=dev)
-        fgemm(y, ow, res, M, n_out_p, H, bias=ob)
+        for r0, r1 in FilmSirenFn._chunks(M):
+            m = r1 - r0
+            # mapping network: (Linear, LeakyReLU(0.2)) * n  -> Linear to 2*n_film*H  (siren.py:114-119)
+            h = cond[r0:r1]
+            for i in range(n_map):
+                fgemm(h, mw[i], hs[i][r0:r1], m, Hm, mw[i].shape[1], bias=mb[i], epi=hip.EPI_LEAKY, p0=0.2)
+                h = hs[i][r0:r1]
+            fp = FP[r0:r1]
+            fgemm(h, mwo, fp, m, 2 * n_film * H, Hm, bias=mbo)
+            # FiLM layers: sin((15 F + 30) (W y + b) + P)  (siren.py:141-144, :200)
+            y = x[r0:r1]
+            for i in range(n_film):
+                fgemm(y, fw[i], ys[i][r0:r1], m, H, fw[i].shape[1], bias=fb[i], epi=hip.EPI_FILM, p0=15.0, p1=30.0,
+                      aux0=fp[:, i * H:(i + 1) * H], aux1=fp[:, (n_film + i) * H:(n_film + i + 1) * H], out1=zs[i][r0:r1])
+                y = ys[i][r0:r1]
+            fgemm(y, ow, res[r0:r1], m, n_out_p, H, bias=ob)
         ctx.save_for_backward(x, cond, FP, *hs, *ys, *zs, *wb)
         ctx.cfg = (n_map, n_film, train_weights, need_dcond, M, H, Hm)
         return res
@@ -224,63 +248,65 @@ class FilmSirenFn(torch.autograd.Function):
         ys = list(sv[3 + n_map:3 + n_map + n_film])
         zs = list(sv[3 + n_map + n_film:3 + n_map + 2 * n_film])
         wb = sv[3 + n_map + 2 * n_film:]
-        mw = [wb[2 * i] for i in range(n_map)]
-        mb = [wb[2 * i + 1] for i in range(n_map)]
-        mwo, mbo = wb[2 * n_map], wb[2 * n_map + 1]
-        o = 2 * n_map + 2
-        fw = [wb[o + 2 * i] for i in range(n_film)]
-        fb = [wb[o + 2 * i + 1] for i in range(n_film)]
-        ow, ob = wb[o + 2 * n_film], wb[o + 2 * n_film + 1]
+        mw, mb, mwo, mbo, fw, fb, ow, ob, o = FilmSirenFn._unpack(wb, n_map, n_film)
         dev = x.device
         grads: List[Optional[torch.Tensor]] = [None] * len(wb)
         d_res = d_res.contiguous()
         n_out_p = ow.shape[0]
-        if train_w:
-            grads[o + 2 * n_film], grads[o + 2 * n_film + 1] = grad_weight(d_res, ys[-1], M, n_out_p, H, ow, ob)
-        dFP = torch.empty(M, 2 * n_film * H, device=dev)
-        d_x = None
-        # walk the FiLM layers backwards; each dX GEMM applies the FiLM backward epilogue of the layer below
-        dZ = torch.empty(M, H, device=dev)
-        i = n_film - 1
-        grad_input(d_res, ow, M, H, n_out_p, dZ, epi=hip.EPI_BWD_FILM, p0=15.0, p1=30.0, aux0=zs[i],
-                   aux1=FP[:, i * H:(i + 1) * H], aux2=FP[:, (n_film + i) * H:(n_film + i + 1) * H],
-                   out1=dFP[:, i * H:(i + 1) * H], out2=dFP[:, (n_film + i) * H:(n_film + i + 1) * H])
-        while True:
-            y_in = ys[i - 1] if i > 0 else x
-            k_in = fw[i].shape[1]
-            if train_w:
-                grads[o + 2 * i], grads[o + 2 * i + 1] = grad_weight(dZ, y_in, M, H, k_in, fw[i], fb[i])
-            if i == 0:
-                if ctx.need_dx:  # gradient w.r.t. the encoded direction rows (DDF multi-view rays, ddf_model.py:297-322)
-                    d_x = torch.empty(M, k_in, device=dev)
-                    grad_input(dZ, fw[0], M, k_in, H, d_x)
-                break
-            dZn = torch.empty(M, H, device=dev)
-            j = i - 1
-            grad_input(dZ, fw[i], M, H, H, dZn, epi=hip.EPI_BWD_FILM, p0=15.0, p1=30.0, aux0=zs[j],
-                       aux1=FP[:, j * H:(j + 1) * H], aux2=FP[:, (n_film + j) * H:(n_film + j + 1) * H],
-                       out1=dFP[:, j * H:(j + 1) * H], out2=dFP[:, (n_film + j) * H:(n_film + j + 1) * H])
-            dZ = dZn
-            i = j
-        # mapping network
         NF = 2 * n_film * H
-        if train_w:
-            grads[2 * n_map], grads[2 * n_map + 1] = grad_weight(dFP, hs[-1], M, NF, Hm, mwo, mbo)
-        dpre = torch.empty(M, Hm, device=dev)
-        grad_input(dFP, mwo, M, Hm, NF, dpre, epi=hip.EPI_BWD_LEAKY, p0=0.2, aux0=hs[-1])
-        d_cond = None
-        for i in range(n_map - 1, -1, -1):
-            h_in = hs[i - 1] if i > 0 else cond
-            k_in = mw[i].shape[1]
+        if train_w:  # gradient accumulators shared by every row chunk
+            for idx in range(len(wb)):
+                grads[idx] = torch.zeros_like(wb[idx])
+        acc = (lambda iw: (grads[iw], grads[iw + 1])) if train_w else (lambda iw: None)
+        d_x = torch.empty(M, fw[0].shape[1], device=dev) if ctx.need_dx else None
+        d_cond = torch.empty(M, mw[0].shape[1], device=dev) if need_dcond else None
+        chunks = FilmSirenFn._chunks(M)
+        mc = max(r1 - r0 for r0, r1 in chunks)
+        dFP_buf = torch.empty(mc, NF, device=dev)
+        dZa, dZb = torch.empty(mc, H, device=dev), torch.empty(mc, H, device=dev)
+        dPa, dPb = torch.empty(mc, Hm, device=dev), torch.empty(mc, Hm, device=dev)
+        for r0, r1 in chunks:
+            m = r1 - r0
+            fp, dFP = FP[r0:r1], dFP_buf[:m]
+            dr = d_res[r0:r1]
             if train_w:
-                grads[2 * i], grads[2 * i + 1] = grad_weight(dpre, h_in, M, Hm, k_in, mw[i], mb[i])
-            if i > 0:
-                nxt = torch.empty(M, Hm, device=dev)
-                grad_input(dpre, mw[i], M, Hm, Hm, nxt, epi=hip.EPI_BWD_LEAKY, p0=0.2, aux0=hs[i - 1])
-                dpre = nxt
-            elif need_dcond:
-                d_cond = torch.empty(M, k_in, device=dev)
-                grad_input(dpre, mw[0], M, k_in, Hm, d_cond)
+                grad_weight(dr, ys[-1][r0:r1], m, n_out_p, H, ow, ob, acc=acc(o + 2 * n_film))
+            # walk the FiLM layers backwards; each dX GEMM applies the FiLM backward epilogue of the layer below
+            i = n_film - 1
+            dZ, dZo = dZa[:m], dZb[:m]
+            grad_input(dr, ow, m, H, n_out_p, dZ, epi=hip.EPI_BWD_FILM, p0=15.0, p1=30.0, aux0=zs[i][r0:r1],
+                       aux1=fp[:, i * H:(i + 1) * H], aux2=fp[:, (n_film + i) * H:(n_film + i + 1) * H],
+                       out1=dFP[:, i * H:(i + 1) * H], out2=dFP[:, (n_film + i) * H:(n_film + i + 1) * H])
+            while True:
+                y_in = ys[i - 1][r0:r1] if i > 0 else x[r0:r1]
+                k_in = fw[i].shape[1]
+                if train_w:
+                    grad_weight(dZ, y_in, m, H, k_in, fw[i], fb[i], acc=acc(o + 2 * i))
+                if i == 0:
+                    if d_x is not None:  # gradient w.r.t. the encoded direction rows (DDF multi-view rays, ddf_model.py:297-322)
+                        grad_input(dZ, fw[0], m, k_in, H, d_x[r0:r1])
+                    break
+                j = i - 1
+                grad_input(dZ, fw[i], m, H, H, dZo, epi=hip.EPI_BWD_FILM, p0=15.0, p1=30.0, aux0=zs[j][r0:r1],
+                           aux1=fp[:, j * H:(j + 1) * H], aux2=fp[:, (n_film + j) * H:(n_film + j + 1) * H],
+                           out1=dFP[:, j * H:(j + 1) * H], out2=dFP[:, (n_film + j) * H:(n_film + j + 1) * H])
+                dZ, dZo = dZo, dZ
+                i = j
+            # mapping network
+            if train_w:
+                grad_weight(dFP, hs[-1][r0:r1], m, NF, Hm, mwo, mbo, acc=acc(2 * n_map))
+            dpre, dpo = dPa[:m], dPb[:m]
+            grad_input(dFP, mwo, m, Hm, NF, dpre, epi=hip.EPI_BWD_LEAKY, p0=0.2, aux0=hs[-1][r0:r1])
+            for i in range(n_map - 1, -1, -1):
+                h_in = hs[i - 1][r0:r1] if i > 0 else cond[r0:r1]
+                k_in = mw[i].shape[1]
+                if train_w:
+                    grad_weight(dpre, h_in, m, Hm, k_in, mw[i], mb[i], acc=acc(2 * i))
+                if i > 0:
+                    grad_input(dpre, mw[i], m, Hm, Hm, dpo, epi=hip.EPI_BWD_LEAKY, p0=0.2, aux0=hs[i - 1][r0:r1])
+                    dpre, dpo = dpo, dpre
+                elif d_cond is not None:
+                    grad_input(dpre, mw[0], m, k_in, Hm, d_cond[r0:r1])
         return (d_x, d_cond, None, None, None, None, *grads)
 
 

@@ -30,7 +30,7 @@ def randomise(pipeline, seed=0, scale=1.0):
     with torch.no_grad():
         for name, p in pipeline.named_parameters():
             if name.endswith("encoding.params") or name.endswith("position_encoding.params"):
-                p.copy_(((torch.rand(p.shape, generator=g) * 2 - 1) * 0.05 * scale).to(p.device))
+                p.copy_(((torch.rand(p.shape, generator=g) * 2 - 1) * 0.02 * scale).to(p.device))
         m.train_illumination_latents.copy_((torch.randn(m.train_illumination_latents.shape, generator=g) * 0.3).to(m.device))
         m.train_scale.copy_((1 + 0.2 * torch.rand(m.train_scale.shape, generator=g)).to(m.device))
         m.visibility_threshold.fill_(0.3)
