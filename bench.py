@@ -224,6 +224,12 @@ def main():
             kernel = "gemm_bf16s_kernel<3,true,true> (fp32 operands split on the fly into 3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate)"
             peak, dtype = PEAK_BF16_MFMA_TFLOPS / 6.0, "f32 (3-term bf16 split on the matrix cores)"
             peak_note = "bf16 dense MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32-equivalent product = 416.7 TFLOP/s of algorithmic FLOPs"
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (not re-collected live)
+            tj = json.load(open(tpath))
+            if tj.get("precision_policy") == ops._POLICY:
+                traffic = tj["traffic_bytes_per_launch"]
         line = {
             "metric": "train rays/sec on NeRF-OSR lk2 @1024 rays x 96 samples",
             "value": rays_total / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -236,7 +242,7 @@ def main():
                        "parallelism": f"ray-sharded dp{world}", "final_loss": float(loss),
                        "launch": "HIP graph replay (1 graph/step + all-reduce + 5 Adam launches)" if use_graph else "eager (host launches every kernel)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None, "kernel": kernel, "peak_note": peak_note,
+                         "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic.json)", "kernel": kernel, "peak_note": peak_note,
                          "precision_policy": ops._POLICY,
                          "launches_timed": n_launch, "avg_launch_ms": k_ms / max(n_launch, 1),
                          "algorithmic_flops_per_launch": k_flops / max(n_launch, 1)},
