@@ -1,0 +1,91 @@
+"""Device-resident image datamanager: ray generation + pixel / mask sampling on the GPU.
+
+Takes the place of `NeuSkyDataManager.next_train / get_sky_ray_bundle` + `NeuSkyPixelSampler`
+(neusky/data/datamanagers/neusky_datamanager.py:277-288, neusky/data/neusky_pixel_sampler.py:36-81) for an image stack
+that is already on the device (`images_on_gpu=True, masks_on_gpu=True`, neusky_config.py:60-61):
+  * masks have 4 channels [static, fg, ground, sky] (neusky/data/datasets/neusky_dataset.py:290); training pixels are
+    drawn uniformly from the pixels whose channel 0 (static) is set (neusky_pixel_sampler.py:36-46);
+  * sky rays are drawn from the pixels whose fg channel (1) is NOT set (`1 - mask[..., 1:2]`, :58-62);
+  * rays come from pinhole cameras in nerfstudio's convention (x right, y up, camera looks along -z; pixel centres at
+    +0.5), directions normalised, `metadata["directions_norm"]` = the norm before normalisation.
+The reference round-trips the sampled indices through the CPU every step (:55-57, datamanager :286); here the valid-pixel
+lists are built once and a step is three `randint` + gathers on the device (static shapes, hipGraph-safe).
+Parsing NeRF-OSR / Cityscapes folders from disk is SURVEY 8(f) item 4 and not part of this class.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from ..cameras.rays import RayBundle
+
+
+class _Dataset:
+    def __init__(self, n, scene_box):
+        self._n, self.scene_box, self.metadata = n, scene_box, {}
+
+    def __len__(self):
+        return self._n
+
+
+class DeviceImageDataManager:
+    def __init__(self, images: torch.Tensor, masks: torch.Tensor, c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float,
+                 train_num_rays_per_batch: int = 1024, device="cuda:0", scene_scale: float = 1.0, num_eval: int = 0, seed: int = 0):
+        """images [N,H,W,3] float, masks [N,H,W,4] bool, c2w [N,3,4] camera-to-world (nerfstudio/OpenGL convention)"""
+        assert images.shape[:3] == masks.shape[:3] and masks.shape[-1] == 4 and c2w.shape[1:] == (3, 4)
+        self.device = device
+        self.images, self.masks, self.c2w = images.to(device), masks.to(device).bool(), c2w.to(device).float()
+        self.N, self.H, self.W = images.shape[:3]
+        self.fx, self.fy, self.cx, self.cy = fx, fy, cx, cy
+        self.train_num_rays_per_batch = train_num_rays_per_batch
+        scene_box = {"aabb": torch.tensor([[-scene_scale] * 3, [scene_scale] * 3])}
+        self.train_dataset = _Dataset(self.N, scene_box)
+        self.eval_dataset = _Dataset(max(num_eval, 1), scene_box)
+        self.num_val = self.num_test = max(num_eval, 1)
+        # valid-pixel lists, built once (the only nonzero() calls; never inside a step)
+        self.static_pixels = torch.nonzero(self.masks[..., 0])        # [K,3] = (image, y, x)
+        self.sky_pixels = torch.nonzero(~self.masks[..., 1])          # 1 - fg
+        assert self.static_pixels.shape[0] > 0, "no pixel with the static mask set"
+        self.gen = torch.Generator(device=device).manual_seed(seed)
+
+    def get_param_groups(self) -> Dict:
+        return {}
+
+    def generate_rays(self, indices: torch.Tensor) -> RayBundle:
+        """indices [R,3] = (image, y, x) on the device -> RayBundle (pinhole, nerfstudio convention)"""
+        c, y, x = indices[:, 0], indices[:, 1].float(), indices[:, 2].float()
+        d_cam = torch.stack([(x + 0.5 - self.cx) / self.fx, -(y + 0.5 - self.cy) / self.fy, -torch.ones_like(x)], -1)
+        R = self.c2w[c, :, :3]
+        d = torch.einsum("rij,rj->ri", R, d_cam)
+        norm = d.norm(dim=-1, keepdim=True)
+        n = indices.shape[0]
+        return RayBundle(origins=self.c2w[c, :, 3].contiguous(), directions=(d / norm).contiguous(),
+                         pixel_area=torch.full((n, 1), 1.0 / (self.fx * self.fy), device=indices.device),
+                         camera_indices=c[:, None].contiguous(), metadata={"directions_norm": norm})
+
+    def _draw(self, pixels: torch.Tensor, n: int) -> torch.Tensor:
+        pick = torch.randint(0, pixels.shape[0], (n,), device=pixels.device, generator=self.gen)
+        return pixels[pick]
+
+    def next_train(self, step: int) -> Tuple[RayBundle, Dict]:
+        idx = self._draw(self.static_pixels, self.train_num_rays_per_batch)
+        c, y, x = idx[:, 0], idx[:, 1], idx[:, 2]
+        batch = {"image": self.images[c, y, x], "mask": self.masks[c, y, x], "indices": idx}
+        return self.generate_rays(idx), batch
+
+    def get_sky_ray_bundle(self, number_of_rays: int) -> RayBundle:
+        pool = self.sky_pixels if self.sky_pixels.shape[0] > 0 else self.static_pixels
+        return self.generate_rays(self._draw(pool, number_of_rays))
+
+    def get_eval_image_half_bundle(self, sample_region: str = "full_image", image_index: int = 0, num_rays: Optional[int] = None):
+        """rays of ONE image restricted to an image half and to the static mask (datamanager :288-333), for eval-latent fitting"""
+        n = num_rays or self.train_num_rays_per_batch
+        sel = self.static_pixels[self.static_pixels[:, 0] == image_index]
+        if sample_region == "left_image_half":
+            sel = sel[sel[:, 2] < self.W // 2]
+        elif sample_region == "right_image_half":
+            sel = sel[sel[:, 2] >= self.W // 2]
+        idx = self._draw(sel, n)
+        c, y, x = idx[:, 0], idx[:, 1], idx[:, 2]
+        return self.generate_rays(idx), {"image": self.images[c, y, x], "mask": self.masks[c, y, x], "indices": idx}

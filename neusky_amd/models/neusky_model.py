@@ -492,6 +492,46 @@ class NeuSkyFactoModel(nn.Module):
         normals = torch.sum(weights * fo[FieldHeadNames.NORMALS], dim=-2).reshape(-1, 3)
         return {"ray_bundle": ray_bundle, "accumulations": accumulations, "mask": mask, "termination_dist": p2p, "normals": normals}
 
+    def fit_latent_codes_for_eval(self, datamanager, global_step: int, steps: int = 250, lr: float = 1e-1, lr_final: float = 1e-7,
+                                  eps: float = 1e-15, sample_region: str = "full_image", image_indices=None, log_every: int = 0):
+        """neusky_model.py:1503-1588 (`eval_latent_optimise_method="per_image"`): optimise the per-eval-image illumination
+        latents + scale with the decoder held fixed; 250 Adam steps, exponential decay 1e-1 -> 1e-7
+        (neusky_config.py:142-147).  Loss = rgb + sky-pixel terms of the eval branch (:1036-1059).  Returns the loss trace."""
+        from ..engine import ExponentialDecaySchedulerConfig
+        self.fitting_eval_latents = True  # forward() now reads the eval latents (:1506-1507)
+        params = [self.eval_illumination_latents, self.eval_scale]
+        with torch.no_grad():  # :1536-1540
+            self.eval_illumination_latents.zero_()
+            self.eval_scale.fill_(1.0)
+        for p in params:
+            p.requires_grad_(True)
+        frozen = [p for p in self.parameters() if p.requires_grad and all(p is not q for q in params)]
+        for p in frozen:
+            p.requires_grad_(False)
+        state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in params]
+        sched = ExponentialDecaySchedulerConfig(lr_final=lr_final, max_steps=steps, lr_init=lr)
+        image_indices = list(range(self.num_eval_data)) if image_indices is None else list(image_indices)
+        trace = []
+        try:
+            for it in range(steps):
+                ray_bundle, batch = datamanager.get_eval_image_half_bundle(sample_region=sample_region,
+                                                                           image_index=image_indices[it % len(image_indices)])
+                for p in params:
+                    p.grad = None
+                outputs = self.forward(ray_bundle=ray_bundle, step=global_step)
+                loss = sum(self.get_loss_dict(outputs, batch).values())
+                loss.backward()
+                for p, (m_, v_) in zip(params, state):
+                    if p.grad is not None:
+                        hip.adam_step(p.data, p.grad.contiguous(), m_, v_, lr * sched.factor(it), 0.9, 0.999, eps, it + 1)
+                if log_every and it % log_every == 0:
+                    trace.append(loss.detach())
+        finally:
+            for p in frozen:
+                p.requires_grad_(True)
+            self.fitting_eval_latents = False  # :1588
+        return trace
+
     def begin_frame(self, camera_index: int, rotation: Optional[torch.Tensor] = None) -> None:
         """decode the illumination of ONE camera for a whole frame (the reference re-decodes it in each of the
         8100 chunks of a 1080p frame, neusky_model.py:1413-1432; the result is the same)"""
