@@ -159,7 +159,8 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: other host threads (e.g. the RCCL watchdog) may legally touch the runtime during the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss, self.loss_dict, self.metrics = self._body(start_step + warmup)
         torch.cuda.synchronize()
 

@@ -597,7 +597,7 @@ class _ChunkRunner:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.out = model.forward(self.rb)
 
     def _load(self, flat: RayBundle, a: int, b: int) -> None:
