@@ -544,7 +544,16 @@ class NeuSkyFactoModel(nn.Module):
             cols = self.illumination_field.forward_grid(dirs, latents[cam][None], scales[cam][None])
         else:
             cols = self.illumination_field(dirs, latents[cam][None].expand(D, -1, -1), scales[cam].expand(D), rotation)[None]
-        self._frame_illumination = (dirs, cols.contiguous(), sel, cam, rotation)
+        # static per-model buffers: a chunk graph captured for one frame stays valid for the next (animation frames
+        # only change the camera / rotation, render_animation.py:196-207)
+        st = getattr(self, "_frame_static", None)
+        if st is None or st[0].shape != dirs.shape or st[0].device != dirs.device:
+            st = (torch.empty_like(dirs), torch.empty_like(cols), torch.empty_like(sel))
+            self._frame_static = st
+            self._chunk_runners = {}
+        st[0].copy_(dirs); st[1].copy_(cols); st[2].copy_(sel)
+        self._frame_illumination = (st[0], st[1], st[2], cam, rotation)
+        self._frame_key = (cam, None if rotation is None else tuple(rotation.reshape(-1).tolist()))
 
     def end_frame(self) -> None:
         self._frame_illumination = None
@@ -567,7 +576,15 @@ class NeuSkyFactoModel(nn.Module):
         keys = ["rgb", "albedo", "accumulation", "depth", "p2p_dist", "normal"]
         out = {k: [] for k in keys}
         try:
-            runner = _ChunkRunner(self, chunk, flat, use_graph)
+            # the background term depends on (camera, rotation) through python values baked into a capture, so graphs
+            # are cached per (chunk, camera, rotation); eager runners are free to share
+            key = (chunk, use_graph, self._frame_key if use_graph else None)
+            runner = self._chunk_runners.get(key)
+            if runner is None:
+                runner = _ChunkRunner(self, chunk, flat, use_graph)
+                if len(self._chunk_runners) >= 4:
+                    self._chunk_runners.clear()
+                self._chunk_runners[key] = runner
             for i in range(0, num_rays, chunk):
                 res = runner.run(flat, i, min(i + chunk, num_rays))
                 for k in keys:

@@ -214,10 +214,19 @@ class FilmSirenFn(torch.autograd.Function):
         mw, mb, mwo, mbo, fw, fb, ow, ob, o = FilmSirenFn._unpack(wb, n_map, n_film)
         H, Hm = fw[0].shape[0], mw[0].shape[0]
         n_out_p = ow.shape[0]
-        hs = [torch.empty(M, Hm, device=dev) for _ in range(n_map)]
+        # nothing has to survive the call when no input needs a gradient (render / eval): two ping-pong activation
+        # buffers, no pre-activation side output
+        save = any(ctx.needs_input_grad)
+        if save:
+            hs = [torch.empty(M, Hm, device=dev) for _ in range(n_map)]
+            ys = [torch.empty(M, H, device=dev) for _ in range(n_film)]
+            zs = [torch.empty(M, H, device=dev) for _ in range(n_film)]
+        else:
+            pp = [torch.empty(M, max(H, Hm), device=dev) for _ in range(2)]
+            hs = [pp[i & 1][:, :Hm] for i in range(n_map)]
+            ys = [pp[(n_map + i) & 1][:, :H] for i in range(n_film)]
+            zs = [None] * n_film
         FP = torch.empty(M, 2 * n_film * H, device=dev)
-        ys = [torch.empty(M, H, device=dev) for _ in range(n_film)]
-        zs = [torch.empty(M, H, device=dev) for _ in range(n_film)]
         res = torch.zeros(M, n_out_p, device=dev)
         for r0, r1 in FilmSirenFn._chunks(M):
             m = r1 - r0
@@ -232,9 +241,12 @@ class FilmSirenFn(torch.autograd.Function):
             y = x[r0:r1]
             for i in range(n_film):
                 fgemm(y, fw[i], ys[i][r0:r1], m, H, fw[i].shape[1], bias=fb[i], epi=hip.EPI_FILM, p0=15.0, p1=30.0,
-                      aux0=fp[:, i * H:(i + 1) * H], aux1=fp[:, (n_film + i) * H:(n_film + i + 1) * H], out1=zs[i][r0:r1])
+                      aux0=fp[:, i * H:(i + 1) * H], aux1=fp[:, (n_film + i) * H:(n_film + i + 1) * H],
+                      out1=zs[i][r0:r1] if save else None)
                 y = ys[i][r0:r1]
             fgemm(y, ow, res[r0:r1], m, n_out_p, H, bias=ob)
+        if not save:
+            return res
         ctx.save_for_backward(x, cond, FP, *hs, *ys, *zs, *wb)
         ctx.cfg = (n_map, n_film, train_weights, need_dcond, M, H, Hm)
         return res
