@@ -161,7 +161,30 @@ class SDFAlbedoField(nn.Module):
         self.softplus_beta = 100.0  # :163
 
     # ------------------------------------------------------------------ weight preparation (tiny torch ops)
+    def invalidate_weight_cache(self) -> None:
+        """call once per optimisation step (before the first use): the weight-normed / permuted / padded matrices are
+        prepared once and shared by every pass of the step (main rays, DDF-fit rays, grid probe, sdf probes)"""
+        self._wcache = {}
+
     def _geo_weights(self):
+        c = getattr(self, "_wcache", None)
+        if c is not None and "geo" in c and torch.is_grad_enabled() == c["geo_grad"]:
+            return c["geo"]
+        w = self._geo_weights_uncached()
+        if c is not None:
+            c["geo"], c["geo_grad"] = w, torch.is_grad_enabled()
+        return w
+
+    def _colour_weights(self):
+        c = getattr(self, "_wcache", None)
+        if c is not None and "col" in c and torch.is_grad_enabled() == c["col_grad"]:
+            return c["col"]
+        w = self._colour_weights_uncached()
+        if c is not None:
+            c["col"], c["col_grad"] = w, torch.is_grad_enabled()
+        return w
+
+    def _geo_weights_uncached(self):
         GF = self.config.geo_feat_dim
         W0, W1, W2 = self.glin0.weight(), self.glin1.weight(), self.glin2.weight()
         z = W2.new_zeros(3, W2.shape[1])
@@ -170,7 +193,7 @@ class SDFAlbedoField(nn.Module):
         b2p = torch.cat([b2[1:], b2[:1], b2.new_zeros(3)], 0).contiguous()
         return (ops.pad_weight(W0), self.glin0.bias.contiguous(), W1.contiguous(), self.glin1.bias.contiguous(), W2p, b2p)
 
-    def _colour_weights(self):
+    def _colour_weights_uncached(self):
         Wc0 = self.clin0.weight()  # columns [x(3) PE(36) feat(GF)]
         H = Wc0.shape[0]
         Wc0p = torch.cat([Wc0[:, 39:], Wc0.new_zeros(H, 4), Wc0[:, :39], Wc0.new_zeros(H, 1)], 1).contiguous()

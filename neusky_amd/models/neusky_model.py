@@ -176,6 +176,13 @@ class NeuSkyFactoModel(nn.Module):
             bias = lambda x, b: (b * x) / ((b - 1) * x + 1)
             self.proposal_sampler.set_anneal(bias(frac, c.proposal_weights_anneal_slope))
 
+    def begin_step(self) -> None:
+        """start of an optimisation step: drop the per-step caches of prepared (weight-normed / padded) matrices"""
+        self.field.invalidate_weight_cache()
+        self.illumination_field.network.invalidate_weight_cache()
+        if self.visibility_field is not None:
+            self.visibility_field.field.ddf.invalidate_weight_cache()
+
     # ------------------------------------------------------------------ collider
     def collider(self, ray_bundle: RayBundle) -> RayBundle:
         """nerfstudio SphereCollider(center=0, radius=1, near_plane=0.05) (neusky_model.py:213)"""
@@ -196,6 +203,8 @@ class NeuSkyFactoModel(nn.Module):
                 step: Optional[int] = None, randoms: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, Any]:
         """neusky_model.py:425-443"""
         ray_bundle = self.collider(ray_bundle)
+        if not self.training:
+            self.begin_step()  # no optimiser between eval forwards, but parameters may have been loaded / fitted
         return self.get_outputs(ray_bundle, batch=batch, rotation=rotation, step=step, randoms=randoms)
 
     # ------------------------------------------------------------------ sampling + field
@@ -518,6 +527,7 @@ class NeuSkyFactoModel(nn.Module):
                                                                            image_index=image_indices[it % len(image_indices)])
                 for p in params:
                     p.grad = None
+                self.begin_step()
                 outputs = self.forward(ray_bundle=ray_bundle, step=global_step)
                 loss = sum(self.get_loss_dict(outputs, batch).values())
                 loss.backward()

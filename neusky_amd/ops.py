@@ -266,9 +266,13 @@ class FilmSirenFn(torch.autograd.Function):
         d_res = d_res.contiguous()
         n_out_p = ow.shape[0]
         NF = 2 * n_film * H
-        if train_w:  # gradient accumulators shared by every row chunk
-            for idx in range(len(wb)):
-                grads[idx] = torch.zeros_like(wb[idx])
+        if train_w:  # gradient accumulators shared by every row chunk: ONE zero-filled slab, carved into views
+            sizes = [(t.numel() + 3) // 4 * 4 for t in wb]
+            flat = torch.zeros(sum(sizes), device=dev)
+            off = 0
+            for idx, t in enumerate(wb):
+                grads[idx] = flat[off:off + t.numel()].view_as(t)
+                off += sizes[idx]
         acc = (lambda iw: (grads[iw], grads[iw + 1])) if train_w else (lambda iw: None)
         d_x = torch.empty(M, fw[0].shape[1], device=dev) if ctx.need_dx else None
         d_cond = torch.empty(M, mw[0].shape[1], device=dev) if need_dcond else None

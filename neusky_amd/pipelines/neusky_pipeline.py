@@ -120,6 +120,7 @@ class NeuSkyPipeline(nn.Module):
         if ray_bundle is None:
             ray_bundle, batch = self.datamanager.next_train(step)
         model.set_step(step)
+        model.begin_step()  # prepared-weight caches are per optimisation step
         model_outputs = model(ray_bundle, batch=batch, step=step, randoms=randoms)
         metrics_dict = model.get_metrics_dict(model_outputs, batch)
         loss_dict = model.get_loss_dict(model_outputs, batch, metrics_dict)

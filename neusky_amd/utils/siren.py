@@ -60,7 +60,19 @@ class FiLMSiren(nn.Module):
                 l.layer.weight.uniform_(-bound, bound)
             self.final_layer.weight.uniform_(-math.sqrt(6.0 / hidden_features) / 25.0, math.sqrt(6.0 / hidden_features) / 25.0)
 
+    def invalidate_weight_cache(self) -> None:
+        self._wcache = {}
+
     def padded_weights(self):
+        c = getattr(self, "_wcache", None)
+        if c is not None and "wb" in c and c["grad"] == torch.is_grad_enabled():
+            return c["wb"]
+        wb = self._padded_weights_uncached()
+        if c is not None:
+            c["wb"], c["grad"] = wb, torch.is_grad_enabled()
+        return wb
+
+    def _padded_weights_uncached(self):
         wb = []
         for lin in self.mapping_network.linears():
             wb += [ops.pad_weight(lin.weight), ops.pad_bias(lin.bias)]
