@@ -76,8 +76,19 @@ class DDFModel(nn.Module):
                                           ends=torch.zeros_like(positions), pixel_area=torch.ones_like(positions[..., 0])))
         return self.field.forward(rs)[NeuSkyFieldHeadNames.TERMINATION_DISTANCE]
 
+    def prepare_queries(self, ray_bundle: RayBundle, batch, mv_points: Optional[torch.Tensor] = None):
+        """(positions [E,3], world directions [E,3]) of EVERY DDF evaluation get_outputs will need, in its order
+        (rays | multi-view | sky).  The pipeline hands them to NeuSkyFactoModel.compute_visibility so that they ride
+        in the same GEMM launches as the 262 144 visibility rows instead of a second chain of small launches."""
+        return self.get_outputs(ray_bundle, batch, None, prepare_only=True, mv_points=mv_points)
+
     def get_outputs(self, ray_bundle: RayBundle, batch, neusky, stop_gradients: bool = True,
-                    mv_points: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                    mv_points: Optional[torch.Tensor] = None, prepare_only: bool = False,
+                    precomputed: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """precomputed = {"mv_points": the points prepare_queries drew, "t_all": DDF output for its rows,
+        "sdf_main": sdf at the termination points of the first span} (see prepare_queries)."""
+        if precomputed is not None:
+            mv_points = precomputed["mv_points"]
         positions = ray_bundle.origins.reshape(-1, 3)
         directions = ray_bundle.directions.reshape(-1, 3)
         outputs: Dict[str, Any] = {}
@@ -106,14 +117,19 @@ class DDFModel(nn.Module):
             sp = ray_sphere_intersection(o, d, self.ddf_radius)
             n0 = sum(t.shape[0] for t in q_pos)
             q_pos.append(sp); q_dir.append(-d); spans["sky"] = (n0, n0 + sp.shape[0])
-        t_all = self.query(torch.cat(q_pos, 0), torch.cat(q_dir, 0))
+        if prepare_only:
+            return {"positions": torch.cat(q_pos, 0), "directions": torch.cat(q_dir, 0), "n_main": positions.shape[0],
+                    "main_directions": directions, "mv_points": mv_points}
+        t_all = precomputed["t_all"] if precomputed is not None else self.query(torch.cat(q_pos, 0), torch.cat(q_dir, 0))
         expected = t_all[spans["main"][0]:spans["main"][1]]
         outputs["expected_termination_dist"] = expected
         if c.include_depth_loss_scene_center_weight and self.training and batch is not None:  # :224-238
             dist = positions.norm(dim=-1) if c.scene_center_weight_include_z else positions[..., :2].norm(dim=-1)
             outputs["distance_weight"] = 1.0 - (dist / self.ddf_radius) ** c.scene_center_weight_exp
         if (c.loss_inclusions["sdf_l1_loss"] or c.loss_inclusions["sdf_l2_loss"]) and self.training:  # :241-254
-            if neusky is not None:
+            if precomputed is not None and precomputed.get("sdf_main") is not None:
+                outputs["sdf_at_termination"] = precomputed["sdf_main"]
+            elif neusky is not None:
                 term = positions + directions * expected.unsqueeze(-1)
                 if stop_gradients:
                     with torch.no_grad():

@@ -304,18 +304,37 @@ class NeuSkyFactoModel(nn.Module):
         term_dist = torch.empty(M, device=dev)
         hip.visibility_rays(origins.detach().contiguous(), ray_directions.detach().contiguous(),
                             depth.detach().reshape(-1).contiguous(), sel_dirs, self.ddf_radius, sphere_pts, xrow, surf_dist, term_dist)
-        t_hat = self.visibility_field.field.forward_rows(sphere_pts, xrow)  # :1716 -> ddf_model.py:217
+        ddf = self.visibility_field
+        extra = getattr(self, "_extra_ddf", None) if self.training else None
+        if extra is not None:
+            # rows of the DDF-fit step (rays | multi-view | sky, ddf_model.py:217,319,360) appended to the visibility rows
+            local = torch.einsum("ijl,ij->il", ddf.get_localised_transforms(extra["positions"]), extra["directions"])
+            t_all = ddf.field.forward_rows(torch.cat([sphere_pts, extra["positions"]], 0),
+                                           torch.cat([xrow, ddf.field.direction_rows(local)], 0))
+            t_hat, t_extra = t_all[:M], t_all[M:]
+        else:
+            t_hat = ddf.field.forward_rows(sphere_pts, xrow)  # :1716 -> ddf_model.py:217
         out: Dict[str, Any] = {"expected_termination_dist": t_hat}
         stop_gradients = self.config.sdf_to_visibility_stop_gradients in ["sdf", "both"]  # :1712-1714
-        vcfg = self.visibility_field.config
-        if (vcfg.loss_inclusions["sdf_l1_loss"] or vcfg.loss_inclusions["sdf_l2_loss"]) and self.visibility_field.training:
+        vcfg = ddf.config
+        sdf_extra = None
+        if (vcfg.loss_inclusions["sdf_l1_loss"] or vcfg.loss_inclusions["sdf_l2_loss"]) and ddf.training:
             world_dirs = (-sel_dirs)[None].expand(R, Dv, 3).reshape(-1, 3)
             term_pts = sphere_pts + world_dirs * t_hat[:, None]  # ddf_model.py:243
+            n_main = 0
+            if extra is not None and not stop_gradients and not extra["stop_gradients"]:
+                n_main = extra["n_main"]  # the fit rays' own termination points (ddf_model.py:243) join the same probe
+                term_pts = torch.cat([term_pts, extra["positions"][:n_main] + extra["main_directions"] * t_extra[:n_main, None]], 0)
             if stop_gradients:
                 with torch.no_grad():
-                    out["sdf_at_termination"] = self.field.get_sdf_at_pos(term_pts).detach()
+                    sdf_all = self.field.get_sdf_at_pos(term_pts).detach()
             else:
-                out["sdf_at_termination"] = self.field.get_sdf_at_pos(term_pts)
+                sdf_all = self.field.get_sdf_at_pos(term_pts)
+            out["sdf_at_termination"] = sdf_all[:M]
+            if n_main:
+                sdf_extra = sdf_all[M:]
+        if extra is not None:
+            self._extra_ddf_out = {"mv_points": extra["mv_points"], "t_all": t_extra, "sdf_main": sdf_extra}
         lower = 1.0 if self.config.lower_hermisphere_visibility else 0.0
         vis = ops.VisibilityFinishFn.apply(t_hat, surf_dist, threshold_distance, float(sigmoid_scale),
                                            sel.contiguous(), R, Dv, D, lower)

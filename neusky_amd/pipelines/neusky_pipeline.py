@@ -9,6 +9,7 @@ here the model is never wrapped, so the same call sites work at any world size.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Type
 
@@ -121,14 +122,31 @@ class NeuSkyPipeline(nn.Module):
             ray_bundle, batch = self.datamanager.next_train(step)
         model.set_step(step)
         model.begin_step()  # prepared-weight caches are per optimisation step
-        model_outputs = model(ray_bundle, batch=batch, step=step, randoms=randoms)
+        fit = model.config.fit_visibility_field and model.visibility_field is not None
+        fuse = fit and model.config.use_visibility and model.training and os.environ.get("NSKY_FUSE_DDF_FIT", "1") != "0"
+        vis_batch = None
+        if fuse:
+            # The DDF-fit rays' ground truth only needs the SDF field, so it is produced first and the DDF evaluations
+            # of the fit step are handed to compute_visibility to share its launches (same arithmetic as :271-289)
+            vis_batch = self.generate_ddf_samples(randoms)
+            prep = model.visibility_field.prepare_queries(vis_batch["ray_bundle"], vis_batch,
+                                                          None if randoms is None else randoms.get("mv_points"))
+            prep["stop_gradients"] = self.config.stop_sdf_gradients
+            model._extra_ddf, model._extra_ddf_out = prep, None
+        try:
+            model_outputs = model(ray_bundle, batch=batch, step=step, randoms=randoms)
+        finally:
+            model._extra_ddf = None
         metrics_dict = model.get_metrics_dict(model_outputs, batch)
         loss_dict = model.get_loss_dict(model_outputs, batch, metrics_dict)
-        if model.config.fit_visibility_field and model.visibility_field is not None:
-            vis_batch = self.generate_ddf_samples(randoms)
+        if fit:
+            if vis_batch is None:
+                vis_batch = self.generate_ddf_samples(randoms)
             vis_outputs = model.visibility_field(ray_bundle=vis_batch["ray_bundle"], batch=vis_batch, neusky=model,
                                                  stop_gradients=self.config.stop_sdf_gradients,
-                                                 mv_points=None if randoms is None else randoms.get("mv_points"))
+                                                 mv_points=None if randoms is None else randoms.get("mv_points"),
+                                                 precomputed=getattr(model, "_extra_ddf_out", None) if fuse else None)
+            model._extra_ddf_out = None
             vis_metrics = model.visibility_field.get_metrics_dict(vis_outputs, vis_batch)
             vis_loss = model.visibility_field.get_loss_dict(vis_outputs, vis_batch, vis_metrics)
             model_outputs = {**model_outputs, **vis_outputs}
