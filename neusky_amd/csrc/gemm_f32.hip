@@ -57,6 +57,21 @@ __device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
   c = ((q + 1) & 2) ? -cc : cc;
 }
 
+// softplus_beta(v) and sigmoid(beta v) from ONE exponential: t = exp(-|beta v|) in (0, 1];
+// softplus = (max(beta v, 0) + log1p(t)) / beta, sigmoid = 1/(1+t) or t/(1+t).  log1p(t) = log(u) * t / (u - 1) with
+// u = fl(1 + t) cancels the rounding of 1 + t (few-ulp result for every t); hardware exp2/log2/rcp based.
+// torch.nn.functional.softplus semantics: beta v > 20 returns v itself (sdf_albedo_field.py geo network, beta = 100).
+__device__ __forceinline__ void softplus_sigmoid(float v, float beta, float inv_beta, float& sp, float& sg) {
+  const float bv = beta * v;
+  const float t = __expf(-fabsf(bv));
+  const float u = 1.0f + t;
+  const float rc = __builtin_amdgcn_rcpf(u);
+  const float um1 = u - 1.0f;
+  const float l = um1 == 0.0f ? t : __logf(u) * (t * __builtin_amdgcn_rcpf(um1));
+  sp = bv > 20.0f ? v : (fmaxf(bv, 0.0f) + l) * inv_beta;
+  sg = bv >= 0.0f ? rc : t * rc;
+}
+
 __device__ __forceinline__ void epilogue_store(const EpiCtx& e, float* C, int ldc, int row, int col, float acc) {
   float v = acc + (e.bias ? e.bias[col] : 0.0f);
   float r;
@@ -67,9 +82,9 @@ __device__ __forceinline__ void epilogue_store(const EpiCtx& e, float* C, int ld
     case NSKY_EPI_LEAKY: r = v > 0.0f ? v : e.p0 * v; break;
     case NSKY_EPI_SIGMOID: r = e.p0 * sigmoidf_(v); break;
     case NSKY_EPI_SOFTPLUS: {
-      float bv = e.p0 * v;
-      r = bv > 20.0f ? v : log1pf(expf(bv)) / e.p0;
-      if (e.out1) e.out1[(long)row * e.ldout1 + col] = sigmoidf_(bv);
+      float sg;
+      softplus_sigmoid(v, e.p0, 1.0f / e.p0, r, sg);
+      if (e.out1) e.out1[(long)row * e.ldout1 + col] = sg;
     } break;
     case NSKY_EPI_FILM: {
       float f = e.p0 * e.aux0[(long)row * e.ldaux0 + col] + e.p1;
@@ -131,12 +146,9 @@ __device__ __forceinline__ void epilogue_store4(const EpiCtx& e, float* C, int l
       break;
     case NSKY_EPI_SOFTPLUS: {
       float sg[4];
+      const float inv_beta = 1.0f / e.p0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float bv = e.p0 * v[i];
-        r[i] = bv > 20.0f ? v[i] : log1pf(expf(bv)) / e.p0;
-        sg[i] = sigmoidf_(bv);
-      }
+      for (int i = 0; i < 4; ++i) softplus_sigmoid(v[i], e.p0, inv_beta, r[i], sg[i]);
       if (e.out1) st4(e.out1 + (long)row * e.ldout1 + col, make_float4(sg[0], sg[1], sg[2], sg[3]));
     } break;
     case NSKY_EPI_FILM: {
@@ -238,6 +250,22 @@ struct TileLoader {
   }
 };
 
+// Output-tile raster: a 1-D grid over (row tiles x column tiles).  Consecutive workgroup ids go round-robin to the 8
+// XCDs (each with a private L2), so id % 8 labels the workgroups that share an L2; the bijective remap hands every
+// label a contiguous run of logical tiles, and the logical order is column-tile fastest: the column tiles of one row
+// tile (which all re-read the same A rows) run back to back on ONE L2 instead of streaming A from HBM once per
+// column tile, while the (small) B operand stays L2-resident for every row tile.
+__device__ __forceinline__ void tile_of_block(int tiles_n, int& m_tile, int& n_tile) {
+  const int nwg = gridDim.x;
+  int id = blockIdx.x;
+  if (nwg >= 16) {
+    const int q = nwg >> 3, r = nwg & 7, x = id & 7;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+  }
+  n_tile = id % tiles_n;
+  m_tile = id / tiles_n;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool AK, bool BKC, int BK, int OCC>
 __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                        float* __restrict__ C, int M, int N, int K, int lda, int ldb,
@@ -253,7 +281,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const float* __restr
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int m_tile, n_tile;
+  tile_of_block((N + BN - 1) / BN, m_tile, n_tile);
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
   const int kbeg = blockIdx.z * k_split_len;
   const int kend = min(K, kbeg + k_split_len);
   const int ntiles = (kend - kbeg + BK - 1) / BK;
@@ -284,7 +314,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const float* __restr
       la.load(A, lda, m0, M, kbeg + (t + 1) * BK, kend, tid);
       lb.load(B, ldb, n0, N, kbeg + (t + 1) * BK, kend, tid);
     }
-    if (a_rowsum != nullptr && blockIdx.y == 0 && tid < BM) {
+    if (a_rowsum != nullptr && n_tile == 0 && tid < BM) {
       // bias gradient for free: sum_k A(m,k) of this K tile (A = dZ^T in the weight-gradient GEMM)
       const float* col = As + cur * BK * LDA_S + tid;
       float sacc = 0.0f;
@@ -325,7 +355,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const float* __restr
     cur ^= 1;
   }
 
-  if (a_rowsum != nullptr && blockIdx.y == 0 && tid < BM && m0 + tid < M) atomicAdd(a_rowsum + m0 + tid, rs_acc);
+  if (a_rowsum != nullptr && n_tile == 0 && tid < BM && m0 + tid < M) atomicAdd(a_rowsum + m0 + tid, rs_acc);
 
   // Epilogue: park the accumulators in LDS (the operand buffers are dead after the last barrier), one
   // wave-row (WM rows) at a time, and sweep them row-major so C, the aux operands and the side outputs move
@@ -403,6 +433,9 @@ __device__ __forceinline__ void split4(const float x[4], uint2 out[NS]) {
   for (int t = 0; t < NS; ++t) {
     const uint32_t p01 = pack2(r[0], r[1]), p23 = pack2(r[2], r[3]);
     out[t] = make_uint2(p01, p23);
+#ifdef NSKY_FAKE_SPLIT  // timing experiment only: skip the residual arithmetic (wrong numerics)
+    continue;
+#endif
     if (t + 1 < NS) {
       r[0] -= bf16_hi_as_f32(p01); r[1] -= bf16_lo_as_f32(p01);
       r[2] -= bf16_hi_as_f32(p23); r[3] -= bf16_lo_as_f32(p23);
@@ -413,6 +446,7 @@ __device__ __forceinline__ void split4(const float x[4], uint2 out[NS]) {
 template <int NS, bool KCONTIG>
 struct SplitLoader {  // 128 x 32 fp32 tile -> NS bf16 images [128][SROW]
   float4 v[4];
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};  // running row sums (every thread stages the same 4 tile rows on every k-tile)
   __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int t0, int T, int k0, int kend, int tid) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -430,8 +464,8 @@ struct SplitLoader {  // 128 x 32 fp32 tile -> NS bf16 images [128][SROW]
       v[it] = x;
     }
   }
-  // images: S + term * (128 * SROW) bf16 ; rowsum (optional, LDS float[128]) accumulates sum_k of the tile rows
-  __device__ __forceinline__ void store(__bf16* S, int tid, float* rowsum) const {
+  // images: S + term * (128 * SROW) bf16 ; rowsum: also accumulate sum_k of the staged tile rows into rs[]
+  __device__ __forceinline__ void store(__bf16* S, int tid, bool rowsum) {
     if (KCONTIG) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
@@ -442,7 +476,7 @@ struct SplitLoader {  // 128 x 32 fp32 tile -> NS bf16 images [128][SROW]
         split4<NS>(x, o);
 #pragma unroll
         for (int t = 0; t < NS; ++t) *reinterpret_cast<uint2*>(S + t * 128 * SROW + row * SROW + kq * 4) = o[t];
-        if (rowsum) atomicAdd(rowsum + row, (x[0] + x[1]) + (x[2] + x[3]));
+        if (rowsum) rs[it] += (x[0] + x[1]) + (x[2] + x[3]);
       }
     } else {
       const int kb = tid & 7, mb = tid >> 3;
@@ -454,9 +488,14 @@ struct SplitLoader {  // 128 x 32 fp32 tile -> NS bf16 images [128][SROW]
         split4<NS>(m[i], o);
 #pragma unroll
         for (int t = 0; t < NS; ++t) *reinterpret_cast<uint2*>(S + t * 128 * SROW + (4 * mb + i) * SROW + 4 * kb) = o[t];
-        if (rowsum) atomicAdd(rowsum + 4 * mb + i, (m[i][0] + m[i][1]) + (m[i][2] + m[i][3]));
+        if (rowsum) rs[i] += (m[i][0] + m[i][1]) + (m[i][2] + m[i][3]);
       }
     }
+  }
+  // fold the running row sums into LDS float[128] (8 threads share a row)
+  __device__ __forceinline__ void flush_rowsum(float* rsum, int tid) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) atomicAdd(rsum + (KCONTIG ? i * 32 + (tid >> 3) : 4 * (tid >> 3) + i), rs[i]);
   }
 };
 
@@ -475,11 +514,13 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : 2) void gemm_bf16s_kerne
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int m_tile, n_tile;
+  tile_of_block((N + BN - 1) / BN, m_tile, n_tile);
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
   const int kbeg = blockIdx.z * k_split_len;
   const int kend = min(K, kbeg + k_split_len);
   const int ntiles = (kend - kbeg + BKT - 1) / BKT;
-  const bool want_rs = (a_rowsum != nullptr) && blockIdx.y == 0;
+  const bool want_rs = (a_rowsum != nullptr) && n_tile == 0;
   if (want_rs && tid < 128) rsum[tid] = 0.0f;
 
   f32x16 acc[TM][TN];
@@ -532,8 +573,8 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : 2) void gemm_bf16s_kerne
     // MFMAs of tile t (matrix pipe); tile t+2's global loads are issued right after and land during the next tile
     if (ntiles > 0) {
       __syncthreads();
-      la.store(S0, tid, want_rs ? rsum : nullptr);
-      lb.store(S0 + NS * IMG, tid, nullptr);
+      la.store(S0, tid, want_rs);
+      lb.store(S0 + NS * IMG, tid, false);
       if (ntiles > 1) {
         la.load(A, lda, m0, M, kbeg + BKT, kend, tid);
         lb.load(B, ldb, n0, N, kbeg + BKT, kend, tid);
@@ -545,8 +586,8 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : 2) void gemm_bf16s_kerne
       __bf16* nxt = S0 + ((t + 1) & 1) * STAGE;
       compute(cur, cur + NS * IMG);
       if (t + 1 < ntiles) {
-        la.store(nxt, tid, want_rs ? rsum : nullptr);
-        lb.store(nxt + NS * IMG, tid, nullptr);
+        la.store(nxt, tid, want_rs);
+        lb.store(nxt + NS * IMG, tid, false);
         if (t + 2 < ntiles) {
           la.load(A, lda, m0, M, kbeg + (t + 2) * BKT, kend, tid);
           lb.load(B, ldb, n0, N, kbeg + (t + 2) * BKT, kend, tid);
@@ -557,8 +598,8 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : 2) void gemm_bf16s_kerne
   } else {
     for (int t = 0; t < ntiles; ++t) {
       __syncthreads();  // previous tile's fragment reads are done
-      la.store(S0, tid, want_rs ? rsum : nullptr);
-      lb.store(S0 + NS * IMG, tid, nullptr);
+      la.store(S0, tid, want_rs);
+      lb.store(S0 + NS * IMG, tid, false);
       __syncthreads();
       if (t + 1 < ntiles) {
         la.load(A, lda, m0, M, kbeg + (t + 1) * BKT, kend, tid);
@@ -567,6 +608,7 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : 2) void gemm_bf16s_kerne
       compute(S0, S0 + NS * IMG);
     }
   }
+  if (want_rs) la.flush_rowsum(rsum, tid);
   __syncthreads();
   if (want_rs && tid < 128 && m0 + tid < M) atomicAdd(a_rowsum + m0 + tid, rsum[tid]);
   __syncthreads();
@@ -615,7 +657,7 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : 2) void gemm_bf16s_kerne
 
 template <int NS, bool DBUF>
 void launch_split(const nsky_gemm_desc* d, const EpiCtx& e, int splits, int k_split_len, int vec4, hipStream_t s) {
-  dim3 grid(ceil_div(d->M, 128), ceil_div(d->N, 128), splits);
+  dim3 grid(ceil_div(d->M, 128) * ceil_div(d->N, 128), 1, splits);
 #define NSKY_SGEMM_LAUNCH(AK, BKC)                                                                          \
   hipLaunchKernelGGL((gemm_bf16s_kernel<NS, AK, BKC, DBUF>), grid, dim3(256), 0, s, d->A, d->B, d->C, d->M, d->N, \
                      d->K, d->lda, d->ldb, d->ldc, k_split_len, vec4, d->a_rowsum, e)
@@ -628,7 +670,7 @@ void launch_split(const nsky_gemm_desc* d, const EpiCtx& e, int splits, int k_sp
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int OCC>
 void launch(const nsky_gemm_desc* d, const EpiCtx& e, int splits, int k_split_len, int vec4, hipStream_t s) {
-  dim3 grid(ceil_div(d->M, BM), ceil_div(d->N, BN), splits);
+  dim3 grid(ceil_div(d->M, BM) * ceil_div(d->N, BN), 1, splits);
 #define NSKY_GEMM_LAUNCH(AK, BKC)                                                                              \
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, AK, BKC, BK, OCC>), grid, dim3(256), 0, s, d->A, d->B, \
                      d->C, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, k_split_len, vec4, d->a_rowsum, e)

@@ -68,11 +68,14 @@ def pad_bias(b: torch.Tensor) -> torch.Tensor:
 
 
 def _splits(M: int, n_out: int = 256, k_in: int = 256) -> int:
-    """split-K factor of a weight-gradient GEMM (reduction over M rows): enough workgroups to fill 256 CUs twice,
-    at least 128 rows and at most 2048 rows per split"""
+    """split-K factor of a weight-gradient GEMM (reduction over M rows).  The split kernel keeps 2 workgroups per CU
+    resident (512 on the chip), so the launch is sized to a whole number of such waves: tiles x splits = 512 w with
+    the smallest w that keeps a split under 4096 rows (520 workgroups cost two full waves, 512 cost one); short
+    reductions keep at least 128 rows per split."""
     tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
-    want = max(1, (512 + tiles - 1) // tiles)
-    return max((M + 2047) // 2048, min(want, max(1, M // 128)))
+    smin = max(1, (M + 4095) // 4096)
+    waves = (tiles * smin + 511) // 512
+    return max(1, min((512 * waves) // tiles, M // 128))
 
 
 def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None, acc=None):
