@@ -10,7 +10,8 @@ that is already on the device (`images_on_gpu=True, masks_on_gpu=True`, neusky_c
     +0.5), directions normalised, `metadata["directions_norm"]` = the norm before normalisation.
 The reference round-trips the sampled indices through the CPU every step (:55-57, datamanager :286); here the valid-pixel
 lists are built once and a step is three `randint` + gathers on the device (static shapes, hipGraph-safe).
-Parsing NeRF-OSR / Cityscapes folders from disk is SURVEY 8(f) item 4 and not part of this class.
+Parsing NeRF-OSR / Cityscapes folders from disk (SURVEY 8(f) item 4) is `neusky_amd.data.dataparsers`;
+`DeviceImageDataManager.from_dataset` uploads what it reads.
 """
 from __future__ import annotations
 
@@ -30,14 +31,16 @@ class _Dataset:
 
 
 class DeviceImageDataManager:
-    def __init__(self, images: torch.Tensor, masks: torch.Tensor, c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float,
+    def __init__(self, images: torch.Tensor, masks: torch.Tensor, c2w: torch.Tensor, fx, fy, cx, cy,
                  train_num_rays_per_batch: int = 1024, device="cuda:0", scene_scale: float = 1.0, num_eval: int = 0, seed: int = 0):
-        """images [N,H,W,3] float, masks [N,H,W,4] bool, c2w [N,3,4] camera-to-world (nerfstudio/OpenGL convention)"""
+        """images [N,H,W,3] float, masks [N,H,W,4] bool, c2w [N,3,4] camera-to-world (nerfstudio/OpenGL convention);
+        fx, fy, cx, cy: one pinhole for every image (floats) or per-image tensors [N]"""
         assert images.shape[:3] == masks.shape[:3] and masks.shape[-1] == 4 and c2w.shape[1:] == (3, 4)
         self.device = device
         self.images, self.masks, self.c2w = images.to(device), masks.to(device).bool(), c2w.to(device).float()
         self.N, self.H, self.W = images.shape[:3]
-        self.fx, self.fy, self.cx, self.cy = fx, fy, cx, cy
+        per_image = lambda v: torch.as_tensor(v, dtype=torch.float32).reshape(-1).expand(self.N).contiguous().to(device)  # noqa: E731
+        self.fx, self.fy, self.cx, self.cy = per_image(fx), per_image(fy), per_image(cx), per_image(cy)
         self.train_num_rays_per_batch = train_num_rays_per_batch
         scene_box = {"aabb": torch.tensor([[-scene_scale] * 3, [scene_scale] * 3])}
         self.train_dataset = _Dataset(self.N, scene_box)
@@ -49,19 +52,31 @@ class DeviceImageDataManager:
         assert self.static_pixels.shape[0] > 0, "no pixel with the static mask set"
         self.gen = torch.Generator(device=device).manual_seed(seed)
 
+    @classmethod
+    def from_dataset(cls, dataset, **kw) -> "DeviceImageDataManager":
+        """upload a parsed on-disk dataset (`neusky_amd.data.dataparsers.NeuSkyDataset`; frames cropped or padded to
+        one size) with its per-image intrinsics, as `images_on_gpu / masks_on_gpu` does (neusky_config.py:60-61)"""
+        from .dataparsers import load_stacks
+        images, masks = load_stacks(dataset)
+        cams = dataset.cameras
+        s = float(dataset.scale_factor)
+        kw.setdefault("scene_scale", float(dataset.scene_box["aabb"][1, 0]))
+        return cls(images, masks, cams.camera_to_worlds, cams.fx * s, cams.fy * s, cams.cx * s, cams.cy * s, **kw)
+
     def get_param_groups(self) -> Dict:
         return {}
 
     def generate_rays(self, indices: torch.Tensor) -> RayBundle:
         """indices [R,3] = (image, y, x) on the device -> RayBundle (pinhole, nerfstudio convention)"""
         c, y, x = indices[:, 0], indices[:, 1].float(), indices[:, 2].float()
-        d_cam = torch.stack([(x + 0.5 - self.cx) / self.fx, -(y + 0.5 - self.cy) / self.fy, -torch.ones_like(x)], -1)
+        fx, fy = self.fx[c], self.fy[c]
+        d_cam = torch.stack([(x + 0.5 - self.cx[c]) / fx, -(y + 0.5 - self.cy[c]) / fy, -torch.ones_like(x)], -1)
         R = self.c2w[c, :, :3]
         d = torch.einsum("rij,rj->ri", R, d_cam)
         norm = d.norm(dim=-1, keepdim=True)
         n = indices.shape[0]
         return RayBundle(origins=self.c2w[c, :, 3].contiguous(), directions=(d / norm).contiguous(),
-                         pixel_area=torch.full((n, 1), 1.0 / (self.fx * self.fy), device=indices.device),
+                         pixel_area=(1.0 / (fx * fy))[:, None],
                          camera_indices=c[:, None].contiguous(), metadata={"directions_norm": norm})
 
     def _draw(self, pixels: torch.Tensor, n: int) -> torch.Tensor:
