@@ -56,9 +56,11 @@ enum {
 };
 
 /* contraction arithmetic: exact fp32 MFMA (default); or operands split on the fly into 2 / 3 bf16 terms and
- * rebuilt from 3 / 6 bf16 MFMAs with fp32 accumulation (relative product error ~2^-16 / ~2^-22).  N <= 64 always
- * runs the fp32 kernel. */
-enum { NSKY_PREC_F32 = 0, NSKY_PREC_BF16X2 = 2, NSKY_PREC_BF16X3 = 3 };
+ * rebuilt from 3 / 6 bf16 MFMAs with fp32 accumulation (relative product error ~2^-16 / ~2^-22); or F16X2: split into
+ * fp16 hi + fp16 residual scaled by 2^11, rebuilt from 3 fp16 MFMAs in two fp32 accumulators (~2^-21, fp32-grade) --
+ * for operands within fp16's range only (|x| <= 65504, larger magnitudes saturate): forward layers, not gradients.
+ * N <= 64 always runs the fp32 kernel. */
+enum { NSKY_PREC_F32 = 0, NSKY_PREC_BF16X2 = 2, NSKY_PREC_BF16X3 = 3, NSKY_PREC_F16X2 = 4 };
 
 typedef struct nsky_gemm_desc {
   const float* A; const float* B; float* C;

@@ -425,6 +425,39 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 __device__ __forceinline__ float bf16_hi_as_f32(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float bf16_lo_as_f32(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
 
+// fp16 split with a SCALED residual (precision NSKY_PREC_F16X2): x = h + 2^-11 l with h = fp16(x), l = fp16(2^11 (x - h)).
+// x - h is exact in fp32 and at most half an fp16 ulp of x, so the scaled residual sits in fp16's normal range whenever
+// x does and carries 11 more bits: h + 2^-11 l reproduces x to ~2^-22 relative (2^-36 absolute below fp16's normal
+// range).  The product is rebuilt from THREE v_mfma_f32_32x32x16_f16: hh into one fp32 accumulator, h l' + l' h into a
+// second one that is folded in with 2^-11 in the epilogue; only l l' (2^-22) is dropped.  fp32-grade products at the
+// cost of the 2-term bf16 form -- valid for operands inside fp16's range (|x| <= 65504; larger magnitudes saturate),
+// i.e. the forward layers' bounded activations and weights, not gradients.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr float F16_RES_SCALE = 2048.0f;
+
+__device__ __forceinline__ uint32_t pack2h(float a, float b) {
+  f32x2 v = {a, b};
+  f16x2 r = __builtin_convertvector(v, f16x2);
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ void unpack2h(uint32_t p, float& a, float& b) {
+  f16x2 h = __builtin_bit_cast(f16x2, p);
+  a = (float)h[0];
+  b = (float)h[1];
+}
+__device__ __forceinline__ void split4h(const float x[4], uint2 out[2]) {
+  float c[4], h[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_fmed3f(x[i], -65504.0f, 65504.0f);
+  const uint32_t h01 = pack2h(c[0], c[1]), h23 = pack2h(c[2], c[3]);
+  unpack2h(h01, h[0], h[1]);
+  unpack2h(h23, h[2], h[3]);
+  out[0] = make_uint2(h01, h23);
+  out[1] = make_uint2(pack2h((c[0] - h[0]) * F16_RES_SCALE, (c[1] - h[1]) * F16_RES_SCALE),
+                      pack2h((c[2] - h[2]) * F16_RES_SCALE, (c[3] - h[3]) * F16_RES_SCALE));
+}
+
 // split 4 floats into NS terms of 4 bf16 each (8 bytes per term)
 template <int NS>
 __device__ __forceinline__ void split4(const float x[4], uint2 out[NS]) {
@@ -443,7 +476,7 @@ __device__ __forceinline__ void split4(const float x[4], uint2 out[NS]) {
   }
 }
 
-template <int NS, bool KCONTIG>
+template <int NS, bool KCONTIG, bool H = false>
 struct SplitLoader {  // 128 x 32 fp32 tile -> NS bf16 images [128][SROW]
   float4 v[4];
   float rs[4] = {0.f, 0.f, 0.f, 0.f};  // running row sums (every thread stages the same 4 tile rows on every k-tile)
@@ -473,7 +506,7 @@ struct SplitLoader {  // 128 x 32 fp32 tile -> NS bf16 images [128][SROW]
         const int row = f >> 3, kq = f & 7;
         const float x[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
         uint2 o[NS];
-        split4<NS>(x, o);
+        if (H) split4h(x, o); else split4<NS>(x, o);
 #pragma unroll
         for (int t = 0; t < NS; ++t) *reinterpret_cast<uint2*>(S + t * 128 * SROW + row * SROW + kq * 4) = o[t];
         if (rowsum) rs[it] += (x[0] + x[1]) + (x[2] + x[3]);
@@ -485,7 +518,7 @@ struct SplitLoader {  // 128 x 32 fp32 tile -> NS bf16 images [128][SROW]
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         uint2 o[NS];
-        split4<NS>(m[i], o);
+        if (H) split4h(m[i], o); else split4<NS>(m[i], o);
 #pragma unroll
         for (int t = 0; t < NS; ++t) *reinterpret_cast<uint2*>(S + t * 128 * SROW + (4 * mb + i) * SROW + 4 * kb) = o[t];
         if (rowsum) rs[i] += (m[i][0] + m[i][1]) + (m[i][2] + m[i][3]);
@@ -499,7 +532,7 @@ struct SplitLoader {  // 128 x 32 fp32 tile -> NS bf16 images [128][SROW]
   }
 };
 
-template <int NS, bool AK, bool BKC, bool DBUF>
+template <int NS, bool AK, bool BKC, bool DBUF, bool H = false>
 __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : 2) void gemm_bf16s_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K, int lda, int ldb,
     int ldc, int k_split_len, int vec4, float* __restrict__ a_rowsum, EpiCtx e) {
@@ -531,8 +564,18 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : 2) void gemm_bf16s_kerne
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  SplitLoader<NS, AK> la;
-  SplitLoader<NS, BKC> lb;
+  static_assert(!H || NS == 2, "the fp16 scaled-residual split has two terms");
+  f32x16 accx[H ? TM : 1][H ? TN : 1];  // H: h l' + l' h, folded in with 2^-11 in the epilogue
+  if (H) {
+#pragma unroll
+    for (int i = 0; i < (H ? TM : 1); ++i)
+#pragma unroll
+      for (int j = 0; j < (H ? TN : 1); ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accx[i][j][r] = 0.0f;
+  }
+  SplitLoader<NS, AK, H> la;
+  SplitLoader<NS, BKC, H> lb;
   const int frow = lane & 31, fh = lane >> 5;
 
   auto compute = [&](const __bf16* As, const __bf16* Bs) {
@@ -552,6 +595,13 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : 2) void gemm_bf16s_kerne
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
+          if (H) {
+            const int ii = H ? i : 0, jj = H ? j : 0;
+            accx[ii][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0][i]), __builtin_bit_cast(f16x8, bfr[1][j]), accx[ii][jj], 0, 0, 0);
+            accx[ii][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[1][i]), __builtin_bit_cast(f16x8, bfr[0][j]), accx[ii][jj], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0][i]), __builtin_bit_cast(f16x8, bfr[0][j]), acc[i][j], 0, 0, 0);
+            continue;
+          }
           if (NS == 3) {  // smallest cross terms first
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], acc[i][j], 0, 0, 0);
@@ -627,7 +677,7 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : 2) void gemm_bf16s_kerne
           for (int r = 0; r < 16; ++r) {
             const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const int cl = wn * WN + j * 32 + (lane & 31);
-            Cs[rl * BN + cl] = acc[i][j][r];
+            Cs[rl * BN + cl] = H ? fmaf(accx[H ? i : 0][H ? j : 0][r], 1.0f / F16_RES_SCALE, acc[i][j][r]) : acc[i][j][r];
           }
     }
     __syncthreads();
@@ -655,11 +705,11 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : 2) void gemm_bf16s_kerne
   }
 }
 
-template <int NS, bool DBUF>
+template <int NS, bool DBUF, bool H = false>
 void launch_split(const nsky_gemm_desc* d, const EpiCtx& e, int splits, int k_split_len, int vec4, hipStream_t s) {
   dim3 grid(ceil_div(d->M, 128) * ceil_div(d->N, 128), 1, splits);
 #define NSKY_SGEMM_LAUNCH(AK, BKC)                                                                          \
-  hipLaunchKernelGGL((gemm_bf16s_kernel<NS, AK, BKC, DBUF>), grid, dim3(256), 0, s, d->A, d->B, d->C, d->M, d->N, \
+  hipLaunchKernelGGL((gemm_bf16s_kernel<NS, AK, BKC, DBUF, H>), grid, dim3(256), 0, s, d->A, d->B, d->C, d->M, d->N, \
                      d->K, d->lda, d->ldb, d->ldc, k_split_len, vec4, d->a_rowsum, e)
   if (d->a_kcontig && d->b_kcontig) NSKY_SGEMM_LAUNCH(true, true);
   else if (d->a_kcontig && !d->b_kcontig) NSKY_SGEMM_LAUNCH(true, false);
@@ -733,11 +783,13 @@ extern "C" int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream) {
                    ok(d->aux2, d->ldaux2) && ok(d->out1, d->ldout1) && ok(d->out2, d->ldout2);
   static const int variant = getenv("NSKY_GEMM_VARIANT") ? atoi(getenv("NSKY_GEMM_VARIANT")) : 0;
   if (d->precision != NSKY_PREC_F32 && d->N > 64) {
-    NSKY_CHECK_ARG(d->precision == NSKY_PREC_BF16X2 || d->precision == NSKY_PREC_BF16X3, "nsky_gemm_f32: unknown precision %d", d->precision);
+    NSKY_CHECK_ARG(d->precision == NSKY_PREC_BF16X2 || d->precision == NSKY_PREC_BF16X3 || d->precision == NSKY_PREC_F16X2,
+                   "nsky_gemm_f32: unknown precision %d", d->precision);
     // the two-stage LDS variant needs 80-120 KB per workgroup (one workgroup per CU) and measured 1.4-2.5x SLOWER than
     // the single-stage kernel at 2 workgroups per CU; kept selectable (NSKY_GEMM_VARIANT=4) for experiments only
     const bool dbuf = (variant & 4) != 0;
-    if (d->precision == NSKY_PREC_BF16X2) { if (dbuf) launch_split<2, true>(d, e, splits, k_split_len, vec4, s); else launch_split<2, false>(d, e, splits, k_split_len, vec4, s); }
+    if (d->precision == NSKY_PREC_F16X2) launch_split<2, false, true>(d, e, splits, k_split_len, vec4, s);
+    else if (d->precision == NSKY_PREC_BF16X2) { if (dbuf) launch_split<2, true>(d, e, splits, k_split_len, vec4, s); else launch_split<2, false>(d, e, splits, k_split_len, vec4, s); }
     else { if (dbuf) launch_split<3, true>(d, e, splits, k_split_len, vec4, s); else launch_split<3, false>(d, e, splits, k_split_len, vec4, s); }
     NSKY_CHECK_LAUNCH("nsky_gemm_f32(split-bf16)");
     return NSKY_OK;

@@ -28,7 +28,7 @@ _lib = C.CDLL(LIB_PATH)
 # ---- epilogues (keep in sync with include/neusky_hip.h)
 EPI_NONE, EPI_RELU, EPI_LEAKY, EPI_SIGMOID, EPI_SOFTPLUS, EPI_FILM, EPI_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 EPI_BWD_RELU, EPI_BWD_LEAKY, EPI_BWD_FILM, EPI_EXP = 7, 8, 9, 10
-PREC_F32, PREC_BF16X2, PREC_BF16X3 = 0, 2, 3
+PREC_F32, PREC_BF16X2, PREC_BF16X3, PREC_F16X2 = 0, 2, 3, 4
 
 
 class GemmDesc(C.Structure):

@@ -19,23 +19,28 @@ from . import hip
 
 
 # Arithmetic of the dense contractions (operands and results are fp32 in memory either way; see include/neusky_hip.h):
-#   forward GEMMs  : exact fp32 MFMA, or 3-term bf16 split (6 bf16 MFMAs, ~2^-22 per product) when NSKY_PRECISION=split
-#   backward GEMMs : 2-term bf16 split (3 bf16 MFMAs, ~2^-16 per product) unless NSKY_PRECISION=f32
+#   forward GEMMs  : NSKY_PRECISION=splith (default) fp16 hi + 2^11-scaled fp16 residual, 3 fp16 MFMAs, ~2^-21 per product
+#                    (operands are bounded activations / weights, inside fp16's range); split = 3-term bf16 split
+#                    (6 bf16 MFMAs, ~2^-22, any range); split2 = 2-term bf16 (2^-16); f32 | mixed = exact fp32 MFMA
+#   backward GEMMs : 2-term bf16 split (3 bf16 MFMAs, ~2^-16 per product; gradients need bf16's exponent range)
+#                    unless NSKY_PRECISION=f32
 import os as _os
 
-_POLICY = _os.environ.get("NSKY_PRECISION", "split")
-if _POLICY not in ("f32", "mixed", "split", "split2"):
-    raise ValueError(f"NSKY_PRECISION={_POLICY!r}: expected f32 | mixed | split")
-FWD_PRECISION = {"split": hip.PREC_BF16X3, "split2": hip.PREC_BF16X2}.get(_POLICY, hip.PREC_F32)
+_POLICIES = ("f32", "mixed", "split", "split2", "splith")
+_FWD = {"split": hip.PREC_BF16X3, "split2": hip.PREC_BF16X2, "splith": hip.PREC_F16X2}
+_POLICY = _os.environ.get("NSKY_PRECISION", "splith")
+if _POLICY not in _POLICIES:
+    raise ValueError(f"NSKY_PRECISION={_POLICY!r}: expected one of {' | '.join(_POLICIES)}")
+FWD_PRECISION = _FWD.get(_POLICY, hip.PREC_F32)
 BWD_PRECISION = hip.PREC_F32 if _POLICY == "f32" else hip.PREC_BF16X2
 
 
 def set_precision_policy(policy: str) -> None:
     global FWD_PRECISION, BWD_PRECISION, _POLICY
-    if policy not in ("f32", "mixed", "split", "split2"):
+    if policy not in _POLICIES:
         raise ValueError(policy)
     _POLICY = policy
-    FWD_PRECISION = {"split": hip.PREC_BF16X3, "split2": hip.PREC_BF16X2}.get(policy, hip.PREC_F32)
+    FWD_PRECISION = _FWD.get(policy, hip.PREC_F32)
     BWD_PRECISION = hip.PREC_F32 if policy == "f32" else hip.PREC_BF16X2
 
 

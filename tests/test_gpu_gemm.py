@@ -122,9 +122,10 @@ def test_errors_are_reported():
         hip.gemm(A, A, torch.zeros(8, 8, device=dev), 8, 8, 6)  # lda % 4 != 0
 
 
-@pytest.mark.parametrize("prec,tol", [(2, 6e-5), (3, 2e-6)])
+@pytest.mark.parametrize("prec,tol", [(2, 6e-5), (3, 2e-6), (4, 2e-6)])
 def test_split_bf16_precision_all_layouts(prec, tol):
-    """operands split into 2 / 3 bf16 terms, rebuilt from 3 / 6 bf16 MFMAs: every layout, ragged sizes, split-K + bias sums"""
+    """operands split into 2 / 3 bf16 terms (3 / 6 bf16 MFMAs) or fp16 hi + scaled fp16 residual (3 fp16 MFMAs): every
+    layout, ragged sizes, split-K + bias sums"""
     from neusky_amd import hip
     dev = "cuda:0"
     torch.manual_seed(5)
@@ -154,3 +155,44 @@ def test_split_bf16_precision_all_layouts(prec, tol):
     r2 = _ref(A, W, None)
     r2 = torch.where(aux.double() > 0, r2, 0.2 * r2)
     assert (C.double() - r2).abs().max().item() < tol * sc
+
+
+def test_f16_scaled_split_range_and_accuracy():
+    """NSKY_PREC_F16X2 (the default forward arithmetic): fp32-grade products (~2^-21 relative) for operands inside fp16's
+    normal range (6.1e-5 <= |x| <= 65504); below it the representation error is an ABSOLUTE 2^-35 per operand (the
+    residual is scaled by 2^11 before it is rounded), i.e. invisible next to the unit-scale terms every layer of this
+    path also sums; magnitudes beyond 65504 saturate instead of turning into inf/NaN."""
+    from neusky_amd import hip
+    dev = "cuda:0"
+    torch.manual_seed(11)
+    M, N, K = 512, 256, 256
+    for sa, sw in ((1.0, 1.0), (1e-2, 1e-2), (2e3, 1e-3), (0.05, 30.0)):
+        A = torch.randn(M, K, device=dev) * sa
+        W = torch.randn(N, K, device=dev) * sw
+        ref = A.double() @ W.double().T
+        C = torch.empty(M, N, device=dev)
+        hip.gemm(A, W, C, M, N, K, precision=hip.PREC_F16X2)
+        err = (C.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-6, (sa, sw, err)
+        hip.gemm(A, W, C, M, N, K, precision=hip.PREC_BF16X3)
+        err3 = (C.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 4 * err3 + 2e-7, (sa, sw, err, err3)  # on a par with the 6-MFMA bf16 form
+    # operands entirely below fp16's normal range: absolute floor 2^-35 per operand -> ~1e-5 relative at |a| ~ 3e-6
+    A = torch.randn(M, K, device=dev) * 3e-6
+    W = torch.randn(N, K, device=dev)
+    ref = A.double() @ W.double().T
+    C = torch.empty(M, N, device=dev)
+    hip.gemm(A, W, C, M, N, K, precision=hip.PREC_F16X2)
+    assert (C.double() - ref).abs().max().item() < 2.0 ** -35 * W.abs().max().item() * K
+    # mixed magnitudes inside one row (hash features next to unit-scale encodings)
+    A = torch.randn(M, K, device=dev) * torch.logspace(-6, 1, K, device=dev)
+    W = torch.randn(N, K, device=dev)
+    ref = A.double() @ W.double().T
+    C = torch.empty(M, N, device=dev)
+    hip.gemm(A, W, C, M, N, K, precision=hip.PREC_F16X2)
+    assert (C.double() - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
+    # out of range: saturates at +-65504, stays finite
+    A = torch.full((M, K), 1e6, device=dev)
+    W = torch.ones(N, K, device=dev) / K
+    hip.gemm(A, W, C, M, N, K, precision=hip.PREC_F16X2)
+    assert torch.isfinite(C).all() and abs(C[0, 0].item() - 65504.0) < 1.0
