@@ -227,10 +227,19 @@ def main():
             kernel = "gemm_f32_kernel<128,128,2,2,true,true,32,2> (exact fp32 MFMA v_mfma_f32_32x32x2_f32, forward NT layout)"
             peak, dtype = PEAK_F32_MFMA_TFLOPS, "f32"
             peak_note = "fp32 matrix peak 157.3 TFLOP/s (MI355X_MICROARCH.md)"
+        elif ops.FWD_PRECISION == _hip.PREC_F16X2:
+            kernel = ("gemm_bf16s_kernel<2,true,true,false,true> (fp32 operands split on the fly into fp16 hi + 2^11-scaled fp16 residual, "
+                      "3 x v_mfma_f32_32x32x16_f16 per product into two fp32 accumulators)")
+            peak, dtype = PEAK_BF16_MFMA_TFLOPS / 3.0, "f32 (fp16 hi + scaled-residual split on the matrix cores, ~2^-21 per product)"
+            peak_note = "fp16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-equivalent product = 833.3 TFLOP/s of algorithmic FLOPs"
         else:
-            kernel = "gemm_bf16s_kernel<3,true,true> (fp32 operands split on the fly into 3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate)"
-            peak, dtype = PEAK_BF16_MFMA_TFLOPS / 6.0, "f32 (3-term bf16 split on the matrix cores)"
-            peak_note = "bf16 dense MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32-equivalent product = 416.7 TFLOP/s of algorithmic FLOPs"
+            n_terms = 3 if ops.FWD_PRECISION == _hip.PREC_BF16X3 else 2
+            n_mfma = 6 if n_terms == 3 else 3
+            kernel = (f"gemm_bf16s_kernel<{n_terms},true,true> (fp32 operands split on the fly into {n_terms} bf16 terms, "
+                      f"{n_mfma} x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate)")
+            peak, dtype = PEAK_BF16_MFMA_TFLOPS / n_mfma, f"f32 ({n_terms}-term bf16 split on the matrix cores)"
+            peak_note = (f"bf16 dense MFMA peak 2500 TFLOP/s / {n_mfma} MFMAs per fp32-equivalent product = "
+                         f"{PEAK_BF16_MFMA_TFLOPS / n_mfma:.1f} TFLOP/s of algorithmic FLOPs")
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(tpath):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (not re-collected live)

@@ -206,6 +206,23 @@ int nsky_pdf_sample(const float* weights, const float* bins, const float* u_base
                     int32_t n0, int32_t nb, float histogram_padding, float eps, float* new_bins, int32_t* inds,
                     nsky_stream_t stream);
 
+/*
+ * Weight-norm parameterisation of the SDF / colour layers (nn.utils.weight_norm as nerfstudio's SDFField applies it;
+ * used by neusky/fields/sdf_albedo_field.py:147-161 for the colour net and the inherited geo net), fused with the row /
+ * column re-ordering and zero padding the consuming GEMMs want:
+ *   out[r][c] = g[sr] * v[sr][sc] / ||v[sr]||_2,  sr = row_map[r], sc = col_map[c]; -1 marks a structural zero.
+ * v [out_features, in_features] (ldv), g [out_features], inv_norm [out_features] (written; saved for the backward).
+ * Every source row must appear at most once in row_map, every source column at most once in col_map.
+ * Backward: d_out [n_rows_out, ldo] -> dv [out_features, ldv-strided rows listed in row_map], dg [out_features];
+ * inverse_col[sc] = output column reading source column sc, or -1.  Rows of v absent from row_map are not written.
+ */
+int nsky_weight_norm_fwd(const float* v, const float* g, int32_t n_rows_out, int32_t n_cols_out, int32_t in_features,
+                         int32_t ldv, const int32_t* row_map, const int32_t* col_map, float* out, int32_t ldo,
+                         float* inv_norm, nsky_stream_t stream);
+int nsky_weight_norm_bwd(const float* d_out, int32_t ldo, const float* v, const float* g, const float* inv_norm,
+                         int32_t n_rows_out, int32_t in_features, int32_t ldv, const int32_t* row_map,
+                         const int32_t* inverse_col, float* dv, float* dg, nsky_stream_t stream);
+
 /* Adam update (torch.optim.Adam semantics, no weight decay / amsgrad) over a flat slab of n floats;
  * the five optimizer groups of neusky/configs/neusky_config.py:216-237.  grad_scale multiplies g first. */
 int nsky_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

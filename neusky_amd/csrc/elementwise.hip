@@ -95,6 +95,73 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   p[i] -= (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
 }
 
+
+// Weight-norm preparation of one dense layer, laid out as the consuming kernel wants it:
+//   out[r][c] = g[sr] * v[sr][sc] / ||v[sr]||   with sr = row_map[r], sc = col_map[c]  (-1 = structural zero)
+// One workgroup (256 threads) per output row; inv_norm[sr] is kept for the backward pass.
+__global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g, int I, int ldv,
+                                                              const int* __restrict__ row_map, const int* __restrict__ col_map,
+                                                              int Cp, float* __restrict__ out, int ldo, float* __restrict__ inv_norm) {
+  const int r = blockIdx.x, sr = row_map[r];
+  float* o = out + (long)r * ldo;
+  if (sr < 0) {
+    for (int c = threadIdx.x; c < Cp; c += 256) o[c] = 0.0f;
+    return;
+  }
+  const float* vr = v + (long)sr * ldv;
+  float ss = 0.0f;
+  for (int c = threadIdx.x; c < I; c += 256) ss = fmaf(vr[c], vr[c], ss);
+  __shared__ float red[256];
+  red[threadIdx.x] = ss;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  const float inv = 1.0f / sqrtf(red[0]);
+  if (threadIdx.x == 0) inv_norm[sr] = inv;
+  const float sc = g[sr] * inv;
+  for (int c = threadIdx.x; c < Cp; c += 256) {
+    const int scn = col_map[c];
+    o[c] = scn >= 0 ? sc * vr[scn] : 0.0f;
+  }
+}
+
+// dW = gathered d_out row;  dot = <dW, v_r>;  dg = dot / ||v||;  dv = g/||v|| (dW - v dot / ||v||^2)
+// inverse_col[sc] = the output column that reads source column sc (or -1: that column of v is not used -> dv = the
+// projection term only)
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ d_out, int ldo, const float* __restrict__ v,
+                                                              const float* __restrict__ g, const float* __restrict__ inv_norm,
+                                                              int I, int ldv, const int* __restrict__ row_map,
+                                                              const int* __restrict__ inverse_col, float* __restrict__ dv,
+                                                              float* __restrict__ dg) {
+  const int r = blockIdx.x, sr = row_map[r];
+  if (sr < 0) return;
+  const float* d = d_out + (long)r * ldo;
+  const float* vr = v + (long)sr * ldv;
+  float dot = 0.0f;
+  for (int c = threadIdx.x; c < I; c += 256) {
+    const int oc = inverse_col[c];
+    if (oc >= 0) dot = fmaf(d[oc], vr[c], dot);
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = dot;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  dot = red[0];
+  const float inv = inv_norm[sr];
+  if (threadIdx.x == 0) dg[sr] = dot * inv;
+  const float a = g[sr] * inv, b = dot * inv * inv;
+  float* dvr = dv + (long)sr * ldv;
+  for (int c = threadIdx.x; c < I; c += 256) {
+    const int oc = inverse_col[c];
+    dvr[c] = a * ((oc >= 0 ? d[oc] : 0.0f) - vr[c] * b);
+  }
+}
+
 }  // namespace
 
 extern "C" int nsky_softplus_tangent_bwd(const float* da, const float* s, const float* ta, const float* dta, const float* ggrad,
@@ -129,5 +196,28 @@ extern "C" int nsky_adam_step(float* p, const float* g, float* m, float* v, int6
   hipLaunchKernelGGL(adam_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2,
                      eps, bc1, bc2, grad_scale);
   NSKY_CHECK_LAUNCH("nsky_adam_step");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_weight_norm_fwd(const float* v, const float* g, int32_t n_rows_out, int32_t n_cols_out, int32_t in_features,
+                                    int32_t ldv, const int32_t* row_map, const int32_t* col_map, float* out, int32_t ldo,
+                                    float* inv_norm, nsky_stream_t stream) {
+  NSKY_CHECK_ARG(v && g && row_map && col_map && out && inv_norm, "nsky_weight_norm_fwd: null argument");
+  NSKY_CHECK_ARG(n_rows_out > 0 && n_cols_out > 0 && in_features > 0 && ldv >= in_features && ldo >= n_cols_out,
+                 "nsky_weight_norm_fwd: bad sizes");
+  hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3(n_rows_out), dim3(256), 0, (hipStream_t)stream, v, g, in_features, ldv, row_map,
+                     col_map, n_cols_out, out, ldo, inv_norm);
+  NSKY_CHECK_LAUNCH("nsky_weight_norm_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_weight_norm_bwd(const float* d_out, int32_t ldo, const float* v, const float* g, const float* inv_norm,
+                                    int32_t n_rows_out, int32_t in_features, int32_t ldv, const int32_t* row_map,
+                                    const int32_t* inverse_col, float* dv, float* dg, nsky_stream_t stream) {
+  NSKY_CHECK_ARG(d_out && v && g && inv_norm && row_map && inverse_col && dv && dg, "nsky_weight_norm_bwd: null argument");
+  NSKY_CHECK_ARG(n_rows_out > 0 && in_features > 0 && ldv >= in_features, "nsky_weight_norm_bwd: bad sizes");
+  hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(n_rows_out), dim3(256), 0, (hipStream_t)stream, d_out, ldo, v, g, inv_norm,
+                     in_features, ldv, row_map, inverse_col, dv, dg);
+  NSKY_CHECK_LAUNCH("nsky_weight_norm_bwd");
   return NSKY_OK;
 }

@@ -184,21 +184,36 @@ class SDFAlbedoField(nn.Module):
             c["col"], c["col_grad"] = w, torch.is_grad_enabled()
         return w
 
+    def _wn(self, lin: "WeightNormLinear", key: str, rows, cols) -> torch.Tensor:
+        """weight-normed matrix of one layer in the layout its consumer wants: one launch (ops.WeightNormFn)"""
+        dev = lin.weight_v.device
+        maps = self._wn_maps.get((key, str(dev))) if hasattr(self, "_wn_maps") else None
+        if maps is None:
+            if not hasattr(self, "_wn_maps"):
+                self._wn_maps = {}
+            o, i = lin.weight_v.shape
+            maps = self._wn_maps[(key, str(dev))] = ops.weight_norm_maps(o, i, rows(o, i), cols(o, i), dev)
+        return ops.WeightNormFn.apply(lin.weight_v, lin.weight_g, *maps)
+
     def _geo_weights_uncached(self):
-        GF = self.config.geo_feat_dim
-        W0, W1, W2 = self.glin0.weight(), self.glin1.weight(), self.glin2.weight()
-        z = W2.new_zeros(3, W2.shape[1])
-        W2p = torch.cat([W2[1:], W2[:1], z], 0).contiguous()  # rows: [feat | sdf | 0 0 0]
+        ident = lambda n, m: list(range(n))  # noqa: E731
+        pad4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
+        W0 = self._wn(self.glin0, "g0", ident, lambda o, i: list(range(i)) + [-1] * (pad4(i) - i))
+        W1 = self._wn(self.glin1, "g1", ident, lambda o, i: list(range(i)))
+        # rows: [feat | sdf | 0 0 0]
+        W2p = self._wn(self.glin2, "g2", lambda o, i: list(range(1, o)) + [0, -1, -1, -1], lambda o, i: list(range(i)))
         b2 = self.glin2.bias
         b2p = torch.cat([b2[1:], b2[:1], b2.new_zeros(3)], 0).contiguous()
-        return (ops.pad_weight(W0), self.glin0.bias.contiguous(), W1.contiguous(), self.glin1.bias.contiguous(), W2p, b2p)
+        return (W0, self.glin0.bias.contiguous(), W1, self.glin1.bias.contiguous(), W2p, b2p)
 
     def _colour_weights_uncached(self):
-        Wc0 = self.clin0.weight()  # columns [x(3) PE(36) feat(GF)]
-        H = Wc0.shape[0]
-        Wc0p = torch.cat([Wc0[:, 39:], Wc0.new_zeros(H, 4), Wc0[:, :39], Wc0.new_zeros(H, 1)], 1).contiguous()
-        return (Wc0p, self.clin0.bias.contiguous(), self.clin1.weight().contiguous(), self.clin1.bias.contiguous(),
-                ops.pad_weight(self.clin2.weight()), ops.pad_bias(self.clin2.bias))
+        ident = lambda n, m: list(range(n))  # noqa: E731
+        pad4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
+        # columns [x(3) PE(36) feat(GF)] -> [feat | 0 0 0 0 | x PE | 0]
+        Wc0p = self._wn(self.clin0, "c0", ident, lambda o, i: list(range(39, i)) + [-1] * 4 + list(range(39)) + [-1])
+        Wc1 = self._wn(self.clin1, "c1", ident, lambda o, i: list(range(i)))
+        Wc2p = self._wn(self.clin2, "c2", lambda o, i: list(range(o)) + [-1] * (pad4(o) - o), lambda o, i: list(range(i)))
+        return (Wc0p, self.clin0.bias.contiguous(), Wc1, self.clin1.bias.contiguous(), Wc2p, ops.pad_bias(self.clin2.bias))
 
     def _encode(self, positions_flat: torch.Tensor, tangents: bool, need_dx: bool) -> torch.Tensor:
         return ops.HashEncodeFn.apply(positions_flat, self.encoding.table, self.geom, self.grid_mode, True, 6, 5.0,

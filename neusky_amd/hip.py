@@ -232,6 +232,8 @@ def visibility_finish_bwd(t_hat, surf_dist, threshold, scale, sel_index, R, Dv, 
 _sp_tan_bwd = _sig("nsky_softplus_tangent_bwd", _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P)
 _pdf_sample = _sig("nsky_pdf_sample", _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P)
 _adam = _sig("nsky_adam_step", _P, _P, _P, _P, C.c_int64, _F, _F, _F, _F, _I, _F, _P)
+_wn_fwd = _sig("nsky_weight_norm_fwd", _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P)
+_wn_bwd = _sig("nsky_weight_norm_bwd", _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P)
 
 
 def softplus_tangent_bwd(da, s, ta, dta, ggrad, wvec, beta, N, Cc, dz, du):
@@ -247,6 +249,18 @@ def pdf_sample(weights, bins, u_base, jitter, num_bins, histogram_padding=0.01, 
     check(_pdf_sample(_c(weights), _c(bins), _c(u_base), _c(jitter), R, n0, num_bins, histogram_padding, eps, _c(new_bins),
                       _c(inds), stream_ptr()), "nsky_pdf_sample")
     return new_bins, inds
+
+
+def weight_norm_fwd(v, g, row_map, col_map, out, inv_norm):
+    """out[r,c] = g[sr] v[sr,sc] / ||v[sr]|| under the row / column maps (int32, -1 = zero); see include/neusky_hip.h"""
+    check(_wn_fwd(ptr(v), ptr(g), row_map.numel(), col_map.numel(), v.shape[1], ld(v), ptr(row_map), ptr(col_map), ptr(out),
+                  ld(out), ptr(inv_norm), stream_ptr()), "nsky_weight_norm_fwd")
+    return out
+
+
+def weight_norm_bwd(d_out, v, g, inv_norm, row_map, inverse_col, dv, dg):
+    check(_wn_bwd(ptr(d_out), ld(d_out), ptr(v), ptr(g), ptr(inv_norm), row_map.numel(), v.shape[1], ld(v), ptr(row_map),
+                  ptr(inverse_col), ptr(dv), ptr(dg), stream_ptr()), "nsky_weight_norm_bwd")
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):

@@ -120,6 +120,44 @@ def grad_input(dZ, W, M, k_in, n_red, out, **epi):
 
 
 # =============================================================================================
+# weight norm (+ row / column re-ordering and zero padding for the consumer) in one launch each way
+class WeightNormFn(torch.autograd.Function):
+    """W[r,c] = g[sr] v[sr,sc] / ||v[sr]||, sr = row_map[r], sc = col_map[c] (-1 = structural zero): nn.utils.weight_norm
+    as the reference's SDF / colour layers carry it (sdf_albedo_field.py:147-161), emitted directly in the layout the
+    field kernels read (rows [feat | sdf | 0 0 0], columns [feat | pad | x PE | pad], ...).  Every row of v must be listed
+    in row_map (so dv is written completely)."""
+
+    @staticmethod
+    def forward(ctx, v, g, row_map, col_map, inverse_col):
+        v = v.contiguous()
+        out = torch.empty(row_map.numel(), col_map.numel(), device=v.device)
+        inv = torch.empty(v.shape[0], device=v.device)
+        hip.weight_norm_fwd(v, g, row_map, col_map, out, inv)
+        ctx.save_for_backward(v, g, inv, row_map, inverse_col)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        v, g, inv, row_map, inverse_col = ctx.saved_tensors
+        dv, dg = torch.empty_like(v), torch.empty_like(g)
+        hip.weight_norm_bwd(d_out.contiguous(), v, g, inv, row_map, inverse_col, dv, dg)
+        return dv, dg, None, None, None
+
+
+def weight_norm_maps(out_features: int, in_features: int, rows, cols, device):
+    """int32 device maps for WeightNormFn from python lists of source indices (-1 = zero row / column)"""
+    assert sorted(r for r in rows if r >= 0) == list(range(out_features)), "every source row exactly once"
+    used = [c for c in cols if c >= 0]
+    assert len(set(used)) == len(used) and all(c < in_features for c in used)
+    inverse = [-1] * in_features
+    for oc, sc in enumerate(cols):
+        if sc >= 0:
+            inverse[sc] = oc
+    t = lambda x: torch.tensor(x, dtype=torch.int32, device=device)  # noqa: E731
+    return t(rows), t(cols), t(inverse)
+
+
+# =============================================================================================
 # hash-grid encode
 # =============================================================================================
 class HashEncodeFn(torch.autograd.Function):

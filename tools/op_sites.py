@@ -37,7 +37,8 @@ class Counter(TorchDispatchMode):
                     site = f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.name}"
                     break
             if site is None:
-                site = "backward/other"
+                node = torch._C._current_autograd_node()
+                site = "backward:" + (node.name() if node is not None else "other")
             sites[site] += 1
             ops_at[site][name] += 1
         return func(*args, **(kwargs or {}))
@@ -51,6 +52,6 @@ byfile = collections.Counter()
 for s, n in sites.items():
     byfile[s.split(":")[0]] += n
 print("by file:", dict(byfile.most_common()))
-for s, n in sites.most_common(70):
+for s, n in sites.most_common(110):
     top = ", ".join(f"{k.replace('aten.', '')}x{v}" for k, v in ops_at[s].most_common(5))
     print(f"{n:5d}  {s:60s} {top}")
