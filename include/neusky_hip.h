@@ -86,6 +86,10 @@ int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream);
 
 /* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients) */
 int nsky_colsum_f32(const float* X, int32_t M, int32_t N, int32_t ldx, float* out, nsky_stream_t stream);
+/* out[c] += sum_r w[r * w_stride] X[r][c]: the weight gradient of a ONE-output dense layer (the sdf head of the geo net,
+ * sdf_albedo_field.py:169-174 and :233-238) -- a matrix-vector product streamed at HBM rate instead of a 1-row GEMM. */
+int nsky_weighted_colsum_f32(const float* X, int32_t M, int32_t N, int32_t ldx, const float* w, int32_t w_stride, float* out,
+                             nsky_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multiresolution hash-grid encode (tiny-cuda-nn HashGrid semantics, fp32) fused with the rest of
@@ -182,6 +186,18 @@ int nsky_visibility_finish_fwd(const float* t_hat, const float* surf_dist, const
 int nsky_visibility_finish_bwd(const float* t_hat, const float* surf_dist, const float* threshold, float scale,
                                const int32_t* sel_index, int32_t R, int32_t Dv, int32_t D, const float* d_vis,
                                float* d_t_hat, float* d_threshold, nsky_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Proposal-network weights: nerfstudio HashMLPDensityField's trunc_exp density + RaySamples.get_weights, as the proposal
+ * sampler drives them (neusky/models/neusky_model.py:561).  raw [R*n] with element stride ld_raw (the padded output of
+ * the 1-wide density head), ebins [R,n+1] euclidean bin edges -> weights [R,n] =
+ * nan_to_num((1 - exp(-delta sigma)) exp(-cumsum_excl(delta sigma))), sigma = exp(raw).  n <= 256.
+ * Backward writes d_raw with the same stride (the ld_raw-1 pad columns are zero-filled).
+ */
+int nsky_density_weights_fwd(const float* raw, int32_t ld_raw, const float* ebins, int32_t R, int32_t n, float* weights,
+                             nsky_stream_t stream);
+int nsky_density_weights_bwd(const float* raw, int32_t ld_raw, const float* ebins, const float* d_weights, int32_t R, int32_t n,
+                             float* d_raw, nsky_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Reverse-over-forward step of one Softplus layer that carries three input tangents.  Together with

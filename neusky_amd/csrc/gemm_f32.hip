@@ -731,15 +731,20 @@ void launch(const nsky_gemm_desc* d, const EpiCtx& e, int splits, int k_split_le
 #undef NSKY_GEMM_LAUNCH
 }
 
-__global__ void colsum_kernel(const float* __restrict__ X, int M, int N, int ldx, float* __restrict__ out, int rows_per_block) {
-  // block: 256 threads = 64 columns x 4 row-phases
+__global__ void colsum_kernel(const float* __restrict__ X, int M, int N, int ldx, const float* __restrict__ w, int w_stride,
+                              float* __restrict__ out, int rows_per_block) {
+  // block: 256 threads = 64 columns x 4 row-phases; out[c] += sum_r (w ? w[r * w_stride] : 1) X[r][c]
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const int phase = threadIdx.x >> 6;
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
   float s = 0.0f;
-  if (col < N)
-    for (int r = r0 + phase; r < r1; r += 4) s += X[(long)r * ldx + col];
+  if (col < N) {
+    if (w)
+      for (int r = r0 + phase; r < r1; r += 4) s = fmaf(w[(long)r * w_stride], X[(long)r * ldx + col], s);
+    else
+      for (int r = r0 + phase; r < r1; r += 4) s += X[(long)r * ldx + col];
+  }
   __shared__ float red[256];
   red[threadIdx.x] = s;
   __syncthreads();
@@ -810,11 +815,25 @@ extern "C" int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream) {
   return NSKY_OK;
 }
 
-extern "C" int nsky_colsum_f32(const float* X, int32_t M, int32_t N, int32_t ldx, float* out, nsky_stream_t stream) {
-  NSKY_CHECK_ARG(X && out && M > 0 && N > 0 && ldx >= N, "nsky_colsum_f32: bad arguments");
+static int colsum_launch(const float* X, int32_t M, int32_t N, int32_t ldx, const float* w, int32_t w_stride, float* out,
+                         hipStream_t stream) {
   const int rows_per_block = 512;
   dim3 grid(ceil_div(N, 64), ceil_div(M, rows_per_block));
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, M, N, ldx, out, rows_per_block);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, X, M, N, ldx, w, w_stride, out, rows_per_block);
+  return 0;
+}
+
+extern "C" int nsky_colsum_f32(const float* X, int32_t M, int32_t N, int32_t ldx, float* out, nsky_stream_t stream) {
+  NSKY_CHECK_ARG(X && out && M > 0 && N > 0 && ldx >= N, "nsky_colsum_f32: bad arguments");
+  colsum_launch(X, M, N, ldx, nullptr, 0, out, (hipStream_t)stream);
   NSKY_CHECK_LAUNCH("nsky_colsum_f32");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_weighted_colsum_f32(const float* X, int32_t M, int32_t N, int32_t ldx, const float* w, int32_t w_stride,
+                                        float* out, nsky_stream_t stream) {
+  NSKY_CHECK_ARG(X && out && w && M > 0 && N > 0 && ldx >= N && w_stride >= 1, "nsky_weighted_colsum_f32: bad arguments");
+  colsum_launch(X, M, N, ldx, w, w_stride, out, (hipStream_t)stream);
+  NSKY_CHECK_LAUNCH("nsky_weighted_colsum_f32");
   return NSKY_OK;
 }

@@ -446,6 +446,110 @@ __global__ void visibility_finish_bwd_kernel(const float* __restrict__ t_hat, co
   if ((threadIdx.x & 63) == 0 && d_threshold && gthr != 0.0f) atomicAdd(d_threshold, gthr);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Proposal-network weights: raw density head -> density = exp(raw) -> volumetric weights of one ray.
+//   dd_i = delta_i exp(raw_i),  w_i = nan_to_num((1 - exp(-dd_i)) exp(-sum_{j<i} dd_j))
+// One wave per ray, lane l owns bins [l*CH, (l+1)*CH).  Backward recomputes the forward terms:
+//   dL/ddd_j = g_j exp(-dd_j) T_j - sum_{i>j} g_i w_i,   d raw_j = dL/ddd_j delta_j exp(clamp(raw_j, -15, 15))
+// (the density activation is nerfstudio's trunc_exp: forward exp, backward exp of the clamped input).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_excl_sum_scan(float v, int lane) {
+  float x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    float y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  float e = __shfl_up(x, 1, 64);
+  return lane == 0 ? 0.0f : e;
+}
+__device__ __forceinline__ float nan_to_num_f(float v) {
+  if (v != v) return 0.0f;
+  return fminf(fmaxf(v, -3.402823466e38f), 3.402823466e38f);
+}
+
+__global__ __launch_bounds__(256) void density_weights_fwd_kernel(const float* __restrict__ raw, int ld_raw,
+                                                                  const float* __restrict__ ebins, int R, int n,
+                                                                  float* __restrict__ weights) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int CH = (n + 63) / 64;
+  float dd[MAXCH];
+  float local = 0.0f;
+#pragma unroll
+  for (int q = 0; q < MAXCH; ++q) {
+    const int i = lane * CH + q;
+    dd[q] = 0.0f;
+    if (q < CH && i < n) {
+      const float delta = ebins[(long)r * (n + 1) + i + 1] - ebins[(long)r * (n + 1) + i];
+      dd[q] = delta * expf(raw[((long)r * n + i) * ld_raw]);
+      local += dd[q];
+    }
+  }
+  float C = wave_excl_sum_scan(local, lane);
+#pragma unroll
+  for (int q = 0; q < MAXCH; ++q) {
+    const int i = lane * CH + q;
+    if (q < CH && i < n) {
+      weights[(long)r * n + i] = nan_to_num_f((1.0f - expf(-dd[q])) * expf(-C));
+      C += dd[q];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void density_weights_bwd_kernel(const float* __restrict__ raw, int ld_raw,
+                                                                  const float* __restrict__ ebins, const float* __restrict__ d_w,
+                                                                  int R, int n, float* __restrict__ d_raw) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int CH = (n + 63) / 64;
+  float dd[MAXCH], gw[MAXCH], gdirect[MAXCH], dens_b[MAXCH];
+  float local = 0.0f;
+#pragma unroll
+  for (int q = 0; q < MAXCH; ++q) {
+    const int i = lane * CH + q;
+    dd[q] = 0.0f;
+    if (q < CH && i < n) {
+      const float delta = ebins[(long)r * (n + 1) + i + 1] - ebins[(long)r * (n + 1) + i];
+      const float rv = raw[((long)r * n + i) * ld_raw];
+      dd[q] = delta * expf(rv);
+      dens_b[q] = delta * expf(fminf(fmaxf(rv, -15.0f), 15.0f));
+      local += dd[q];
+    }
+  }
+  float C = wave_excl_sum_scan(local, lane);
+  float gsum = 0.0f;
+#pragma unroll
+  for (int q = 0; q < MAXCH; ++q) {
+    const int i = lane * CH + q;
+    gw[q] = 0.0f; gdirect[q] = 0.0f;
+    if (q < CH && i < n) {
+      const float T = expf(-C), e = expf(-dd[q]);
+      const float w = (1.0f - e) * T;
+      const bool pass = (w == w) && fabsf(w) <= 3.402823466e38f;  // nan_to_num passes gradients of finite values only
+      const float g = pass ? d_w[(long)r * n + i] : 0.0f;
+      gw[q] = g * w;
+      gdirect[q] = g * e * T;
+      gsum += gw[q];
+      C += dd[q];
+    }
+  }
+  float suffix = wave_excl_sum_scan_rev(gsum, lane);  // sum of g w over later lanes
+#pragma unroll
+  for (int q = MAXCH - 1; q >= 0; --q) {
+    const int i = lane * CH + q;
+    if (q < CH && i < n) {
+      float* o = d_raw + ((long)r * n + i) * ld_raw;
+      o[0] = (gdirect[q] - suffix) * dens_b[q];
+      for (int c = 1; c < ld_raw; ++c) o[c] = 0.0f;
+      suffix += gw[q];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int nsky_hemi_composite_fwd(const float* albedo, const float* normals, const float* weights, const float* dirs,
@@ -536,5 +640,27 @@ extern "C" int nsky_visibility_finish_bwd(const float* t_hat, const float* surf_
   hipLaunchKernelGGL(visibility_finish_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, t_hat, surf_dist,
                      threshold, scale, sel_index, R, Dv, D, d_vis, d_t_hat, d_threshold);
   NSKY_CHECK_LAUNCH("nsky_visibility_finish_bwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_density_weights_fwd(const float* raw, int32_t ld_raw, const float* ebins, int32_t R, int32_t n, float* weights,
+                                        nsky_stream_t stream) {
+  if (R == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(raw && ebins && weights && ld_raw >= 1, "nsky_density_weights_fwd: bad argument");
+  NSKY_CHECK_ARG(R > 0 && n > 0 && n <= 64 * MAXCH, "nsky_density_weights_fwd: n=%d out of range (<= %d)", n, 64 * MAXCH);
+  hipLaunchKernelGGL(density_weights_fwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, (hipStream_t)stream, raw, ld_raw, ebins, R, n,
+                     weights);
+  NSKY_CHECK_LAUNCH("nsky_density_weights_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_density_weights_bwd(const float* raw, int32_t ld_raw, const float* ebins, const float* d_weights, int32_t R,
+                                        int32_t n, float* d_raw, nsky_stream_t stream) {
+  if (R == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(raw && ebins && d_weights && d_raw && ld_raw >= 1, "nsky_density_weights_bwd: bad argument");
+  NSKY_CHECK_ARG(R > 0 && n > 0 && n <= 64 * MAXCH, "nsky_density_weights_bwd: n=%d out of range (<= %d)", n, 64 * MAXCH);
+  hipLaunchKernelGGL(density_weights_bwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, (hipStream_t)stream, raw, ld_raw, ebins,
+                     d_weights, R, n, d_raw);
+  NSKY_CHECK_LAUNCH("nsky_density_weights_bwd");
   return NSKY_OK;
 }

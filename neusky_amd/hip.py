@@ -100,6 +100,15 @@ def gemm(A, B, Cout, M, N, K, *, a_kcontig=True, b_kcontig=True, bias=None, epi=
     return Cout
 
 
+_wcolsum = _sig("nsky_weighted_colsum_f32", C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p)
+
+
+def weighted_colsum(X, M, N, w, w_stride, out):
+    """out[c] += sum_r w[r * w_stride] X[r, c]"""
+    check(_wcolsum(ptr(X), M, N, ld(X), ptr(w), w_stride, ptr(out), stream_ptr()), "nsky_weighted_colsum_f32")
+    return out
+
+
 def colsum(X, M, N, out):
     check(_colsum(ptr(X), M, N, ld(X), ptr(out), stream_ptr()), "nsky_colsum_f32")
     return out
@@ -249,6 +258,23 @@ def pdf_sample(weights, bins, u_base, jitter, num_bins, histogram_padding=0.01, 
     check(_pdf_sample(_c(weights), _c(bins), _c(u_base), _c(jitter), R, n0, num_bins, histogram_padding, eps, _c(new_bins),
                       _c(inds), stream_ptr()), "nsky_pdf_sample")
     return new_bins, inds
+
+
+_dw_fwd = _sig("nsky_density_weights_fwd", _P, _I, _P, _I, _I, _P, _P)
+_dw_bwd = _sig("nsky_density_weights_bwd", _P, _I, _P, _P, _I, _I, _P, _P)
+
+
+def density_weights_fwd(raw, ebins, weights):
+    """raw [R*n, ld] (column 0 = density-head output), ebins [R,n+1] -> weights [R,n]"""
+    R, n = weights.shape
+    check(_dw_fwd(ptr(raw), ld(raw), _c(ebins), R, n, _c(weights), stream_ptr()), "nsky_density_weights_fwd")
+    return weights
+
+
+def density_weights_bwd(raw, ebins, d_weights, d_raw):
+    R, n = d_weights.shape
+    check(_dw_bwd(ptr(raw), ld(raw), _c(ebins), _c(d_weights), R, n, _c(d_raw), stream_ptr()), "nsky_density_weights_bwd")
+    return d_raw
 
 
 def weight_norm_fwd(v, g, row_map, col_map, out, inv_norm):

@@ -32,15 +32,23 @@ class HashMLPDensityField(nn.Module):
         self.lin1 = nn.Linear(hidden_dim, 1)
         self.mode = contraction_mode
 
+    def raw_density(self, positions: torch.Tensor) -> torch.Tensor:
+        """positions [R,n,3] -> pre-activation of the density head, [R*n, 4] (column 0; columns 1-3 are padding)"""
+        x = positions.reshape(-1, 3).detach()
+        feat = ops.HashEncodeFn.apply(x, self.encoding.table, self.geom, self.mode, False, 0, 0.0, False, False)
+        h = ops.DenseFn.apply(feat, ops.pad_weight(self.lin0.weight), ops.pad_bias(self.lin0.bias), self.lin0.out_features, "relu", True)
+        return ops.DenseFn.apply(h, ops.pad_weight(self.lin1.weight), ops.pad_bias(self.lin1.bias), 1, "none", True)
+
     def density_fn(self, positions: torch.Tensor) -> torch.Tensor:
         """positions [R,n,3] -> density [R,n,1].  Under scene contraction every point maps strictly inside
         (0,1)^3, so nerfstudio's `selector` mask is identically one and is not materialised."""
         R, n, _ = positions.shape
-        x = positions.reshape(-1, 3).detach()
-        feat = ops.HashEncodeFn.apply(x, self.encoding.table, self.geom, self.mode, False, 0, 0.0, False, False)
-        h = ops.DenseFn.apply(feat, ops.pad_weight(self.lin0.weight), ops.pad_bias(self.lin0.bias), self.lin0.out_features, "relu", True)
-        d = ops.DenseFn.apply(h, ops.pad_weight(self.lin1.weight), ops.pad_bias(self.lin1.bias), 1, "none", True)
-        return ops.TruncExpFn.apply(d[:, :1]).view(R, n, 1)
+        return ops.TruncExpFn.apply(self.raw_density(positions)[:, :1]).view(R, n, 1)
+
+    def weights_fn(self, positions: torch.Tensor, ebins: torch.Tensor) -> torch.Tensor:
+        """positions [R,n,3] (bin mid-points), ebins [R,n+1] -> volumetric weights [R,n]: density activation and
+        `weights_from_density` fused into one launch each way (ops.DensityWeightsFn)"""
+        return ops.DensityWeightsFn.apply(self.raw_density(positions), ebins)
 
 
 def weights_from_density(density: torch.Tensor, deltas: torch.Tensor) -> torch.Tensor:
@@ -117,8 +125,12 @@ class ProposalNetworkSampler(nn.Module):
             if lvl < n:
                 mid = (ebins[:, :-1] + ebins[:, 1:]) / 2
                 pos = origins[:, None, :] + directions[:, None, :] * mid[..., None]
-                dens = density_fns[lvl](pos)
-                weights = weights_from_density(dens, (ebins[:, 1:] - ebins[:, :-1])[..., None])[..., 0]
+                owner = getattr(density_fns[lvl], "__self__", None)
+                if isinstance(owner, HashMLPDensityField):  # this package's proposal field: fused density -> weights
+                    weights = owner.weights_fn(pos, ebins)
+                else:  # any other density callable (nerfstudio's `density_fns` contract)
+                    dens = density_fns[lvl](pos)
+                    weights = weights_from_density(dens, (ebins[:, 1:] - ebins[:, :-1])[..., None])[..., 0]
                 weights_list.append(weights)
                 sbins_list.append(sbins)
         return sbins, ebins, weights_list, sbins_list, inds_list

@@ -415,6 +415,7 @@ class SDFAlbedoFn(torch.autograd.Function):
         fgemm(C1, Wc2, ALB, N, 3, Hc, bias=bc2, epi=hip.EPI_SIGMOID, p0=1.0)
         ctx.save_for_backward(ET, A0, S0, A1, S1, CIN, C0, C1, ALB, W0, b0, W1, b1, W2, b2, Wc0, bc0, Wc1, bc1, Wc2, bc2)
         ctx.cfg = (N, Hd, Kin, GF, ldc, Hc, beta)
+        ctx.set_materialize_grads(False)
         sdf = CIN[:, GF].clone()
         grad = G.view(3, N, 4)[:, :, 0].t().contiguous()
         return sdf, grad, ALB[:, :3].clone()
@@ -451,11 +452,8 @@ class SDFAlbedoFn(torch.autograd.Function):
         if g_grad is None:
             g_grad = torch.zeros(N, 3, device=dev)
         g_grad = g_grad.contiguous()
-        ggT = torch.zeros(3 * N, 4, device=dev)
-        ggT[:, 0] = g_grad.t().reshape(-1)
-        dw2s = torch.zeros(4, Hd, device=dev)
-        hip.gemm(ggT, A1[N:], dw2s, 1, Hd, 3 * N, a_kcontig=False, b_kcontig=False, k_splits=_splits(3 * N))
-        dW2[GF] += dw2s[0]
+        # d w_sdf += sum_{k,n} g_grad[n,k] ta1_k[n,:] : accumulated straight into the sdf row of dW2
+        hip.weighted_colsum(A1[N:], 3 * N, Hd, g_grad.t().contiguous(), 1, dW2[GF])
         w2s = W2[GF].contiguous()
         # ---- layer 1 (reverse over forward)
         D1 = torch.empty(4 * N, Hd, device=dev)
@@ -511,9 +509,7 @@ class SDFValueFn(torch.autograd.Function):
         dW0 = db0 = dW1 = db1 = dW2 = db2 = None
         if train_w:
             dW2 = torch.zeros_like(W2); db2 = torch.zeros_like(b2)
-            dw = torch.zeros(4, Hd, device=dev)
-            hip.gemm(g, A1, dw, 1, Hd, M, a_kcontig=False, b_kcontig=False, k_splits=_splits(M))
-            dW2[GF] = dw[0]
+            hip.weighted_colsum(A1, M, Hd, g, 4, dW2[GF])
             db2[GF] = g_sdf.sum()
             dW1, db1 = grad_weight(dZ1, A0, M, Hd, Hd, W1, b1)
             dW0, db0 = grad_weight(dZ0, E, M, Hd, Kin, W0, b0)
@@ -569,6 +565,7 @@ class NeusWeightsFn(torch.autograd.Function):
         hip.neus_weights_fwd(sdf, grad, ray_dirs, starts, ends, variance, anneal, None, w, tb, acc, dep)
         ctx.save_for_backward(sdf, grad, ray_dirs, starts, ends, variance, w)
         ctx.anneal = anneal
+        ctx.set_materialize_grads(False)  # absent output gradients arrive as None, not as zero-filled tensors
         ctx.mark_non_differentiable(acc, dep)
         return w, tb, acc, dep
 
@@ -603,6 +600,27 @@ class VisibilityFinishFn(torch.autograd.Function):
         d_thr = torch.zeros_like(threshold)
         hip.visibility_finish_bwd(t_hat, surf_dist, threshold, scale, sel_index, R, Dv, D, d_vis.contiguous(), d_t, d_thr)
         return d_t, None, d_thr, None, None, None, None, None, None
+
+
+class DensityWeightsFn(torch.autograd.Function):
+    """proposal-network weights from the raw density head: raw [R*n, ld] (column 0), ebins [R,n+1] -> weights [R,n]
+    (trunc_exp density + RaySamples.get_weights in one launch each way; see include/neusky_hip.h)"""
+
+    @staticmethod
+    def forward(ctx, raw, ebins):
+        R, n = ebins.shape[0], ebins.shape[1] - 1
+        ebins = ebins.contiguous()
+        w = torch.empty(R, n, device=raw.device)
+        hip.density_weights_fwd(raw, ebins, w)
+        ctx.save_for_backward(raw, ebins)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        raw, ebins = ctx.saved_tensors
+        d_raw = torch.empty_like(raw)
+        hip.density_weights_bwd(raw, ebins, dw.contiguous(), d_raw)
+        return d_raw, None
 
 
 class TruncExpFn(torch.autograd.Function):

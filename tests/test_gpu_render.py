@@ -167,3 +167,32 @@ def test_visibility_geometry_golden():
         gt, gth = torch.autograd.grad((v.view(R, Dv) * gv[:, sel].double()).sum(), [td, thr])
         assert (dth.cpu().double() - gt).abs().max().item() < 1e-4 * gt.abs().max().item()
         assert abs(dthr.item() - gth.item()) < 1e-3 * abs(gth.item())
+
+
+def test_density_weights_matches_torch_formulation():
+    """nsky_density_weights_fwd/bwd == trunc_exp density + nerfstudio RaySamples.get_weights (the torch formulation kept
+    in ray_samplers.weights_from_density) incl. the gradient w.r.t. the raw density head, for the proposal sizes 256 / 96,
+    a ragged size, a padded head (ld 4) and saturated / overflowing densities (nan_to_num path)."""
+    from neusky_amd import ops
+    from neusky_amd.model_components.ray_samplers import weights_from_density
+    dev = "cuda:0"
+    torch.manual_seed(9)
+    for R, n in ((64, 256), (37, 96), (5, 77)):
+        raw = torch.randn(R * n, 4, device=dev) * 2.0
+        raw[:, 1:] = 0.0
+        raw[3, 0] = 40.0    # huge density: alpha = 1, later weights exactly 0
+        raw[7, 0] = -30.0   # below trunc_exp's backward clamp (-15)
+        ebins = torch.sort(torch.rand(R, n + 1, device=dev) * 2 + 0.05, dim=1).values
+        probe = torch.randn(R, n, device=dev)
+        r64 = raw.double().requires_grad_(True)
+        dens = ops.TruncExpFn.apply(r64[:, :1]).view(R, n, 1)
+        ref = weights_from_density(dens, (ebins[:, 1:] - ebins[:, :-1]).double()[..., None])[..., 0]
+        (ref * probe.double()).sum().backward()
+        r32 = raw.clone().requires_grad_(True)
+        w = ops.DensityWeightsFn.apply(r32, ebins)
+        assert w.shape == (R, n)
+        assert (w.double() - ref).abs().max().item() < 2e-6
+        (w * probe).sum().backward()
+        assert (r32.grad[:, 1:] == 0).all()
+        gref = r64.grad[:, 0]
+        assert (r32.grad[:, 0].double() - gref).abs().max().item() < 1e-5 * max(gref.abs().max().item(), 1.0)

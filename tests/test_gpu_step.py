@@ -13,6 +13,10 @@ DEV = "cuda:0"
 
 @pytest.fixture(scope="module")
 def step():
+    return compute_step()
+
+
+def compute_step():
     torch.manual_seed(0)
     R = 16
     pipe = small_pipeline_config(R=R).setup(device=DEV)
@@ -110,11 +114,13 @@ def _module_grads(pipe):
 
 def test_parameter_gradients(step):
     """bar per tensor: 2e-3 of its max + the fp32 conditioning of that gradient, measured as the distance of the
-    float32 oracle from the float64 oracle (own tensor x3, or the median of its network x5 - a single fp32 sample can
-    sit atypically close to exact math).  SIREN chains with frequencies ~30 and hash grids at scale 2047 make some
+    float32 oracle from the float64 oracle (own tensor x3, or the median of its sub-network x5 - a single fp32 sample
+    can sit atypically close to exact math; the DDF's mapping network sits at ~5e-3 in fp32, its FiLM layers at ~4e-4,
+    and tools/grad_err.py shows the HIP figures do not move between 2-term, 3-term and exact-fp32 backward GEMMs).  SIREN chains with frequencies ~30 and hash grids at scale 2047 make some
     gradients ill-conditioned in fp32 for ANY evaluator; the bar lets the HIP path be as far from exact math as the
     reference's own fp32 arithmetic, not further."""
     import statistics
+    net_of = lambda k: k.split("_")[0] if k.startswith("ddf.") else k.split(".")[0]  # noqa: E731  ddf.map / ddf.film / ddf.out / field / ...
     got = _module_grads(step["pipe"])
     rel_gap, per_net = {}, {}
     for k, ref in step["grads"].items():
@@ -122,7 +128,7 @@ def test_parameter_gradients(step):
             continue
         b = ref.reshape(-1)
         rel_gap[k] = (step["grads32"][k].double().reshape(-1) - b).abs().max().item() / (b.abs().max().item() + 1e-30)
-        per_net.setdefault(k.split(".")[0], []).append(rel_gap[k])
+        per_net.setdefault(net_of(k), []).append(rel_gap[k])
     med = {n: statistics.median(v) for n, v in per_net.items()}
     bad = []
     for k, ref in step["grads"].items():
@@ -133,7 +139,7 @@ def test_parameter_gradients(step):
         a, b = gg.detach().cpu().double().reshape(-1), ref.reshape(-1)
         scale = b.abs().max().item()
         err = (a - b).abs().max().item()
-        bar = (3e-3 + max(3.0 * rel_gap[k], 5.0 * med[k.split(".")[0]])) * scale + 1e-12
+        bar = (3e-3 + max(3.0 * rel_gap[k], 5.0 * med[net_of(k)])) * scale + 1e-12
         if err > bar:
             bad.append((k, err, scale, bar))
     assert not bad, bad

@@ -24,12 +24,18 @@ SKIP = {"aten.view.default", "aten._unsafe_view.default", "aten.reshape.default"
         "aten.is_same_size.default", "aten.lift_fresh.default", "aten._local_scalar_dense.default", "aten.narrow.default",
         "aten.unfold.default", "aten.new_empty.default", "aten.split_with_sizes.default", "aten.chunk.default"}
 sites = collections.Counter()
+views = collections.Counter()
 ops_at = collections.defaultdict(collections.Counter)
 
 
 class Counter(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func)
+        if name in ("aten.slice.Tensor", "aten.select.int", "aten.index.Tensor") and isinstance(args[0], torch.Tensor) and args[0].requires_grad:
+            for fr in reversed(traceback.extract_stack(limit=40)):
+                if "/neusky_amd/" in fr.filename and "hip.py" not in fr.filename:
+                    views[f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.name} {name}"] += 1
+                    break
         if name not in SKIP:
             site = None
             for fr in reversed(traceback.extract_stack(limit=40)):
@@ -55,3 +61,6 @@ print("by file:", dict(byfile.most_common()))
 for s, n in sites.most_common(110):
     top = ", ".join(f"{k.replace('aten.', '')}x{v}" for k, v in ops_at[s].most_common(5))
     print(f"{n:5d}  {s:60s} {top}")
+print("---- slices / selects / index of tensors that require grad (each costs a zeros + copy pair in backward)")
+for s_, n in views.most_common(40):
+    print(f"{n:5d}  {s_}")
