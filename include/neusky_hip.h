@@ -188,6 +188,24 @@ int nsky_visibility_finish_bwd(const float* t_hat, const float* surf_dist, const
                                float* d_t_hat, float* d_threshold, nsky_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Ray set-up of the proposal sampler (nerfstudio SphereCollider + UniformSampler + the spacing->euclidean map and
+ * bin mid-points that ProposalNetworkSampler applies between levels; driven from neusky/models/neusky_model.py:213,561).
+ * No gradient flows through any of these.
+ *   nsky_sphere_collider : origins, directions [R,3] -> nears, fars [R] against the sphere |x| = radius
+ *                          (nears >= near_plane, fars >= nears + 1e-6; rays that miss get [near_plane, near_plane + 1e-6])
+ *   nsky_uniform_bins    : sbins [R,n+1] = linspace(0,1,n+1) jittered inside its own bin by jitter[R] (NULL: plain
+ *                          lattice), ebins = sbins * far + (1 - sbins) * near
+ *   nsky_bins_to_samples : sbins [R,n+1] -> ebins [R,n+1] (optional) and positions [R,n,3] = o + d (e_i + e_{i+1}) / 2
+ *                          (optional)
+ */
+int nsky_sphere_collider(const float* origins, const float* directions, int32_t R, float radius, float near_plane, float* nears,
+                         float* fars, nsky_stream_t stream);
+int nsky_uniform_bins(const float* nears, const float* fars, const float* jitter, int32_t R, int32_t n, float* sbins, float* ebins,
+                      nsky_stream_t stream);
+int nsky_bins_to_samples(const float* sbins, const float* nears, const float* fars, const float* origins, const float* directions,
+                         int32_t R, int32_t n, float* ebins, float* positions, nsky_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Proposal-network weights: nerfstudio HashMLPDensityField's trunc_exp density + RaySamples.get_weights, as the proposal
  * sampler drives them (neusky/models/neusky_model.py:561).  raw [R*n] with element stride ld_raw (the padded output of
  * the 1-wide density head), ebins [R,n+1] euclidean bin edges -> weights [R,n] =

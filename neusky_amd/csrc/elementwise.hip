@@ -162,6 +162,73 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __res
   }
 }
 
+
+// ---- ray set-up of the proposal sampler (no gradients flow through any of it) ------------------------------------
+// nerfstudio SphereCollider(center 0, radius, near_plane): near / far of every ray against the scene sphere
+__global__ void sphere_collider_kernel(const float* __restrict__ o, const float* __restrict__ d, int R, float radius,
+                                       float near_plane, float* __restrict__ nears, float* __restrict__ fars) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float ox = o[3 * r], oy = o[3 * r + 1], oz = o[3 * r + 2];
+  const float dx = d[3 * r], dy = d[3 * r + 1], dz = d[3 * r + 2];
+  const float a = dx * dx + dy * dy + dz * dz;
+  const float b = 2.0f * (ox * dx + oy * dy + oz * dz);
+  const float c = ox * ox + oy * oy + oz * oz - radius * radius;
+  const float disc = b * b - 4.0f * a * c;
+  const bool ok = disc > 0.0f;
+  const float sq = sqrtf(ok ? disc : 0.0f);
+  const float t0 = (-b - sq) / (2.0f * a), t1 = (-b + sq) / (2.0f * a);
+  const float nr = fmaxf(ok ? t0 : 0.0f, near_plane);
+  nears[r] = nr;
+  fars[r] = fmaxf(ok ? t1 : 0.0f, nr + 1e-6f);
+}
+
+// spacing bin s in [0,1] -> euclidean distance along the ray; ONE explicit rounding sequence shared by every kernel
+__device__ __forceinline__ float spacing_to_euclid(float s, float nr, float fr) { return fmaf(s, fr, (1.0f - s) * nr); }
+
+__device__ __forceinline__ float linspace01(int i, int steps) {  // torch.linspace(0, 1, steps)[i] as the GPU kernel forms it
+  const float step = 1.0f / (float)(steps - 1);
+  return i < steps / 2 ? step * (float)i : 1.0f - step * (float)(steps - i - 1);
+}
+
+// UniformSampler(single_jitter): spacing bins [R,n+1] (one jitter per ray, or the plain lattice) and euclidean bins
+__global__ void uniform_bins_kernel(const float* __restrict__ nears, const float* __restrict__ fars,
+                                    const float* __restrict__ jitter, int R, int n, float* __restrict__ sbins,
+                                    float* __restrict__ ebins) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)R * (n + 1)) return;
+  const int r = (int)(idx / (n + 1)), i = (int)(idx % (n + 1));
+  float s = linspace01(i, n + 1);
+  if (jitter) {
+    const float lo = i == 0 ? s : (s + linspace01(i - 1, n + 1)) / 2.0f;
+    const float hi = i == n ? s : (linspace01(i + 1, n + 1) + s) / 2.0f;
+    s = lo + (hi - lo) * jitter[r];
+  }
+  sbins[idx] = s;
+  ebins[idx] = spacing_to_euclid(s, nears[r], fars[r]);
+}
+
+// spacing bins -> euclidean bins (optional) and the bin mid-points along the ray, pos = o + d (e_i + e_{i+1}) / 2
+__global__ void bins_to_samples_kernel(const float* __restrict__ sbins, const float* __restrict__ nears,
+                                       const float* __restrict__ fars, const float* __restrict__ o, const float* __restrict__ d,
+                                       int R, int n, float* __restrict__ ebins, float* __restrict__ pos) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)R * (n + 1)) return;
+  const int r = (int)(idx / (n + 1)), i = (int)(idx % (n + 1));
+  const float nr = nears[r], fr = fars[r];
+  const float s0 = sbins[idx];
+  const float e0 = spacing_to_euclid(s0, nr, fr);
+  if (ebins) ebins[idx] = e0;
+  if (pos && i < n) {
+    const float s1 = sbins[idx + 1];
+    const float mid = (e0 + spacing_to_euclid(s1, nr, fr)) / 2.0f;
+    float* p = pos + ((long)r * n + i) * 3;
+    p[0] = o[3 * r] + d[3 * r] * mid;
+    p[1] = o[3 * r + 1] + d[3 * r + 1] * mid;
+    p[2] = o[3 * r + 2] + d[3 * r + 2] * mid;
+  }
+}
+
 }  // namespace
 
 extern "C" int nsky_softplus_tangent_bwd(const float* da, const float* s, const float* ta, const float* dta, const float* ggrad,
@@ -219,5 +286,37 @@ extern "C" int nsky_weight_norm_bwd(const float* d_out, int32_t ldo, const float
   hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(n_rows_out), dim3(256), 0, (hipStream_t)stream, d_out, ldo, v, g, inv_norm,
                      in_features, ldv, row_map, inverse_col, dv, dg);
   NSKY_CHECK_LAUNCH("nsky_weight_norm_bwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_sphere_collider(const float* origins, const float* directions, int32_t R, float radius, float near_plane,
+                                    float* nears, float* fars, nsky_stream_t stream) {
+  if (R == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(origins && directions && nears && fars && R > 0 && radius > 0.0f, "nsky_sphere_collider: bad argument");
+  hipLaunchKernelGGL(sphere_collider_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, (hipStream_t)stream, origins, directions, R,
+                     radius, near_plane, nears, fars);
+  NSKY_CHECK_LAUNCH("nsky_sphere_collider");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_uniform_bins(const float* nears, const float* fars, const float* jitter, int32_t R, int32_t n, float* sbins,
+                                 float* ebins, nsky_stream_t stream) {
+  if (R == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(nears && fars && sbins && ebins && R > 0 && n > 0, "nsky_uniform_bins: bad argument");
+  hipLaunchKernelGGL(uniform_bins_kernel, dim3(ceil_div((long)R * (n + 1), 256)), dim3(256), 0, (hipStream_t)stream, nears, fars,
+                     jitter, R, n, sbins, ebins);
+  NSKY_CHECK_LAUNCH("nsky_uniform_bins");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_bins_to_samples(const float* sbins, const float* nears, const float* fars, const float* origins,
+                                    const float* directions, int32_t R, int32_t n, float* ebins, float* positions,
+                                    nsky_stream_t stream) {
+  if (R == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(sbins && nears && fars && R > 0 && n > 0 && (ebins || positions), "nsky_bins_to_samples: bad argument");
+  NSKY_CHECK_ARG(!positions || (origins && directions), "nsky_bins_to_samples: positions need origins and directions");
+  hipLaunchKernelGGL(bins_to_samples_kernel, dim3(ceil_div((long)R * (n + 1), 256)), dim3(256), 0, (hipStream_t)stream, sbins,
+                     nears, fars, origins, directions, R, n, ebins, positions);
+  NSKY_CHECK_LAUNCH("nsky_bins_to_samples");
   return NSKY_OK;
 }

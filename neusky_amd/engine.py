@@ -16,6 +16,7 @@ import torch
 import torch.distributed as dist
 
 from . import hip
+from .model_components.losses import total_loss
 
 
 @dataclass
@@ -121,7 +122,7 @@ def train_iteration(pipeline, optimizers: Optimizers, step: int, **kw):
     """one step of the reference's training loop: forward + losses, backward, (all-reduce), 5 Adam steps"""
     optimizers.zero_grad_all()
     _, loss_dict, metrics_dict = pipeline.get_train_loss_dict(step, **kw)
-    loss = sum(loss_dict.values())
+    loss = total_loss(loss_dict)
     loss.backward()
     optimizers.all_reduce_gradients()
     optimizers.optimizer_scheduler_step_all(step)
@@ -167,7 +168,7 @@ class GraphedTrainStep:
     def _body(self, step):
         self.opt.zero_grad_all()
         _, loss_dict, metrics = self.pipeline.get_train_loss_dict(step, ray_bundle=self.rb, batch=self.batch, randoms=self.randoms)
-        loss = sum(loss_dict.values())
+        loss = total_loss(loss_dict)
         loss.backward()
         return loss.detach(), {k: v.detach() for k, v in loss_dict.items()}, metrics
 

@@ -260,6 +260,39 @@ def pdf_sample(weights, bins, u_base, jitter, num_bins, histogram_padding=0.01, 
     return new_bins, inds
 
 
+_collider = _sig("nsky_sphere_collider", _P, _P, _I, _F, _F, _P, _P, _P)
+_ubins = _sig("nsky_uniform_bins", _P, _P, _P, _I, _I, _P, _P, _P)
+_b2s = _sig("nsky_bins_to_samples", _P, _P, _P, _P, _P, _I, _I, _P, _P, _P)
+
+
+def sphere_collider(origins, directions, radius, near_plane):
+    """origins, directions [R,3] -> nears, fars [R,1] (nerfstudio SphereCollider)"""
+    R = origins.shape[0]
+    nears = torch.empty(R, 1, device=origins.device)
+    fars = torch.empty(R, 1, device=origins.device)
+    check(_collider(_c(origins), _c(directions), R, radius, near_plane, ptr(nears), ptr(fars), stream_ptr()), "nsky_sphere_collider")
+    return nears, fars
+
+
+def uniform_bins(nears, fars, n, jitter):
+    """-> sbins, ebins [R,n+1] (UniformSampler, single jitter per ray or None)"""
+    R = nears.shape[0]
+    sbins = torch.empty(R, n + 1, device=nears.device)
+    ebins = torch.empty(R, n + 1, device=nears.device)
+    check(_ubins(_c(nears), _c(fars), _c(jitter), R, n, ptr(sbins), ptr(ebins), stream_ptr()), "nsky_uniform_bins")
+    return sbins, ebins
+
+
+def bins_to_samples(sbins, nears, fars, origins=None, directions=None, want_ebins=True, want_positions=False):
+    """sbins [R,n+1] -> (ebins [R,n+1] | None, positions [R,n,3] | None)"""
+    R, n = sbins.shape[0], sbins.shape[1] - 1
+    ebins = torch.empty(R, n + 1, device=sbins.device) if want_ebins else None
+    pos = torch.empty(R, n, 3, device=sbins.device) if want_positions else None
+    check(_b2s(_c(sbins), _c(nears), _c(fars), _c(origins), _c(directions), R, n, ptr(ebins), ptr(pos), stream_ptr()),
+          "nsky_bins_to_samples")
+    return ebins, pos
+
+
 _dw_fwd = _sig("nsky_density_weights_fwd", _P, _I, _P, _I, _I, _P, _P)
 _dw_bwd = _sig("nsky_density_weights_bwd", _P, _I, _P, _P, _I, _I, _P, _P)
 

@@ -1,7 +1,7 @@
 """Closed-form losses of the train step (torch ops on small tensors): SURVEY.md section 8 A12."""
 from __future__ import annotations
 
-from typing import Dict, Sequence
+from typing import Optional, Dict, Sequence
 
 import torch
 import torch.nn.functional as F
@@ -45,7 +45,40 @@ def interlevel_loss(weights_list: Sequence[torch.Tensor], sbins_list: Sequence[t
     return loss
 
 
+class LossDict(dict):
+    """scaled loss terms; `.total` = their sum from ONE stacked multiply + reduction (13 scalar adds and 12 scalar
+    multiplies, and as many again in backward, become 3 launches each way)"""
+    total: Optional[torch.Tensor] = None
+
+
+_COEF_CACHE: Dict[tuple, torch.Tensor] = {}
+
+
+def total_loss(loss_dict: Dict[str, torch.Tensor]) -> torch.Tensor:
+    t = getattr(loss_dict, "total", None)
+    return t if t is not None else sum(loss_dict.values())
+
+
+def merge_loss_dicts(a: Dict[str, torch.Tensor], b: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    out = LossDict({**a, **b})
+    if not (set(a) & set(b)):
+        out.total = total_loss(a) + total_loss(b)
+    return out
+
+
 def scale_dict(d: Dict[str, torch.Tensor], coefficients: Dict[str, float]) -> Dict[str, torch.Tensor]:
     """nerfstudio misc.scale_dict: only keys present in `coefficients` are scaled (so the reference's
     'eikonal_loss' entry never meets its 'eikonal loss' coefficient - reproduced, see oracle)."""
-    return {k: (v * coefficients[k] if k in coefficients else v) for k, v in d.items()}
+    keys = list(d)
+    vals = [d[k] for k in keys]
+    if len(keys) < 2 or not all(isinstance(v, torch.Tensor) and v.numel() == 1 for v in vals):
+        return {k: (v * coefficients[k] if k in coefficients else v) for k, v in d.items()}
+    dev = vals[0].device
+    ck = (tuple(keys), tuple(float(coefficients.get(k, 1.0)) for k in keys), str(dev))
+    coef = _COEF_CACHE.get(ck)
+    if coef is None:
+        coef = _COEF_CACHE[ck] = torch.tensor(ck[1], dtype=vals[0].dtype).to(dev)
+    scaled = torch.stack([v.reshape(()) for v in vals]) * coef
+    out = LossDict({k: scaled[i] for i, k in enumerate(keys)})
+    out.total = scaled.sum()
+    return out

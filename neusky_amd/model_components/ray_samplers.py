@@ -111,8 +111,9 @@ class ProposalNetworkSampler(nn.Module):
         for lvl in range(n + 1):
             ns = self.num_proposal_samples_per_ray[lvl] if lvl < n else self.num_nerf_samples_per_ray
             jit = None if jitters is None else jitters[lvl]
+            o_c, d_c = origins.detach().contiguous(), directions.detach().contiguous()
             if lvl == 0:
-                sbins, ebins = uniform_bins(nears, fars, ns, jit)
+                sbins, ebins = hip.uniform_bins(nears, fars, ns, None if jit is None else jit.reshape(-1).contiguous())
             else:
                 if self._anneal_t is None:
                     self._anneal_t = torch.full((1,), float(self._anneal), device=weights.device)
@@ -121,10 +122,10 @@ class ProposalNetworkSampler(nn.Module):
                                              None if jit is None else jit.reshape(-1).contiguous(), ns + 1,
                                              self.histogram_padding, 1e-5, want_inds)
                 inds_list.append(inds)
-                ebins = (sbins * fars + (1 - sbins) * nears).contiguous()
             if lvl < n:
-                mid = (ebins[:, :-1] + ebins[:, 1:]) / 2
-                pos = origins[:, None, :] + directions[:, None, :] * mid[..., None]
+                # euclidean bins (levels > 0) and the bin mid-points along the ray in one launch
+                e_new, pos = hip.bins_to_samples(sbins, nears, fars, o_c, d_c, want_ebins=lvl > 0, want_positions=True)
+                ebins = e_new if lvl > 0 else ebins
                 owner = getattr(density_fns[lvl], "__self__", None)
                 if isinstance(owner, HashMLPDensityField):  # this package's proposal field: fused density -> weights
                     weights = owner.weights_fn(pos, ebins)
@@ -133,4 +134,6 @@ class ProposalNetworkSampler(nn.Module):
                     weights = weights_from_density(dens, (ebins[:, 1:] - ebins[:, :-1])[..., None])[..., 0]
                 weights_list.append(weights)
                 sbins_list.append(sbins)
+            else:
+                ebins, _ = hip.bins_to_samples(sbins, nears, fars)
         return sbins, ebins, weights_list, sbins_list, inds_list

@@ -28,7 +28,7 @@ from ..cameras.rays import Frustums, RayBundle, RaySamples
 from ..field_components.neusky_fieldheadnames import FieldHeadNames, NeuSkyFieldHeadNames
 from ..fields.sdf_albedo_field import SDFAlbedoFieldConfig
 from ..model_components.illumination import IcosahedronSamplerConfig, RENIFieldConfig
-from ..model_components.losses import RENISkyPixelLoss, interlevel_loss, monosdf_normal_loss, scale_dict
+from ..model_components.losses import RENISkyPixelLoss, interlevel_loss, monosdf_normal_loss, scale_dict, total_loss
 from ..model_components.ray_samplers import HashMLPDensityField, ProposalNetworkSampler
 from ..model_components.renderers import RGBLambertianRendererWithVisibility
 from ..utils.utils import linear_to_sRGB, to_device_async
@@ -186,17 +186,9 @@ class NeuSkyFactoModel(nn.Module):
     # ------------------------------------------------------------------ collider
     def collider(self, ray_bundle: RayBundle) -> RayBundle:
         """nerfstudio SphereCollider(center=0, radius=1, near_plane=0.05) (neusky_model.py:213)"""
-        o, d = ray_bundle.origins, ray_bundle.directions
-        a = (d * d).sum(-1)
-        b = 2 * (o * d).sum(-1)
-        c = (o * o).sum(-1) - 1.0
-        disc = b * b - 4 * a * c
-        ok = disc > 0
-        sq = torch.sqrt(torch.where(ok, disc, torch.zeros_like(disc)))
-        t0, t1 = (-b - sq) / (2 * a), (-b + sq) / (2 * a)
-        nears = torch.clamp(torch.where(ok, t0, torch.zeros_like(t0)), min=self.config.near_plane)
-        fars = torch.maximum(torch.where(ok, t1, torch.zeros_like(t1)), nears + 1e-6)
-        ray_bundle.nears, ray_bundle.fars = nears[:, None], fars[:, None]
+        nears, fars = hip.sphere_collider(ray_bundle.origins.detach().contiguous(), ray_bundle.directions.detach().contiguous(),
+                                          1.0, float(self.config.near_plane))
+        ray_bundle.nears, ray_bundle.fars = nears, fars
         return ray_bundle
 
     def forward(self, ray_bundle: RayBundle, batch: Optional[Dict] = None, rotation: Optional[torch.Tensor] = None,
@@ -548,7 +540,7 @@ class NeuSkyFactoModel(nn.Module):
                     p.grad = None
                 self.begin_step()
                 outputs = self.forward(ray_bundle=ray_bundle, step=global_step)
-                loss = sum(self.get_loss_dict(outputs, batch).values())
+                loss = total_loss(self.get_loss_dict(outputs, batch))
                 loss.backward()
                 for p, (m_, v_) in zip(params, state):
                     if p.grad is not None:

@@ -91,8 +91,12 @@ def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None, acc
     if acc is not None:
         dW, db = acc
     else:
-        dW = torch.zeros_like(like)
-        db = torch.zeros_like(bias_like) if bias_like is not None else None
+        if bias_like is not None:  # one zero-filled slab for both accumulators (16-byte aligned views)
+            nw = (like.numel() + 3) // 4 * 4
+            flat = torch.zeros(nw + bias_like.numel(), device=like.device, dtype=like.dtype)
+            dW, db = flat[:like.numel()].view_as(like), flat[nw:].view_as(bias_like)
+        else:
+            dW, db = torch.zeros_like(like), None
     splits = _splits(M, n_out, k_in)
     kw = dict(a_kcontig=False, b_kcontig=False, k_splits=splits, precision=BWD_PRECISION)
     if acc is not None and splits <= 1:

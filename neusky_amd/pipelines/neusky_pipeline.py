@@ -19,6 +19,7 @@ from torch.nn import Parameter
 
 from ..data.synthetic_datamanager import SyntheticDataManagerConfig
 from ..model_components.ddf_sampler import VMFDDFSamplerConfig
+from ..model_components.losses import merge_loss_dicts
 from ..models.ddf_model import DDFModelConfig
 from ..models.neusky_model import NeuSkyFactoModelConfig
 
@@ -150,7 +151,7 @@ class NeuSkyPipeline(nn.Module):
             vis_metrics = model.visibility_field.get_metrics_dict(vis_outputs, vis_batch)
             vis_loss = model.visibility_field.get_loss_dict(vis_outputs, vis_batch, vis_metrics)
             model_outputs = {**model_outputs, **vis_outputs}
-            loss_dict = {**loss_dict, **vis_loss}
+            loss_dict = merge_loss_dicts(loss_dict, vis_loss)
             metrics_dict = {**metrics_dict, **vis_metrics}
         return model_outputs, loss_dict, metrics_dict
 

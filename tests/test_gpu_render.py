@@ -196,3 +196,38 @@ def test_density_weights_matches_torch_formulation():
         assert (r32.grad[:, 1:] == 0).all()
         gref = r64.grad[:, 0]
         assert (r32.grad[:, 0].double() - gref).abs().max().item() < 1e-5 * max(gref.abs().max().item(), 1.0)
+
+
+def test_ray_setup_kernels_match_oracle():
+    """nsky_sphere_collider / nsky_uniform_bins / nsky_bins_to_samples against the oracle's SphereCollider and
+    UniformSampler restatements: rays from inside and outside the unit sphere, rays that miss it, non-unit directions;
+    jittered and plain lattices; mid-point positions."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import neusky_oracle as O
+    from neusky_amd import hip
+    dev = "cuda:0"
+    torch.manual_seed(21)
+    R = 777
+    o = torch.randn(R, 3) * 0.8
+    d = torch.randn(R, 3)
+    d[: R // 2] = d[: R // 2] / d[: R // 2].norm(dim=1, keepdim=True)
+    o[:40] = o[:40] * 6.0  # far outside: most of these miss the sphere
+    nears, fars = hip.sphere_collider(o.to(dev), d.to(dev), 1.0, 0.05)
+    rn, rf = O.sphere_collider(o.double(), d.double(), 1.0, 0.05)
+    assert nears.shape == (R, 1) and fars.shape == (R, 1)
+    assert (nears.cpu().double() - rn).abs().max().item() < 2e-5 and (fars.cpu().double() - rf).abs().max().item() < 2e-5
+    assert bool((fars > nears).all())
+    for n, jit in ((256, True), (96, False), (7, True)):
+        j = torch.rand(R, 1) if jit else None
+        sb, eb = hip.uniform_bins(nears, fars, n, None if j is None else j.reshape(-1).to(dev))
+        rsb, reb = O.uniform_bins(nears.cpu().double(), fars.cpu().double(), n, None if j is None else j.double())
+        assert sb.shape == (R, n + 1)
+        assert (sb.cpu().double() - rsb).abs().max().item() < 3e-7
+        assert (eb.cpu().double() - reb).abs().max().item() < 1e-5
+        assert float(sb[:, 0].min()) >= 0.0 and float(sb[:, -1].max()) <= 1.0 and bool((sb[:, 1:] >= sb[:, :-1]).all())
+        eb2, pos = hip.bins_to_samples(sb, nears, fars, o.to(dev), d.to(dev), want_ebins=True, want_positions=True)
+        assert torch.equal(eb2, eb)
+        mid = (reb[:, :-1] + reb[:, 1:]) / 2
+        ref_pos = o.double()[:, None, :] + d.double()[:, None, :] * mid[..., None]
+        assert (pos.cpu().double() - ref_pos).abs().max().item() < 1e-5 * max(1.0, ref_pos.abs().max().item())
