@@ -188,6 +188,17 @@ int nsky_visibility_finish_bwd(const float* t_hat, const float* surf_dist, const
                                float* d_t_hat, float* d_threshold, nsky_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Interlevel (proposal) loss, nerfstudio interlevel_loss as neusky/models/neusky_model.py:987-988 calls it.
+ *   c [R,S+1] final spacing bins, w [R,S] final weights (both constants), sb [R,n+1] / wp [R,n] one proposal level.
+ *   per_ray[r] = sum_s max(w_s - w_outer_s, 0)^2 / (w_s + 1e-7)   (the loss term is mean over R*S = sum(per_ray)/(R S))
+ * Backward: d_per_ray [R] -> d_wp [R,n] (every element written).  n <= 4096.
+ */
+int nsky_interlevel_fwd(const float* c, const float* w, const float* sb, const float* wp, int32_t R, int32_t S, int32_t n,
+                        float* per_ray, nsky_stream_t stream);
+int nsky_interlevel_bwd(const float* c, const float* w, const float* sb, const float* wp, const float* d_per_ray, int32_t R,
+                        int32_t S, int32_t n, float* d_wp, nsky_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Ray set-up of the proposal sampler (nerfstudio SphereCollider + UniformSampler + the spacing->euclidean map and
  * bin mid-points that ProposalNetworkSampler applies between levels; driven from neusky/models/neusky_model.py:213,561).
  * No gradient flows through any of these.

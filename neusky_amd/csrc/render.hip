@@ -550,6 +550,83 @@ __global__ __launch_bounds__(256) void density_weights_bwd_kernel(const float* _
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Interlevel (proposal) loss of mip-NeRF 360 as nerfstudio states it: for every final-level interval [c_s, c_{s+1}] with
+// weight w_s, the proposal histogram's outer measure  w_outer = sum_{j = lo..hi} wp_j,
+//   lo = clamp(searchsorted_right(starts, c_s) - 1, 0, n-1),  hi = clamp(searchsorted_right(ends, c_{s+1}), 0, n-1),
+// and the per-ray sum of max(w_s - w_outer, 0)^2 / (w_s + 1e-7).  One wave per ray; the proposal bins and the prefix
+// sums of wp live in LDS.  Backward: d wp_j = sum over the s whose [lo, hi] contains j of  -2 g max(.)/(w_s + 1e-7),
+// scattered as a difference array and prefix-summed.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int upper_bound_f(const float* a, int n, float v) {  // first index with a[idx] > v
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] <= v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void interlevel_kernel(const float* __restrict__ c, const float* __restrict__ w,
+                                                         const float* __restrict__ sb, const float* __restrict__ wp,
+                                                         const float* __restrict__ g_ray, int R, int S, int n,
+                                                         float* __restrict__ per_ray, float* __restrict__ d_wp) {
+  extern __shared__ float sm[];  // per wave: bins[n+1], cy[n+1] (exclusive prefix sums), diff[n+1]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  float* bins = sm + wave * 3 * (n + 1);
+  float* cy = bins + (n + 1);
+  float* diff = cy + (n + 1);
+  for (int i = lane; i <= n; i += 64) {
+    bins[i] = sb[(long)r * (n + 1) + i];
+    if (BWD) diff[i] = 0.0f;
+  }
+  if (lane == 0) {  // sequential prefix sums (n <= 256), the order torch.cumsum uses on one row
+    float acc = 0.0f;
+    cy[0] = 0.0f;
+    for (int i = 0; i < n; ++i) {
+      acc += wp[(long)r * n + i];
+      cy[i + 1] = acc;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  const float g = BWD ? g_ray[r] : 0.0f;
+  float sum = 0.0f;
+  for (int s_ = lane; s_ < S; s_ += 64) {
+    const float c0 = c[(long)r * (S + 1) + s_], c1 = c[(long)r * (S + 1) + s_ + 1];
+    const int lo = min(max(upper_bound_f(bins, n, c0) - 1, 0), n - 1);      // starts = bins[0..n)
+    const int hi = min(max(upper_bound_f(bins + 1, n, c1), 0), n - 1);      // ends   = bins[1..n]
+    const float w_outer = cy[hi + 1] - cy[lo];
+    const float ws = w[(long)r * S + s_];
+    const float dlt = fmaxf(ws - w_outer, 0.0f);
+    if (!BWD) {
+      sum += dlt * dlt / (ws + 1e-7f);
+    } else if (dlt > 0.0f && hi >= lo) {
+      const float gj = -2.0f * g * dlt / (ws + 1e-7f);
+      atomicAdd(diff + lo, gj);
+      atomicAdd(diff + hi + 1, -gj);
+    }
+  }
+  if (!BWD) {
+    sum = wave_sum(sum);
+    if (lane == 0) per_ray[r] = sum;
+    return;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  if (lane == 0) {
+    float acc = 0.0f;
+    for (int i = 0; i < n; ++i) {
+      acc += diff[i];
+      d_wp[(long)r * n + i] = acc;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int nsky_hemi_composite_fwd(const float* albedo, const float* normals, const float* weights, const float* dirs,
@@ -662,5 +739,27 @@ extern "C" int nsky_density_weights_bwd(const float* raw, int32_t ld_raw, const 
   hipLaunchKernelGGL(density_weights_bwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, (hipStream_t)stream, raw, ld_raw, ebins,
                      d_weights, R, n, d_raw);
   NSKY_CHECK_LAUNCH("nsky_density_weights_bwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_interlevel_fwd(const float* c, const float* w, const float* sb, const float* wp, int32_t R, int32_t S, int32_t n,
+                                   float* per_ray, nsky_stream_t stream) {
+  if (R == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(c && w && sb && wp && per_ray && R > 0 && S > 0 && n > 0 && n <= 4096, "nsky_interlevel_fwd: bad argument");
+  const size_t smem = 4 * 3 * (size_t)(n + 1) * sizeof(float);
+  hipLaunchKernelGGL((interlevel_kernel<false>), dim3(ceil_div(R, 4)), dim3(256), smem, (hipStream_t)stream, c, w, sb, wp, nullptr, R,
+                     S, n, per_ray, nullptr);
+  NSKY_CHECK_LAUNCH("nsky_interlevel_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_interlevel_bwd(const float* c, const float* w, const float* sb, const float* wp, const float* d_per_ray,
+                                   int32_t R, int32_t S, int32_t n, float* d_wp, nsky_stream_t stream) {
+  if (R == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(c && w && sb && wp && d_per_ray && d_wp && R > 0 && S > 0 && n > 0 && n <= 4096, "nsky_interlevel_bwd: bad argument");
+  const size_t smem = 4 * 3 * (size_t)(n + 1) * sizeof(float);
+  hipLaunchKernelGGL((interlevel_kernel<true>), dim3(ceil_div(R, 4)), dim3(256), smem, (hipStream_t)stream, c, w, sb, wp, d_per_ray, R,
+                     S, n, nullptr, d_wp);
+  NSKY_CHECK_LAUNCH("nsky_interlevel_bwd");
   return NSKY_OK;
 }

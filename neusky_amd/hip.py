@@ -260,6 +260,22 @@ def pdf_sample(weights, bins, u_base, jitter, num_bins, histogram_padding=0.01, 
     return new_bins, inds
 
 
+_il_fwd = _sig("nsky_interlevel_fwd", _P, _P, _P, _P, _I, _I, _I, _P, _P)
+_il_bwd = _sig("nsky_interlevel_bwd", _P, _P, _P, _P, _P, _I, _I, _I, _P, _P)
+
+
+def interlevel_fwd(c, w, sb, wp, per_ray):
+    R, S = w.shape
+    check(_il_fwd(_c(c), _c(w), _c(sb), _c(wp), R, S, wp.shape[1], _c(per_ray), stream_ptr()), "nsky_interlevel_fwd")
+    return per_ray
+
+
+def interlevel_bwd(c, w, sb, wp, d_per_ray, d_wp):
+    R, S = w.shape
+    check(_il_bwd(_c(c), _c(w), _c(sb), _c(wp), _c(d_per_ray), R, S, wp.shape[1], _c(d_wp), stream_ptr()), "nsky_interlevel_bwd")
+    return d_wp
+
+
 _collider = _sig("nsky_sphere_collider", _P, _P, _I, _F, _F, _P, _P, _P)
 _ubins = _sig("nsky_uniform_bins", _P, _P, _P, _I, _I, _P, _P, _P)
 _b2s = _sig("nsky_bins_to_samples", _P, _P, _P, _P, _P, _I, _I, _P, _P, _P)

@@ -39,6 +39,11 @@ def interlevel_loss(weights_list: Sequence[torch.Tensor], sbins_list: Sequence[t
     """nerfstudio interlevel_loss (called neusky_model.py:987-988); weights [R,n], spacing bins [R,n+1]."""
     c, w = sbins_list[-1].detach(), weights_list[-1].detach()
     loss = 0.0
+    if w.is_cuda:  # one launch per proposal level each way (ops.InterlevelFn) instead of ~45 small torch kernels
+        from .. import ops
+        for sb, wp in zip(sbins_list[:-1], weights_list[:-1]):
+            loss = loss + ops.InterlevelFn.apply(c, w, sb.detach(), wp).sum() / w.numel()
+        return loss
     for sb, wp in zip(sbins_list[:-1], weights_list[:-1]):
         w_outer = _outer(c[..., :-1], c[..., 1:], sb[..., :-1], sb[..., 1:], wp)
         loss = loss + torch.mean(torch.clip(w - w_outer, min=0) ** 2 / (w + 1e-7))

@@ -606,6 +606,25 @@ class VisibilityFinishFn(torch.autograd.Function):
         return d_t, None, d_thr, None, None, None, None, None, None
 
 
+class InterlevelFn(torch.autograd.Function):
+    """per-ray interlevel loss sums of one proposal level (see include/neusky_hip.h); gradient w.r.t. the proposal weights"""
+
+    @staticmethod
+    def forward(ctx, c, w, sb, wp):
+        c, w, sb, wp = c.contiguous(), w.contiguous(), sb.contiguous(), wp.contiguous()
+        per_ray = torch.empty(w.shape[0], device=w.device)
+        hip.interlevel_fwd(c, w, sb, wp, per_ray)
+        ctx.save_for_backward(c, w, sb, wp)
+        return per_ray
+
+    @staticmethod
+    def backward(ctx, g):
+        c, w, sb, wp = ctx.saved_tensors
+        d_wp = torch.empty_like(wp)
+        hip.interlevel_bwd(c, w, sb, wp, g.contiguous(), d_wp)
+        return None, None, None, d_wp
+
+
 class DensityWeightsFn(torch.autograd.Function):
     """proposal-network weights from the raw density head: raw [R*n, ld] (column 0), ebins [R,n+1] -> weights [R,n]
     (trunc_exp density + RaySamples.get_weights in one launch each way; see include/neusky_hip.h)"""

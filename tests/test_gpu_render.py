@@ -231,3 +231,36 @@ def test_ray_setup_kernels_match_oracle():
         mid = (reb[:, :-1] + reb[:, 1:]) / 2
         ref_pos = o.double()[:, None, :] + d.double()[:, None, :] * mid[..., None]
         assert (pos.cpu().double() - ref_pos).abs().max().item() < 1e-5 * max(1.0, ref_pos.abs().max().item())
+
+
+def test_interlevel_kernel_matches_torch_formulation():
+    """nsky_interlevel_fwd/bwd == nerfstudio interlevel_loss (the torch formulation kept in model_components/losses.py for
+    host tensors) for the two proposal levels (256 and 96 bins against 96 final samples), value and gradient."""
+    from neusky_amd import ops
+    from neusky_amd.model_components import losses as L
+    dev = "cuda:0"
+    torch.manual_seed(13)
+    R, S = 53, 96
+
+    def bins(n):
+        b = torch.sort(torch.rand(R, n + 1, device=dev), dim=1).values
+        b[:, 0], b[:, -1] = 0.0, 1.0
+        return b
+
+    c = bins(S)
+    w = torch.rand(R, S, device=dev) * 0.05
+    w[:, 10:14] += 0.3
+    for n in (256, 96, 5):
+        sb = bins(n)
+        wp = (torch.rand(R, n, device=dev) * 0.02)
+        wp64 = wp.double().requires_grad_(True)
+        w_outer = L._outer(c[..., :-1].double(), c[..., 1:].double(), sb[..., :-1].double(), sb[..., 1:].double(), wp64)
+        ref = torch.mean(torch.clip(w.double() - w_outer, min=0) ** 2 / (w.double() + 1e-7))
+        ref.backward()
+        assert float(ref) > 0
+        wp32 = wp.clone().requires_grad_(True)
+        got = ops.InterlevelFn.apply(c, w, sb, wp32).sum() / w.numel()
+        assert abs(float(got) - float(ref)) < 2e-5 * float(ref)
+        got.backward()
+        gref = wp64.grad
+        assert (wp32.grad.double() - gref).abs().max().item() < 2e-5 * gref.abs().max().item()
