@@ -454,6 +454,10 @@ __device__ __forceinline__ void split4h(const float x[4], uint2 out[2]) {
   unpack2h(h01, h[0], h[1]);
   unpack2h(h23, h[2], h[3]);
   out[0] = make_uint2(h01, h23);
+#ifdef NSKY_FAKE_SPLIT
+  out[1] = out[0];
+  return;
+#endif
   out[1] = make_uint2(pack2h((c[0] - h[0]) * F16_RES_SCALE, (c[1] - h[1]) * F16_RES_SCALE),
                       pack2h((c[2] - h[2]) * F16_RES_SCALE, (c[3] - h[3]) * F16_RES_SCALE));
 }
@@ -472,6 +476,57 @@ __device__ __forceinline__ void split4(const float x[4], uint2 out[NS]) {
     if (t + 1 < NS) {
       r[0] -= bf16_hi_as_f32(p01); r[1] -= bf16_lo_as_f32(p01);
       r[2] -= bf16_hi_as_f32(p23); r[3] -= bf16_lo_as_f32(p23);
+    }
+  }
+}
+
+// Epilogue shared by the split kernels: park the 2x2 32x32 accumulators of each wave in LDS (the operand images are dead),
+// one wave-row (64 tile rows) at a time, and sweep them row-major so C, the aux operands and the side outputs move as
+// whole rows.  H: fold the scaled cross-term accumulator in with 2^-11.
+template <bool H, int TMX, int TNX>
+__device__ __forceinline__ void tile_epilogue(float* Cs, f32x16 (&acc)[2][2], f32x16 (&accx)[TMX][TNX], int wm, int wn, int lane,
+                                              int tid, int m0, int n0, int M, int N, float* __restrict__ C, int ldc, int vec4,
+                                              bool atomic, const EpiCtx& e) {
+  constexpr int BN = 128, WM = 64, WN = 64;
+#ifdef NSKY_LAB_NOEPI  // timing experiment only: no output unless an accumulator is NaN
+  if (!(acc[0][0][0] != acc[0][0][0] || acc[1][1][5] != acc[1][1][5] || acc[0][1][3] != acc[0][1][3] || acc[1][0][9] != acc[1][0][9])) return;
+#endif
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass > 0) __syncthreads();
+    if (wm == pass) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int cl = wn * WN + j * 32 + (lane & 31);
+            Cs[rl * BN + cl] = H ? fmaf(accx[H ? i : 0][H ? j : 0][r], 1.0f / F16_RES_SCALE, acc[i][j][r]) : acc[i][j][r];
+          }
+    }
+    __syncthreads();
+    const int mrow0 = m0 + pass * WM;
+    if (vec4 && !atomic) {
+      constexpr int C4 = BN / 4;
+      for (int c = tid; c < WM * C4; c += 256) {
+        const int rl = c / C4, cl = (c % C4) * 4;
+        const int row = mrow0 + rl, col = n0 + cl;
+        if (row < M && col < N) epilogue_store4(e, C, ldc, row, col, *reinterpret_cast<const float4*>(Cs + rl * BN + cl));
+      }
+    } else {
+      for (int idx = tid; idx < WM * BN; idx += 256) {
+        const int rl = idx / BN, cl = idx % BN;
+        const int row = mrow0 + rl, col = n0 + cl;
+        if (row < M && col < N) {
+          const float v = Cs[idx];
+          if (atomic)
+            atomicAdd(C + (long)row * ldc + col, v);
+          else
+            epilogue_store(e, C, ldc, row, col, v);
+        }
+      }
     }
   }
 }
@@ -532,8 +587,14 @@ struct SplitLoader {  // 128 x 32 fp32 tile -> NS bf16 images [128][SROW]
   }
 };
 
-template <int NS, bool AK, bool BKC, bool DBUF, bool H = false>
-__global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : 2) void gemm_bf16s_kernel(
+#ifndef NSKY_LAB_PF2
+#define NSKY_LAB_PF2 false
+#endif
+template <int NS, bool AK, bool BKC, bool DBUF, bool H = false, bool PF2 = NSKY_LAB_PF2>
+#ifndef NSKY_LAB_OCC
+#define NSKY_LAB_OCC 2
+#endif
+__global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : NSKY_LAB_OCC) void gemm_bf16s_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K, int lda, int ldb,
     int ldc, int k_split_len, int vec4, float* __restrict__ a_rowsum, EpiCtx e) {
   constexpr int BM = 128, BN = 128, BKT = 32, WM = 64, WN = 64, TM = 2, TN = 2;
@@ -645,17 +706,57 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : 2) void gemm_bf16s_kerne
       }
       __syncthreads();
     }
+  } else if (PF2) {
+    // prefetch distance 2: a second register set holds tile t+1 while tile t+2 is requested, so a tile's HBM round trip is
+    // covered by two MFMA phases and one split/store phase instead of one MFMA phase (lab: the loads, not the MFMAs or the
+    // split, set the k-loop time at distance 1)
+    SplitLoader<NS, AK, H> la1;
+    SplitLoader<NS, BKC, H> lb1;
+    if (ntiles > 1) {
+      la1.load(A, lda, m0, M, kbeg + BKT, kend, tid);
+      lb1.load(B, ldb, n0, N, kbeg + BKT, kend, tid);
+    }
+    for (int t = 0; t < ntiles; t += 2) {
+      __syncthreads();
+      la.store(S0, tid, want_rs);
+      lb.store(S0 + NS * IMG, tid, false);
+      __syncthreads();
+      if (t + 2 < ntiles) {
+        la.load(A, lda, m0, M, kbeg + (t + 2) * BKT, kend, tid);
+        lb.load(B, ldb, n0, N, kbeg + (t + 2) * BKT, kend, tid);
+      }
+      compute(S0, S0 + NS * IMG);
+      if (t + 1 < ntiles) {
+        __syncthreads();
+        la1.store(S0, tid, want_rs);
+        lb1.store(S0 + NS * IMG, tid, false);
+        __syncthreads();
+        if (t + 3 < ntiles) {
+          la1.load(A, lda, m0, M, kbeg + (t + 3) * BKT, kend, tid);
+          lb1.load(B, ldb, n0, N, kbeg + (t + 3) * BKT, kend, tid);
+        }
+        compute(S0, S0 + NS * IMG);
+      }
+    }
+    if (want_rs) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) la.rs[i] += la1.rs[i];
+    }
   } else {
     for (int t = 0; t < ntiles; ++t) {
       __syncthreads();  // previous tile's fragment reads are done
       la.store(S0, tid, want_rs);
       lb.store(S0 + NS * IMG, tid, false);
       __syncthreads();
+#ifndef NSKY_LAB_NOLOAD
       if (t + 1 < ntiles) {
         la.load(A, lda, m0, M, kbeg + (t + 1) * BKT, kend, tid);
         lb.load(B, ldb, n0, N, kbeg + (t + 1) * BKT, kend, tid);
       }
+#endif
+#ifndef NSKY_LAB_NOMFMA
       compute(S0, S0 + NS * IMG);
+#endif
     }
   }
   if (want_rs) la.flush_rowsum(rsum, tid);
@@ -663,44 +764,215 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : 2) void gemm_bf16s_kerne
   if (want_rs && tid < 128 && m0 + tid < M) atomicAdd(a_rowsum + m0 + tid, rsum[tid]);
   __syncthreads();
 
-  float* Cs = reinterpret_cast<float*>(smem_raw);
-  const bool atomic = gridDim.z > 1;
+  tile_epilogue<H>(reinterpret_cast<float*>(smem_raw), acc, accx, wm, wn, lane, tid, m0, n0, M, N, C, ldc, vec4, gridDim.z > 1, e);
+}
+
+// =================================================================================================
+// LDS-DMA variant of the split kernels for a k-contiguous fp32 A (activations, gradients) against PRE-SPLIT weights.
+//
+// The lab (tools/gemm_lab) shows the register-staged kernel above spends its k-loop on three phases that add up instead
+// of overlapping: the global loads (~1/3), the fp32 -> 16-bit split of both operands (~1/5) and the MFMAs (~1/2).  Here
+//   * B (a weight matrix, re-read by every one of the M/128 row tiles) is split ONCE per step into two 16-bit planes
+//     (nsky_split_planes) and streamed by global_load_lds_dwordx4 straight into its LDS image: no registers, no VALU;
+//   * A is streamed as raw fp32 by the same LDS-DMA into a 3-deep ring and split IN PLACE: a 16-byte chunk of 4 floats
+//     becomes 8 bytes of the hi plane + 8 bytes of the lo plane inside the same 32-byte pair of chunks, by the lane that
+//     issued its DMA (so the wave's own vmcnt wait orders it, no barrier), one tile ahead of the MFMAs;
+//   * one barrier per k-tile; tile t+2 of A and t+1 of B are in flight while tile t is multiplied.
+// Stage image (A and B alike): [128 rows][128 B] = 8 chunks of 16 B per row, chunk c stored at position c ^ ((row >> 1) & 7):
+// the DMA writes lane-linear (1 KB per wave instruction = 8 rows), the swizzle is applied to the SOURCE address, and the
+// ds_read_b128 operand fetch (32 rows x one chunk) is bank-conflict free.  A chunks after the split: 2q = hi(k 8q..8q+7),
+// 2q+1 = lo; B chunks: 0..3 = hi plane k 0..31, 4..7 = lo plane.
+// LDS: 3 x 16 KB (A ring) + 2 x 16 KB (B ring) = 80 KB -> two workgroups per CU.
+// Requires K % 32 == 0 (no partial k-tile), planes zero padded to whole 128-row tiles; M tails re-read row M-1.
+// =================================================================================================
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+  // LDS-DMA hidden from hipcc's waitcnt bookkeeping (it would drain vmcnt(0) before every ds_read otherwise); M0 is saved
+  // and restored inside the statement.  Completion is counted by hand: vmcnt_wait<N>().
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vmcnt_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <bool H>
+__global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const float* __restrict__ A, const uint16_t* __restrict__ Bhi,
+                                                             const uint16_t* __restrict__ Blo, float* __restrict__ C, int M, int N,
+                                                             int K, int lda, int ldp, int ldc, int vec4, EpiCtx e) {
+  constexpr int STAGE = 16384, A_STAGES = 3, B_OFF = A_STAGES * STAGE;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[B_OFF + 2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int m_tile, n_tile;
+  tile_of_block((N + 127) / 128, m_tile, n_tile);
+  const int m0 = m_tile * 128, n0 = n_tile * 128;
+  const int T = K / 32;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+
+  // DMA geometry of this lane: instruction j of this wave fills rows 32 wave + 8 j + lane / 8, chunk position lane % 8
+  const int prow = lane >> 3, ppos = lane & 7;
+  const float* a_src[4];
+  const uint16_t* b_src[4];
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass > 0) __syncthreads();
-    if (wm == pass) {
+  for (int j = 0; j < 4; ++j) {
+    const int r = 32 * wave + 8 * j + prow;
+    const int c = ppos ^ ((r >> 1) & 7);
+    a_src[j] = A + (long)min(m0 + r, M - 1) * lda + 4 * c;
+    b_src[j] = (c < 4 ? Bhi : Blo) + (long)(n0 + r) * ldp + 8 * (c & 3);
+  }
+  const uint32_t wave_off = wave * 4096;
+  auto issue_a = [&](int t) {
+    const uint32_t dst = lds0 + (t % A_STAGES) * STAGE + wave_off;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < 4; ++j) glds16(a_src[j] + t * 32, dst + j * 1024);
+  };
+  auto issue_b = [&](int t) {
+    const uint32_t dst = lds0 + B_OFF + (t & 1) * STAGE + wave_off;
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < 4; ++j) glds16(b_src[j] + t * 32, dst + j * 1024);
+  };
+  // in-place split of the 4 chunks this lane's DMAs delivered (tile t)
+  auto convert = [&](int t) {
+    unsigned char* st = smem + (t % A_STAGES) * STAGE + wave_off;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int cl = wn * WN + j * 32 + (lane & 31);
-            Cs[rl * BN + cl] = H ? fmaf(accx[H ? i : 0][H ? j : 0][r], 1.0f / F16_RES_SCALE, acc[i][j][r]) : acc[i][j][r];
+    for (int j = 0; j < 4; ++j) {
+      const int r = 32 * wave + 8 * j + prow;
+      const int sw = (r >> 1) & 7;
+      const int g = ppos ^ sw;  // raw chunk held at this position: floats k = 4g .. 4g+3
+      unsigned char* rowp = st + j * 1024 + prow * 128;
+      const float4 v = *reinterpret_cast<const float4*>(rowp + ppos * 16);
+      const float x[4] = {v.x, v.y, v.z, v.w};
+      uint2 o[2];
+      if (H) split4h(x, o); else split4<2>(x, o);
+      const int q2 = g & ~1, half = g & 1;
+      *reinterpret_cast<uint2*>(rowp + ((q2 ^ sw) * 16) + half * 8) = o[0];
+      *reinterpret_cast<uint2*>(rowp + (((q2 + 1) ^ sw) * 16) + half * 8) = o[1];
+    }
+  };
+
+  f32x16 acc[2][2];
+  f32x16 accx[H ? 2 : 1][H ? 2 : 1];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.0f;
+        if (H) accx[H ? i : 0][H ? j : 0][r] = 0.0f;
+      }
+
+  const int frow = lane & 31, fh = lane >> 5;
+  auto compute = [&](int t) {
+    const unsigned char* As = smem + (t % A_STAGES) * STAGE;
+    const unsigned char* Bs = smem + B_OFF + (t & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[2][2], bfr[2][2];
+      const int q = 2 * ks + fh;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = wm * 64 + i * 32 + frow, sw = (r >> 1) & 7;
+        af[0][i] = *reinterpret_cast<const bf16x8*>(As + r * 128 + (((2 * q) ^ sw) * 16));
+        af[1][i] = *reinterpret_cast<const bf16x8*>(As + r * 128 + (((2 * q + 1) ^ sw) * 16));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = wn * 64 + j * 32 + frow, sw = (r >> 1) & 7;
+        bfr[0][j] = *reinterpret_cast<const bf16x8*>(Bs + r * 128 + ((q ^ sw) * 16));
+        bfr[1][j] = *reinterpret_cast<const bf16x8*>(Bs + r * 128 + (((4 + q) ^ sw) * 16));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (H) {
+            const int ii = H ? i : 0, jj = H ? j : 0;
+            accx[ii][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0][i]), __builtin_bit_cast(f16x8, bfr[1][j]), accx[ii][jj], 0, 0, 0);
+            accx[ii][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[1][i]), __builtin_bit_cast(f16x8, bfr[0][j]), accx[ii][jj], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0][i]), __builtin_bit_cast(f16x8, bfr[0][j]), acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
           }
+        }
+    }
+  };
+
+  // prologue: queue = B0, A0, A1
+  issue_b(0);
+  issue_a(0);
+  if (T > 1) { issue_a(1); vmcnt_wait<4>(); } else { vmcnt_wait<0>(); }
+  convert(0);
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const bool n1 = t + 1 < T, n2 = t + 2 < T;
+#ifndef NSKY_LABP_NOGLDS
+    if (n1) issue_b(t + 1);  // B stage (t+1)&1 and A stage (t+2)%3 were last read by the MFMAs of tile t-1 (barrier passed)
+    if (n2) issue_a(t + 2);
+#endif
+#ifndef NSKY_LABP_NOMFMA
+    compute(t);
+#endif
+    if (n1) {  // queue (oldest first): A(t+1), B(t+1), A(t+2)
+      if (n2) vmcnt_wait<8>(); else vmcnt_wait<4>();
+#ifndef NSKY_LABP_NOCONV
+      convert(t + 1);
+#endif
+      if (n2) vmcnt_wait<4>(); else vmcnt_wait<0>();
     }
     __syncthreads();
-    const int mrow0 = m0 + pass * WM;
-    if (vec4 && !atomic) {
-      constexpr int C4 = BN / 4;
-      for (int c = tid; c < WM * C4; c += 256) {
-        const int rl = c / C4, cl = (c % C4) * 4;
-        const int row = mrow0 + rl, col = n0 + cl;
-        if (row < M && col < N) epilogue_store4(e, C, ldc, row, col, *reinterpret_cast<const float4*>(Cs + rl * BN + cl));
+  }
+  tile_epilogue<H>(reinterpret_cast<float*>(smem), acc, accx, wm, wn, lane, tid, m0, n0, M, N, C, ldc, vec4, false, e);
+}
+
+// fp32 matrix -> two 16-bit planes [rows_pad][ldp] (zero padded): out(n, k) = W[n][k] (transpose = 0) or W[k][n] (1)
+template <bool H>
+__global__ void split_planes_kernel(const float* __restrict__ W, int n_rows, int n_k, int ldw, int transpose,
+                                    uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int rows_pad, int ldp) {
+  __shared__ float tile[32][33];
+  const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int a = ty + 8 * i;
+    float v = 0.0f;
+    if (transpose) {  // tile[k][n] read along n
+      const int k = k0 + a, n = n0 + tx;
+      if (k < n_k && n < n_rows) v = W[(long)k * ldw + n];
+      tile[a][tx] = v;
+    } else {  // tile[n][k] read along k
+      const int n = n0 + a, k = k0 + tx;
+      if (n < n_rows && k < n_k) v = W[(long)n * ldw + k];
+      tile[a][tx] = v;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int nn = ty + 8 * i, kk = tx;
+    const float v = transpose ? tile[kk][nn] : tile[nn][kk];
+    const int n = n0 + nn, k = k0 + kk;
+    if (n < rows_pad && k < ldp) {
+      uint16_t h, l;
+      if (H) {
+        const float c = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+        const _Float16 hh = (_Float16)c;
+        const _Float16 ll = (_Float16)((c - (float)hh) * F16_RES_SCALE);
+        h = __builtin_bit_cast(uint16_t, hh);
+        l = __builtin_bit_cast(uint16_t, ll);
+      } else {
+        const __bf16 hh = (__bf16)v;
+        const __bf16 ll = (__bf16)(v - (float)hh);
+        h = __builtin_bit_cast(uint16_t, hh);
+        l = __builtin_bit_cast(uint16_t, ll);
       }
-    } else {
-      for (int idx = tid; idx < WM * BN; idx += 256) {
-        const int rl = idx / BN, cl = idx % BN;
-        const int row = mrow0 + rl, col = n0 + cl;
-        if (row < M && col < N) {
-          const float v = Cs[idx];
-          if (atomic)
-            atomicAdd(C + (long)row * ldc + col, v);
-          else
-            epilogue_store(e, C, ldc, row, col, v);
-        }
-      }
+      hi[(long)n * ldp + k] = h;
+      lo[(long)n * ldp + k] = l;
     }
   }
 }
@@ -812,6 +1084,53 @@ extern "C" int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream) {
   else
     launch<128, 128, 2, 2, 32, 2>(d, e, splits, k_split_len, vec4, s);
   NSKY_CHECK_LAUNCH("nsky_gemm_f32");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_split_planes(const float* W, int32_t n_rows, int32_t n_k, int32_t ldw, int32_t transpose, int32_t precision,
+                                 uint16_t* hi, uint16_t* lo, int32_t rows_pad, int32_t ldp, nsky_stream_t stream) {
+  NSKY_CHECK_ARG(W && hi && lo && n_rows > 0 && n_k > 0, "nsky_split_planes: bad arguments");
+  NSKY_CHECK_ARG(rows_pad >= n_rows && rows_pad % 128 == 0 && ldp >= n_k && ldp % 32 == 0, "nsky_split_planes: planes must be padded to 128 rows x 32 k (rows_pad=%d ldp=%d)", rows_pad, ldp);
+  NSKY_CHECK_ARG(ldw >= (transpose ? n_rows : n_k), "nsky_split_planes: ldw too small");
+  NSKY_CHECK_ARG(precision == NSKY_PREC_F16X2 || precision == NSKY_PREC_BF16X2, "nsky_split_planes: precision must be F16X2 or BF16X2");
+  dim3 grid(ldp / 32, rows_pad / 32);
+  if (precision == NSKY_PREC_F16X2)
+    hipLaunchKernelGGL((split_planes_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, W, n_rows, n_k, ldw, transpose, hi, lo, rows_pad, ldp);
+  else
+    hipLaunchKernelGGL((split_planes_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, W, n_rows, n_k, ldw, transpose, hi, lo, rows_pad, ldp);
+  NSKY_CHECK_LAUNCH("nsky_split_planes");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_gemm_f32_planes(const nsky_gemm_desc* d, const uint16_t* B_hi, const uint16_t* B_lo, int32_t ldp, nsky_stream_t stream) {
+  NSKY_CHECK_ARG(d && d->A && d->C && B_hi && B_lo, "nsky_gemm_f32_planes: null operand");
+  NSKY_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0 && d->K % 32 == 0, "nsky_gemm_f32_planes: K=%d must be a positive multiple of 32", d->K);
+  NSKY_CHECK_ARG(d->a_kcontig && d->lda >= d->K && d->lda % 4 == 0 && ((uintptr_t)d->A % 16) == 0, "nsky_gemm_f32_planes: A must be k-contiguous, 16-byte aligned, lda %% 4 == 0");
+  NSKY_CHECK_ARG(ldp >= d->K && ldp % 8 == 0 && ((uintptr_t)B_hi % 16) == 0 && ((uintptr_t)B_lo % 16) == 0, "nsky_gemm_f32_planes: planes must be 16-byte aligned with ldp %% 8 == 0");
+  NSKY_CHECK_ARG(d->ldc >= d->N, "nsky_gemm_f32_planes: ldc < N");
+  NSKY_CHECK_ARG(d->k_splits <= 1 && d->a_rowsum == nullptr, "nsky_gemm_f32_planes: no split-K / row sums");
+  NSKY_CHECK_ARG(d->precision == NSKY_PREC_F16X2 || d->precision == NSKY_PREC_BF16X2, "nsky_gemm_f32_planes: precision must be F16X2 or BF16X2");
+  switch (d->epi) {
+    case NSKY_EPI_FILM: NSKY_CHECK_ARG(d->aux0 && d->aux1, "nsky_gemm_f32_planes: FILM needs aux0 (freq) and aux1 (phase)"); break;
+    case NSKY_EPI_MUL_AUX: case NSKY_EPI_BWD_RELU: case NSKY_EPI_BWD_LEAKY: NSKY_CHECK_ARG(d->aux0, "nsky_gemm_f32_planes: epilogue needs aux0"); break;
+    case NSKY_EPI_BWD_FILM: NSKY_CHECK_ARG(d->aux0 && d->aux1 && d->aux2 && d->out1 && d->out2, "nsky_gemm_f32_planes: BWD_FILM needs aux0..2, out1, out2"); break;
+    default: break;
+  }
+  EpiCtx e;
+  e.bias = d->bias; e.epi = d->epi; e.p0 = d->p0; e.p1 = d->p1;
+  e.aux0 = d->aux0; e.ldaux0 = d->ldaux0; e.aux1 = d->aux1; e.ldaux1 = d->ldaux1; e.aux2 = d->aux2; e.ldaux2 = d->ldaux2;
+  e.out1 = d->out1; e.ldout1 = d->ldout1; e.out2 = d->out2; e.ldout2 = d->ldout2;
+  e.row_mod = d->row_mod > 0 ? d->row_mod : d->M;
+  e.beta = d->beta;
+  auto ok = [](const void* p, int ld) { return p == nullptr || ((((uintptr_t)p) % 16 == 0) && (ld % 4 == 0)); };
+  const int vec4 = (d->N % 4 == 0) && ok(d->C, d->ldc) && ok(d->bias, 4) && ok(d->aux0, d->ldaux0) && ok(d->aux1, d->ldaux1) &&
+                   ok(d->aux2, d->ldaux2) && ok(d->out1, d->ldout1) && ok(d->out2, d->ldout2);
+  dim3 grid(ceil_div(d->M, 128) * ceil_div(d->N, 128));
+  if (d->precision == NSKY_PREC_F16X2)
+    hipLaunchKernelGGL((gemm_planes_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, d->A, B_hi, B_lo, d->C, d->M, d->N, d->K, d->lda, ldp, d->ldc, vec4, e);
+  else
+    hipLaunchKernelGGL((gemm_planes_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, d->A, B_hi, B_lo, d->C, d->M, d->N, d->K, d->lda, ldp, d->ldc, vec4, e);
+  NSKY_CHECK_LAUNCH("nsky_gemm_f32_planes");
   return NSKY_OK;
 }
 

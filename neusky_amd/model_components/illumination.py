@@ -44,6 +44,37 @@ def antipodal_sphere(n: int) -> torch.Tensor:
     return torch.cat([up, -up], 0).float()
 
 
+def icosphere_vertices(nu: int) -> torch.Tensor:
+    """Vertices of the class-I geodesic icosahedron of subdivision frequency nu (10 nu^2 + 2 unit vectors, z up): what
+    `icosphere.icosphere(nu)` returns to IcosahedronSampler (neusky/model_components/illumination_samplers.py:97; the
+    `icosphere` package itself is absent here -> restated from its published construction, ordering parity unpinned):
+    the 12 icosahedron vertices (0, +-1, +-phi) and cyclic shifts, every edge and face subdivided linearly into nu parts,
+    all points pushed onto the unit sphere.  Order: base vertices, edge points, face-interior points.  The set is
+    centrally symmetric, so under any rotation half of the off-equator vertices have z > 0."""
+    assert nu >= 1
+    phi = (1.0 + 5.0**0.5) / 2.0
+    half = np.array([[0, 1, phi], [0, -1, phi], [1, phi, 0], [-1, phi, 0], [phi, 0, 1], [-phi, 0, 1]], dtype=np.float64)
+    base = np.concatenate([half, -half], 0) / np.sqrt(1.0 + phi * phi)
+    d2 = ((base[:, None] - base[None]) ** 2).sum(-1)
+    edge2 = d2[d2 > 1e-9].min()
+    adj = np.abs(d2 - edge2) < 1e-9
+    edges = [(i, j) for i in range(12) for j in range(i + 1, 12) if adj[i, j]]
+    faces = [(i, j, k) for i in range(12) for j in range(i + 1, 12) for k in range(j + 1, 12) if adj[i, j] and adj[j, k] and adj[i, k]]
+    assert len(edges) == 30 and len(faces) == 20
+    pts = [base]
+    if nu > 1:
+        w = np.arange(1, nu, dtype=np.float64)[:, None] / nu
+        pts += [(1.0 - w) * base[i] + w * base[j] for i, j in edges]
+        for i, j, k in faces:
+            for a in range(1, nu - 1):
+                for b in range(1, nu - a):
+                    pts.append(((nu - a - b) * base[i] + a * base[j] + b * base[k])[None] / nu)
+    v = np.concatenate(pts, 0)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    assert v.shape[0] == 10 * nu * nu + 2
+    return torch.from_numpy(v).float()
+
+
 _SKEW_BASIS: dict = {}
 
 
@@ -79,6 +110,10 @@ class IcosahedronSamplerConfig:
     num_directions: int = 512
     apply_random_rotation: bool = True
     remove_lower_hemisphere: bool = False
+    icosphere_order: Optional[int] = None
+    """in-tree IcosahedronSamplerConfig member (illumination_samplers.py:77): when set, the direction set is the icosphere
+    of that order (10 nu^2 + 2 vertices) and `num_directions` is ignored; None -> `num_directions` antipodal lattice points
+    (reni's mapping from num_directions=512 to an order is not in the reference tree)"""
 
     def setup(self, **kwargs):
         return self._target(self, **kwargs)
@@ -89,11 +124,27 @@ class IcosahedronSampler:
 
     def __init__(self, config: IcosahedronSamplerConfig):
         self.config = config
-        d = antipodal_sphere(config.num_directions)
-        if config.remove_lower_hemisphere:
-            d = d[d[:, 2] > 0]
+        self.icosphere_order = config.icosphere_order
+        self._dev_cache = {}
+        self._build()
+
+    def _build(self) -> None:
+        cfg = self.config
+        d = icosphere_vertices(self.icosphere_order) if self.icosphere_order is not None else antipodal_sphere(cfg.num_directions)
+        if cfg.remove_lower_hemisphere and not cfg.apply_random_rotation:
+            d = d[d[:, 2] > 0]  # :117-118 (after the rotation there; a fixed set is filtered once)
         self.directions = d
         self._dev_cache = {}
+
+    def set_icosphere_order(self, icosphere_order: int) -> None:
+        """illumination_samplers.py:100-103"""
+        self.icosphere_order = icosphere_order
+        self._build()
+
+    @staticmethod
+    def icosphere_order_from_num_directions(num_directions: int) -> int:
+        """illumination_samplers.py:105-107 (verbatim arithmetic: (n - 2) / 10 without the square root)"""
+        return int((num_directions - 2) / 10)
 
     def on_device(self, device, apply_random_rotation: Optional[bool] = None, rotation: Optional[torch.Tensor] = None):
         """directions [D,3] on `device` (+ the indices of the D/2 with the largest z, ascending: for the antipodal set
@@ -108,6 +159,10 @@ class IcosahedronSampler:
         elif rot:
             rotation = random_rotation_device(device)
         dirs = base if rotation is None else base @ rotation.T
+        if self.config.remove_lower_hemisphere:
+            if rotation is not None:
+                raise NotImplementedError("remove_lower_hemisphere after a random rotation has a data-dependent size; use __call__")
+            return dirs.contiguous(), torch.arange(dirs.shape[0], device=dirs.device, dtype=torch.int32)
         half = dirs.shape[0] // 2
         sel = torch.sort(torch.topk(dirs[:, 2], half).indices).values.to(torch.int32)
         return dirs.contiguous(), sel
@@ -117,7 +172,10 @@ class IcosahedronSampler:
         rot = self.config.apply_random_rotation if apply_random_rotation is None else apply_random_rotation
         if rotation is None and rot:
             rotation = random_rotation(generator)
-        return self.directions if rotation is None else self.directions @ rotation.T.to(self.directions)
+        d = self.directions if rotation is None else self.directions @ rotation.T.to(self.directions)
+        if self.config.remove_lower_hemisphere and rotation is not None:
+            d = d[d[:, 2] > 0]  # illumination_samplers.py:117-118
+        return d
 
 
 @dataclass

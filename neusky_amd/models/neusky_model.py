@@ -14,6 +14,8 @@ step is reproducible against the CPU oracle.
 """
 from __future__ import annotations
 
+import os
+
 import math
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Tuple, Type, Union
@@ -267,6 +269,12 @@ class NeuSkyFactoModel(nn.Module):
         bg = self.illumination_field(ray_directions, latents[camera_indices], scales[camera_indices], rot_r)  # :535-549
         return dirs, cols, inverse.to(torch.int32), bg
 
+    def _illumination_stream(self):
+        s = getattr(self, "_illum_stream", None)
+        if s is None:
+            s = self._illum_stream = torch.cuda.Stream()
+        return s
+
     def render_depth(self, weights: torch.Tensor, ray_samples: RaySamples) -> torch.Tensor:
         """nerfstudio DepthRenderer('expected') (neusky_model.py:591): weights [R,S,1] -> [R,1]"""
         steps = (ray_samples.frustums.starts + ray_samples.frustums.ends) / 2
@@ -339,13 +347,29 @@ class NeuSkyFactoModel(nn.Module):
 
     def sample_and_forward_field(self, ray_bundle: RayBundle, batch=None, rotation=None, step=None, randoms=None) -> Dict[str, Any]:
         """neusky_model.py:553-736"""
+        cam = ray_bundle.camera_indices.reshape(-1)
+        # The illumination decode (big dense layers, nothing but the camera indices as input) runs on a second HIP stream
+        # beside the proposal sampler + field pass (hundreds of small launches): a fork/join that the HIP graph keeps as
+        # two parallel branches, forward and backward (autograd replays each node on its forward stream).
+        fork = self.training and cam.is_cuda and os.environ.get("NSKY_PARALLEL_ILLUMINATION", "1") != "0"
+        if fork:
+            main = torch.cuda.current_stream()
+            side = self._illumination_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dirs, cam_colours, cam_of_ray, hdr_bg = self.sample_illumination(cam, ray_bundle.directions, rotation, randoms)
         ray_samples, weights_list, sbins_list, sbins, inds_list = self._sample(ray_bundle, randoms, want_inds=randoms is not None)
         field_outputs = self.field(ray_samples, return_alphas=True)
         weights = field_outputs["weights"]
         weights_list = weights_list + [weights[..., 0]]
         sbins_list = sbins_list + [sbins]
-        cam = ray_bundle.camera_indices.reshape(-1)
-        dirs, cam_colours, cam_of_ray, hdr_bg = self.sample_illumination(cam, ray_bundle.directions, rotation, randoms)
+        if fork:
+            main.wait_stream(side)
+            for t in (dirs, cam_colours, cam_of_ray, hdr_bg, getattr(self, "_upper_sel", None)):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)  # allocated on the side stream, consumed on this one from here on
+        else:
+            dirs, cam_colours, cam_of_ray, hdr_bg = self.sample_illumination(cam, ray_bundle.directions, rotation, randoms)
         out: Dict[str, Any] = {
             "ray_samples": ray_samples, "field_outputs": field_outputs, "weights": weights,
             "bg_transmittance": field_outputs["bg_transmittance"], "weights_list": weights_list, "sbins_list": sbins_list,
