@@ -45,35 +45,43 @@ def build_pipeline(device, world_size, local_rank, rays=RAYS, samples=SAMPLES, d
 
 
 class GemmTimer:
-    """HIP-event timing of every launch of ONE gemm kernel variant (the dominant one) on torch's current stream."""
+    """HIP-event timing of every launch of ONE gemm kernel (the dominant one) on torch's current stream: either a variant of
+    the register-staged kernel behind hip.gemm, or the LDS-DMA kernel behind hip.gemm_planes at one precision."""
 
-    def __init__(self, variant):
+    def __init__(self, variant, planes=False):
         self.variant = variant  # (a_kcontig, b_kcontig, wide, precision)
+        self.planes = planes
         self.records = []
+
+    def _timed_call(self, fn, flops, *a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*a, **kw)
+        e1.record()
+        self.records.append((e0, e1, flops))
+        return out
 
     def install(self):
         from neusky_amd import hip
-        self._orig = hip.gemm
+        self._orig, self._orig_planes = hip.gemm, hip.gemm_planes
         timer = self
 
         def timed(A, B, Cout, M, N, K, **kw):
             v = (bool(kw.get("a_kcontig", True)), bool(kw.get("b_kcontig", True)), N > 64, int(kw.get("precision", 0)))
-            if v != timer.variant:
+            if timer.planes or v != timer.variant:
                 return timer._orig(A, B, Cout, M, N, K, **kw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = timer._orig(A, B, Cout, M, N, K, **kw)
-            e1.record()
-            timer.records.append((e0, e1, 2.0 * M * N * K))
-            return out
+            return timer._timed_call(timer._orig, 2.0 * M * N * K, A, B, Cout, M, N, K, **kw)
 
-        hip.gemm = timed
-        import neusky_amd.ops as ops
-        ops.hip.gemm = timed
+        def timed_planes(A, planes, Cout, M, N, K, **kw):
+            if not timer.planes or int(kw.get("precision", 0)) != timer.variant[3]:
+                return timer._orig_planes(A, planes, Cout, M, N, K, **kw)
+            return timer._timed_call(timer._orig_planes, 2.0 * M * N * K, A, planes, Cout, M, N, K, **kw)
+
+        hip.gemm, hip.gemm_planes = timed, timed_planes
 
     def uninstall(self):
         from neusky_amd import hip
-        hip.gemm = self._orig
+        hip.gemm, hip.gemm_planes = self._orig, self._orig_planes
 
     def summary(self):
         ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
@@ -173,7 +181,9 @@ def main():
     import neusky_amd.ops as ops
     from neusky_amd import hip as _hip
     # dominant kernel of the step = the forward (NT layout) dense-layer kernel of the active precision policy
-    timer = GemmTimer((True, True, True, ops.FWD_PRECISION))
+    # (the LDS-DMA kernel when the policy routes the forward layers to it, i.e. the default fp16-split policy)
+    fwd_planes = ops.USE_PLANES_FWD and ops.FWD_PRECISION == _hip.PREC_F16X2
+    timer = GemmTimer((True, True, True, ops.FWD_PRECISION), planes=fwd_planes)
     use_graph = not args.no_graph
     skies = [pipe.datamanager.get_sky_ray_bundle(pipe.config.num_sky_rays) for _ in range(args.steps + args.warmup)]
     graph_note = ""
@@ -228,8 +238,10 @@ def main():
             peak, dtype = PEAK_F32_MFMA_TFLOPS, "f32"
             peak_note = "fp32 matrix peak 157.3 TFLOP/s (MI355X_MICROARCH.md)"
         elif ops.FWD_PRECISION == _hip.PREC_F16X2:
-            kernel = ("gemm_bf16s_kernel<2,true,true,false,true> (fp32 operands split on the fly into fp16 hi + 2^11-scaled fp16 residual, "
-                      "3 x v_mfma_f32_32x32x16_f16 per product into two fp32 accumulators)")
+            kernel = ("gemm_planes_kernel<true> (weights pre-split once per step into fp16 hi + 2^11-scaled fp16 residual planes, activations "
+                      "split in LDS after LDS-DMA; " if fwd_planes else
+                      "gemm_bf16s_kernel<2,true,true,false,true> (fp32 operands split on the fly into fp16 hi + 2^11-scaled fp16 residual, ")
+            kernel += "3 x v_mfma_f32_32x32x16_f16 per product into two fp32 accumulators)"
             peak, dtype = PEAK_BF16_MFMA_TFLOPS / 3.0, "f32 (fp16 hi + scaled-residual split on the matrix cores, ~2^-21 per product)"
             peak_note = "fp16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-equivalent product = 833.3 TFLOP/s of algorithmic FLOPs"
         else:

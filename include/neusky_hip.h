@@ -84,6 +84,19 @@ typedef struct nsky_gemm_desc {
 
 int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream);
 
+/* Same contraction against a PRE-SPLIT B operand (a weight matrix, re-read by every row tile of A): the two 16-bit
+ * planes of B -- fp16 hi + 2^11-scaled fp16 residual (NSKY_PREC_F16X2) or bf16 hi + bf16 residual (NSKY_PREC_BF16X2) --
+ * are produced once per optimisation step by nsky_split_planes and streamed into LDS by LDS-DMA, as is the raw fp32 A,
+ * which is split in place there (no register staging; same MFMA sequence and results as nsky_gemm_f32 with that precision).
+ *   nsky_split_planes: planes(n, k) = W[n][k] (transpose = 0: forward layers, W = torch Linear weight [out, in]) or
+ *                      W[k][n] (transpose = 1: input gradients dX = dZ W); hi / lo are [rows_pad][ldp] uint16, zero padded,
+ *                      rows_pad % 256 == 0, ldp % 32 == 0.
+ *   nsky_gemm_f32_planes: d->B, ldb, b_kcontig are ignored; A must be k-contiguous; K % 32 == 0; no split-K, no a_rowsum;
+ *                      d->precision selects the plane format (must match the split); epilogues as nsky_gemm_f32. */
+int nsky_split_planes(const float* W, int32_t n_rows, int32_t n_k, int32_t ldw, int32_t transpose, int32_t precision,
+                      uint16_t* hi, uint16_t* lo, int32_t rows_pad, int32_t ldp, nsky_stream_t stream);
+int nsky_gemm_f32_planes(const nsky_gemm_desc* d, const uint16_t* B_hi, const uint16_t* B_lo, int32_t ldp, nsky_stream_t stream);
+
 /* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients) */
 int nsky_colsum_f32(const float* X, int32_t M, int32_t N, int32_t ldx, float* out, nsky_stream_t stream);
 /* out[c] += sum_r w[r * w_stride] X[r][c]: the weight gradient of a ONE-output dense layer (the sdf head of the geo net,

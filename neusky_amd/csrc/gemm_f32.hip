@@ -483,11 +483,11 @@ __device__ __forceinline__ void split4(const float x[4], uint2 out[NS]) {
 // Epilogue shared by the split kernels: park the 2x2 32x32 accumulators of each wave in LDS (the operand images are dead),
 // one wave-row (64 tile rows) at a time, and sweep them row-major so C, the aux operands and the side outputs move as
 // whole rows.  H: fold the scaled cross-term accumulator in with 2^-11.
-template <bool H, int TMX, int TNX>
+template <bool H, int BN = 128, int TMX, int TNX>
 __device__ __forceinline__ void tile_epilogue(float* Cs, f32x16 (&acc)[2][2], f32x16 (&accx)[TMX][TNX], int wm, int wn, int lane,
                                               int tid, int m0, int n0, int M, int N, float* __restrict__ C, int ldc, int vec4,
                                               bool atomic, const EpiCtx& e) {
-  constexpr int BN = 128, WM = 64, WN = 64;
+  constexpr int WM = 64, WN = 64, NT = 2 * BN;  // BN / 64 wave columns x 2 wave rows x 64 lanes
 #ifdef NSKY_LAB_NOEPI  // timing experiment only: no output unless an accumulator is NaN
   if (!(acc[0][0][0] != acc[0][0][0] || acc[1][1][5] != acc[1][1][5] || acc[0][1][3] != acc[0][1][3] || acc[1][0][9] != acc[1][0][9])) return;
 #endif
@@ -510,13 +510,13 @@ __device__ __forceinline__ void tile_epilogue(float* Cs, f32x16 (&acc)[2][2], f3
     const int mrow0 = m0 + pass * WM;
     if (vec4 && !atomic) {
       constexpr int C4 = BN / 4;
-      for (int c = tid; c < WM * C4; c += 256) {
+      for (int c = tid; c < WM * C4; c += NT) {
         const int rl = c / C4, cl = (c % C4) * 4;
         const int row = mrow0 + rl, col = n0 + cl;
         if (row < M && col < N) epilogue_store4(e, C, ldc, row, col, *reinterpret_cast<const float4*>(Cs + rl * BN + cl));
       }
     } else {
-      for (int idx = tid; idx < WM * BN; idx += 256) {
+      for (int idx = tid; idx < WM * BN; idx += NT) {
         const int rl = idx / BN, cl = idx % BN;
         const int row = mrow0 + rl, col = n0 + cl;
         if (row < M && col < N) {
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : NSKY_LAB_OCC) void gemm_
 // the DMA writes lane-linear (1 KB per wave instruction = 8 rows), the swizzle is applied to the SOURCE address, and the
 // ds_read_b128 operand fetch (32 rows x one chunk) is bank-conflict free.  A chunks after the split: 2q = hi(k 8q..8q+7),
 // 2q+1 = lo; B chunks: 0..3 = hi plane k 0..31, 4..7 = lo plane.
-// LDS: 3 x 16 KB (A ring) + 2 x 16 KB (B ring) = 80 KB -> two workgroups per CU.
+// LDS: 3 x 16 KB (A ring) + 2 x BN x 128 B (B ring) = 80 KB (BN = 128, two workgroups per CU) or 112 KB (BN = 256, one).
 // Requires K % 32 == 0 (no partial k-tile), planes zero padded to whole 128-row tiles; M tails re-read row M-1.
 // =================================================================================================
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
@@ -797,54 +797,87 @@ __device__ __forceinline__ void vmcnt_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <bool H>
-__global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const float* __restrict__ A, const uint16_t* __restrict__ Bhi,
+template <bool H, int BN>
+__global__ __launch_bounds__(2 * BN, BN == 128 ? 2 : 1) void gemm_planes_kernel(const float* __restrict__ A, const uint16_t* __restrict__ Bhi,
                                                              const uint16_t* __restrict__ Blo, float* __restrict__ C, int M, int N,
                                                              int K, int lda, int ldp, int ldc, int vec4, EpiCtx e) {
-  constexpr int STAGE = 16384, A_STAGES = 3, B_OFF = A_STAGES * STAGE;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[B_OFF + 2 * STAGE];
+  // BN = 128: 4 waves (2 x 2), two workgroups per CU, every wave streams its share of A and of B (A ring of 3 stages).
+  // BN = 256: 8 waves (2 x 4), one workgroup per CU covering a whole 256-wide layer (A fetched and split once per row tile),
+  //   with the streaming SPLIT BY WAVE: waves 0-3 stream and split A, waves 4-7 stream B.  vmcnt is one in-order counter per
+  //   wave, so a wave that waits for its newest B tile also drains every older A tile; with the roles on different waves the
+  //   A ring runs 2 tiles and the B ring 2 tiles (64 KB) ahead of the MFMAs, each waited by its own counter.
+  constexpr bool SPEC = BN == 256;
+  constexpr int NW = BN / 32, WCOLS = BN / 64;
+  constexpr int STAGE = 16384, A_STAGES = SPEC ? 4 : 3, PD = A_STAGES - 1, B_STAGES = SPEC ? 3 : 2, B_OFF = A_STAGES * STAGE, B_STAGE = BN * 128;
+  constexpr int NA = SPEC ? 4 : 16 / NW, NB = SPEC ? 8 : 4;  // LDS-DMA instructions per streaming wave and tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[B_OFF + B_STAGES * B_STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WCOLS, wn = wave % WCOLS;
+  const bool a_wave = !SPEC || wave < 4, b_wave = !SPEC || wave >= 4;
+  const int aw = wave & 3, bw = SPEC ? (wave & 3) : wave;
   int m_tile, n_tile;
-  tile_of_block((N + 127) / 128, m_tile, n_tile);
-  const int m0 = m_tile * 128, n0 = n_tile * 128;
+  tile_of_block((N + BN - 1) / BN, m_tile, n_tile);
+  const int m0 = m_tile * 128, n0 = n_tile * BN;
   const int T = K / 32;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
-  // DMA geometry of this lane: instruction j of this wave fills rows 32 wave + 8 j + lane / 8, chunk position lane % 8
+  // DMA geometry of this lane: A instruction j of streaming wave aw fills rows 8 (NA aw + j) + lane / 8, B instruction j of
+  // streaming wave bw rows 8 (NB bw + j) + lane / 8, chunk position lane % 8
   const int prow = lane >> 3, ppos = lane & 7;
-  const float* a_src[4];
-  const uint16_t* b_src[4];
+  const float* a_src[NA];
+  const uint16_t* b_src[NB];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int r = 32 * wave + 8 * j + prow;
+  for (int j = 0; j < NA; ++j) {
+    const int r = 8 * (NA * aw + j) + prow;
     const int c = ppos ^ ((r >> 1) & 7);
     a_src[j] = A + (long)min(m0 + r, M - 1) * lda + 4 * c;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int r = 8 * (NB * bw + j) + prow;
+    const int c = ppos ^ ((r >> 1) & 7);
     b_src[j] = (c < 4 ? Bhi : Blo) + (long)(n0 + r) * ldp + 8 * (c & 3);
   }
-  const uint32_t wave_off = wave * 4096;
+  const uint32_t a_off = aw * (NA * 1024);
   auto issue_a = [&](int t) {
-    const uint32_t dst = lds0 + (t % A_STAGES) * STAGE + wave_off;
+    const uint32_t dst = lds0 + (t % A_STAGES) * STAGE + a_off;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(a_src[j] + t * 32, dst + j * 1024);
+    for (int j = 0; j < NA; ++j) glds16(a_src[j] + t * 32, dst + j * 1024);
   };
   auto issue_b = [&](int t) {
-    const uint32_t dst = lds0 + B_OFF + (t & 1) * STAGE + wave_off;
+    const uint32_t dst = lds0 + B_OFF + (t % B_STAGES) * B_STAGE + bw * (NB * 1024);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(b_src[j] + t * 32, dst + j * 1024);
+    for (int j = 0; j < NB; ++j) glds16(b_src[j] + t * 32, dst + j * 1024);
   };
-  // in-place split of the 4 chunks this lane's DMAs delivered (tile t)
-  auto convert = [&](int t) {
-    unsigned char* st = smem + (t % A_STAGES) * STAGE + wave_off;
+  // wait until at most `younger` A tiles issued after the wanted one are still in flight (SPEC A waves: only A in the queue)
+  auto wait_a_tiles = [&](int younger) {
+    switch (younger) {
+      case 0: vmcnt_wait<0>(); break;
+      case 1: vmcnt_wait<NA>(); break;
+      case 2: vmcnt_wait<2 * NA>(); break;
+      case 3: vmcnt_wait<3 * NA>(); break;
+      default: vmcnt_wait<4 * NA>(); break;
+    }
+  };
+  // in-place split of the chunks this lane's DMAs delivered (tile t): raw_load reads them (before the MFMAs of the current
+  // tile are issued), split_store converts and writes the two 8-byte halves (after them, so the VALU work can be scheduled
+  // into the MFMA shadow)
+  float4 raw[NA];
+  auto raw_load = [&](int t) {
+    const unsigned char* st = smem + (t % A_STAGES) * STAGE + a_off;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = 32 * wave + 8 * j + prow;
+    for (int j = 0; j < NA; ++j) raw[j] = *reinterpret_cast<const float4*>(st + j * 1024 + lane * 16);
+  };
+  auto split_store = [&](int t) {
+    unsigned char* st = smem + (t % A_STAGES) * STAGE + a_off;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int r = 8 * (NA * aw + j) + prow;
       const int sw = (r >> 1) & 7;
       const int g = ppos ^ sw;  // raw chunk held at this position: floats k = 4g .. 4g+3
       unsigned char* rowp = st + j * 1024 + prow * 128;
-      const float4 v = *reinterpret_cast<const float4*>(rowp + ppos * 16);
-      const float x[4] = {v.x, v.y, v.z, v.w};
+      const float x[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
       uint2 o[2];
       if (H) split4h(x, o); else split4<2>(x, o);
       const int q2 = g & ~1, half = g & 1;
@@ -868,20 +901,28 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const float* __rest
   const int frow = lane & 31, fh = lane >> 5;
   auto compute = [&](int t) {
     const unsigned char* As = smem + (t % A_STAGES) * STAGE;
-    const unsigned char* Bs = smem + B_OFF + (t & 1) * STAGE;
+    const unsigned char* Bs = smem + B_OFF + (t % B_STAGES) * B_STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[2][2], bfr[2][2];
       const int q = 2 * ks + fh;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
+#ifdef NSKY_LABP_BCAST  // timing experiment: every lane reads the same row (broadcast, no bank conflicts possible)
+        const int r = wm * 64 + i * 32, sw = (r >> 1) & 7;
+#else
         const int r = wm * 64 + i * 32 + frow, sw = (r >> 1) & 7;
+#endif
         af[0][i] = *reinterpret_cast<const bf16x8*>(As + r * 128 + (((2 * q) ^ sw) * 16));
         af[1][i] = *reinterpret_cast<const bf16x8*>(As + r * 128 + (((2 * q + 1) ^ sw) * 16));
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+#ifdef NSKY_LABP_BCAST
+        const int r = wn * 64 + j * 32, sw = (r >> 1) & 7;
+#else
         const int r = wn * 64 + j * 32 + frow, sw = (r >> 1) & 7;
+#endif
         bfr[0][j] = *reinterpret_cast<const bf16x8*>(Bs + r * 128 + ((q ^ sw) * 16));
         bfr[1][j] = *reinterpret_cast<const bf16x8*>(Bs + r * 128 + (((4 + q) ^ sw) * 16));
       }
@@ -903,31 +944,69 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const float* __rest
     }
   };
 
-  // prologue: queue = B0, A0, A1
-  issue_b(0);
-  issue_a(0);
-  if (T > 1) { issue_a(1); vmcnt_wait<4>(); } else { vmcnt_wait<0>(); }
-  convert(0);
-  __syncthreads();
-  for (int t = 0; t < T; ++t) {
-    const bool n1 = t + 1 < T, n2 = t + 2 < T;
-#ifndef NSKY_LABP_NOGLDS
-    if (n1) issue_b(t + 1);  // B stage (t+1)&1 and A stage (t+2)%3 were last read by the MFMAs of tile t-1 (barrier passed)
-    if (n2) issue_a(t + 2);
-#endif
-#ifndef NSKY_LABP_NOMFMA
-    compute(t);
-#endif
-    if (n1) {  // queue (oldest first): A(t+1), B(t+1), A(t+2)
-      if (n2) vmcnt_wait<8>(); else vmcnt_wait<4>();
-#ifndef NSKY_LABP_NOCONV
-      convert(t + 1);
-#endif
-      if (n2) vmcnt_wait<4>(); else vmcnt_wait<0>();
+  if (SPEC) {
+    if (a_wave) {  // queue of an A wave: A tiles only, oldest first
+      const int n0t = min(PD, T);
+      for (int i = 0; i < n0t; ++i) issue_a(i);
+      wait_a_tiles(n0t - 1);
+      raw_load(0);
+      split_store(0);
+    } else {  // queue of a B wave: B tiles only; two tiles ahead of the MFMAs
+      issue_b(0);
+      if (T > 1) { issue_b(1); vmcnt_wait<NB>(); } else { vmcnt_wait<0>(); }
     }
     __syncthreads();
+    for (int t = 0; t < T; ++t) {
+      const bool n1 = t + 1 < T;
+      if (a_wave) {
+        // A stage (t+PD) % A_STAGES = (t-1) % A_STAGES and B stage (t+1)&1 were last read by the MFMAs of tile t-1 (barrier passed)
+        if (t + PD < T) issue_a(t + PD);
+        if (n1) {
+          wait_a_tiles(min(T, t + PD + 1) - (t + 2));
+          raw_load(t + 1);
+        }
+      } else if (t + 2 < T) {
+        issue_b(t + 2);  // B stage (t+2) % 3 = (t-1) % 3: free since the barrier that closed tile t-1
+      }
+      compute(t);
+      if (n1) {
+        if (a_wave) split_store(t + 1);
+        else if (t + 2 < T) vmcnt_wait<NB>();
+        else vmcnt_wait<0>();
+      }
+      __syncthreads();
+    }
+  } else {
+    // prologue: queue = B0, A0, A1
+    issue_b(0);
+    issue_a(0);
+    if (T > 1) { issue_a(1); vmcnt_wait<NA>(); } else { vmcnt_wait<0>(); }
+    raw_load(0);
+    split_store(0);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+      const bool n1 = t + 1 < T, n2 = t + 2 < T;
+#ifndef NSKY_LABP_NOGLDS
+      if (n1) issue_b(t + 1);  // B stage (t+1)&1 and A stage (t+2)%3 were last read by the MFMAs of tile t-1 (barrier passed)
+      if (n2) issue_a(t + 2);
+#endif
+      if (n1) {  // queue (oldest first): A(t+1), B(t+1), A(t+2); A(t+1) has been in flight for a whole tile
+        if (n2) vmcnt_wait<NB + NA>(); else vmcnt_wait<NB>();
+        raw_load(t + 1);
+      }
+#ifndef NSKY_LABP_NOMFMA
+      compute(t);
+#endif
+      if (n1) {
+#ifndef NSKY_LABP_NOCONV
+        split_store(t + 1);
+#endif
+        if (n2) vmcnt_wait<NA>(); else vmcnt_wait<0>();
+      }
+      __syncthreads();
+    }
   }
-  tile_epilogue<H>(reinterpret_cast<float*>(smem), acc, accx, wm, wn, lane, tid, m0, n0, M, N, C, ldc, vec4, false, e);
+  tile_epilogue<H, BN>(reinterpret_cast<float*>(smem), acc, accx, wm, wn, lane, tid, m0, n0, M, N, C, ldc, vec4, false, e);
 }
 
 // fp32 matrix -> two 16-bit planes [rows_pad][ldp] (zero padded): out(n, k) = W[n][k] (transpose = 0) or W[k][n] (1)
@@ -1090,7 +1169,7 @@ extern "C" int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream) {
 extern "C" int nsky_split_planes(const float* W, int32_t n_rows, int32_t n_k, int32_t ldw, int32_t transpose, int32_t precision,
                                  uint16_t* hi, uint16_t* lo, int32_t rows_pad, int32_t ldp, nsky_stream_t stream) {
   NSKY_CHECK_ARG(W && hi && lo && n_rows > 0 && n_k > 0, "nsky_split_planes: bad arguments");
-  NSKY_CHECK_ARG(rows_pad >= n_rows && rows_pad % 128 == 0 && ldp >= n_k && ldp % 32 == 0, "nsky_split_planes: planes must be padded to 128 rows x 32 k (rows_pad=%d ldp=%d)", rows_pad, ldp);
+  NSKY_CHECK_ARG(rows_pad >= n_rows && rows_pad % 256 == 0 && ldp >= n_k && ldp % 32 == 0, "nsky_split_planes: planes must be padded to 256 rows x 32 k (rows_pad=%d ldp=%d)", rows_pad, ldp);
   NSKY_CHECK_ARG(ldw >= (transpose ? n_rows : n_k), "nsky_split_planes: ldw too small");
   NSKY_CHECK_ARG(precision == NSKY_PREC_F16X2 || precision == NSKY_PREC_BF16X2, "nsky_split_planes: precision must be F16X2 or BF16X2");
   dim3 grid(ldp / 32, rows_pad / 32);
@@ -1125,11 +1204,18 @@ extern "C" int nsky_gemm_f32_planes(const nsky_gemm_desc* d, const uint16_t* B_h
   auto ok = [](const void* p, int ld) { return p == nullptr || ((((uintptr_t)p) % 16 == 0) && (ld % 4 == 0)); };
   const int vec4 = (d->N % 4 == 0) && ok(d->C, d->ldc) && ok(d->bias, 4) && ok(d->aux0, d->ldaux0) && ok(d->aux1, d->ldaux1) &&
                    ok(d->aux2, d->ldaux2) && ok(d->out1, d->ldout1) && ok(d->out2, d->ldout2);
-  dim3 grid(ceil_div(d->M, 128) * ceil_div(d->N, 128));
-  if (d->precision == NSKY_PREC_F16X2)
-    hipLaunchKernelGGL((gemm_planes_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, d->A, B_hi, B_lo, d->C, d->M, d->N, d->K, d->lda, ldp, d->ldc, vec4, e);
-  else
-    hipLaunchKernelGGL((gemm_planes_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, d->A, B_hi, B_lo, d->C, d->M, d->N, d->K, d->lda, ldp, d->ldc, vec4, e);
+  // 128-wide tiles, two workgroups per CU, by default: the 256-wide wave-specialised variant (A fetched and split once per
+  // row tile, one 8-wave workgroup per CU) measured 0.5 % slower on the train step (36.7 vs 36.5 ms); NSKY_PLANES_BN=256
+  // selects it for experiments
+  static const int force_bn = getenv("NSKY_PLANES_BN") ? atoi(getenv("NSKY_PLANES_BN")) : 0;
+  const bool wide = force_bn == 256 && d->N > 128;
+  const bool h = d->precision == NSKY_PREC_F16X2;
+#define NSKY_PLANES_LAUNCH(HH, BNN)                                                                                          \
+  hipLaunchKernelGGL((gemm_planes_kernel<HH, BNN>), dim3(ceil_div(d->M, 128) * ceil_div(d->N, BNN)), dim3(2 * BNN), 0,      \
+                     (hipStream_t)stream, d->A, B_hi, B_lo, d->C, d->M, d->N, d->K, d->lda, ldp, d->ldc, vec4, e)
+  if (wide) { if (h) NSKY_PLANES_LAUNCH(true, 256); else NSKY_PLANES_LAUNCH(false, 256); }
+  else { if (h) NSKY_PLANES_LAUNCH(true, 128); else NSKY_PLANES_LAUNCH(false, 128); }
+#undef NSKY_PLANES_LAUNCH
   NSKY_CHECK_LAUNCH("nsky_gemm_f32_planes");
   return NSKY_OK;
 }

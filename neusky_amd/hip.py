@@ -100,6 +100,33 @@ def gemm(A, B, Cout, M, N, K, *, a_kcontig=True, b_kcontig=True, bias=None, epi=
     return Cout
 
 
+_split_planes = _sig("nsky_split_planes", C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                     C.c_int32, C.c_int32, C.c_void_p)
+_gemm_planes = _sig("nsky_gemm_f32_planes", C.POINTER(GemmDesc), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
+
+
+def split_planes(W, n_rows, n_k, transpose, precision):
+    """two 16-bit planes [2, rows_pad, ldp] (int16 storage) of a weight matrix for gemm_planes; see include/neusky_hip.h"""
+    rows_pad, ldp = (n_rows + 255) // 256 * 256, (n_k + 31) // 32 * 32
+    planes = torch.empty(2, rows_pad, ldp, dtype=torch.int16, device=W.device)
+    check(_split_planes(ptr(W), n_rows, n_k, ld(W), int(transpose), precision, planes[0].data_ptr(), planes[1].data_ptr(),
+                        rows_pad, ldp, stream_ptr()), "nsky_split_planes")
+    return planes
+
+
+def gemm_planes(A, planes, Cout, M, N, K, *, precision, bias=None, epi=EPI_NONE, p0=0.0, p1=0.0, aux0=None, aux1=None, aux2=None,
+                out1=None, out2=None, row_mod=0, beta=0.0):
+    """C[M,N] = epi(sum_k A(m,k) B(n,k) + bias) with B given as the planes of split_planes (LDS-DMA kernel)"""
+    d = GemmDesc(
+        A=ptr(A), B=None, C=ptr(Cout), M=M, N=N, K=K, lda=ld(A), ldb=0, ldc=ld(Cout), a_kcontig=1, b_kcontig=1, bias=ptr(bias),
+        epi=epi, p0=p0, p1=p1, aux0=ptr(aux0), ldaux0=ld(aux0), aux1=ptr(aux1), ldaux1=ld(aux1), aux2=ptr(aux2), ldaux2=ld(aux2),
+        out1=ptr(out1), ldout1=ld(out1), out2=ptr(out2), ldout2=ld(out2), row_mod=row_mod, k_splits=0, beta=beta,
+        a_rowsum=None, precision=precision,
+    )
+    check(_gemm_planes(C.byref(d), planes[0].data_ptr(), planes[1].data_ptr(), planes.shape[2], stream_ptr()), "nsky_gemm_f32_planes")
+    return Cout
+
+
 _wcolsum = _sig("nsky_weighted_colsum_f32", C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p)
 
 

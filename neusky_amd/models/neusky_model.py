@@ -180,6 +180,7 @@ class NeuSkyFactoModel(nn.Module):
 
     def begin_step(self) -> None:
         """start of an optimisation step: drop the per-step caches of prepared (weight-normed / padded) matrices"""
+        ops.begin_step()
         self.field.invalidate_weight_cache()
         self.illumination_field.network.invalidate_weight_cache()
         if self.visibility_field is not None:

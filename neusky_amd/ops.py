@@ -49,9 +49,11 @@ def set_precision_policy(policy: str) -> None:
 FILM_ROW_CHUNK = int(_os.environ.get("NSKY_FILM_ROW_CHUNK", "0"))
 
 
-def fgemm(*a, **k):
-    """forward-pass dense layer"""
-    return hip.gemm(*a, precision=FWD_PRECISION, **k)
+def fgemm(A, W, Cout, M, N, K, **k):
+    """forward-pass dense layer (W = [out, in] weight, k-contiguous)"""
+    if USE_PLANES_FWD and FWD_PRECISION == hip.PREC_F16X2 and K % 32 == 0 and N > 64 and M >= 4096:
+        return hip.gemm_planes(A, _planes(W, N, K, False, FWD_PRECISION), Cout, M, N, K, precision=FWD_PRECISION, **k)
+    return hip.gemm(A, W, Cout, M, N, K, precision=FWD_PRECISION, **k)
 
 
 def pad4(n: int) -> int:
@@ -118,8 +120,34 @@ def grad_bias(dZ, M, n_out, like):
     return db
 
 
+# Per-step cache of pre-split weight planes (hip.split_planes) for the LDS-DMA dense-layer kernel.  Keyed by the weight's
+# storage; the weight tensor itself is held so its address cannot be recycled inside the step.  Dropped by begin_step()
+# (the optimiser has changed the weights) -- models call it from their own begin_step.
+_PLANES: dict = {}
+USE_PLANES = _os.environ.get("NSKY_GEMM_PLANES", "1") != "0"
+USE_PLANES_FWD = _os.environ.get("NSKY_GEMM_PLANES_FWD", "1") != "0"
+
+
+def begin_step() -> None:
+    _PLANES.clear()
+
+
+def _planes(W, n_rows, n_k, transpose, precision):
+    key = (W.data_ptr(), W._version, ld(W), n_rows, n_k, transpose, precision)
+    hit = _PLANES.get(key)
+    if hit is None:
+        hit = _PLANES[key] = (W, hip.split_planes(W, n_rows, n_k, transpose, precision))
+    return hit[1]
+
+
+def ld(t):
+    return hip.ld(t)
+
+
 def grad_input(dZ, W, M, k_in, n_red, out, **epi):
     """dX[M, k_in] = dZ[M, n_red] @ W[n_red, k_in]   (W stored [out, in] = [n_red, k_in])."""
+    if USE_PLANES and BWD_PRECISION == hip.PREC_BF16X2 and n_red % 32 == 0 and k_in > 64 and M >= 4096:
+        return hip.gemm_planes(dZ, _planes(W, k_in, n_red, True, BWD_PRECISION), out, M, k_in, n_red, precision=BWD_PRECISION, **epi)
     return hip.gemm(dZ, W, out, M, k_in, n_red, a_kcontig=True, b_kcontig=False, precision=BWD_PRECISION, **epi)
 
 

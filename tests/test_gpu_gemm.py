@@ -196,3 +196,62 @@ def test_f16_scaled_split_range_and_accuracy():
     W = torch.ones(N, K, device=dev) / K
     hip.gemm(A, W, C, M, N, K, precision=hip.PREC_F16X2)
     assert torch.isfinite(C).all() and abs(C[0, 0].item() - 65504.0) < 1.0
+
+
+@pytest.mark.parametrize("M,N,K,prec_name", [(128, 128, 32, "f16x2"), (1000, 300, 256, "f16x2"), (4096, 2560, 256, "f16x2"),
+                                             (777, 257, 64, "bf16x2"), (4099, 256, 2560, "bf16x2"), (2048, 128, 128, "f16x2")])
+def test_planes_kernel_matches_register_staged_kernel(M, N, K, prec_name):
+    """nsky_split_planes + nsky_gemm_f32_planes (LDS-DMA kernel, pre-split weights): same MFMA sequence as nsky_gemm_f32 at
+    that precision -> bit-identical results; and within the precision's bound of the float64 product.  Row tails (M % 128),
+    column tails (N % 128), both plane orientations (forward layer / input gradient) and a fused epilogue."""
+    from neusky_amd import hip
+    dev = "cuda:0"
+    prec = hip.PREC_F16X2 if prec_name == "f16x2" else hip.PREC_BF16X2
+    torch.manual_seed(M * 7 + N + K)
+    A = torch.randn(M, K, device=dev)
+    b = torch.randn(N, device=dev)
+    ldc = (N + 3) // 4 * 4
+    for transpose in (False, True):
+        # the register-staged kernel wants ld % 4 == 0: a [K, N] weight lives in a padded buffer
+        W = (torch.randn(K, ldc, device=dev) / K**0.5)[:, :N] if transpose else torch.randn(N, K, device=dev) / K**0.5
+        planes = hip.split_planes(W, N, K, transpose, prec)
+        assert planes.shape == (2, (N + 255) // 256 * 256, K) and planes.dtype == torch.int16
+        ref_c = torch.full((M, ldc), float("nan"), device=dev)
+        new_c = torch.full((M, ldc), float("nan"), device=dev)
+        hip.gemm(A, W, ref_c, M, N, K, b_kcontig=not transpose, bias=b, epi=hip.EPI_LEAKY, p0=0.2, precision=prec)
+        hip.gemm_planes(A, planes, new_c, M, N, K, precision=prec, bias=b, epi=hip.EPI_LEAKY, p0=0.2)
+        assert torch.equal(ref_c[:, :N], new_c[:, :N])
+        assert bool(torch.isnan(new_c[:, N:]).all())  # pad columns of C untouched
+        ref = torch.nn.functional.leaky_relu(_ref(A, W.T if transpose else W, b), 0.2)
+        tol = (3e-5 if prec == hip.PREC_F16X2 else 2e-4) * max(1.0, ref.abs().max().item())
+        assert (new_c[:, :N].double() - ref).abs().max().item() < tol
+
+
+def test_planes_kernel_film_backward_epilogue_and_argument_checks():
+    from neusky_amd import hip
+    dev = "cuda:0"
+    torch.manual_seed(5)
+    M, H = 1500, 256
+    dZn = torch.randn(M, H, device=dev) * 1e-3
+    W = torch.randn(H, H, device=dev) / 16
+    z, F_, P_ = torch.randn(M, H, device=dev), torch.randn(M, H, device=dev) * 0.3, torch.randn(M, H, device=dev)
+    outs = []
+    for use_planes in (False, True):
+        dz, dF, dP = (torch.empty(M, H, device=dev) for _ in range(3))
+        kw = dict(epi=hip.EPI_BWD_FILM, p0=15.0, p1=30.0, aux0=z, aux1=F_, aux2=P_, out1=dF, out2=dP)
+        if use_planes:
+            hip.gemm_planes(dZn, hip.split_planes(W, H, H, True, hip.PREC_BF16X2), dz, M, H, H, precision=hip.PREC_BF16X2, **kw)
+        else:
+            hip.gemm(dZn, W, dz, M, H, H, a_kcontig=True, b_kcontig=False, precision=hip.PREC_BF16X2, **kw)
+        outs.append((dz, dF, dP))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # K must be a whole number of 32-deep tiles; the planes must carry the padding the kernel reads
+    A = torch.randn(256, 48, device=dev)
+    Wb = torch.randn(128, 48, device=dev)
+    with pytest.raises(hip.NeuSkyHipError):
+        hip.gemm_planes(A, hip.split_planes(Wb, 128, 48, False, hip.PREC_F16X2), torch.empty(256, 128, device=dev), 256, 128, 48,
+                        precision=hip.PREC_F16X2)
+    with pytest.raises(hip.NeuSkyHipError):
+        hip.gemm_planes(torch.randn(256, 64, device=dev), hip.split_planes(torch.randn(128, 64, device=dev), 128, 64, False, hip.PREC_F16X2),
+                        torch.empty(256, 128, device=dev), 256, 128, 64, precision=hip.PREC_F32)

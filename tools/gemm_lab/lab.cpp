@@ -71,6 +71,9 @@ planes:
     {"D  planes b2 262144x256x2560", M, 256, 2560, 1, NSKY_PREC_BF16X2, NSKY_EPI_NONE},
     {"F  planes H  153600x128x128 ", 153600, 128, 128, 0, NSKY_PREC_F16X2, NSKY_EPI_NONE},
     {"F  planes H  1000x300x256   ", 1000, 300, 256, 0, NSKY_PREC_F16X2, NSKY_EPI_RELU},
+    {"D  planes b2 153600x128x128 bwdfilm", 153600, 128, 128, 1, NSKY_PREC_BF16X2, NSKY_EPI_BWD_FILM},
+    {"D  planes b2 153600x128x128 plain  ", 153600, 128, 128, 1, NSKY_PREC_BF16X2, NSKY_EPI_NONE},
+    {"D  planes b2 264448x256x256 bwdfilm", M, 256, 256, 1, NSKY_PREC_BF16X2, NSKY_EPI_BWD_FILM},
   };
   for (auto& c : pc) {
     nsky_gemm_desc d = {};
@@ -78,8 +81,19 @@ planes:
     d.a_kcontig = 1; d.b_kcontig = !c.transpose; d.lda = c.K; d.ldb = c.transpose ? c.N : c.K; d.ldc = c.N;
     d.epi = c.epi; d.precision = c.prec;
     if (c.epi == NSKY_EPI_FILM) { d.aux0 = aux; d.ldaux0 = 256; d.aux1 = aux + (size_t)M * 256; d.ldaux1 = 256; d.out1 = aux + (size_t)M * 512; d.ldout1 = 256; d.p0 = 15.f; d.p1 = 30.f; }
+    if (c.epi == NSKY_EPI_BWD_FILM) { d.aux0 = aux; d.ldaux0 = 256; d.aux1 = aux + (size_t)M * 256; d.ldaux1 = 256; d.aux2 = aux + (size_t)M * 512; d.ldaux2 = 256;
+                                      d.out1 = X + (size_t)M * 1024; d.ldout1 = 256; d.out2 = X + (size_t)M * 1536; d.ldout2 = 256; d.p0 = 15.f; d.p1 = 30.f; }
+    {
+      hipEvent_t r0, r1; hipEventCreate(&r0); hipEventCreate(&r1);
+      for (int i = 0; i < 2; ++i) nsky_gemm_f32(&d, 0);
+      hipEventRecord(r0, 0);
+      for (int i = 0; i < 10; ++i) nsky_gemm_f32(&d, 0);
+      hipEventRecord(r1, 0); hipEventSynchronize(r1);
+      float rms; hipEventElapsedTime(&rms, r0, r1);
+      printf("   [register-staged kernel: %8.1f us] ", rms * 100);
+    }
     if (nsky_gemm_f32(&d, 0)) { printf("ERR %s\n", nsky_last_error()); return 1; }
-    const int rows_pad = (c.N + 127) / 128 * 128, ldp = c.K;
+    const int rows_pad = (c.N + 255) / 256 * 256, ldp = c.K;
     uint16_t* hi = planes; uint16_t* lo = planes + (size_t)rows_pad * ldp;
     if (nsky_split_planes(W, c.N, c.K, c.transpose ? c.N : c.K, c.transpose, c.prec, hi, lo, rows_pad, ldp, 0)) { printf("ERR %s\n", nsky_last_error()); return 1; }
     d.C = Cb;
