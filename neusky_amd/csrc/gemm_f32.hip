@@ -531,8 +531,8 @@ __device__ __forceinline__ void tile_epilogue(float* Cs, f32x16 (&acc)[2][2], f3
   }
 }
 
-template <int NS, bool KCONTIG, bool H = false>
-struct SplitLoader {  // 128 x 32 fp32 tile -> NS bf16 images [128][SROW]
+template <int NS, bool KCONTIG, bool H = false, int ROWS = 128>
+struct SplitLoader {  // ROWS x 32 fp32 tile -> NS bf16 images [ROWS][SROW]; ROWS = threads / 2 (non-k-contiguous form: any 8 x ROWS/4 threads)
   float4 v[4];
   float rs[4] = {0.f, 0.f, 0.f, 0.f};  // running row sums (every thread stages the same 4 tile rows on every k-tile)
   __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int t0, int T, int k0, int kend, int tid) {
@@ -563,7 +563,7 @@ struct SplitLoader {  // 128 x 32 fp32 tile -> NS bf16 images [128][SROW]
         uint2 o[NS];
         if (H) split4h(x, o); else split4<NS>(x, o);
 #pragma unroll
-        for (int t = 0; t < NS; ++t) *reinterpret_cast<uint2*>(S + t * 128 * SROW + row * SROW + kq * 4) = o[t];
+        for (int t = 0; t < NS; ++t) *reinterpret_cast<uint2*>(S + t * ROWS * SROW + row * SROW + kq * 4) = o[t];
         if (rowsum) rs[it] += (x[0] + x[1]) + (x[2] + x[3]);
       }
     } else {
@@ -575,7 +575,7 @@ struct SplitLoader {  // 128 x 32 fp32 tile -> NS bf16 images [128][SROW]
         uint2 o[NS];
         if (H) split4h(m[i], o); else split4<NS>(m[i], o);
 #pragma unroll
-        for (int t = 0; t < NS; ++t) *reinterpret_cast<uint2*>(S + t * 128 * SROW + (4 * mb + i) * SROW + 4 * kb) = o[t];
+        for (int t = 0; t < NS; ++t) *reinterpret_cast<uint2*>(S + t * ROWS * SROW + (4 * mb + i) * SROW + 4 * kb) = o[t];
         if (rowsum) rs[i] += (m[i][0] + m[i][1]) + (m[i][2] + m[i][3]);
       }
     }

@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
     {"W  tn b2   256x256x262144 ", 256, 256, M, 0, 0, NSKY_PREC_BF16X2, 128, NSKY_EPI_NONE},
     {"W  tn b2   2560x256x262144", 2560, 256, M, 0, 0, NSKY_PREC_BF16X2, 76, NSKY_EPI_NONE},
   };
-  if (argc > 1) goto planes;
+  if (argc > 1 && argv[1][0] == 'p') goto planes;
   for (auto& c : cases) {
     nsky_gemm_desc d = {};
     d.A = X; d.B = (c.akc && !c.bkc) || c.akc ? W : X + (size_t)M * 256; d.C = Cb;
