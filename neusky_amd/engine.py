@@ -18,6 +18,10 @@ import torch.distributed as dist
 from . import hip
 from .model_components.losses import total_loss
 
+import os as _os
+
+_GRAD_SINK = _os.environ.get("NSKY_GRAD_SINK", "1") != "0"
+
 
 @dataclass
 class AdamOptimizerConfig:
@@ -87,6 +91,7 @@ class _Group:
             self.flat_p[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat_p[off:off + k].view_as(p)
             p.grad = self.flat_g[off:off + k].view_as(p)
+            p._nsky_grad_sink = _GRAD_SINK  # custom backward passes may accumulate into p.grad directly (zeroed by zero_grad_all)
             off += (k + 3) // 4 * 4
         if isinstance(sched, ExponentialDecaySchedulerConfig):
             sched.lr_init = opt.lr

@@ -206,6 +206,9 @@ class HashEncodeFn(torch.autograd.Function):
         hip.encode_fwd(geom, table, x, mode, include_x, pe_freqs, pe_max_exp, out[:P], T)
         ctx.save_for_backward(x, table)
         ctx.cfg = (geom, mode, include_x, pe_freqs, pe_max_exp, tangents, need_dx, P, ldy)
+        # Parameters re-homed into an optimizer slab (engine._Group) own a pre-zeroed gradient view: the backward scatters
+        # straight into it instead of zero-filling a 49 MB table of its own and adding that to .grad afterwards
+        ctx.sink = table if getattr(table, "_nsky_grad_sink", False) else None
         return out
 
     @staticmethod
@@ -213,11 +216,13 @@ class HashEncodeFn(torch.autograd.Function):
         x, table = ctx.saved_tensors
         geom, mode, include_x, pe_freqs, pe_max_exp, tangents, need_dx, P, ldy = ctx.cfg
         d_out = d_out.contiguous()
-        dtable = torch.zeros_like(table)
+        sink = ctx.sink
+        accumulate = sink is not None and sink.grad is not None and sink.grad.is_contiguous() and sink.grad.shape == table.shape
+        dtable = sink.grad if accumulate else torch.zeros_like(table)
         dx = torch.empty(P, 3, device=x.device) if need_dx else None
         dT = d_out[P:].view(3, P, ldy) if tangents else None
         hip.encode_bwd(geom, table, x, mode, include_x, pe_freqs, pe_max_exp, d_out[:P], dT, dtable, dx)
-        return dx, dtable, None, None, None, None, None, None, None
+        return dx, (None if accumulate else dtable), None, None, None, None, None, None, None
 
 
 # =============================================================================================
@@ -327,6 +332,8 @@ class FilmSirenFn(torch.autograd.Function):
             return res
         ctx.save_for_backward(x, cond, FP, *hs, *ys, *zs, *wb)
         ctx.cfg = (n_map, n_film, train_weights, need_dcond, M, H, Hm)
+        # weights that ARE optimizer-slab parameters (no padding copy in between) take their gradient in place
+        ctx.sinks = [w if getattr(w, "_nsky_grad_sink", False) else None for w in wb]
         return res
 
     @staticmethod
@@ -344,13 +351,20 @@ class FilmSirenFn(torch.autograd.Function):
         d_res = d_res.contiguous()
         n_out_p = ow.shape[0]
         NF = 2 * n_film * H
-        if train_w:  # gradient accumulators shared by every row chunk: ONE zero-filled slab, carved into views
-            sizes = [(t.numel() + 3) // 4 * 4 for t in wb]
-            flat = torch.zeros(sum(sizes), device=dev)
+        sunk = [False] * len(wb)
+        if train_w:  # gradient accumulators shared by every row chunk: the parameter's own .grad view where the weight is an
+            # optimizer-slab parameter, otherwise views of ONE zero-filled slab
+            for idx, t in enumerate(wb):
+                sk = ctx.sinks[idx]
+                if sk is not None and sk.grad is not None and sk.grad.shape == t.shape and sk.grad.is_contiguous():
+                    grads[idx], sunk[idx] = sk.grad, True
+            sizes = [0 if sunk[idx] else (t.numel() + 3) // 4 * 4 for idx, t in enumerate(wb)]
+            flat = torch.zeros(max(sum(sizes), 4), device=dev)
             off = 0
             for idx, t in enumerate(wb):
-                grads[idx] = flat[off:off + t.numel()].view_as(t)
-                off += sizes[idx]
+                if not sunk[idx]:
+                    grads[idx] = flat[off:off + t.numel()].view_as(t)
+                    off += sizes[idx]
         acc = (lambda iw: (grads[iw], grads[iw + 1])) if train_w else (lambda iw: None)
         d_x = torch.empty(M, fw[0].shape[1], device=dev) if ctx.need_dx else None
         d_cond = torch.empty(M, mw[0].shape[1], device=dev) if need_dcond else None
@@ -401,7 +415,7 @@ class FilmSirenFn(torch.autograd.Function):
                     dpre, dpo = dpo, dpre
                 elif d_cond is not None:
                     grad_input(dpre, mw[0], m, k_in, Hm, d_cond[r0:r1])
-        return (d_x, d_cond, None, None, None, None, *grads)
+        return (d_x, d_cond, None, None, None, None, *[None if sunk[i] else g for i, g in enumerate(grads)])
 
 
 # =============================================================================================
