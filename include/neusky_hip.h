@@ -80,6 +80,8 @@ typedef struct nsky_gemm_desc {
   float beta;        /* C = result + beta * C_old (non-split only; 0 or 1) */
   float* a_rowsum;   /* optional [M]: ACCUMULATES sum_k A(m,k) (bias gradient when A = dZ^T); atomics */
   int32_t precision; /* NSKY_PREC_*: arithmetic of the contraction (operands and result stay fp32 in memory) */
+  int32_t rowsum_k_limit; /* a_rowsum sums only k < rowsum_k_limit (multiple of 32; 0 = all of K): the value rows of a stacked
+                             [value; tangent] gradient matrix carry the bias, the tangent rows do not */
 } nsky_gemm_desc;
 
 int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream);

@@ -45,6 +45,7 @@ class GemmDesc(C.Structure):
         ("out1", C.c_void_p), ("ldout1", C.c_int32),
         ("out2", C.c_void_p), ("ldout2", C.c_int32),
         ("row_mod", C.c_int32), ("k_splits", C.c_int32), ("beta", C.c_float), ("a_rowsum", C.c_void_p), ("precision", C.c_int32),
+        ("rowsum_k_limit", C.c_int32),
     ]
 
 
@@ -87,14 +88,15 @@ _colsum = _sig("nsky_colsum_f32", C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C
 
 
 def gemm(A, B, Cout, M, N, K, *, a_kcontig=True, b_kcontig=True, bias=None, epi=EPI_NONE, p0=0.0, p1=0.0,
-         aux0=None, aux1=None, aux2=None, out1=None, out2=None, row_mod=0, k_splits=0, beta=0.0, a_rowsum=None, precision=0):
+         aux0=None, aux1=None, aux2=None, out1=None, out2=None, row_mod=0, k_splits=0, beta=0.0, a_rowsum=None, precision=0,
+         rowsum_k_limit=0):
     """C[M,N] = epi(sum_k A(m,k) B(n,k) + bias).  A/B/C are 2-D row-major views (rows contiguous)."""
     d = GemmDesc(
         A=ptr(A), B=ptr(B), C=ptr(Cout), M=M, N=N, K=K, lda=ld(A), ldb=ld(B), ldc=ld(Cout),
         a_kcontig=int(a_kcontig), b_kcontig=int(b_kcontig), bias=ptr(bias), epi=epi, p0=p0, p1=p1,
         aux0=ptr(aux0), ldaux0=ld(aux0), aux1=ptr(aux1), ldaux1=ld(aux1), aux2=ptr(aux2), ldaux2=ld(aux2),
         out1=ptr(out1), ldout1=ld(out1), out2=ptr(out2), ldout2=ld(out2), row_mod=row_mod, k_splits=k_splits, beta=beta,
-        a_rowsum=ptr(a_rowsum), precision=precision,
+        a_rowsum=ptr(a_rowsum), precision=precision, rowsum_k_limit=rowsum_k_limit,
     )
     check(_gemm(C.byref(d), stream_ptr()), "nsky_gemm_f32")
     return Cout

@@ -108,6 +108,8 @@ def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None, acc
         return dW
     if bias_rows is None or bias_rows == M:
         hip.gemm(dZ, X, dW, n_out, k_in, M, a_rowsum=db, **kw)
+    elif bias_rows % 32 == 0:  # row sums over the leading (value) rows only, from the same pass over dZ
+        hip.gemm(dZ, X, dW, n_out, k_in, M, a_rowsum=db, rowsum_k_limit=bias_rows, **kw)
     else:
         hip.gemm(dZ, X, dW, n_out, k_in, M, **kw)
         hip.colsum(dZ, bias_rows, n_out, db)

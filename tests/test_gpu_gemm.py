@@ -255,3 +255,45 @@ def test_planes_kernel_film_backward_epilogue_and_argument_checks():
     with pytest.raises(hip.NeuSkyHipError):
         hip.gemm_planes(torch.randn(256, 64, device=dev), hip.split_planes(torch.randn(128, 64, device=dev), 128, 64, False, hip.PREC_F16X2),
                         torch.empty(256, 128, device=dev), 256, 128, 64, precision=hip.PREC_F32)
+
+
+@pytest.mark.parametrize("M,N,ld", [(1000, 256, 256), (98304, 256, 260), (777, 37, 40), (4099, 4, 4), (513, 300, 300)])
+def test_column_sums_plain_and_weighted(M, N, ld):
+    """nsky_colsum_f32 / nsky_weighted_colsum_f32 (bias gradients, sdf-head weight gradient): float4 and scalar forms,
+    accumulate semantics, strided weights."""
+    from neusky_amd import hip
+    dev = "cuda:0"
+    torch.manual_seed(M + N)
+    X = torch.randn(M, ld, device=dev)[:, :N]
+    out = torch.full((N,), 0.5, device=dev)
+    hip.colsum(X, M, N, out)
+    ref = 0.5 + X.double().sum(0)
+    assert (out.double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    W = torch.randn(M, 4, device=dev)
+    out2 = torch.zeros(N, device=dev)
+    hip.weighted_colsum(X, M, N, W[:, 1:2], 4, out2)  # weights read with stride 4
+    ref2 = (W[:, 1:2].double() * X.double()).sum(0)
+    assert (out2.double() - ref2).abs().max().item() < 1e-4 * max(1.0, ref2.abs().max().item())
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x2"])
+def test_weight_gradient_row_sums_over_leading_rows_only(prec):
+    """a_rowsum with rowsum_k_limit: dW = dZ^T X over all 4N stacked rows, db = column sums of dZ over the first N (value)
+    rows only -- the bias gradient of the geo net's stacked [value; tangent] backward (sdf_albedo_field.py:235-238)."""
+    from neusky_amd import hip
+    dev = "cuda:0"
+    torch.manual_seed(11)
+    N4, n_out, k_in, lim = 4 * 2048, 256, 72, 2048
+    dZ = torch.randn(N4, n_out, device=dev)
+    X = torch.randn(N4, k_in, device=dev)
+    p = hip.PREC_F32 if prec == "f32" else hip.PREC_BF16X2
+    for splits in (1, 8):
+        dW = torch.zeros(n_out, k_in, device=dev)
+        db = torch.zeros(n_out, device=dev)
+        hip.gemm(dZ, X, dW, n_out, k_in, N4, a_kcontig=False, b_kcontig=False, k_splits=splits, a_rowsum=db, rowsum_k_limit=lim, precision=p)
+        ref_w = dZ.double().T @ X.double()
+        ref_b = dZ[:lim].double().sum(0)
+        assert (dW.double() - ref_w).abs().max().item() < 2e-4 * ref_w.abs().max().item()
+        assert (db.double() - ref_b).abs().max().item() < 1e-4 * ref_b.abs().max().item()
+    with pytest.raises(hip.NeuSkyHipError):
+        hip.gemm(dZ, X, dW, n_out, k_in, N4, a_kcontig=False, b_kcontig=False, k_splits=8, a_rowsum=db, rowsum_k_limit=100, precision=p)
