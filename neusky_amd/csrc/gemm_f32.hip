@@ -256,15 +256,31 @@ struct TileLoader {
 // label a contiguous run of logical tiles, and the logical order is column-tile fastest: the column tiles of one row
 // tile (which all re-read the same A rows) run back to back on ONE L2 instead of streaming A from HBM once per
 // column tile, while the (small) B operand stays L2-resident for every row tile.
-__device__ __forceinline__ void tile_of_block(int tiles_n, int& m_tile, int& n_tile) {
+__device__ __forceinline__ int xcd_contiguous_id() {
   const int nwg = gridDim.x;
   int id = blockIdx.x;
   if (nwg >= 16) {
     const int q = nwg >> 3, r = nwg & 7, x = id & 7;
     id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
   }
+  return id;
+}
+__device__ __forceinline__ void tile_of_block(int tiles_n, int& m_tile, int& n_tile) {
+  const int id = xcd_contiguous_id();
   n_tile = id % tiles_n;
   m_tile = id / tiles_n;
+}
+// Split-K launches put (output tile, k-split) on ONE grid axis, output tile fastest: the tiles of one k-split -- which read the
+// same rows of both operands (a weight gradient's 2 x 2 tiles each read dZ and X of their split) -- get consecutive logical
+// ids, i.e. the same XCD and neighbouring dispatch slots, so the re-reads hit that XCD's L2 instead of going out to HBM once
+// per tile (PMC: the weight-gradient kernel fetched 2.1x its operand bytes with the split on grid.z).
+__device__ __forceinline__ void tile_split_of_block(int tiles_m, int tiles_n, int& m_tile, int& n_tile, int& split) {
+  const int id = xcd_contiguous_id();
+  const int tiles = tiles_m * tiles_n;
+  split = id / tiles;
+  const int t = id - split * tiles;
+  n_tile = t % tiles_n;
+  m_tile = t / tiles_n;
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool AK, bool BKC, int BK, int OCC>
@@ -282,10 +298,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const float* __restr
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  int m_tile, n_tile;
-  tile_of_block((N + BN - 1) / BN, m_tile, n_tile);
+  int m_tile, n_tile, split;
+  tile_split_of_block((M + BM - 1) / BM, (N + BN - 1) / BN, m_tile, n_tile, split);
   const int m0 = m_tile * BM, n0 = n_tile * BN;
-  const int kbeg = blockIdx.z * k_split_len;
+  const int kbeg = split * k_split_len;
   const int kend = min(K, kbeg + k_split_len);
   const int ntiles = (kend - kbeg + BK - 1) / BK;
 
@@ -362,7 +378,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const float* __restr
   // wave-row (WM rows) at a time, and sweep them row-major so C, the aux operands and the side outputs move
   // as whole rows.
   float* Cs = smem;
-  const bool atomic = gridDim.z > 1;
+  const bool atomic = k_split_len < K;
 #pragma unroll
   for (int pass = 0; pass < WAVES_M; ++pass) {
     if (pass > 0) __syncthreads();
@@ -609,10 +625,10 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : NSKY_LAB_OCC) void gemm_
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  int m_tile, n_tile;
-  tile_of_block((N + BN - 1) / BN, m_tile, n_tile);
+  int m_tile, n_tile, split;
+  tile_split_of_block((M + BM - 1) / BM, (N + BN - 1) / BN, m_tile, n_tile, split);
   const int m0 = m_tile * BM, n0 = n_tile * BN;
-  const int kbeg = blockIdx.z * k_split_len;
+  const int kbeg = split * k_split_len;
   const int kend = min(K, kbeg + k_split_len);
   const int ntiles = (kend - kbeg + BKT - 1) / BKT;
   const bool want_rs = (a_rowsum != nullptr) && n_tile == 0;
@@ -765,7 +781,7 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : NSKY_LAB_OCC) void gemm_
   if (want_rs && tid < 128 && m0 + tid < M) atomicAdd(a_rowsum + m0 + tid, rsum[tid]);
   __syncthreads();
 
-  tile_epilogue<H>(reinterpret_cast<float*>(smem_raw), acc, accx, wm, wn, lane, tid, m0, n0, M, N, C, ldc, vec4, gridDim.z > 1, e);
+  tile_epilogue<H>(reinterpret_cast<float*>(smem_raw), acc, accx, wm, wn, lane, tid, m0, n0, M, N, C, ldc, vec4, k_split_len < K, e);
 }
 
 // =================================================================================================
@@ -1059,7 +1075,7 @@ __global__ void split_planes_kernel(const float* __restrict__ W, int n_rows, int
 
 template <int NS, bool DBUF, bool H = false>
 void launch_split(const nsky_gemm_desc* d, const EpiCtx& e, int splits, int k_split_len, int vec4, hipStream_t s) {
-  dim3 grid(ceil_div(d->M, 128) * ceil_div(d->N, 128), 1, splits);
+  dim3 grid(ceil_div(d->M, 128) * ceil_div(d->N, 128) * splits);
 #define NSKY_SGEMM_LAUNCH(AK, BKC)                                                                          \
   hipLaunchKernelGGL((gemm_bf16s_kernel<NS, AK, BKC, DBUF, H>), grid, dim3(256), 0, s, d->A, d->B, d->C, d->M, d->N, \
                      d->K, d->lda, d->ldb, d->ldc, k_split_len, vec4, d->a_rowsum, e)
@@ -1072,7 +1088,7 @@ void launch_split(const nsky_gemm_desc* d, const EpiCtx& e, int splits, int k_sp
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int OCC>
 void launch(const nsky_gemm_desc* d, const EpiCtx& e, int splits, int k_split_len, int vec4, hipStream_t s) {
-  dim3 grid(ceil_div(d->M, BM) * ceil_div(d->N, BN), 1, splits);
+  dim3 grid(ceil_div(d->M, BM) * ceil_div(d->N, BN) * splits);
 #define NSKY_GEMM_LAUNCH(AK, BKC)                                                                              \
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, AK, BKC, BK, OCC>), grid, dim3(256), 0, s, d->A, d->B, \
                      d->C, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, k_split_len, vec4, d->a_rowsum, e)
