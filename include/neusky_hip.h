@@ -288,6 +288,56 @@ int nsky_weight_norm_bwd(const float* d_out, int32_t ldo, const float* v, const 
 int nsky_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, int32_t step, float grad_scale, nsky_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Closed-form loss terms, one launch each way per model (instead of ~300 small torch launches per step).
+ * NeuSky model, train branch of get_loss_dict, neusky/models/neusky_model.py:933-1035 (+ RENISkyPixelLoss,
+ * neusky/model_components/losses.py:44-58, linear_to_sRGB neusky/utils/utils.py:25-30, nerfstudio monosdf_normal_loss):
+ *   terms[8] = { rgb_l1 (:947-950), eikonal (:958-960), fg_mask BCE (:963-967), hashgrid density L1 (:990-993),
+ *                ground-plane normal (:995-1000), sky pixel (:1002-1009), visibility-threshold MSE (:1011-1030),
+ *                sdf level set (:1032-1035) }, UNSCALED (the coefficients are applied by the caller); a term whose input
+ *   pointer is NULL is left 0.  wsum [R] (side output) = per-ray weight sums, needed by the backward.
+ *   Backward: d_terms[8] -> gradients (every element written) for the inputs whose output pointer is non-NULL.
+ */
+typedef struct nsky_main_losses_desc {
+  int32_t R, S, P, M;     /* rays, samples per ray, hash-grid probe points, sdf-at-termination rows */
+  const float* rgb;       /* [R,3] rendered radiance */
+  const float* image;     /* [R,3] */
+  const float* mask;      /* [R,4] float {static, fg, ground, sky} (neusky_dataset.py:290) */
+  const float* eik;       /* [R*S,3] sdf gradients */
+  const float* weights;   /* [R,S] */
+  const float* normal;    /* [R,3] rendered normals */
+  const float* hdr_bg;    /* [R,3] linear HDR background */
+  const float* grid;      /* [P*3] hash-grid probe alphas */
+  const float* sdf_term;  /* [M] */
+  const float* vis_thr;   /* [1] learnable visibility threshold */
+  float sky_alpha, vis_target;
+} nsky_main_losses_desc;
+int nsky_main_losses_fwd(const nsky_main_losses_desc* d, float* terms, float* wsum, nsky_stream_t stream);
+int nsky_main_losses_bwd(const nsky_main_losses_desc* d, const float* wsum, const float* d_terms, float* d_rgb, float* d_eik,
+                         float* d_weights, float* d_normal, float* d_hdr_bg, float* d_grid, float* d_sdf_term, float* d_vis_thr,
+                         nsky_stream_t stream);
+
+/* DDF model, get_loss_dict, neusky/models/ddf_model.py:407-493:
+ *   terms[5] = { depth L1 x scene-centre weight (:427-433), sdf L2, sdf L1, multi-view hinge^2 with the reference's
+ *                [M] - [M,1] -> [M,M] broadcast (:475-483), sky-ray L1 (:485-490) }, unscaled. */
+typedef struct nsky_ddf_losses_desc {
+  int32_t Mr, Mm, Ms;          /* fit rays, multi-view rays, sky rays */
+  const float* expected;       /* [Mr] expected termination distance */
+  const float* term;           /* [Mr] target termination distance */
+  const float* mask;           /* [Mr] */
+  const float* dist_weight;    /* [Mr] or NULL */
+  const float* sdf;            /* [Mr] sdf at termination or NULL */
+  const float* mv_expected; const float* mv_term;    /* [Mm] */
+  const float* sky_expected; const float* sky_term;  /* [Ms] */
+  int32_t want_depth, want_sdf_l2, want_sdf_l1, mask_to_circumference, inverse_depth_weight;
+  float radius;
+} nsky_ddf_losses_desc;
+int nsky_ddf_losses_fwd(const nsky_ddf_losses_desc* d, float* terms, nsky_stream_t stream);
+/* d_term / d_mv_term: gradients w.r.t. the target distances (the field's own rendering of the fit rays; NULL when the pipeline
+ * detached them, neusky_pipeline.py stop_sdf_gradients) */
+int nsky_ddf_losses_bwd(const nsky_ddf_losses_desc* d, const float* d_terms, float* d_expected, float* d_sdf, float* d_mv_expected,
+                        float* d_sky_expected, float* d_term, float* d_mv_term, nsky_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

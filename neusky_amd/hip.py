@@ -371,3 +371,44 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     n = p.numel()
     assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
     check(_adam(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, beta1, beta2, eps, step, grad_scale, stream_ptr()), "nsky_adam_step")
+
+
+# ------------------------------------------------------------------------------------------ fused loss terms
+class MainLossesDesc(C.Structure):
+    _fields_ = [("R", C.c_int32), ("S", C.c_int32), ("P", C.c_int32), ("M", C.c_int32),
+                ("rgb", C.c_void_p), ("image", C.c_void_p), ("mask", C.c_void_p), ("eik", C.c_void_p), ("weights", C.c_void_p),
+                ("normal", C.c_void_p), ("hdr_bg", C.c_void_p), ("grid", C.c_void_p), ("sdf_term", C.c_void_p), ("vis_thr", C.c_void_p),
+                ("sky_alpha", C.c_float), ("vis_target", C.c_float)]
+
+
+class DDFLossesDesc(C.Structure):
+    _fields_ = [("Mr", C.c_int32), ("Mm", C.c_int32), ("Ms", C.c_int32),
+                ("expected", C.c_void_p), ("term", C.c_void_p), ("mask", C.c_void_p), ("dist_weight", C.c_void_p), ("sdf", C.c_void_p),
+                ("mv_expected", C.c_void_p), ("mv_term", C.c_void_p), ("sky_expected", C.c_void_p), ("sky_term", C.c_void_p),
+                ("want_depth", C.c_int32), ("want_sdf_l2", C.c_int32), ("want_sdf_l1", C.c_int32), ("mask_to_circumference", C.c_int32),
+                ("inverse_depth_weight", C.c_int32), ("radius", C.c_float)]
+
+
+_main_losses_fwd = _sig("nsky_main_losses_fwd", C.POINTER(MainLossesDesc), C.c_void_p, C.c_void_p, C.c_void_p)
+_main_losses_bwd = _sig("nsky_main_losses_bwd", C.POINTER(MainLossesDesc), *([C.c_void_p] * 11))
+_ddf_losses_fwd = _sig("nsky_ddf_losses_fwd", C.POINTER(DDFLossesDesc), C.c_void_p, C.c_void_p)
+_ddf_losses_bwd = _sig("nsky_ddf_losses_bwd", C.POINTER(DDFLossesDesc), *([C.c_void_p] * 8))
+N_MAIN_TERMS, N_DDF_TERMS = 8, 5
+
+
+def main_losses_fwd(desc: MainLossesDesc, terms, wsum):
+    check(_main_losses_fwd(C.byref(desc), ptr(terms), ptr(wsum), stream_ptr()), "nsky_main_losses_fwd")
+
+
+def main_losses_bwd(desc: MainLossesDesc, wsum, d_terms, d_rgb, d_eik, d_weights, d_normal, d_hdr_bg, d_grid, d_sdf_term, d_vis_thr):
+    check(_main_losses_bwd(C.byref(desc), ptr(wsum), ptr(d_terms), ptr(d_rgb), ptr(d_eik), ptr(d_weights), ptr(d_normal), ptr(d_hdr_bg),
+                           ptr(d_grid), ptr(d_sdf_term), ptr(d_vis_thr), stream_ptr()), "nsky_main_losses_bwd")
+
+
+def ddf_losses_fwd(desc: DDFLossesDesc, terms):
+    check(_ddf_losses_fwd(C.byref(desc), ptr(terms), stream_ptr()), "nsky_ddf_losses_fwd")
+
+
+def ddf_losses_bwd(desc: DDFLossesDesc, d_terms, d_expected, d_sdf, d_mv_expected, d_sky_expected, d_term, d_mv_term):
+    check(_ddf_losses_bwd(C.byref(desc), ptr(d_terms), ptr(d_expected), ptr(d_sdf), ptr(d_mv_expected), ptr(d_sky_expected), ptr(d_term),
+                          ptr(d_mv_term), stream_ptr()), "nsky_ddf_losses_bwd")

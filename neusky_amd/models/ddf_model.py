@@ -3,6 +3,7 @@
 `get_param_groups` (:151-156).  Image / metric code (:550-674) is out of scope."""
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Type
 
@@ -14,7 +15,10 @@ from torch.nn import Parameter
 from ..cameras.rays import Frustums, RayBundle, RaySamples
 from ..field_components.neusky_fieldheadnames import NeuSkyFieldHeadNames
 from ..fields.directional_distance_field import DirectionalDistanceFieldConfig
-from ..model_components.losses import scale_dict
+from .. import ops
+from ..model_components.losses import LossDict, scale_dict
+
+_COEF_VECTORS: Dict[tuple, torch.Tensor] = {}
 from ..utils.utils import ray_sphere_intersection
 
 
@@ -162,6 +166,33 @@ class DDFModel(nn.Module):
         """ddf_model.py:407-493"""
         c = self.config
         loss_dict: Dict[str, torch.Tensor] = {}
+        li = c.loss_inclusions
+        exp_d = outputs["expected_termination_dist"]
+        if (exp_d.is_cuda and os.environ.get("NSKY_FUSED_LOSSES", "1") in ("1", "ddf")
+                and (c.include_depth_loss_scene_center_weight or not c.inverse_depth_weight)):
+            # one launch each way for the five closed-form terms (ops.DDFLossesFn; same formulas, keys and scaling)
+            want_sdf = (li["sdf_l2_loss"] or li["sdf_l1_loss"])
+            mv = li["multi_view_loss"]
+            sky = li["sky_ray_loss"]
+            flags = dict(want_depth=int(li["depth_l1_loss"]), want_sdf_l2=int(li["sdf_l2_loss"]), want_sdf_l1=int(li["sdf_l1_loss"]),
+                         mask_to_circumference=int(c.mask_to_circumference), inverse_depth_weight=int(c.inverse_depth_weight),
+                         radius=float(self.ddf_radius))
+            terms = ops.DDFLossesFn.apply(
+                exp_d, batch["termination_dist"], batch["mask"],
+                outputs["distance_weight"] if c.include_depth_loss_scene_center_weight else None,
+                outputs["sdf_at_termination"] if want_sdf else None,
+                outputs["multi_view_expected_termination_dist"] if mv else None, outputs["multi_view_termintation_dist"] if mv else None,
+                outputs["sky_ray_expected_termination_dist"] if sky else None, outputs["sky_ray_termination_dist"] if sky else None, flags)
+            names = ("depth_l1_loss", "sdf_l2_loss", "sdf_l1_loss", "multi_view_loss", "sky_ray_loss")
+            present = (li["depth_l1_loss"], li["sdf_l2_loss"], li["sdf_l1_loss"], mv, sky)
+            key = (tuple(float(c.loss_coefficients.get(k, 1.0)) if p else 0.0 for k, p in zip(names, present)), str(terms.device))
+            cv = _COEF_VECTORS.get(key)
+            if cv is None:
+                cv = _COEF_VECTORS[key] = torch.tensor(key[0], dtype=torch.float32).to(terms.device)
+            scaled = terms * cv
+            out = LossDict({k: scaled[i] for i, (k, p) in enumerate(zip(names, present)) if p})
+            out.total = scaled.sum()
+            return out
         if c.mask_to_circumference:
             expected = outputs["expected_termination_dist"].unsqueeze(1)
             gt = batch["termination_dist"].clone()

@@ -30,7 +30,7 @@ from ..cameras.rays import Frustums, RayBundle, RaySamples
 from ..field_components.neusky_fieldheadnames import FieldHeadNames, NeuSkyFieldHeadNames
 from ..fields.sdf_albedo_field import SDFAlbedoFieldConfig
 from ..model_components.illumination import IcosahedronSamplerConfig, RENIFieldConfig
-from ..model_components.losses import RENISkyPixelLoss, interlevel_loss, monosdf_normal_loss, scale_dict, total_loss
+from ..model_components.losses import LossDict, RENISkyPixelLoss, interlevel_loss, monosdf_normal_loss, scale_dict, total_loss
 from ..model_components.ray_samplers import HashMLPDensityField, ProposalNetworkSampler
 from ..model_components.renderers import RGBLambertianRendererWithVisibility
 from ..utils.utils import linear_to_sRGB, to_device_async
@@ -47,6 +47,9 @@ def _default_loss_inclusions() -> Dict[str, Any]:  # neusky/configs/neusky_confi
                                     "optimise_sigmoid_scale": False, "target_min_bias": 0.1, "target_max_scale": 25,
                                     "steps_until_min_bias": 50000},
     }
+
+
+_COEF_VECTORS: Dict[tuple, torch.Tensor] = {}
 
 
 def _default_loss_coefficients() -> Dict[str, float]:  # neusky/configs/neusky_config.py:127-141
@@ -472,6 +475,9 @@ class NeuSkyFactoModel(nn.Module):
         li = self.config.loss_inclusions
         ld: Dict[str, torch.Tensor] = {}
         image = batch["image"].to(dev)
+        if (image.is_cuda and self.training and not self.fitting_eval_latents and not li["rgb_l2_loss"] and not li["cosine_colour_loss"]
+                and os.environ.get("NSKY_FUSED_LOSSES", "1") in ("1", "main")):
+            return self._fused_loss_dict(outputs, image, mask)
         keep = (1 - sky_mask.float()).unsqueeze(1)
         img, pred = image * keep, outputs["rgb"] * keep  # :947-948
         if li["rgb_l1_loss"]:
@@ -509,6 +515,46 @@ class NeuSkyFactoModel(nn.Module):
             sm = sky_mask.float().unsqueeze(1).expand(-1, 3)
             ld["sky_pixel_loss"] = self.sky_pixel_loss(inputs=linear_to_sRGB(outputs["hdr_background_colours"]), targets=image, mask=sm)
         return scale_dict(ld, self.config.loss_coefficients)
+
+    _FUSED_TERMS = ("rgb_l1_loss", "eikonal_loss", "fg_mask_loss", "hashgrid_density_loss", "ground_plane_loss", "sky_pixel_loss",
+                    "visibility_sigmoid_loss", "sdf_level_set_visibility_loss")
+
+    def _fused_loss_dict(self, outputs: Dict[str, Any], image: torch.Tensor, mask: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """the train branch of get_loss_dict (:933-1035) through ops.MainLossesFn: one launch each way for the eight
+        closed-form terms (same formulas, same keys, same scale_dict semantics); the interlevel term keeps its own kernel"""
+        li = self.config.loss_inclusions
+        learn = self.visibility_field is not None and self.visibility_threshold_method == "learnable"
+        sdf_t = outputs.get("sdf_at_termination") if li["sdf_level_set_visibility_loss"] else None
+        present = {
+            "rgb_l1_loss": li["rgb_l1_loss"], "eikonal_loss": li["eikonal loss"], "fg_mask_loss": li["fg_mask_loss"],
+            "hashgrid_density_loss": li["hashgrid_density_loss"]["enabled"], "ground_plane_loss": li["ground_plane_loss"],
+            "sky_pixel_loss": li["sky_pixel_loss"]["enabled"], "visibility_sigmoid_loss": learn,
+            "sdf_level_set_visibility_loss": sdf_t is not None,
+        }
+        w = outputs["weights"]
+        terms = ops.MainLossesFn.apply(
+            outputs["rgb"] if present["rgb_l1_loss"] else None, image, mask.float(),
+            outputs["eik_grad"] if present["eikonal_loss"] else None,
+            w.reshape(w.shape[0], w.shape[1]) if present["fg_mask_loss"] else None,
+            outputs["normal"] if present["ground_plane_loss"] else None,
+            outputs["hdr_background_colours"] if present["sky_pixel_loss"] else None,
+            outputs["grid_density"] if present["hashgrid_density_loss"] else None,
+            sdf_t, self.visibility_threshold if learn else None,
+            self.sky_pixel_loss.alpha, li["visibility_sigmoid_loss"]["target_min_bias"])
+        coefs = self.config.loss_coefficients
+        key = (tuple(float(coefs.get(k, 1.0)) if present[k] else 0.0 for k in self._FUSED_TERMS), str(terms.device))
+        cv = _COEF_VECTORS.get(key)
+        if cv is None:
+            cv = _COEF_VECTORS[key] = torch.tensor(key[0], dtype=torch.float32).to(terms.device)
+        scaled = terms * cv  # nerfstudio scale_dict: keys missing from the coefficient table ('eikonal_loss') stay unscaled
+        ld = LossDict({k: scaled[i] for i, k in enumerate(self._FUSED_TERMS) if present[k]})
+        total = scaled.sum()
+        if li["interlevel_loss"]:
+            il = interlevel_loss(outputs["weights_list"], outputs["sbins_list"]) * float(coefs.get("interlevel_loss", 1.0))  # :987-988
+            ld["interlevel_loss"] = il
+            total = total + il
+        ld.total = total
+        return ld
 
     def get_metrics_dict(self, outputs, batch) -> Dict[str, Any]:
         """neusky_model.py:1064-1077"""

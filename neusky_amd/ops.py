@@ -701,3 +701,74 @@ class TruncExpFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g * torch.exp(ctx.saved_tensors[0].clamp(-15, 15))
+
+
+# =============================================================================================
+# fused closed-form loss terms (one launch each way per model)
+# =============================================================================================
+def _c(t):
+    return None if t is None else t.detach().contiguous().float()
+
+
+class MainLossesFn(torch.autograd.Function):
+    """terms[8] = unscaled {rgb_l1, eikonal, fg_mask, hashgrid_density, ground_plane, sky_pixel, visibility_sigmoid,
+    sdf_level_set} of NeuSkyFactoModel.get_loss_dict's train branch (neusky_model.py:933-1035); an absent input (None) leaves
+    its term at 0.  See include/neusky_hip.h."""
+
+    @staticmethod
+    def forward(ctx, rgb, image, mask, eik, weights, normal, hdr_bg, grid, sdf_term, vis_thr, sky_alpha, vis_target):
+        R = image.shape[0]
+        ins = [_c(rgb), _c(image), _c(mask), _c(eik), _c(weights), _c(normal), _c(hdr_bg), _c(grid), _c(sdf_term), _c(vis_thr)]
+        S = weights.shape[1] if weights is not None else (eik.shape[1] if eik is not None else 0)
+        d = hip.MainLossesDesc(R=R, S=S, P=(grid.numel() // 3 if grid is not None else 0),
+                               M=(sdf_term.numel() if sdf_term is not None else 0), sky_alpha=float(sky_alpha), vis_target=float(vis_target))
+        for name, t in zip(("rgb", "image", "mask", "eik", "weights", "normal", "hdr_bg", "grid", "sdf_term", "vis_thr"), ins):
+            setattr(d, name, hip.ptr(t))
+        terms = torch.empty(hip.N_MAIN_TERMS, device=image.device)
+        wsum = torch.empty(R, device=image.device) if weights is not None else None
+        hip.main_losses_fwd(d, terms, wsum)
+        ctx.desc, ctx.keep, ctx.wsum = d, ins, wsum
+        ctx.shapes = [None if t is None else t.shape for t in (rgb, eik, weights, normal, hdr_bg, grid, sdf_term, vis_thr)]
+        return terms
+
+    @staticmethod
+    def backward(ctx, g):
+        need = ctx.needs_input_grad
+        idx = (0, 3, 4, 5, 6, 7, 8, 9)  # rgb, eik, weights, normal, hdr_bg, grid, sdf_term, vis_thr among the forward arguments
+        outs = []
+        for k, i in enumerate(idx):
+            shp = ctx.shapes[k]
+            outs.append(torch.empty(shp, device=g.device) if (need[i] and shp is not None) else None)
+        hip.main_losses_bwd(ctx.desc, ctx.wsum, g.contiguous(), *outs)
+        res = [None] * 12
+        for k, i in enumerate(idx):
+            res[i] = outs[k]
+        return tuple(res)
+
+
+class DDFLossesFn(torch.autograd.Function):
+    """terms[5] = unscaled {depth_l1, sdf_l2, sdf_l1, multi_view, sky_ray} of DDFModel.get_loss_dict (ddf_model.py:407-493)"""
+
+    @staticmethod
+    def forward(ctx, expected, term, mask, dist_weight, sdf, mv_expected, mv_term, sky_expected, sky_term, flags):
+        ins = [_c(expected), _c(term), _c(mask), _c(dist_weight), _c(sdf), _c(mv_expected), _c(mv_term), _c(sky_expected), _c(sky_term)]
+        d = hip.DDFLossesDesc(Mr=expected.numel(), Mm=(mv_expected.numel() if mv_expected is not None else 0),
+                              Ms=(sky_expected.numel() if sky_expected is not None else 0), **flags)
+        for name, t in zip(("expected", "term", "mask", "dist_weight", "sdf", "mv_expected", "mv_term", "sky_expected", "sky_term"), ins):
+            setattr(d, name, hip.ptr(t))
+        terms = torch.empty(hip.N_DDF_TERMS, device=expected.device)
+        hip.ddf_losses_fwd(d, terms)
+        ctx.desc, ctx.keep = d, ins
+        ctx.shapes = [None if t is None else t.shape for t in (expected, sdf, mv_expected, sky_expected, term, mv_term)]
+        return terms
+
+    @staticmethod
+    def backward(ctx, g):
+        need = ctx.needs_input_grad
+        idx = (0, 4, 5, 7, 1, 6)  # expected, sdf, mv_expected, sky_expected, term, mv_term among the forward arguments
+        outs = [torch.empty(ctx.shapes[k], device=g.device) if (need[i] and ctx.shapes[k] is not None) else None for k, i in enumerate(idx)]
+        hip.ddf_losses_bwd(ctx.desc, g.contiguous(), *outs)
+        res = [None] * 10
+        for k, i in enumerate(idx):
+            res[i] = outs[k]
+        return tuple(res)
