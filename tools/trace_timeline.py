@@ -17,9 +17,14 @@ _, a, b = best
 step = rows[a:b]
 t0 = step[0][0]
 run = []
+import collections
 def flush():
     if run:
         span = run[-1][1] - run[0][0]
+        if len(run) >= 40:
+            c = collections.Counter(n.replace("void at::native::", "").replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:70] for _, _, n in run)
+            for k, v in c.most_common(14):
+                print(f"                 {v:4d} x {k}")
         print(f"{(run[0][0]-t0)/1e3:9.1f} us  [{len(run):4d} small kernels]  wall {span/1e3:8.1f} us  busy {sum(e-s for s,e,_ in run)/1e3:8.1f} us")
         run.clear()
 tot_small_wall = 0
