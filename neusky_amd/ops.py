@@ -116,6 +116,29 @@ def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None, acc
     return dW, db
 
 
+# Gradient accumulators shared by every backward node of ONE backward pass that trains the same prepared weight (the geo /
+# colour matrices feed three SDFAlbedoFn calls and the sdf probe): the node autograd runs first allocates the zero-filled
+# (dW, db) pair and returns it, the later ones add into it in place (split-K atomics / beta = 1) and return None -- autograd
+# runs the weight's producer only after all of them, so it sees the finished sum without 2 x 15 separate zero fills and adds.
+_SHARED_GRADS: dict = {}
+
+
+def shared_grad(like, bias_like):
+    """-> (dW, db, first)"""
+    key = (like.data_ptr(), tuple(like.shape), 0 if bias_like is None else bias_like.data_ptr())
+    hit = _SHARED_GRADS.get(key)
+    if hit is not None:
+        return hit[1], hit[2], False
+    if not _SHARED_GRADS:  # first shared accumulator of this backward pass: forget them all when the pass ends
+        torch.autograd.Variable._execution_engine.queue_callback(_SHARED_GRADS.clear)
+    nw = (like.numel() + 3) // 4 * 4
+    flat = torch.zeros(nw + (bias_like.numel() if bias_like is not None else 0), device=like.device, dtype=like.dtype)
+    dW = flat[:like.numel()].view_as(like)
+    db = flat[nw:].view_as(bias_like) if bias_like is not None else None
+    _SHARED_GRADS[key] = (like, dW, db)
+    return dW, db, True
+
+
 def grad_bias(dZ, M, n_out, like):
     db = torch.zeros_like(like)
     hip.colsum(dZ, M, n_out, db)
@@ -478,13 +501,16 @@ class SDFAlbedoFn(torch.autograd.Function):
         if g_alb is not None:
             alb = ALB[:, :3]
             dpc2[:, :3] = g_alb * alb * (1.0 - alb)
-        dWc2, dbc2 = grad_weight(dpc2, C1, N, 4, Hc, Wc2, bc2)
+        dWc2, dbc2, f_c2 = shared_grad(Wc2, bc2)
+        grad_weight(dpc2, C1, N, 4, Hc, Wc2, bc2, acc=(dWc2, dbc2))
         dpc1 = torch.empty(N, Hc, device=dev)
         grad_input(dpc2, Wc2, N, Hc, 4, dpc1, epi=hip.EPI_BWD_RELU, aux0=C1)
-        dWc1, dbc1 = grad_weight(dpc1, C0, N, Hc, Hc, Wc1, bc1)
+        dWc1, dbc1, f_c1 = shared_grad(Wc1, bc1)
+        grad_weight(dpc1, C0, N, Hc, Hc, Wc1, bc1, acc=(dWc1, dbc1))
         dpc0 = torch.empty(N, Hc, device=dev)
         grad_input(dpc1, Wc1, N, Hc, Hc, dpc0, epi=hip.EPI_BWD_RELU, aux0=C0)
-        dWc0, dbc0 = grad_weight(dpc0, CIN, N, Hc, ldc, Wc0, bc0)
+        dWc0, dbc0, f_c0 = shared_grad(Wc0, bc0)
+        grad_weight(dpc0, CIN, N, Hc, ldc, Wc0, bc0, acc=(dWc0, dbc0))
         dCIN = torch.empty(N, ldc, device=dev)
         grad_input(dpc0, Wc0, N, ldc, Hc, dCIN)
         # the sdf slot / pad columns of Wc0 are structural zeros: overwrite them with the upstream sdf gradient
@@ -493,7 +519,8 @@ class SDFAlbedoFn(torch.autograd.Function):
             dCIN[:, GF] = g_sdf
         dH = dCIN[:, :GF + 4]
         # ---- geo net, last layer (value rows)
-        dW2, db2 = grad_weight(dH, A1[:N], N, GF + 4, Hd, W2, b2)
+        dW2, db2, f_2 = shared_grad(W2, b2)
+        grad_weight(dH, A1[:N], N, GF + 4, Hd, W2, b2, acc=(dW2, db2))
         dA1v = torch.empty(N, Hd, device=dev)
         grad_input(dH, W2, N, Hd, GF + 4, dA1v)
         # tangent rows of the last layer: grad_k = ta1_k . w_sdf
@@ -506,18 +533,22 @@ class SDFAlbedoFn(torch.autograd.Function):
         # ---- layer 1 (reverse over forward)
         D1 = torch.empty(4 * N, Hd, device=dev)
         hip.softplus_tangent_bwd(dA1v, S1, A1[N:], None, g_grad, w2s, beta, N, Hd, D1[:N], D1[N:])
-        dW1, db1 = grad_weight(D1, A0, 4 * N, Hd, Hd, W1, b1, bias_rows=N)
+        dW1, db1, f_1 = shared_grad(W1, b1)
+        grad_weight(D1, A0, 4 * N, Hd, Hd, W1, b1, bias_rows=N, acc=(dW1, db1))
         dA0 = torch.empty(4 * N, Hd, device=dev)
         grad_input(D1, W1, 4 * N, Hd, Hd, dA0)
         # ---- layer 0
         D0 = torch.empty(4 * N, Hd, device=dev)
         hip.softplus_tangent_bwd(dA0[:N], S0, A0[N:], dA0[N:], None, None, beta, N, Hd, D0[:N], D0[N:])
-        dW0, db0 = grad_weight(D0, ET, 4 * N, Hd, Kin, W0, b0, bias_rows=N)
+        dW0, db0, f_0 = shared_grad(W0, b0)
+        grad_weight(D0, ET, 4 * N, Hd, Kin, W0, b0, bias_rows=N, acc=(dW0, db0))
         dET = torch.empty(4 * N, Kin, device=dev)
         grad_input(D0, W0, 4 * N, Kin, Hd, dET)
         # x / PE columns of the colour-net input came straight from the encode row
         dET[:N, :39] += dCIN[:, GF + 4:GF + 4 + 39]
-        return dET, dW0, db0, dW1, db1, dW2, db2, dWc0, dbc0, dWc1, dbc1, dWc2, dbc2, None
+        k = lambda first, t: t if first else None  # noqa: E731  later nodes of the pass added in place
+        return (dET, k(f_0, dW0), k(f_0, db0), k(f_1, dW1), k(f_1, db1), k(f_2, dW2), k(f_2, db2), k(f_c0, dWc0), k(f_c0, dbc0),
+                k(f_c1, dWc1), k(f_c1, dbc1), k(f_c2, dWc2), k(f_c2, dbc2), None)
 
 
 class SDFValueFn(torch.autograd.Function):
@@ -556,11 +587,16 @@ class SDFValueFn(torch.autograd.Function):
         grad_input(dZ0, W0, M, Kin, Hd, dE)
         dW0 = db0 = dW1 = db1 = dW2 = db2 = None
         if train_w:
-            dW2 = torch.zeros_like(W2); db2 = torch.zeros_like(b2)
+            dW2, db2, f2 = shared_grad(W2, b2)
             hip.weighted_colsum(A1, M, Hd, g, 4, dW2[GF])
-            db2[GF] = g_sdf.sum()
-            dW1, db1 = grad_weight(dZ1, A0, M, Hd, Hd, W1, b1)
-            dW0, db0 = grad_weight(dZ0, E, M, Hd, Kin, W0, b0)
+            db2[GF] += g_sdf.sum()
+            dW1, db1, f1 = shared_grad(W1, b1)
+            grad_weight(dZ1, A0, M, Hd, Hd, W1, b1, acc=(dW1, db1))
+            dW0, db0, f0 = shared_grad(W0, b0)
+            grad_weight(dZ0, E, M, Hd, Kin, W0, b0, acc=(dW0, db0))
+            if not f2: dW2 = db2 = None
+            if not f1: dW1 = db1 = None
+            if not f0: dW0 = db0 = None
         return dE, dW0, db0, dW1, db1, dW2, db2, None, None
 
 
