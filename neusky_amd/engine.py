@@ -136,7 +136,7 @@ def train_iteration(pipeline, optimizers: Optimizers, step: int, **kw):
 
 class GraphedTrainStep:
     """One training iteration captured in a HIP graph (torch.cuda.graph): zero-grad, forward, every loss and the whole
-    backward replay as ONE graph launch, so the ~2300 kernel launches of a step cost no host time; the gradient
+    backward replay as ONE graph launch, so the ~1100 kernel launches of a step cost no host time; the gradient
     all-reduce and the five Adam launches stay outside (the learning rates change every step).
 
     Everything inside the graph has static shapes and no host dependency: the step's inputs live in fixed device
