@@ -273,6 +273,21 @@ class NeuSkyFactoModel(nn.Module):
         bg = self.illumination_field(ray_directions, latents[camera_indices], scales[camera_indices], rot_r)  # :535-549
         return dirs, cols, inverse.to(torch.int32), bg
 
+    def start_illumination(self, ray_bundle: RayBundle, rotation=None, randoms=None) -> None:
+        """Launch the step's illumination decode on the second stream NOW (it depends on nothing but the batch's camera
+        indices, ray directions and the latents); sample_and_forward_field picks the result up.  The pipeline calls this
+        before the DDF-fit ground-truth pass, whose sampler geometry is a run of ~180 small launches that leave the chip
+        idle, so the decode's dense layers fill it."""
+        cam = ray_bundle.camera_indices.reshape(-1)
+        if not (self.training and cam.is_cuda and os.environ.get("NSKY_PARALLEL_ILLUMINATION", "1") != "0"
+                and os.environ.get("NSKY_EARLY_ILLUMINATION", "1") != "0"):
+            return
+        main = torch.cuda.current_stream()
+        side = self._illumination_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._illumination_pending = self.sample_illumination(cam, ray_bundle.directions, rotation, randoms)
+
     def _illumination_stream(self):
         s = getattr(self, "_illum_stream", None)
         if s is None:
@@ -356,7 +371,12 @@ class NeuSkyFactoModel(nn.Module):
         # beside the proposal sampler + field pass (hundreds of small launches): a fork/join that the HIP graph keeps as
         # two parallel branches, forward and backward (autograd replays each node on its forward stream).
         fork = self.training and cam.is_cuda and os.environ.get("NSKY_PARALLEL_ILLUMINATION", "1") != "0"
-        if fork:
+        pending = getattr(self, "_illumination_pending", None)
+        self._illumination_pending = None
+        if fork and pending is not None:  # started by start_illumination (the pipeline, before the DDF-fit ground truth pass)
+            main, side = torch.cuda.current_stream(), self._illumination_stream()
+            dirs, cam_colours, cam_of_ray, hdr_bg = pending
+        elif fork:
             main = torch.cuda.current_stream()
             side = self._illumination_stream()
             side.wait_stream(main)

@@ -126,6 +126,8 @@ class NeuSkyPipeline(nn.Module):
         fit = model.config.fit_visibility_field and model.visibility_field is not None
         fuse = fit and model.config.use_visibility and model.training and os.environ.get("NSKY_FUSE_DDF_FIT", "1") != "0"
         vis_batch = None
+        if model.training:
+            model.start_illumination(ray_bundle, randoms=randoms)  # second stream; joined inside the model's forward
         if fuse:
             # The DDF-fit rays' ground truth only needs the SDF field, so it is produced first and the DDF evaluations
             # of the fit step are handed to compute_visibility to share its launches (same arithmetic as :271-289)
