@@ -125,7 +125,9 @@ _SHARED_GRADS: dict = {}
 
 def shared_grad(like, bias_like):
     """-> (dW, db, first)"""
-    key = (like.data_ptr(), tuple(like.shape), 0 if bias_like is None else bias_like.data_ptr())
+    # per stream: nodes replayed on different streams are ordered only along autograd's edges, so they do not share a buffer
+    sid = torch.cuda.current_stream().cuda_stream if like.is_cuda else 0
+    key = (like.data_ptr(), tuple(like.shape), 0 if bias_like is None else bias_like.data_ptr(), sid)
     hit = _SHARED_GRADS.get(key)
     if hit is not None:
         return hit[1], hit[2], False
