@@ -162,8 +162,11 @@ def begin_step() -> None:
 def _planes(W, n_rows, n_k, transpose, precision):
     key = (W.data_ptr(), W._version, ld(W), n_rows, n_k, transpose, precision)
     hit = _PLANES.get(key)
+    cur = torch.cuda.current_stream()
     if hit is None:
-        hit = _PLANES[key] = (W, hip.split_planes(W, n_rows, n_k, transpose, precision))
+        hit = _PLANES[key] = (W, hip.split_planes(W, n_rows, n_k, transpose, precision), cur)
+    elif hit[2] != cur:  # split on another stream (parallel passes of one step share the weights): order this stream after it
+        cur.wait_stream(hit[2])
     return hit[1]
 
 
