@@ -93,7 +93,7 @@ int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream);
  *   nsky_split_planes: planes(n, k) = W[n][k] (transpose = 0: forward layers, W = torch Linear weight [out, in]) or
  *                      W[k][n] (transpose = 1: input gradients dX = dZ W); hi / lo are [rows_pad][ldp] uint16, zero padded,
  *                      rows_pad % 256 == 0, ldp % 32 == 0.
- *   nsky_gemm_f32_planes: d->B, ldb, b_kcontig are ignored; A must be k-contiguous; K % 32 == 0; no split-K, no a_rowsum;
+ *   nsky_gemm_f32_planes: d->B, ldb, b_kcontig are ignored; A must be k-contiguous; K % 4 == 0 (finite A); no split-K, no a_rowsum;
  *                      d->precision selects the plane format (must match the split); epilogues as nsky_gemm_f32. */
 int nsky_split_planes(const float* W, int32_t n_rows, int32_t n_k, int32_t ldw, int32_t transpose, int32_t precision,
                       uint16_t* hi, uint16_t* lo, int32_t rows_pad, int32_t ldp, nsky_stream_t stream);

@@ -800,7 +800,8 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : NSKY_LAB_OCC) void gemm_
 // ds_read_b128 operand fetch (32 rows x one chunk) is bank-conflict free.  A chunks after the split: 2q = hi(k 8q..8q+7),
 // 2q+1 = lo; B chunks: 0..3 = hi plane k 0..31, 4..7 = lo plane.
 // LDS: 3 x 16 KB (A ring) + 2 x BN x 128 B (B ring) = 80 KB (BN = 128, two workgroups per CU) or 112 KB (BN = 256, one).
-// Requires K % 32 == 0 (no partial k-tile), planes zero padded to whole 128-row tiles; M tails re-read row M-1.
+// Requires K % 4 == 0 and planes zero padded to whole 256-row x 32-k tiles; a partial last k-tile re-reads column 0 of A for
+// the missing chunks (multiplied by the planes' zero padding), M tails re-read row M-1.
 // =================================================================================================
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
   // LDS-DMA hidden from hipcc's waitcnt bookkeeping (it would drain vmcnt(0) before every ds_read otherwise); M0 is saved
@@ -836,18 +837,21 @@ __global__ __launch_bounds__(2 * BN, BN == 128 ? 2 : 1) void gemm_planes_kernel(
   int m_tile, n_tile;
   tile_of_block((N + BN - 1) / BN, m_tile, n_tile);
   const int m0 = m_tile * 128, n0 = n_tile * BN;
-  const int T = K / 32;
+  const int T = (K + 31) / 32;  // a partial last k-tile reads its missing A chunks from column 0 (any finite data: the planes
+                                // are zero there), so K only has to be a multiple of 4
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
   // DMA geometry of this lane: A instruction j of streaming wave aw fills rows 8 (NA aw + j) + lane / 8, B instruction j of
   // streaming wave bw rows 8 (NB bw + j) + lane / 8, chunk position lane % 8
   const int prow = lane >> 3, ppos = lane & 7;
   const float* a_src[NA];
+  int a_col[NA];
   const uint16_t* b_src[NB];
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int r = 8 * (NA * aw + j) + prow;
     const int c = ppos ^ ((r >> 1) & 7);
+    a_col[j] = 4 * c;
     a_src[j] = A + (long)min(m0 + r, M - 1) * lda + 4 * c;
   }
 #pragma unroll
@@ -860,7 +864,7 @@ __global__ __launch_bounds__(2 * BN, BN == 128 ? 2 : 1) void gemm_planes_kernel(
   auto issue_a = [&](int t) {
     const uint32_t dst = lds0 + (t % A_STAGES) * STAGE + a_off;
 #pragma unroll
-    for (int j = 0; j < NA; ++j) glds16(a_src[j] + t * 32, dst + j * 1024);
+    for (int j = 0; j < NA; ++j) glds16(t * 32 + a_col[j] < K ? a_src[j] + t * 32 : a_src[j] - a_col[j], dst + j * 1024);
   };
   auto issue_b = [&](int t) {
     const uint32_t dst = lds0 + B_OFF + (t % B_STAGES) * B_STAGE + bw * (NB * 1024);
@@ -1230,9 +1234,9 @@ extern "C" int nsky_split_planes(const float* W, int32_t n_rows, int32_t n_k, in
 
 extern "C" int nsky_gemm_f32_planes(const nsky_gemm_desc* d, const uint16_t* B_hi, const uint16_t* B_lo, int32_t ldp, nsky_stream_t stream) {
   NSKY_CHECK_ARG(d && d->A && d->C && B_hi && B_lo, "nsky_gemm_f32_planes: null operand");
-  NSKY_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0 && d->K % 32 == 0, "nsky_gemm_f32_planes: K=%d must be a positive multiple of 32", d->K);
+  NSKY_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0 && d->K % 4 == 0, "nsky_gemm_f32_planes: K=%d must be a positive multiple of 4", d->K);
   NSKY_CHECK_ARG(d->a_kcontig && d->lda >= d->K && d->lda % 4 == 0 && ((uintptr_t)d->A % 16) == 0, "nsky_gemm_f32_planes: A must be k-contiguous, 16-byte aligned, lda %% 4 == 0");
-  NSKY_CHECK_ARG(ldp >= d->K && ldp % 8 == 0 && ((uintptr_t)B_hi % 16) == 0 && ((uintptr_t)B_lo % 16) == 0, "nsky_gemm_f32_planes: planes must be 16-byte aligned with ldp %% 8 == 0");
+  NSKY_CHECK_ARG(ldp >= (d->K + 31) / 32 * 32 && ldp % 8 == 0 && ((uintptr_t)B_hi % 16) == 0 && ((uintptr_t)B_lo % 16) == 0, "nsky_gemm_f32_planes: planes must be 16-byte aligned with ldp %% 8 == 0 and cover K rounded up to 32");
   NSKY_CHECK_ARG(d->ldc >= d->N, "nsky_gemm_f32_planes: ldc < N");
   NSKY_CHECK_ARG(d->k_splits <= 1 && d->a_rowsum == nullptr, "nsky_gemm_f32_planes: no split-K / row sums");
   NSKY_CHECK_ARG(d->precision == NSKY_PREC_F16X2 || d->precision == NSKY_PREC_BF16X2, "nsky_gemm_f32_planes: precision must be F16X2 or BF16X2");

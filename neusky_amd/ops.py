@@ -51,7 +51,7 @@ FILM_ROW_CHUNK = int(_os.environ.get("NSKY_FILM_ROW_CHUNK", "0"))
 
 def fgemm(A, W, Cout, M, N, K, **k):
     """forward-pass dense layer (W = [out, in] weight, k-contiguous)"""
-    if USE_PLANES_FWD and FWD_PRECISION == hip.PREC_F16X2 and K % 32 == 0 and N > 64 and M >= 4096:
+    if USE_PLANES_FWD and FWD_PRECISION == hip.PREC_F16X2 and K % _PLANES_K_STEP == 0 and K >= _PLANES_MIN_K and N > 64 and M >= 4096:
         return hip.gemm_planes(A, _planes(W, N, K, False, FWD_PRECISION), Cout, M, N, K, precision=FWD_PRECISION, **k)
     return hip.gemm(A, W, Cout, M, N, K, precision=FWD_PRECISION, **k)
 
@@ -153,6 +153,8 @@ def grad_bias(dZ, M, n_out, like):
 _PLANES: dict = {}
 USE_PLANES = _os.environ.get("NSKY_GEMM_PLANES", "1") != "0"
 USE_PLANES_FWD = _os.environ.get("NSKY_GEMM_PLANES_FWD", "1") != "0"
+_PLANES_K_STEP = 4 if _os.environ.get("NSKY_PLANES_KTAIL", "1") != "0" else 32
+_PLANES_MIN_K = int(_os.environ.get("NSKY_PLANES_MIN_K", "36"))  # below: the layer is all epilogue, the 32-deep k-tile mostly padding
 
 
 def begin_step() -> None:
@@ -176,7 +178,7 @@ def ld(t):
 
 def grad_input(dZ, W, M, k_in, n_red, out, **epi):
     """dX[M, k_in] = dZ[M, n_red] @ W[n_red, k_in]   (W stored [out, in] = [n_red, k_in])."""
-    if USE_PLANES and BWD_PRECISION == hip.PREC_BF16X2 and n_red % 32 == 0 and k_in > 64 and M >= 4096:
+    if USE_PLANES and BWD_PRECISION == hip.PREC_BF16X2 and n_red % _PLANES_K_STEP == 0 and n_red >= _PLANES_MIN_K and k_in > 64 and M >= 4096:
         return hip.gemm_planes(dZ, _planes(W, k_in, n_red, True, BWD_PRECISION), out, M, k_in, n_red, precision=BWD_PRECISION, **epi)
     return hip.gemm(dZ, W, out, M, k_in, n_red, a_kcontig=True, b_kcontig=False, precision=BWD_PRECISION, **epi)
 

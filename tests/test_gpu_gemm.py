@@ -199,11 +199,13 @@ def test_f16_scaled_split_range_and_accuracy():
 
 
 @pytest.mark.parametrize("M,N,K,prec_name", [(128, 128, 32, "f16x2"), (1000, 300, 256, "f16x2"), (4096, 2560, 256, "f16x2"),
-                                             (777, 257, 64, "bf16x2"), (4099, 256, 2560, "bf16x2"), (2048, 128, 128, "f16x2")])
+                                             (777, 257, 64, "bf16x2"), (4099, 256, 2560, "bf16x2"), (2048, 128, 128, "f16x2"),
+                                             (4096, 256, 72, "f16x2"), (1031, 256, 300, "bf16x2"), (513, 128, 36, "f16x2")])
 def test_planes_kernel_matches_register_staged_kernel(M, N, K, prec_name):
     """nsky_split_planes + nsky_gemm_f32_planes (LDS-DMA kernel, pre-split weights): same MFMA sequence as nsky_gemm_f32 at
     that precision -> bit-identical results; and within the precision's bound of the float64 product.  Row tails (M % 128),
-    column tails (N % 128), both plane orientations (forward layer / input gradient) and a fused epilogue."""
+    column tails (N % 128), partial last k-tiles (K % 32), both plane orientations (forward layer / input gradient) and a
+    fused epilogue."""
     from neusky_amd import hip
     dev = "cuda:0"
     prec = hip.PREC_F16X2 if prec_name == "f16x2" else hip.PREC_BF16X2
@@ -215,7 +217,7 @@ def test_planes_kernel_matches_register_staged_kernel(M, N, K, prec_name):
         # the register-staged kernel wants ld % 4 == 0: a [K, N] weight lives in a padded buffer
         W = (torch.randn(K, ldc, device=dev) / K**0.5)[:, :N] if transpose else torch.randn(N, K, device=dev) / K**0.5
         planes = hip.split_planes(W, N, K, transpose, prec)
-        assert planes.shape == (2, (N + 255) // 256 * 256, K) and planes.dtype == torch.int16
+        assert planes.shape == (2, (N + 255) // 256 * 256, (K + 31) // 32 * 32) and planes.dtype == torch.int16
         ref_c = torch.full((M, ldc), float("nan"), device=dev)
         new_c = torch.full((M, ldc), float("nan"), device=dev)
         hip.gemm(A, W, ref_c, M, N, K, b_kcontig=not transpose, bias=b, epi=hip.EPI_LEAKY, p0=0.2, precision=prec)
@@ -246,11 +248,14 @@ def test_planes_kernel_film_backward_epilogue_and_argument_checks():
         outs.append((dz, dF, dP))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
-    # K must be a whole number of 32-deep tiles; the planes must carry the padding the kernel reads
-    A = torch.randn(256, 48, device=dev)
-    Wb = torch.randn(128, 48, device=dev)
+    # K must be a multiple of 4 (16-byte chunks); the planes must carry the padding the kernel reads
+    A = torch.randn(256, 52, device=dev)
+    Wb = torch.randn(128, 52, device=dev)
     with pytest.raises(hip.NeuSkyHipError):
-        hip.gemm_planes(A, hip.split_planes(Wb, 128, 48, False, hip.PREC_F16X2), torch.empty(256, 128, device=dev), 256, 128, 48,
+        hip.gemm_planes(A[:, :50], hip.split_planes(Wb, 128, 50, False, hip.PREC_F16X2), torch.empty(256, 128, device=dev), 256, 128, 50,
+                        precision=hip.PREC_F16X2)
+    with pytest.raises(hip.NeuSkyHipError):  # planes of a 32-wide split handed to a 52-deep product
+        hip.gemm_planes(A, hip.split_planes(Wb, 128, 32, False, hip.PREC_F16X2), torch.empty(256, 128, device=dev), 256, 128, 52,
                         precision=hip.PREC_F16X2)
     with pytest.raises(hip.NeuSkyHipError):
         hip.gemm_planes(torch.randn(256, 64, device=dev), hip.split_planes(torch.randn(128, 64, device=dev), 128, 64, False, hip.PREC_F16X2),
