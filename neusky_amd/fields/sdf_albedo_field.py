@@ -230,10 +230,11 @@ class SDFAlbedoField(nn.Module):
         sdf = ops.SDFValueFn.apply(E, *self._geo_weights(), self.softplus_beta, True)
         return sdf[:, None]
 
-    def field_values(self, positions_flat: torch.Tensor):
-        """sdf [N], gradients [N,3], albedo [N,3] at flat positions (sdf_albedo_field.py:225-246)."""
+    def field_values(self, positions_flat: torch.Tensor, want_albedo: bool = True):
+        """sdf [N], gradients [N,3], albedo [N,3] at flat positions (sdf_albedo_field.py:225-246).  want_albedo=False: the
+        colour net is skipped each way and albedo comes back as zeros (geometry-only passes: DDF-fit ground truth, grid probe)."""
         ET = self._encode(positions_flat.detach(), True, False)
-        return ops.SDFAlbedoFn.apply(ET, *self._geo_weights(), *self._colour_weights(), self.softplus_beta)
+        return ops.SDFAlbedoFn.apply(ET, *self._geo_weights(), *self._colour_weights(), self.softplus_beta, want_albedo)
 
     def get_alpha(self, ray_samples: RaySamples, sdf: Optional[torch.Tensor] = None, gradients: Optional[torch.Tensor] = None):
         """nerfstudio SDFField.get_alpha for isolated samples (used by the hash-grid density probe,
@@ -250,7 +251,8 @@ class SDFAlbedoField(nn.Module):
                                              self._cos_anneal_ratio)
         return w  # with a single sample, weight == alpha
 
-    def get_outputs(self, ray_samples: RaySamples, density_embedding=None, return_alphas: bool = False) -> Dict:
+    def get_outputs(self, ray_samples: RaySamples, density_embedding=None, return_alphas: bool = False,
+                    want_albedo: bool = True) -> Dict:
         """sdf_albedo_field.py:211-269.  Besides the reference keys, `weights` [R,S,1], `bg_transmittance` [R,1],
         `accumulation` [R,1] and `p2p_dist` [R,1] come out of the same fused NeuS kernel when return_alphas."""
         if ray_samples.camera_indices is None:
@@ -258,7 +260,7 @@ class SDFAlbedoField(nn.Module):
         fr = ray_samples.frustums
         R, S = fr.origins.shape[:2]
         x = fr.get_start_positions().reshape(-1, 3)
-        sdf, grad, albedo = self.field_values(x)
+        sdf, grad, albedo = self.field_values(x, want_albedo)
         outputs = {
             NeuSkyFieldHeadNames.ALBEDO: albedo.view(R, S, 3),
             FieldHeadNames.SDF: sdf.view(R, S, 1),
@@ -276,5 +278,6 @@ class SDFAlbedoField(nn.Module):
             outputs["p2p_dist_unclipped"] = dep[:, None]
         return outputs
 
-    def forward(self, ray_samples: RaySamples, compute_normals: bool = False, return_alphas: bool = False) -> Dict:
-        return self.get_outputs(ray_samples, return_alphas=return_alphas)
+    def forward(self, ray_samples: RaySamples, compute_normals: bool = False, return_alphas: bool = False,
+                want_albedo: bool = True) -> Dict:
+        return self.get_outputs(ray_samples, return_alphas=return_alphas, want_albedo=want_albedo)

@@ -442,7 +442,7 @@ class NeuSkyFactoModel(nn.Module):
     def _grid_alpha(self, grid_samples: RaySamples) -> torch.Tensor:
         x = grid_samples.frustums.origins
         d = grid_samples.frustums.directions
-        sdf, grad, _ = self.field.field_values(x)
+        sdf, grad, _ = self.field.field_values(x, want_albedo=False)
         P = x.shape[0]
         cols = []
         for a in range(3):
@@ -593,7 +593,7 @@ class NeuSkyFactoModel(nn.Module):
         ray_bundle = self.collider(ray_bundle)
         sub = None if randoms is None or "ddf_jitters" not in randoms else {"jitters": randoms["ddf_jitters"]}
         ray_samples, _, _, _, _ = self._sample(ray_bundle, sub)
-        fo = self.field(ray_samples, return_alphas=True)
+        fo = self.field(ray_samples, return_alphas=True, want_albedo=False)  # depth / mask / normals only (:1337-1367)
         weights = fo["weights"]
         accumulations = weights.sum(dim=-2).reshape(-1, 1)
         mask = (accumulations > mask_threshold).float()

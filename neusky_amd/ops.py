@@ -463,7 +463,7 @@ class SDFAlbedoFn(torch.autograd.Function):
     Returns sdf [N], gradients [N,3], albedo [N,3]."""
 
     @staticmethod
-    def forward(ctx, ET, W0, b0, W1, b1, W2, b2, Wc0, bc0, Wc1, bc1, Wc2, bc2, beta):
+    def forward(ctx, ET, W0, b0, W1, b1, W2, b2, Wc0, bc0, Wc1, bc1, Wc2, bc2, beta, want_albedo=True):
         N = ET.shape[0] // 4
         dev = ET.device
         Hd = W0.shape[0]
@@ -485,17 +485,25 @@ class SDFAlbedoFn(torch.autograd.Function):
         G = torch.zeros(3 * N, 4, device=dev)
         fgemm(A1[N:], W2[GF:GF + 1], G, 3 * N, 1, Hd)  # d sdf / d x_k = tangent . w_sdf
         Hc = Wc0.shape[0]
-        C0 = torch.empty(N, Hc, device=dev)
-        fgemm(CIN, Wc0, C0, N, Hc, ldc, bias=bc0, epi=hip.EPI_RELU)
-        C1 = torch.empty(N, Hc, device=dev)
-        fgemm(C0, Wc1, C1, N, Hc, Hc, bias=bc1, epi=hip.EPI_RELU)
-        ALB = torch.zeros(N, 4, device=dev)
-        fgemm(C1, Wc2, ALB, N, 3, Hc, bias=bc2, epi=hip.EPI_SIGMOID, p0=1.0)
+        if want_albedo:
+            C0 = torch.empty(N, Hc, device=dev)
+            fgemm(CIN, Wc0, C0, N, Hc, ldc, bias=bc0, epi=hip.EPI_RELU)
+            C1 = torch.empty(N, Hc, device=dev)
+            fgemm(C0, Wc1, C1, N, Hc, Hc, bias=bc1, epi=hip.EPI_RELU)
+            ALB = torch.zeros(N, 4, device=dev)
+            fgemm(C1, Wc2, ALB, N, 3, Hc, bias=bc2, epi=hip.EPI_SIGMOID, p0=1.0)
+        else:  # geometry-only pass (DDF-fit ground truth, hash-grid density probe): the colour net's output is never read
+            C0 = C1 = ALB = CIN.new_empty(0)
         ctx.save_for_backward(ET, A0, S0, A1, S1, CIN, C0, C1, ALB, W0, b0, W1, b1, W2, b2, Wc0, bc0, Wc1, bc1, Wc2, bc2)
         ctx.cfg = (N, Hd, Kin, GF, ldc, Hc, beta)
+        ctx.want_albedo = want_albedo
         ctx.set_materialize_grads(False)
         sdf = CIN[:, GF].clone()
         grad = G.view(3, N, 4)[:, :, 0].t().contiguous()
+        if not want_albedo:
+            alb = sdf.new_zeros(N, 3)
+            ctx.mark_non_differentiable(alb)
+            return sdf, grad, alb
         return sdf, grad, ALB[:, :3].clone()
 
     @staticmethod
@@ -503,6 +511,11 @@ class SDFAlbedoFn(torch.autograd.Function):
         ET, A0, S0, A1, S1, CIN, C0, C1, ALB, W0, b0, W1, b1, W2, b2, Wc0, bc0, Wc1, bc1, Wc2, bc2 = ctx.saved_tensors
         N, Hd, Kin, GF, ldc, Hc, beta = ctx.cfg
         dev = ET.device
+        colour = ctx.want_albedo and g_alb is not None
+        if not colour:
+            # no gradient reaches the colour net (geometry-only pass, or albedo unused downstream): only the sdf slot of the
+            # geo net's [feat | sdf | 0 0 0] output carries one
+            return SDFAlbedoFn._backward_geo(ctx, g_sdf, g_grad, None)
         # ---- colour net
         dpc2 = torch.zeros(N, 4, device=dev)
         if g_alb is not None:
@@ -524,7 +537,22 @@ class SDFAlbedoFn(torch.autograd.Function):
         dCIN[:, GF:GF + 4] = 0.0
         if g_sdf is not None:
             dCIN[:, GF] = g_sdf
-        dH = dCIN[:, :GF + 4]
+        return SDFAlbedoFn._backward_geo(ctx, g_sdf, g_grad, (dCIN, dWc0, dbc0, f_c0, dWc1, dbc1, f_c1, dWc2, dbc2, f_c2))
+
+    @staticmethod
+    def _backward_geo(ctx, g_sdf, g_grad, colour):
+        """geo-net part of the backward; colour = (dCIN, colour-net weight gradients ...) or None when the colour net took none"""
+        ET, A0, S0, A1, S1, CIN, C0, C1, ALB, W0, b0, W1, b1, W2, b2, Wc0, bc0, Wc1, bc1, Wc2, bc2 = ctx.saved_tensors
+        N, Hd, Kin, GF, ldc, Hc, beta = ctx.cfg
+        dev = ET.device
+        if colour is not None:
+            dCIN, dWc0, dbc0, f_c0, dWc1, dbc1, f_c1, dWc2, dbc2, f_c2 = colour
+            dH = dCIN[:, :GF + 4]
+        else:
+            dCIN = None
+            dH = torch.zeros(N, GF + 4, device=dev)
+            if g_sdf is not None:
+                dH[:, GF] = g_sdf
         # ---- geo net, last layer (value rows)
         dW2, db2, f_2 = shared_grad(W2, b2)
         grad_weight(dH, A1[:N], N, GF + 4, Hd, W2, b2, acc=(dW2, db2))
@@ -551,11 +579,14 @@ class SDFAlbedoFn(torch.autograd.Function):
         grad_weight(D0, ET, 4 * N, Hd, Kin, W0, b0, bias_rows=N, acc=(dW0, db0))
         dET = torch.empty(4 * N, Kin, device=dev)
         grad_input(D0, W0, 4 * N, Kin, Hd, dET)
-        # x / PE columns of the colour-net input came straight from the encode row
-        dET[:N, :39] += dCIN[:, GF + 4:GF + 4 + 39]
+        if dCIN is not None:  # x / PE columns of the colour-net input came straight from the encode row
+            dET[:N, :39] += dCIN[:, GF + 4:GF + 4 + 39]
         k = lambda first, t: t if first else None  # noqa: E731  later nodes of the pass added in place
+        if colour is None:
+            return (dET, k(f_0, dW0), k(f_0, db0), k(f_1, dW1), k(f_1, db1), k(f_2, dW2), k(f_2, db2), None, None, None, None, None, None,
+                    None, None)
         return (dET, k(f_0, dW0), k(f_0, db0), k(f_1, dW1), k(f_1, db1), k(f_2, dW2), k(f_2, db2), k(f_c0, dWc0), k(f_c0, dbc0),
-                k(f_c1, dWc1), k(f_c1, dbc1), k(f_c2, dWc2), k(f_c2, dbc2), None)
+                k(f_c1, dWc1), k(f_c1, dbc1), k(f_c2, dWc2), k(f_c2, dbc2), None, None)
 
 
 class SDFValueFn(torch.autograd.Function):
