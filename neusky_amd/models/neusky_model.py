@@ -317,19 +317,23 @@ class NeuSkyFactoModel(nn.Module):
         Dv = sel.numel()
         sel_dirs = illumination_directions[sel.long()].contiguous()
         M = R * Dv
-        sphere_pts = torch.empty(M, 3, device=dev)
-        xrow = torch.empty(M, 16, device=dev)
+        ddf = self.visibility_field
+        extra = getattr(self, "_extra_ddf", None) if self.training else None
+        E = extra["positions"].shape[0] if extra is not None else 0
+        # the DDF-fit rows (rays | multi-view | sky, ddf_model.py:217,319,360) ride behind the visibility rows in the same
+        # buffers: the ray kernel writes the first M rows in place, the few fit rows are copied in (no 17 MB torch.cat)
+        pts_all = torch.empty(M + E, 3, device=dev)
+        xrow_all = torch.empty(M + E, 16, device=dev)
+        sphere_pts, xrow = pts_all[:M], xrow_all[:M]
         surf_dist = torch.empty(M, device=dev)
         term_dist = torch.empty(M, device=dev)
         hip.visibility_rays(origins.detach().contiguous(), ray_directions.detach().contiguous(),
                             depth.detach().reshape(-1).contiguous(), sel_dirs, self.ddf_radius, sphere_pts, xrow, surf_dist, term_dist)
-        ddf = self.visibility_field
-        extra = getattr(self, "_extra_ddf", None) if self.training else None
         if extra is not None:
-            # rows of the DDF-fit step (rays | multi-view | sky, ddf_model.py:217,319,360) appended to the visibility rows
             local = torch.einsum("ijl,ij->il", ddf.get_localised_transforms(extra["positions"]), extra["directions"])
-            t_all = ddf.field.forward_rows(torch.cat([sphere_pts, extra["positions"]], 0),
-                                           torch.cat([xrow, ddf.field.direction_rows(local)], 0))
+            pts_all[M:] = extra["positions"]
+            xrow_all[M:] = ddf.field.direction_rows(local)
+            t_all = ddf.field.forward_rows(pts_all, xrow_all)
             t_hat, t_extra = t_all[:M], t_all[M:]
         else:
             t_hat = ddf.field.forward_rows(sphere_pts, xrow)  # :1716 -> ddf_model.py:217
