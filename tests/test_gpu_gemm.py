@@ -302,3 +302,29 @@ def test_weight_gradient_row_sums_over_leading_rows_only(prec):
         assert (db.double() - ref_b).abs().max().item() < 1e-4 * ref_b.abs().max().item()
     with pytest.raises(hip.NeuSkyHipError):
         hip.gemm(dZ, X, dW, n_out, k_in, N4, a_kcontig=False, b_kcontig=False, k_splits=8, a_rowsum=db, rowsum_k_limit=100, precision=p)
+
+
+def test_planes_kernel_race_screen():
+    """The LDS-DMA kernel orders its DMA writes, in-place splits and fragment reads with hand-counted vmcnt waits and one
+    barrier per k-tile: a mis-count shows up as rare wrong tiles that come and go with load.  Screen: 40 back-to-back launches
+    at the step's largest shapes (other launches in flight, L2 / HBM busy), every result compared bit for bit with the
+    register-staged kernel's."""
+    from neusky_amd import hip
+    dev = "cuda:0"
+    torch.manual_seed(9)
+    for (M, N, K, prec, transpose) in [(262144, 256, 256, hip.PREC_F16X2, False), (65536, 256, 2560, hip.PREC_BF16X2, True),
+                                       (153600, 128, 128, hip.PREC_F16X2, False), (98304, 256, 72, hip.PREC_F16X2, False)]:
+        A = torch.randn(M, K, device=dev)
+        W = (torch.randn(K, N, device=dev) if transpose else torch.randn(N, K, device=dev)) / K**0.5
+        ref = torch.empty(M, N, device=dev)
+        hip.gemm(A, W, ref, M, N, K, b_kcontig=not transpose, precision=prec)
+        planes = hip.split_planes(W, N, K, transpose, prec)
+        outs = [torch.empty(M, N, device=dev) for _ in range(4)]
+        bad = 0
+        for it in range(40):
+            o = outs[it % 4]
+            o.fill_(float("nan"))
+            hip.gemm_planes(A, planes, o, M, N, K, precision=prec)
+            if it % 4 == 3:
+                bad += sum(int(not torch.equal(x, ref)) for x in outs)
+        assert bad == 0, (M, N, K, bad)
