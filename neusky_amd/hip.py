@@ -51,6 +51,9 @@ class GemmDesc(C.Structure):
 
 _lib.nsky_last_error.restype = C.c_char_p
 _lib.nsky_abi_version.restype = C.c_int
+ABI_VERSION = 2  # the ctypes structures below mirror this version of include/neusky_hip.h
+if _lib.nsky_abi_version() != ABI_VERSION:
+    raise NeuSkyHipError(f"libneusky_hip.so has ABI version {_lib.nsky_abi_version()}, this package binds version {ABI_VERSION}: rebuild (build.sh)")
 
 
 def _sig(name, *argtypes):
