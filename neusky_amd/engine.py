@@ -79,10 +79,14 @@ class _Group:
         self.name, self.opt, self.sched = name, opt, sched
         self.params = [p for p in params if p.requires_grad]
         # every parameter starts on a 16-byte boundary of the slab (the GEMM operands are read with float4 loads)
-        n = sum((p.numel() + 3) // 4 * 4 for p in self.params)
+        self.numel = sum((p.numel() + 3) // 4 * 4 for p in self.params)
+
+    def bind(self, flat_g: torch.Tensor) -> None:
+        """flat_g: this group's slice of the ONE gradient slab all groups share (one zero fill, one all-reduce per step)"""
+        n = self.numel
         dev = self.params[0].device
         self.flat_p = torch.zeros(n, device=dev)
-        self.flat_g = torch.zeros(n, device=dev)
+        self.flat_g = flat_g
         self.m = torch.zeros(n, device=dev)
         self.v = torch.zeros(n, device=dev)
         off = 0
@@ -93,8 +97,8 @@ class _Group:
             p.grad = self.flat_g[off:off + k].view_as(p)
             p._nsky_grad_sink = _GRAD_SINK  # custom backward passes may accumulate into p.grad directly (zeroed by zero_grad_all)
             off += (k + 3) // 4 * 4
-        if isinstance(sched, ExponentialDecaySchedulerConfig):
-            sched.lr_init = opt.lr
+        if isinstance(self.sched, ExponentialDecaySchedulerConfig):
+            self.sched.lr_init = self.opt.lr
         self.steps = 0
 
 
@@ -103,18 +107,26 @@ class Optimizers:
         self.groups = [_Group(k, param_groups[k], config[k]["optimizer"], config[k]["scheduler"])
                        for k in config if k in param_groups and len(param_groups[k]) > 0]
         self.world_size = world_size
+        # ONE gradient slab for all groups: a step zero-fills it once and all-reduces it once (~110 MB, dominated by the two
+        # hash tables) instead of five messages of which three are latency-only (the visibility threshold is one float)
+        self.flat_g = torch.zeros(sum(g.numel for g in self.groups), device=self.groups[0].params[0].device)
+        off = 0
+        for g in self.groups:
+            g.bind(self.flat_g[off:off + g.numel])
+            off += g.numel
 
     def zero_grad_all(self) -> None:
-        for g in self.groups:
-            g.flat_g.zero_()
+        self.flat_g.zero_()
 
     def all_reduce_gradients(self) -> None:
-        """one RCCL all-reduce (mean) per optimizer slab; 5 messages, the 'fields' and 'ddf_field' slabs carry the hash tables"""
+        """one all-reduce (mean) of the whole gradient slab over RCCL / xGMI"""
         if self.world_size <= 1:
             return
-        for g in self.groups:
-            dist.all_reduce(g.flat_g, op=dist.ReduceOp.SUM)
-            g.flat_g.div_(self.world_size)
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.AVG)
+        else:  # gloo (CPU tests) has no AVG
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+            self.flat_g.div_(self.world_size)
 
     def optimizer_scheduler_step_all(self, step: int) -> None:
         for g in self.groups:

@@ -33,7 +33,19 @@ def _worker(rank, world, port, out_q):
     # reference: one process, concatenated batch (batch-mean losses => average, not sum, of the shard gradients)
     w2, b2 = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
     ((X @ w2.T + b2 - Y) ** 2).mean().backward()
-    out_q.put((rank, w.detach().clone(), w.grad.clone(), b.grad.clone(), unused.grad.clone(), w2.grad.clone(), b2.grad.clone()))
+    # the engine's form (bench.py / train loop): every optimizer group's gradients live in ONE slab that is all-reduced once;
+    # a parameter that receives no gradient keeps its zero-filled slot (find_unused_parameters semantics, neusky_pipeline.py:199)
+    from neusky_amd.engine import AdamOptimizerConfig, Optimizers
+    wa = torch.nn.Parameter(w.detach().clone()); ba = torch.nn.Parameter(b.detach().clone()); ua = torch.nn.Parameter(torch.randn(3))
+    opt = Optimizers({"fields": {"optimizer": AdamOptimizerConfig(), "scheduler": None},
+                      "ddf_field": {"optimizer": AdamOptimizerConfig(), "scheduler": None}},
+                     {"fields": [wa, ua], "ddf_field": [ba]}, world_size=world)
+    opt.zero_grad_all()
+    ((xs @ wa.T + ba - ys) ** 2).mean().backward()
+    opt.all_reduce_gradients()
+    slab_ok = (torch.allclose(wa.grad, w.grad, atol=1e-7) and torch.allclose(ba.grad, b.grad, atol=1e-7)
+               and torch.equal(ua.grad, torch.zeros(3)) and wa.grad.data_ptr() == opt.flat_g.data_ptr())
+    out_q.put((rank, w.detach().clone(), w.grad.clone(), b.grad.clone(), unused.grad.clone(), w2.grad.clone(), b2.grad.clone(), slab_ok))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -49,7 +61,8 @@ def test_two_rank_gradient_allreduce_equals_single_process():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, w0, gw0, gb0, gu0, rw0, rb0), (_, w1, gw1, gb1, gu1, _, _) = res
+    (_, w0, gw0, gb0, gu0, rw0, rb0, ok0), (_, w1, gw1, gb1, gu1, _, _, ok1) = res
+    assert ok0 and ok1, "engine.Optimizers: single-slab all-reduce differs from the per-parameter one"
     assert torch.equal(w0, w1), "replicas differ after the parameter broadcast"
     assert torch.allclose(gw0, gw1) and torch.allclose(gb0, gb1), "ranks disagree after the all-reduce"
     assert torch.allclose(gw0, rw0, atol=1e-6) and torch.allclose(gb0, rb0, atol=1e-6), "N-GPU gradient != 1-GPU gradient"
