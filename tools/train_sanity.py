@@ -25,7 +25,7 @@ for i in range(steps):
         hist.append((i, v))
         print(i, round(v, 4), {k: round(float(x), 5) for k, x in ld.items() if k in ("rgb_l1_loss", "eikonal_loss", "depth_l1_loss", "sdf_level_set_visibility_loss")}, flush=True)
 torch.cuda.synchronize()
-print("ms/step", (time.perf_counter() - t0) / steps * 1e3)
+print("ms/step", (time.perf_counter() - t0) / steps * 1e3, " peak GB", torch.cuda.max_memory_allocated() / 1e9, " now GB", torch.cuda.memory_allocated() / 1e9)
 assert all(v == v and abs(v) < 1e6 for _, v in hist), "loss diverged"
 assert hist[-1][1] < 0.5 * hist[0][1], "loss did not fall"
 bad = [n for n, p in pipe.named_parameters() if not torch.isfinite(p).all()]
