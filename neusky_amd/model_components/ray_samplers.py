@@ -32,12 +32,27 @@ class HashMLPDensityField(nn.Module):
         self.lin1 = nn.Linear(hidden_dim, 1)
         self.mode = contraction_mode
 
+    def invalidate_weight_cache(self) -> None:
+        """once per optimisation step: the zero-padded copies of the two small layers are shared by every pass of the step"""
+        self._wcache = {}
+
+    def _padded(self):
+        c = getattr(self, "_wcache", None)
+        key = torch.is_grad_enabled()
+        if c is not None and key in c:
+            return c[key]
+        w = (ops.pad_weight(self.lin0.weight), ops.pad_bias(self.lin0.bias), ops.pad_weight(self.lin1.weight), ops.pad_bias(self.lin1.bias))
+        if c is not None:
+            c[key] = w
+        return w
+
     def raw_density(self, positions: torch.Tensor) -> torch.Tensor:
         """positions [R,n,3] -> pre-activation of the density head, [R*n, 4] (column 0; columns 1-3 are padding)"""
         x = positions.reshape(-1, 3).detach()
         feat = ops.HashEncodeFn.apply(x, self.encoding.table, self.geom, self.mode, False, 0, 0.0, False, False)
-        h = ops.DenseFn.apply(feat, ops.pad_weight(self.lin0.weight), ops.pad_bias(self.lin0.bias), self.lin0.out_features, "relu", True)
-        return ops.DenseFn.apply(h, ops.pad_weight(self.lin1.weight), ops.pad_bias(self.lin1.bias), 1, "none", True)
+        w0, b0, w1, b1 = self._padded()
+        h = ops.DenseFn.apply(feat, w0, b0, self.lin0.out_features, "relu", True)
+        return ops.DenseFn.apply(h, w1, b1, 1, "none", True)
 
     def density_fn(self, positions: torch.Tensor) -> torch.Tensor:
         """positions [R,n,3] -> density [R,n,1].  Under scene contraction every point maps strictly inside

@@ -185,6 +185,8 @@ class NeuSkyFactoModel(nn.Module):
         """start of an optimisation step: drop the per-step caches of prepared (weight-normed / padded) matrices"""
         ops.begin_step()
         self.field.invalidate_weight_cache()
+        for net in self.proposal_networks:
+            net.invalidate_weight_cache()
         self.illumination_field.network.invalidate_weight_cache()
         if self.visibility_field is not None:
             self.visibility_field.field.ddf.invalidate_weight_cache()
