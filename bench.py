@@ -164,7 +164,7 @@ def main():
     from neusky_amd.engine import GraphedTrainStep, Optimizers, neusky_optimizers, train_iteration
     torch.manual_seed(1234 + rank)
     pipe = build_pipeline(device, world, local_rank)
-    from util_step import randomise
+    from neusky_amd.utils.randomise import randomise  # package code: the oracle is only imported by the cpu_baseline leg
     randomise(pipe, seed=rank)  # identical replicas are restored by the parameter broadcast in the pipeline for N>1
     if world > 1:
         pipe.grad_sync.broadcast_parameters()

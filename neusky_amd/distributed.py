@@ -16,14 +16,37 @@ import torch
 import torch.distributed as dist
 
 
+def broadcast_module_state(module: torch.nn.Module, src: int = 0) -> int:
+    """Make every replica identical to rank `src`: EVERY parameter (frozen ones included - the RENI decoder is frozen but
+    drawn from each process's own RNG) and every buffer, like the DDP wrapper's initial state broadcast
+    (neusky/pipelines/neusky_pipeline.py:198-199).  Returns the number of tensors sent."""
+    n = 0
+    seen = set()
+    for t in list(module.parameters()) + list(module.buffers()):
+        if id(t) in seen:
+            continue
+        seen.add(id(t))
+        dist.broadcast(t.data, src=src)
+        n += 1
+    return n
+
+
 class GradientAllReduce:
-    def __init__(self, params: List[torch.nn.Parameter], world_size: int):
+    """Per-parameter form of the gradient all-reduce (any list of parameters, gradients wherever autograd put them).  The
+    training engine does not use it: `engine.Optimizers` keeps all gradients in one slab and all-reduces that in place
+    (`Optimizers.all_reduce_gradients`).  The staging buffer here is therefore allocated on first use only."""
+
+    def __init__(self, params: List[torch.nn.Parameter], world_size: int, module: torch.nn.Module = None):
         self.params = list(params)
         self.world_size = world_size
+        self.module = module
         self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(self.numel, device=self.params[0].device, dtype=torch.float32)
+        self.flat = None
 
     def broadcast_parameters(self, src: int = 0) -> None:
+        if self.module is not None:
+            broadcast_module_state(self.module, src)
+            return
         for p in self.params:
             dist.broadcast(p.data, src=src)
 
@@ -31,6 +54,8 @@ class GradientAllReduce:
         dist.barrier()
 
     def all_reduce(self) -> None:
+        if self.flat is None:
+            self.flat = torch.zeros(self.numel, device=self.params[0].device, dtype=torch.float32)
         off = 0
         for p in self.params:
             n = p.numel()

@@ -118,6 +118,23 @@ class Optimizers:
     def zero_grad_all(self) -> None:
         self.flat_g.zero_()
 
+    def state_dict(self) -> Dict[str, Dict]:
+        """per group: Adam moments, bias-correction step count and the flat parameter slab (what nerfstudio's trainer keeps
+        under "optimizers" / "schedulers" in step-%09d.ckpt; the schedulers here are pure functions of the global step)"""
+        return {g.name: {"m": g.m.detach().clone(), "v": g.v.detach().clone(), "steps": g.steps, "numel": g.numel}
+                for g in self.groups}
+
+    def load_state_dict(self, state: Dict[str, Dict]) -> None:
+        for g in self.groups:
+            if g.name not in state:
+                raise KeyError(f"optimizer state has no group {g.name!r} (has {sorted(state)})")
+            st = state[g.name]
+            if int(st["numel"]) != g.numel:
+                raise ValueError(f"optimizer group {g.name!r}: {st['numel']} saved elements, {g.numel} expected")
+            g.m.copy_(st["m"].to(g.m.device))
+            g.v.copy_(st["v"].to(g.v.device))
+            g.steps = int(st["steps"])
+
     def all_reduce_gradients(self) -> None:
         """one all-reduce (mean) of the whole gradient slab over RCCL / xGMI"""
         if self.world_size <= 1:
@@ -156,8 +173,10 @@ class GraphedTrainStep:
     points are drawn on the device, every training camera's illumination is decoded (no torch.unique), and the
     upper-hemisphere direction subset has the static size D/2 (antipodal direction set)."""
 
-    def __init__(self, pipeline, optimizers: Optimizers, ray_bundle, batch, warmup: int = 3, start_step: int = 0):
-        import copy
+    def __init__(self, pipeline, optimizers: Optimizers, ray_bundle, batch, warmup: int = 3, start_step: int = 0,
+                 randoms: Optional[Dict] = None):
+        """randoms: optional injected random draws (tests): cloned into static device buffers the graph reads on every
+        replay, so a replay can be compared with the eager step / the oracle on the same draws."""
         from .cameras.rays import RayBundle
         self.pipeline, self.opt = pipeline, optimizers
         dev = ray_bundle.origins.device
@@ -168,6 +187,14 @@ class GraphedTrainStep:
         sky = pipeline.datamanager.get_sky_ray_bundle(pipeline.config.num_sky_rays)
         self.sky = RayBundle(origins=c(sky.origins), directions=c(sky.directions))
         self.randoms = {"sky_ray_bundle": self.sky}
+        if randoms is not None:
+            def static(v):
+                if torch.is_tensor(v):
+                    return c(v.to(dev))
+                if isinstance(v, (list, tuple)):
+                    return type(v)(static(x) for x in v)
+                return v
+            self.randoms.update({k: static(v) for k, v in randoms.items() if k != "sky_ray_bundle"})
         self.step_idx = start_step
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

@@ -163,6 +163,16 @@ class IcosahedronSampler:
             if rotation is not None:
                 raise NotImplementedError("remove_lower_hemisphere after a random rotation has a data-dependent size; use __call__")
             return dirs.contiguous(), torch.arange(dirs.shape[0], device=dirs.device, dtype=torch.int32)
+        if rotation is None:
+            # fixed (unrotated) set, e.g. eval with fix_test_illumination_directions: the reference's strict z > 0 mask
+            # (neusky_model.py:1650-1657), computed once on the host -> static shape, equatorial vertices of an icosphere
+            # (z == 0) stay in the lower set like there
+            skey = key + ":sel"
+            if skey not in self._dev_cache:
+                self._dev_cache[skey] = torch.nonzero(self.directions[:, 2] > 0)[:, 0].to(torch.int32).to(device)
+            return dirs.contiguous(), self._dev_cache[skey]
+        # randomly rotated set: exactly D/2 directions have z > 0 for the centrally symmetric sets used here (ties on the
+        # equator have probability zero), so the D/2 largest z ARE the z > 0 subset and the shape is static under a graph
         half = dirs.shape[0] // 2
         sel = torch.sort(torch.topk(dirs[:, 2], half).indices).values.to(torch.int32)
         return dirs.contiguous(), sel

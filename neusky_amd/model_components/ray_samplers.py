@@ -97,13 +97,18 @@ class ProposalNetworkSampler(nn.Module):
         self.num_proposal_network_iterations = num_proposal_network_iterations
         self.histogram_padding = histogram_padding
         self._anneal = 1.0
-        self._anneal_t: Optional[torch.Tensor] = None  # device scalar mirror of _anneal (a captured graph reads it)
+        # device scalar mirror of _anneal: a captured graph reads it, so it is only ever written OUTSIDE a capture
+        self.register_buffer("_anneal_t", torch.ones(1), persistent=False)
         self._u_cache: Dict[Tuple[int, bool, str], torch.Tensor] = {}
 
     def set_anneal(self, anneal: float) -> None:
+        """nerfstudio's set_anneal callback.  The device mirror is NOT written while a HIP graph is being captured: a
+        captured fill would bake the capture-time value into every replay and overwrite what the caller set before the
+        replay (GraphedTrainStep.step writes it eagerly, then replays)."""
         self._anneal = anneal
-        if self._anneal_t is not None:
-            self._anneal_t.fill_(anneal)
+        if self._anneal_t.is_cuda and torch.cuda.is_current_stream_capturing():
+            return
+        self._anneal_t.fill_(anneal)
 
     def _u_base(self, num_bins: int, stratified: bool, device) -> torch.Tensor:
         key = (num_bins, stratified, str(device))
@@ -130,8 +135,6 @@ class ProposalNetworkSampler(nn.Module):
             if lvl == 0:
                 sbins, ebins = hip.uniform_bins(nears, fars, ns, None if jit is None else jit.reshape(-1).contiguous())
             else:
-                if self._anneal_t is None:
-                    self._anneal_t = torch.full((1,), float(self._anneal), device=weights.device)
                 annealed = torch.pow(weights.detach(), self._anneal_t)  # tensor exponent: the value can change under a captured graph
                 sbins, inds = hip.pdf_sample(annealed.contiguous(), sbins, self._u_base(ns + 1, jit is not None, sbins.device),
                                              None if jit is None else jit.reshape(-1).contiguous(), ns + 1,

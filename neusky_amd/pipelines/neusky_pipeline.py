@@ -71,8 +71,8 @@ class NeuSkyPipeline(nn.Module):
         self.grad_sync = None
         if world_size > 1:
             from ..distributed import GradientAllReduce
-            self.grad_sync = GradientAllReduce([p for p in self.parameters() if p.requires_grad], world_size)
-            self.grad_sync.broadcast_parameters()  # identical replicas, then the :200 barrier
+            self.grad_sync = GradientAllReduce([p for p in self.parameters() if p.requires_grad], world_size, module=self)
+            self.grad_sync.broadcast_parameters()  # identical replicas (all parameters, frozen ones too, and buffers), then the :200 barrier
             self.grad_sync.barrier()
 
     @property

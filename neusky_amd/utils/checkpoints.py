@@ -65,3 +65,39 @@ def load_reference_pipeline_state(pipeline, state: Dict[str, torch.Tensor], stri
         elif k.startswith("_model."):
             unmapped.append(k)
     return loaded, unmapped
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# saving / resuming THIS package's runs, in the layout nerfstudio's trainer uses (what the reference's load code expects
+# to find: `<dir>/nerfstudio_models/step-%09d.ckpt` with the pipeline state dict under "pipeline", neusky_pipeline.py:174-194)
+def checkpoint_path(base_dir, step: int):
+    import os
+    return os.path.join(str(base_dir), "nerfstudio_models", f"step-{int(step):09d}.ckpt")
+
+
+def save_checkpoint(base_dir, step: int, pipeline, optimizers=None) -> str:
+    """{"step", "pipeline": state_dict, "optimizers": Adam moments + step counts per group, "schedulers": {}} (the
+    schedulers are pure functions of the global step and carry no state).  Returns the file written."""
+    import os
+    path = checkpoint_path(base_dir, step)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    ckpt = {"step": int(step), "pipeline": {k: v.detach().cpu().clone() for k, v in pipeline.state_dict().items()},
+            "optimizers": {} if optimizers is None else {k: {kk: (vv.cpu() if torch.is_tensor(vv) else vv) for kk, vv in st.items()}
+                                                        for k, st in optimizers.state_dict().items()},
+            "schedulers": {}}
+    torch.save(ckpt, path)
+    return path
+
+
+def load_checkpoint(path, pipeline, optimizers=None) -> int:
+    """resume: parameters are copied IN PLACE (they are views into the optimizer slabs and stay so), Adam moments and the
+    per-group bias-correction counters are restored; returns the step to continue from."""
+    ckpt = torch.load(str(path), map_location="cpu", weights_only=False)
+    pipeline.load_state_dict(ckpt["pipeline"], strict=True)
+    if optimizers is not None:
+        if not ckpt.get("optimizers"):
+            raise ValueError(f"{path}: no optimizer state to resume from")
+        optimizers.load_state_dict(ckpt["optimizers"])
+    if hasattr(pipeline.model, "begin_step"):
+        pipeline.model.begin_step()  # prepared (weight-normed / padded / split) copies of the old weights are stale
+    return int(ckpt["step"])

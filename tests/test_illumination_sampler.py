@@ -52,6 +52,16 @@ def test_sampler_options():
     assert bool((d[:, 2] > 0).all()) and 70 <= d.shape[0] <= 81
 
 
+def test_fixed_icosphere_uses_strict_upper_hemisphere():
+    """eval with fix_test_illumination_directions: the unrotated icosphere has vertices ON the equator; the reference's mask is
+    the strict z > 0 (neusky_model.py:1650-1657), so they get the constant lower-hemisphere visibility, not a DDF query"""
+    s = IcosahedronSamplerConfig(icosphere_order=2, apply_random_rotation=True).setup()
+    dirs, sel = s.on_device("cpu", apply_random_rotation=False)
+    assert dirs.shape[0] == 42 and sel.numel() == 17 and bool((dirs[sel.long(), 2] > 0).all())
+    rest = torch.ones(42, dtype=torch.bool); rest[sel.long()] = False
+    assert bool((dirs[rest, 2] <= 0).all()) and int((dirs[rest, 2] == 0).sum()) == 8
+
+
 def test_default_lattice_unchanged():
     s = IcosahedronSamplerConfig().setup()  # num_directions = 512 (neusky_config.py:97-101): antipodal lattice
     assert torch.equal(s.directions, antipodal_sphere(512))
