@@ -107,6 +107,39 @@ int nsky_weighted_colsum_f32(const float* X, int32_t M, int32_t N, int32_t ldx, 
                              nsky_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * FiLM-SIREN chain as ONE kernel per row tile (no per-layer launches, no [M, 2 n_film H] frequency / phase matrix, no
+ * layer-to-layer activation round trip through HBM).  Replaces the whole module neusky/utils/siren.py:108-208
+ * (CustomMappingNetwork :108-131, FiLMLayer :133-145, DDFFiLMSiren.forward :189-208; frequencies = raw * 15 + 30 :200) at
+ * its call sites neusky/fields/directional_distance_field.py:233-243,275-276 (DDF) and the RENI-shaped illumination
+ * decode driven from neusky/models/neusky_model.py:488-506,535-549.
+ *   net: geometry + the fp32 parameter pointers in torch nn.Linear layout ([out, in], rows contiguous, leading dimensions
+ *        in elements).  hidden = width of the FiLM layers AND of the mapping layers (128 or 256); cond_dim <= 320,
+ *        x_dim <= 16, out_dim <= 4, at most NSKY_FILM_MAX_LAYERS layers each.
+ *   nsky_film_stream_layout: bytes of the packed weight stream and number of 32-feature weight tiles (= tile_scales floats).
+ *   nsky_film_pack: once per optimisation step: every weight tile -> power-of-two scaled fp16 hi + fp16 residual planes in
+ *        MFMA-fragment order (direction 0 = forward stream), one reciprocal scale per tile.
+ *   nsky_film_chain_fwd: cond [M, ldcond] (first cond_dim columns), x [M, ldx] -> res [M, ldres] (first out_dim columns,
+ *        raw head output; columns out_dim..3 are written too).  Side outputs, each [M, hidden] contiguous:
+ *        y_save[i] (FiLM layer outputs; REQUIRED: they are also the hand-off to the next layer), z_save[i] (FiLM
+ *        pre-activations W y + b; optional), h_save[l] (mapping activations after LeakyReLU(0.2); optional).
+ *        Products are fp32-grade (three fp16 MFMAs on power-of-two pre-scaled hi / residual planes, fp32 accumulate).
+ */
+#define NSKY_FILM_MAX_LAYERS 12
+typedef struct nsky_film_net {
+  int32_t hidden, n_map, n_film;
+  int32_t cond_dim, x_dim, out_dim;
+  const float* map_w[NSKY_FILM_MAX_LAYERS]; const float* map_b[NSKY_FILM_MAX_LAYERS]; int32_t map_ld[NSKY_FILM_MAX_LAYERS];
+  const float* mo_w; const float* mo_b; int32_t mo_ld;     /* mapping head [2 n_film hidden, hidden]: frequencies, then phases */
+  const float* film_w[NSKY_FILM_MAX_LAYERS]; const float* film_b[NSKY_FILM_MAX_LAYERS]; int32_t film_ld[NSKY_FILM_MAX_LAYERS];
+  const float* out_w; const float* out_b; int32_t out_ld;  /* head [out_dim, hidden] */
+} nsky_film_net;
+int nsky_film_stream_layout(const nsky_film_net* net, int32_t direction, int64_t* stream_bytes, int32_t* n_tiles);
+int nsky_film_pack(const nsky_film_net* net, int32_t direction, void* stream_buf, float* tile_scales, nsky_stream_t stream);
+int nsky_film_chain_fwd(const nsky_film_net* net, const void* stream_buf, const float* tile_scales, const float* cond,
+                        int32_t ldcond, const float* x, int32_t ldx, int32_t M, float* const* h_save, float* const* z_save,
+                        float* const* y_save, float* res, int32_t ldres, nsky_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Multiresolution hash-grid encode (tiny-cuda-nn HashGrid semantics, fp32) fused with the rest of
  * the MLP input row.  Replaces tcnn.Encoding + NeRFEncoding + torch.cat at
  *   neusky/fields/sdf_albedo_field.py:119-130 (+ inherited forward_geonetwork, called :172,180,233)

@@ -1,0 +1,577 @@
+// FiLM-SIREN chain (neusky/utils/siren.py:108-208; call sites neusky/fields/directional_distance_field.py:233-299 and the
+// RENI-shaped illumination decode, neusky/models/neusky_model.py:488-506) as ONE kernel per row tile, forward and backward.
+//
+// Transposed formulation: a wave owns 32 batch rows and carries them through the whole network.  A layer is
+//   X_out[feature, row] = W[feature, k] X_in[k, row]:   weights = MFMA A operand, activations = MFMA B operand,
+// so the 32x32 fp32 accumulator of v_mfma_f32_32x32x16_f16 (feature on the register index, batch row on the lane) IS, after
+// the fp16 hi/lo split, the B operand of the next layer's product (the product sums over the accumulator's ROW index: no lane
+// movement, no LDS; cdna_hip_programming.md section 3).  The k order this imposes (element j of lane half h of k-step s is
+// feature 16 s + 8 (j >> 2) + 4 h + (j & 3)) is baked into the packed weight stream.  The mapping network's hidden state
+// never leaves the registers; the 2 n_film H wide frequency / phase matrix is never formed: F, phase and z of one 32-feature
+// tile are three accumulators that meet in the tile's epilogue (arg = (15 F + 30) z + phase).
+//
+// Arithmetic: fp32-grade products from three fp16 MFMAs into ONE fp32 accumulator, a b ~ ah bh + ah bl + al bh with
+// a = ah + al exactly to 2^-22: both operands are pre-scaled by powers of two (weights per 32-row tile, activations per batch
+// row, which sits on the lane, so the scale is a per-lane scalar) so that hi AND the unscaled residual stay inside fp16's
+// normal range for every element within 2^-16 of its row's maximum (smaller elements keep an absolute error of 2^-39 of the
+// maximum).  The scales are undone in the epilogue (exact: powers of two).
+//
+// Weights: packed once per optimisation step (film_pack_kernel) into the exact byte order the kernel consumes, and streamed
+// by every workgroup through a 128 KB LDS ring with global_load_lds_dwordx4 (lane-linear 1 KB pieces): slab = one k-step of
+// one 32-feature tile = 1 KB hi plane + 1 KB lo plane, [lane][8 fp16] so the A fragment is one conflict-free ds_read_b128;
+// group = 8 slabs = 16 KB = the DMA / hand-shake unit (one counted s_waitcnt + one s_barrier per group, 7 groups in flight).
+#include "common.h"
+#include "../../include/neusky_hip.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int SLAB = 2048;
+constexpr int GSLABS = 8;
+constexpr int GROUP = SLAB * GSLABS;  // 16 KB
+constexpr int RING_GROUPS = 8;
+constexpr int LOOKAHEAD = 7;
+constexpr int RING_BYTES = GROUP * RING_GROUPS;  // 128 KB
+constexpr int BIAS_FLOATS = 6144;                // 24 KB: every bias of the network
+constexpr int MAXL = NSKY_FILM_MAX_LAYERS;
+constexpr float Y_SCALE = 16384.0f;              // sine outputs live in [-1, 1]: fixed power-of-two scale
+constexpr int PACK_KMAX = 320;
+
+__host__ __device__ inline int ksteps_of(int K) { return (K + 15) / 16; }
+__host__ __device__ inline int groups_of(int K) { return (ksteps_of(K) + GSLABS - 1) / GSLABS; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// stream layout.  Forward order (tile = 32 output features x K):
+//   mapping layer 0: NT tiles (K = cond_dim) | mapping layers 1..: NT tiles each (K = H)
+//   FiLM layer i, feature tile t: F tile (rows i H + 32 t of the mapping head), phase tile (rows (n_film + i) H + 32 t),
+//                                 z tile (FiLM weight rows 32 t; K = x_dim for i = 0, else H)
+//   head: one tile (rows 0..out_dim-1, zero padded to 32)
+// Backward order (direction 1): for FiLM layer i = n_film-1 .. 0: for t: F tile, phase tile (as above; recomputed, never
+//   stored) ; then for input-feature tile u: transposed FiLM weight tile (rows = input features 32 u.., k = output features)
+//   (skipped for i = 0); then the mapping head transposed, k-group outer: for kg (128 of the 2 n_film H head rows): for u:
+//   tile (rows = hidden features 32 u.., k = head rows 128 kg ..); then mapping layers n_map-1 .. 1 transposed (for u: tile,
+//   K = H); then mapping layer 0 transposed: tiles over ceil(cond_dim / 32) input-feature tiles, K = H.
+// Every tile occupies a whole number of groups.
+struct Layout {
+  int NT, Gc, Gx, Gh;
+  long base_map, base_film0, base_film, base_head, total_groups;
+  int n_tiles;
+};
+
+__host__ __device__ inline Layout fwd_layout(const nsky_film_net& n) {
+  Layout L;
+  L.NT = n.hidden / 32;
+  L.Gc = groups_of(n.cond_dim);
+  L.Gx = groups_of(n.x_dim);
+  L.Gh = groups_of(n.hidden);
+  L.base_map = (long)L.NT * L.Gc;
+  L.base_film0 = L.base_map + (long)(n.n_map - 1) * L.NT * L.Gh;
+  L.base_film = L.base_film0 + (long)L.NT * (2 * L.Gh + L.Gx);
+  L.base_head = L.base_film + (long)(n.n_film - 1) * L.NT * 3 * L.Gh;
+  L.total_groups = L.base_head + L.Gh;
+  L.n_tiles = n.n_map * L.NT + n.n_film * L.NT * 3 + 1;
+  return L;
+}
+
+struct TileDesc {
+  const float* W;
+  int ld, row0, nrows, K, transposed, k0;
+  long group;
+};
+
+__device__ inline TileDesc fwd_tile(const nsky_film_net& n, const Layout& L, int idx) {
+  TileDesc d;
+  d.transposed = 0;
+  d.k0 = 0;
+  const int NT = L.NT, H = n.hidden;
+  if (idx < NT) {
+    d.W = n.map_w[0]; d.ld = n.map_ld[0]; d.row0 = 32 * idx; d.nrows = 32; d.K = n.cond_dim; d.group = (long)idx * L.Gc;
+    return d;
+  }
+  idx -= NT;
+  if (idx < (n.n_map - 1) * NT) {
+    const int l = 1 + idx / NT, t = idx % NT;
+    d.W = n.map_w[l]; d.ld = n.map_ld[l]; d.row0 = 32 * t; d.nrows = 32; d.K = H; d.group = L.base_map + (long)idx * L.Gh;
+    return d;
+  }
+  idx -= (n.n_map - 1) * NT;
+  if (idx < n.n_film * NT * 3) {
+    const int i = idx / (3 * NT), t = (idx / 3) % NT, which = idx % 3;
+    const long tb = i == 0 ? L.base_film0 + (long)t * (2 * L.Gh + L.Gx) : L.base_film + ((long)(i - 1) * NT + t) * 3 * L.Gh;
+    d.nrows = 32;
+    if (which < 2) {
+      d.W = n.mo_w; d.ld = n.mo_ld; d.row0 = (which == 0 ? i : n.n_film + i) * H + 32 * t; d.K = H; d.group = tb + which * L.Gh;
+    } else {
+      d.W = n.film_w[i]; d.ld = n.film_ld[i]; d.row0 = 32 * t; d.K = i == 0 ? n.x_dim : H; d.group = tb + 2 * L.Gh;
+    }
+    return d;
+  }
+  d.W = n.out_w; d.ld = n.out_ld; d.row0 = 0; d.nrows = n.out_dim; d.K = H; d.group = L.base_head;
+  return d;
+}
+
+// one block per tile: absmax -> power-of-two scale -> fp16 hi / residual planes in fragment order
+__global__ __launch_bounds__(256) void film_pack_kernel(nsky_film_net net, int direction, unsigned char* __restrict__ stream,
+                                                        float* __restrict__ scales) {
+  __shared__ float w[32][PACK_KMAX + 1];
+  __shared__ float red[256];
+  const Layout L = fwd_layout(net);
+  const TileDesc d = fwd_tile(net, L, blockIdx.x);
+  (void)direction;
+  const int tid = threadIdx.x;
+  const int Kp = ksteps_of(d.K) * 16;
+  float m = 0.0f;
+  for (int idx = tid; idx < 32 * Kp; idx += 256) {
+    const int r = idx / Kp, k = idx % Kp;
+    float v = 0.0f;
+    if (r < d.nrows && k < d.K) v = d.transposed ? d.W[(long)(d.k0 + k) * d.ld + d.row0 + r] : d.W[(long)(d.row0 + r) * d.ld + k];
+    w[r][k] = v;
+    m = fmaxf(m, fabsf(v));
+  }
+  red[tid] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+    __syncthreads();
+  }
+  m = red[0];
+  float sc = 1.0f;
+  if (m > 0.0f && m < 3.0e38f) {
+    int e;
+    (void)frexpf(m, &e);  // m < 2^e
+    e = max(-100, min(100, e));
+    sc = ldexpf(1.0f, 15 - e);  // m sc < 2^15
+  }
+  if (tid == 0) scales[blockIdx.x] = 1.0f / sc;
+  unsigned char* base = stream + d.group * GROUP;
+  const int KS = ksteps_of(d.K);
+  for (int idx = tid; idx < KS * 64; idx += 256) {
+    const int ks = idx >> 6, lane = idx & 63;
+    const int r = lane & 31, h = lane >> 5;
+    f16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = w[r][16 * ks + 8 * (j >> 2) + 4 * h + (j & 3)] * sc;
+      const _Float16 xh = (_Float16)x;
+      hi[j] = xh;
+      lo[j] = (_Float16)(x - (float)xh);
+    }
+    *reinterpret_cast<f16x8*>(base + (long)ks * SLAB + lane * 16) = hi;
+    *reinterpret_cast<f16x8*>(base + (long)ks * SLAB + 1024 + lane * 16) = lo;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+  // LDS-DMA hidden from hipcc's waitcnt bookkeeping; M0 saved and restored inside the statement; completion counted by hand
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+struct Ring {
+  const unsigned char* src;  // this lane's source address inside group 0 (stream + wave * 4096 + lane * 16)
+  uint32_t dst;              // this wave's destination inside ring slot 0 (lds0 + wave * 4096)
+  int g;                     // next group to consume
+};
+
+__device__ __forceinline__ void ring_issue(const Ring& r, int group) {
+  const unsigned char* s = r.src + (long)group * GROUP;
+  const uint32_t d = r.dst + (uint32_t)(group & (RING_GROUPS - 1)) * GROUP;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) glds16(s + p * 1024, d + p * 1024);
+}
+
+// Hand-shake before the first read of group r.g: this wave's own pieces of that group have landed (at most LOOKAHEAD - 1
+// younger groups x 4 pieces outstanding; every other vector-memory operation of the wave only makes the wait longer), every
+// LDS read of the previous group has returned, then the barrier: all four waves' pieces landed AND nobody still reads the slot
+// of group g - 1, which is refilled right away with group g + LOOKAHEAD.
+__device__ __forceinline__ const unsigned char* ring_advance(Ring& r, const unsigned char* smem) {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 * (LOOKAHEAD - 1)) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  ring_issue(r, r.g + LOOKAHEAD);
+  const unsigned char* cur = smem + (r.g & (RING_GROUPS - 1)) * GROUP;
+  ++r.g;
+  return cur;
+}
+
+// acc += W_tile X: KS k-steps (ksn <= KS of them real), B planes in registers
+template <int KS>
+__device__ __forceinline__ void product(Ring& r, const unsigned char* smem, int lane, int ksn, const f16x8 (&bh)[KS],
+                                        const f16x8 (&bl)[KS], f32x16& acc) {
+  const unsigned char* cur = nullptr;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (ks < ksn) {
+      if ((ks & (GSLABS - 1)) == 0) cur = ring_advance(r, smem);
+      const unsigned char* s = cur + (ks & (GSLABS - 1)) * SLAB + lane * 16;
+      const f16x8 ah = *reinterpret_cast<const f16x8*>(s);
+      const f16x8 al = *reinterpret_cast<const f16x8*>(s + 1024);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc, 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ void split8(const float (&x)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const _Float16 xh = (_Float16)x[j];
+    hi[j] = xh;
+    lo[j] = (_Float16)(x[j] - (float)xh);
+  }
+}
+
+// power-of-two scale s with m s < 2^15 (m = largest magnitude of the row); returns s, inv = 1 / s
+__device__ __forceinline__ float row_scale(float m, float& inv) {
+  m = fmaxf(m, __shfl_xor(m, 32, 64));  // lanes l and l ^ 32 hold the two halves of one batch row
+  if (!(m > 0.0f) || !(m < 3.0e38f)) {
+    inv = 1.0f;
+    return 1.0f;
+  }
+  int e;
+  (void)frexpf(m, &e);
+  e = max(-100, min(100, e));
+  inv = ldexpf(1.0f, e - 15);
+  return ldexpf(1.0f, 15 - e);
+}
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg4_nt(const float* p) {  // bypasses this CU's vector L1 (served by the XCD's L2)
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void stg4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// B planes of KS k-steps from an fp32 row [dim] (dim % 4 == 0, columns >= dim read as 0): returns 1 / scale
+template <int KS>
+__device__ __forceinline__ float load_planes(const float* __restrict__ rowp, int dim, int ksn, int h, f16x8 (&ph)[KS], f16x8 (&pl)[KS]) {
+  float v[KS][8];
+  float m = 0.0f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int feat = 16 * ks + 8 * u + 4 * h;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ks < ksn && feat < dim) q = ldg4(rowp + feat);
+      v[ks][4 * u] = q.x; v[ks][4 * u + 1] = q.y; v[ks][4 * u + 2] = q.z; v[ks][4 * u + 3] = q.w;
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+    }
+  float inv;
+  const float s = row_scale(m, inv);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = v[ks][j] * s;
+    split8(x, ph[ks], pl[ks]);
+  }
+  return inv;
+}
+
+// sin with Cody-Waite reduction to [-pi/4, pi/4] + minimax polynomials (|err| < 2e-7 for |x| < 1e4), cos alongside
+__device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
+  const float k = rintf(x * 0.6366197723675814f);
+  float r = fmaf(-k, 1.5707962513e+00f, x);
+  r = fmaf(-k, 7.5497894159e-08f, r);
+  r = fmaf(-k, 5.3903029534e-15f, r);
+  const float r2 = r * r;
+  float sp = fmaf(r2, 2.7183114939e-06f, -1.9839334836e-04f);
+  sp = fmaf(sp, r2, 8.3333293855e-03f);
+  sp = fmaf(sp, r2, -1.6666666567e-01f);
+  sp = fmaf(sp * r2, r, r);
+  float cp = fmaf(r2, 2.4433157117e-05f, -1.3887316255e-03f);
+  cp = fmaf(cp, r2, 4.1666645683e-02f);
+  cp = fmaf(cp, r2, -0.5f);
+  cp = fmaf(cp, r2, 1.0f);
+  const int q = (int)k;
+  const float ss = (q & 1) ? cp : sp;
+  const float cc = (q & 1) ? sp : cp;
+  s = (q & 2) ? -ss : ss;
+  c = ((q + 1) & 2) ? -cc : cc;
+}
+
+struct FwdArgs {
+  nsky_film_net net;
+  const unsigned char* stream;
+  const float* scales;
+  const float* cond; int ldcond;
+  const float* x; int ldx;
+  int M;
+  float* h_save[MAXL];  // mapping activations (after LeakyReLU), [M, H]; NULL = not kept
+  float* z_save[MAXL];  // FiLM pre-activations W y + b, [M, H]; NULL = not kept
+  float* y_save[MAXL];  // FiLM outputs, [M, H]; never NULL: also the hand-off to the next layer
+  float* res; int ldres;
+};
+
+// bias table in LDS: [mapping layer l: H][mapping head: 2 n_film H][FiLM layer i: H][head: 32]
+__device__ __forceinline__ void load_biases(const nsky_film_net& n, float* bl, int tid) {
+  const int H = n.hidden;
+  int off = 0;
+  for (int l = 0; l < n.n_map; ++l, off += H)
+    for (int i = tid; i < H; i += 256) bl[off + i] = n.map_b[l] ? n.map_b[l][i] : 0.0f;
+  for (int i = tid; i < 2 * n.n_film * H; i += 256) bl[off + i] = n.mo_b ? n.mo_b[i] : 0.0f;
+  off += 2 * n.n_film * H;
+  for (int l = 0; l < n.n_film; ++l, off += H)
+    for (int i = tid; i < H; i += 256) bl[off + i] = n.film_b[l] ? n.film_b[l][i] : 0.0f;
+  for (int i = tid; i < 32; i += 256) bl[off + i] = (n.out_b && i < n.out_dim) ? n.out_b[i] : 0.0f;
+}
+
+// accumulator layout: register 4 g + q of lane (c, h) = feature 8 g + 4 h + q of batch row c
+__device__ __forceinline__ void store_tile(float* rowp, int h, const float (&v)[16], bool live) {
+  if (!live) return;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) stg4(rowp + 8 * g + 4 * h, make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]));
+}
+
+template <int H, int KSC>
+__global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
+  constexpr int NT = H / 32, KS = H / 16;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + BIAS_FLOATS * 4];
+  float* bl = reinterpret_cast<float*>(smem + RING_BYTES);
+  const nsky_film_net& net = a.net;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  load_biases(net, bl, tid);
+  __syncthreads();
+
+  Ring ring;
+  ring.src = a.stream + wave * 4096 + lane * 16;
+  ring.dst = (uint32_t)(uintptr_t)smem + wave * 4096;
+  ring.g = 0;
+#pragma unroll
+  for (int g = 0; g < LOOKAHEAD; ++g) ring_issue(ring, g);
+
+  const long row = (long)blockIdx.x * 128 + wave * 32 + c;
+  const bool live = row < a.M;
+  const long rowc = live ? row : a.M - 1;
+  const int n_map = net.n_map, n_film = net.n_film;
+  int tile = 0;  // index into scales[], stream order
+
+  // ------------------------------------------------------------------ mapping network
+  f16x8 hh[KS], hl[KS];  // hidden state planes
+  float h_inv;           // 1 / row scale of the planes
+  {
+    f16x8 ch[KSC], cl[KSC];
+    const int ksc = ksteps_of(net.cond_dim);
+    const float c_inv = load_planes<KSC>(a.cond + rowc * a.ldcond, (net.cond_dim + 3) & ~3, ksc, h, ch, cl);
+    float hn[NT][16];
+    float m = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      product<KSC>(ring, smem, lane, ksc, ch, cl, acc);
+      const float inv = c_inv * a.scales[tile++];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(bl + 32 * t + 8 * g + 4 * h);
+        const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v = fmaf(acc[4 * g + q], inv, bb[q]);
+          const float o = v > 0.0f ? v : 0.2f * v;
+          hn[t][4 * g + q] = o;
+          m = fmaxf(m, fabsf(o));
+        }
+      }
+      if (a.h_save[0]) store_tile(a.h_save[0] + rowc * H + 32 * t, h, hn[t], live);
+    }
+    const float s = row_scale(m, h_inv);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float x8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x8[j] = hn[t][8 * u + j] * s;
+        split8(x8, hh[2 * t + u], hl[2 * t + u]);
+      }
+  }
+  for (int l = 1; l < n_map; ++l) {
+    float hn[NT][16];
+    float m = 0.0f;
+    const float* bias = bl + l * H;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      product<KS>(ring, smem, lane, KS, hh, hl, acc);
+      const float inv = h_inv * a.scales[tile++];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + 32 * t + 8 * g + 4 * h);
+        const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v = fmaf(acc[4 * g + q], inv, bb[q]);
+          const float o = v > 0.0f ? v : 0.2f * v;
+          hn[t][4 * g + q] = o;
+          m = fmaxf(m, fabsf(o));
+        }
+      }
+      if (a.h_save[l]) store_tile(a.h_save[l] + rowc * H + 32 * t, h, hn[t], live);
+    }
+    const float s = row_scale(m, h_inv);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float x8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x8[j] = hn[t][8 * u + j] * s;
+        split8(x8, hh[2 * t + u], hl[2 * t + u]);
+      }
+  }
+
+  // ------------------------------------------------------------------ FiLM layers
+  f16x8 xh[1], xl[1];
+  const float x_inv = load_planes<1>(a.x + rowc * a.ldx, (net.x_dim + 3) & ~3, 1, h, xh, xl);
+  f16x8 yh[KS], yl[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { yh[ks][j] = (_Float16)0.0f; yl[ks][j] = (_Float16)0.0f; }
+  const float* bias_mo = bl + n_map * H;
+  const float* bias_film = bias_mo + 2 * n_film * H;
+  for (int i = 0; i < n_film; ++i) {
+    const float* bF = bias_mo + i * H;
+    const float* bP = bias_mo + (n_film + i) * H;
+    const float* bZ = bias_film + i * H;
+    float* zrow = a.z_save[i] ? a.z_save[i] + rowc * H : nullptr;
+    float* yrow = a.y_save[i] + rowc * H;
+    for (int t = 0; t < NT; ++t) {
+      f32x16 aF, aP, aZ;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { aF[r] = 0.0f; aP[r] = 0.0f; aZ[r] = 0.0f; }
+      product<KS>(ring, smem, lane, KS, hh, hl, aF);
+      product<KS>(ring, smem, lane, KS, hh, hl, aP);
+      float z_unscale;
+      if (i == 0) {
+        product<1>(ring, smem, lane, 1, xh, xl, aZ);
+        z_unscale = x_inv;
+      } else {
+        product<KS>(ring, smem, lane, KS, yh, yl, aZ);
+        z_unscale = 1.0f / Y_SCALE;
+      }
+      const float iF = h_inv * a.scales[tile], iP = h_inv * a.scales[tile + 1], iZ = z_unscale * a.scales[tile + 2];
+      tile += 3;
+      float zz[16], yy[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int fo = 32 * t + 8 * g + 4 * h;
+        const float4 b4F = *reinterpret_cast<const float4*>(bF + fo);
+        const float4 b4P = *reinterpret_cast<const float4*>(bP + fo);
+        const float4 b4Z = *reinterpret_cast<const float4*>(bZ + fo);
+        const float bf[4] = {b4F.x, b4F.y, b4F.z, b4F.w}, bp[4] = {b4P.x, b4P.y, b4P.z, b4P.w}, bz[4] = {b4Z.x, b4Z.y, b4Z.z, b4Z.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 4 * g + q;
+          const float F = fmaf(aF[r], iF, bf[q]), P = fmaf(aP[r], iP, bp[q]), z = fmaf(aZ[r], iZ, bz[q]);
+          float sn, cs;
+          sincos_cw(fmaf(fmaf(15.0f, F, 30.0f), z, P), sn, cs);
+          zz[r] = z;
+          yy[r] = sn;
+        }
+      }
+      if (zrow) store_tile(zrow + 32 * t, h, zz, live);
+      store_tile(yrow + 32 * t, h, yy, live);
+    }
+    // hand-off: this lane reads back exactly the 16-byte pieces it stored (feature 16 ks + 8 u + 4 h of its own row)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float x8[8];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float4 q = ldg4_nt(yrow + 16 * ks + 8 * u + 4 * h);
+        x8[4 * u] = q.x * Y_SCALE; x8[4 * u + 1] = q.y * Y_SCALE; x8[4 * u + 2] = q.z * Y_SCALE; x8[4 * u + 3] = q.w * Y_SCALE;
+      }
+      split8(x8, yh[ks], yl[ks]);
+    }
+  }
+
+  // ------------------------------------------------------------------ head
+  {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    product<KS>(ring, smem, lane, KS, yh, yl, acc);
+    const float inv = a.scales[tile] / Y_SCALE;
+    const float* bO = bias_film + n_film * H;
+    if (live && h == 0)
+      stg4(a.res + row * a.ldres, make_float4(fmaf(acc[0], inv, bO[0]), fmaf(acc[1], inv, bO[1]), fmaf(acc[2], inv, bO[2]),
+                                              fmaf(acc[3], inv, bO[3])));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail groups of the ring are still landing
+}
+
+int check_net(const nsky_film_net* n, const char* who) {
+  NSKY_CHECK_ARG(n, "%s: null network", who);
+  NSKY_CHECK_ARG(n->hidden == 128 || n->hidden == 256, "%s: hidden width %d (128 or 256)", who, n->hidden);
+  NSKY_CHECK_ARG(n->n_map >= 1 && n->n_map <= MAXL && n->n_film >= 1 && n->n_film <= MAXL, "%s: layer counts %d / %d", who, n->n_map, n->n_film);
+  NSKY_CHECK_ARG(n->cond_dim >= 1 && n->cond_dim <= PACK_KMAX && n->x_dim >= 1 && n->x_dim <= 16 && n->out_dim >= 1 && n->out_dim <= 4,
+                 "%s: cond_dim %d (<= %d), x_dim %d (<= 16), out_dim %d (<= 4)", who, n->cond_dim, PACK_KMAX, n->x_dim, n->out_dim);
+  const int nb = n->n_map * n->hidden + 3 * n->n_film * n->hidden + 32;
+  NSKY_CHECK_ARG(nb <= BIAS_FLOATS, "%s: %d bias values exceed the LDS table (%d)", who, nb, BIAS_FLOATS);
+  for (int l = 0; l < n->n_map; ++l) NSKY_CHECK_ARG(n->map_w[l] && n->map_ld[l] >= (l == 0 ? n->cond_dim : n->hidden), "%s: mapping layer %d", who, l);
+  for (int l = 0; l < n->n_film; ++l) NSKY_CHECK_ARG(n->film_w[l] && n->film_ld[l] >= (l == 0 ? n->x_dim : n->hidden), "%s: FiLM layer %d", who, l);
+  NSKY_CHECK_ARG(n->mo_w && n->mo_ld >= n->hidden && n->out_w && n->out_ld >= n->hidden, "%s: head weights", who);
+  return NSKY_OK;
+}
+
+}  // namespace
+
+extern "C" int nsky_film_stream_layout(const nsky_film_net* net, int32_t direction, int64_t* stream_bytes, int32_t* n_tiles) {
+  if (int rc = check_net(net, "nsky_film_stream_layout")) return rc;
+  NSKY_CHECK_ARG(direction == 0, "nsky_film_stream_layout: direction %d", direction);
+  const Layout L = fwd_layout(*net);
+  if (stream_bytes) *stream_bytes = (L.total_groups + LOOKAHEAD + 1) * (int64_t)GROUP;
+  if (n_tiles) *n_tiles = L.n_tiles;
+  return NSKY_OK;
+}
+
+extern "C" int nsky_film_pack(const nsky_film_net* net, int32_t direction, void* stream_buf, float* tile_scales, nsky_stream_t stream) {
+  if (int rc = check_net(net, "nsky_film_pack")) return rc;
+  NSKY_CHECK_ARG(direction == 0 && stream_buf && tile_scales && ((uintptr_t)stream_buf % 16) == 0, "nsky_film_pack: bad arguments");
+  const Layout L = fwd_layout(*net);
+  hipLaunchKernelGGL(film_pack_kernel, dim3(L.n_tiles), dim3(256), 0, (hipStream_t)stream, *net, direction, (unsigned char*)stream_buf, tile_scales);
+  NSKY_CHECK_LAUNCH("nsky_film_pack");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_film_chain_fwd(const nsky_film_net* net, const void* stream_buf, const float* tile_scales, const float* cond,
+                                   int32_t ldcond, const float* x, int32_t ldx, int32_t M, float* const* h_save, float* const* z_save,
+                                   float* const* y_save, float* res, int32_t ldres, nsky_stream_t stream) {
+  if (int rc = check_net(net, "nsky_film_chain_fwd")) return rc;
+  NSKY_CHECK_ARG(stream_buf && tile_scales && cond && x && res && y_save && M > 0, "nsky_film_chain_fwd: null operand / empty batch");
+  NSKY_CHECK_ARG(ldcond % 4 == 0 && ldcond >= ((net->cond_dim + 3) & ~3) && ldx % 4 == 0 && ldx >= ((net->x_dim + 3) & ~3) && ldres >= 4 && ldres % 4 == 0,
+                 "nsky_film_chain_fwd: leading dimensions (cond %d, x %d, res %d) must be multiples of 4 covering the padded widths", ldcond, ldx, ldres);
+  NSKY_CHECK_ARG(((uintptr_t)cond % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)res % 16) == 0 && ((uintptr_t)stream_buf % 16) == 0,
+                 "nsky_film_chain_fwd: operands must be 16-byte aligned");
+  FwdArgs a;
+  a.net = *net;
+  a.stream = (const unsigned char*)stream_buf; a.scales = tile_scales;
+  a.cond = cond; a.ldcond = ldcond; a.x = x; a.ldx = ldx; a.M = M; a.res = res; a.ldres = ldres;
+  for (int l = 0; l < MAXL; ++l) {
+    a.h_save[l] = (h_save && l < net->n_map) ? h_save[l] : nullptr;
+    a.z_save[l] = (z_save && l < net->n_film) ? z_save[l] : nullptr;
+    a.y_save[l] = l < net->n_film ? y_save[l] : nullptr;
+    if (l < net->n_film) NSKY_CHECK_ARG(a.y_save[l] && ((uintptr_t)a.y_save[l] % 16) == 0, "nsky_film_chain_fwd: y_save[%d] missing / unaligned", l);
+  }
+  const dim3 grid(ceil_div(M, 128));
+  const int ksc = ksteps_of(net->cond_dim);
+#define NSKY_FILM_FWD(HH, KK) hipLaunchKernelGGL((film_fwd_kernel<HH, KK>), grid, dim3(256), 0, (hipStream_t)stream, a)
+  if (net->hidden == 256) { if (ksc <= 4) NSKY_FILM_FWD(256, 4); else NSKY_FILM_FWD(256, 20); }
+  else { if (ksc <= 4) NSKY_FILM_FWD(128, 4); else NSKY_FILM_FWD(128, 20); }
+#undef NSKY_FILM_FWD
+  NSKY_CHECK_LAUNCH("nsky_film_chain_fwd");
+  return NSKY_OK;
+}

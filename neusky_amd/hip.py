@@ -415,3 +415,67 @@ def ddf_losses_fwd(desc: DDFLossesDesc, terms):
 def ddf_losses_bwd(desc: DDFLossesDesc, d_terms, d_expected, d_sdf, d_mv_expected, d_sky_expected, d_term, d_mv_term):
     check(_ddf_losses_bwd(C.byref(desc), ptr(d_terms), ptr(d_expected), ptr(d_sdf), ptr(d_mv_expected), ptr(d_sky_expected), ptr(d_term),
                           ptr(d_mv_term), stream_ptr()), "nsky_ddf_losses_bwd")
+
+
+# ------------------------------------------------------------------------------------------ fused FiLM-SIREN chain
+FILM_MAX_LAYERS = 12
+
+
+class FilmNet(C.Structure):
+    _fields_ = [("hidden", C.c_int32), ("n_map", C.c_int32), ("n_film", C.c_int32),
+                ("cond_dim", C.c_int32), ("x_dim", C.c_int32), ("out_dim", C.c_int32),
+                ("map_w", C.c_void_p * FILM_MAX_LAYERS), ("map_b", C.c_void_p * FILM_MAX_LAYERS), ("map_ld", C.c_int32 * FILM_MAX_LAYERS),
+                ("mo_w", C.c_void_p), ("mo_b", C.c_void_p), ("mo_ld", C.c_int32),
+                ("film_w", C.c_void_p * FILM_MAX_LAYERS), ("film_b", C.c_void_p * FILM_MAX_LAYERS), ("film_ld", C.c_int32 * FILM_MAX_LAYERS),
+                ("out_w", C.c_void_p), ("out_b", C.c_void_p), ("out_ld", C.c_int32)]
+
+
+_film_layout = _sig("nsky_film_stream_layout", C.POINTER(FilmNet), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32))
+_film_pack = _sig("nsky_film_pack", C.POINTER(FilmNet), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p)
+_film_fwd = _sig("nsky_film_chain_fwd", C.POINTER(FilmNet), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
+
+
+def film_supported(hidden, map_hidden, n_map, n_film, cond_dim, x_dim, out_dim) -> bool:
+    """shapes the fused chain kernels are built for (anything else runs the per-layer dense kernels)"""
+    return (hidden in (128, 256) and map_hidden == hidden and 1 <= n_map <= FILM_MAX_LAYERS and 1 <= n_film <= FILM_MAX_LAYERS
+            and 1 <= cond_dim <= 320 and 1 <= x_dim <= 16 and 1 <= out_dim <= 4
+            and n_map * hidden + 3 * n_film * hidden + 32 <= 6144)
+
+
+def film_net(cond_dim, x_dim, out_dim, map_w, map_b, mo_w, mo_b, film_w, film_b, out_w, out_b) -> FilmNet:
+    """describe a FiLM-SIREN by its fp32 parameter tensors (torch nn.Linear layout, rows contiguous); the caller keeps
+    the tensors alive while the descriptor is in use"""
+    n = FilmNet(hidden=film_w[0].shape[0], n_map=len(map_w), n_film=len(film_w), cond_dim=cond_dim, x_dim=x_dim, out_dim=out_dim)
+    for i, (w, b) in enumerate(zip(map_w, map_b)):
+        n.map_w[i], n.map_b[i], n.map_ld[i] = ptr(w), ptr(b), ld(w)
+    for i, (w, b) in enumerate(zip(film_w, film_b)):
+        n.film_w[i], n.film_b[i], n.film_ld[i] = ptr(w), ptr(b), ld(w)
+    n.mo_w, n.mo_b, n.mo_ld = ptr(mo_w), ptr(mo_b), ld(mo_w)
+    n.out_w, n.out_b, n.out_ld = ptr(out_w), ptr(out_b), ld(out_w)
+    return n
+
+
+def film_stream_layout(net: FilmNet, direction: int = 0):
+    nbytes, ntiles = C.c_int64(0), C.c_int32(0)
+    check(_film_layout(C.byref(net), direction, C.byref(nbytes), C.byref(ntiles)), "nsky_film_stream_layout")
+    return nbytes.value, ntiles.value
+
+
+def film_pack(net: FilmNet, stream_buf, scales, direction: int = 0):
+    check(_film_pack(C.byref(net), direction, ptr(stream_buf), ptr(scales), stream_ptr()), "nsky_film_pack")
+
+
+def _ptr_array(ts, n):
+    arr = (C.c_void_p * FILM_MAX_LAYERS)()
+    for i in range(n):
+        arr[i] = None if ts is None or ts[i] is None else ts[i].data_ptr()
+    return arr
+
+
+def film_chain_fwd(net: FilmNet, stream_buf, scales, cond, x, M, h_save, z_save, y_save, res):
+    """see include/neusky_hip.h; h_save / z_save: lists (entries may be None) or None; y_save: list of [M, hidden] tensors"""
+    check(_film_fwd(C.byref(net), ptr(stream_buf), ptr(scales), ptr(cond), ld(cond), ptr(x), ld(x), M,
+                    _ptr_array(h_save, net.n_map), _ptr_array(z_save, net.n_film), _ptr_array(y_save, net.n_film), ptr(res), ld(res),
+                    stream_ptr()), "nsky_film_chain_fwd")
+    return res

@@ -1,0 +1,109 @@
+"""The fused FiLM-SIREN chain kernel (nsky_film_pack + nsky_film_chain_fwd / _bwd) against a float64 restatement of
+neusky/utils/siren.py:108-208 (oracle.film_siren, pinned by golden G8) and against the per-layer dense kernels."""
+import pytest
+import torch
+
+from oracle import neusky_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _net(H, n_map, n_film, cond_dim, x_dim, out_dim, seed=0, device=DEV):
+    from neusky_amd.utils.siren import FiLMSiren
+    torch.manual_seed(seed)
+    net = FiLMSiren(in_dim=x_dim, hidden_layers=n_film, hidden_features=H, mapping_network_in_dim=cond_dim,
+                    mapping_network_layers=n_map, mapping_network_features=H, out_dim=out_dim).to(device)
+    with torch.no_grad():  # biases away from zero so they are exercised
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.3, 0.3)
+    return net
+
+
+def _oracle_params(net, dtype=torch.float64):
+    c = lambda t: t.detach().cpu().to(dtype)  # noqa: E731
+    p = {}
+    lins = net.mapping_network.linears()
+    for i, lin in enumerate(lins[:-1]):
+        p[f"ddf.map_w{i}"], p[f"ddf.map_b{i}"] = c(lin.weight), c(lin.bias)
+    p["ddf.map_wo"], p["ddf.map_bo"] = c(lins[-1].weight), c(lins[-1].bias)
+    for i, l in enumerate(net.net):
+        p[f"ddf.film_w{i}"], p[f"ddf.film_b{i}"] = c(l.layer.weight), c(l.layer.bias)
+    p["ddf.out_w"], p["ddf.out_b"] = c(net.final_layer.weight), c(net.final_layer.bias)
+    return p
+
+
+def _inputs(M, cond_dim, x_dim, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    pad4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
+    cond = torch.zeros(M, pad4(cond_dim)); cond[:, :cond_dim] = torch.randn(M, cond_dim, generator=g) * 0.5
+    x = torch.zeros(M, pad4(x_dim)); x[:, :x_dim] = torch.rand(M, x_dim, generator=g) * 2 - 1
+    return cond, x
+
+
+def _run_fused(net, cond, x, save=True):
+    from neusky_amd import hip
+    H, n_map, n_film = net.hidden, net.n_map, net.n_film
+    lins = net.mapping_network.linears()
+    desc = hip.film_net(net.cond_dim, net.in_dim, net.out_dim, [l.weight for l in lins[:-1]], [l.bias for l in lins[:-1]],
+                        lins[-1].weight, lins[-1].bias, [l.layer.weight for l in net.net], [l.layer.bias for l in net.net],
+                        net.final_layer.weight, net.final_layer.bias)
+    nbytes, ntiles = hip.film_stream_layout(desc)
+    stream = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    scales = torch.empty(ntiles, device=DEV)
+    hip.film_pack(desc, stream, scales)
+    M = cond.shape[0]
+    mk = lambda n: [torch.full((M, H), float("nan"), device=DEV) for _ in range(n)]  # noqa: E731
+    hs, zs, ys = (mk(n_map), mk(n_film), mk(n_film)) if save else (None, None, mk(n_film))
+    res = torch.full((M, 4), float("nan"), device=DEV)
+    hip.film_chain_fwd(desc, stream, scales, cond.to(DEV), x.to(DEV), M, hs, zs, ys, res)
+    torch.cuda.synchronize()
+    return res, hs, zs, ys
+
+
+@pytest.mark.parametrize("H,n_map,n_film,cond_dim,x_dim,out_dim,M", [
+    (256, 5, 5, 35, 15, 1, 300),      # the DDF network (neusky_config.py:163-177), ragged M
+    (128, 5, 9, 300, 10, 3, 257),     # the RENI-shaped illumination decoder (latent 100 x 3)
+    (128, 2, 3, 24, 10, 3, 64),       # small-latent test configuration
+    (256, 1, 1, 16, 16, 4, 1),        # minimum depth, single row
+])
+def test_fused_forward_matches_float64_siren(H, n_map, n_film, cond_dim, x_dim, out_dim, M):
+    net = _net(H, n_map, n_film, cond_dim, x_dim, out_dim)
+    cond, x = _inputs(M, cond_dim, x_dim)
+    res, hs, zs, ys = _run_fused(net, cond, x)
+    p = _oracle_params(net)
+    ref = O.film_siren(x[:, :x_dim].double(), cond[:, :cond_dim].double(), p)
+    got = res[:, :out_dim].cpu().double()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+    # float32 evaluation of the same chain (torch CPU) for scale: the SIREN frequencies ~30 amplify rounding
+    p32 = _oracle_params(net, torch.float32)
+    ref32 = O.film_siren(x[:, :x_dim].float(), cond[:, :cond_dim].float(), p32).double()
+    err32 = (ref32 - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+    assert err < max(2e-5, 4 * err32), (err, err32)
+    # saved activations: the last FiLM output and the last mapping activation against float64
+    h = cond[:, :cond_dim].double()
+    for i in range(n_map):
+        h = torch.nn.functional.leaky_relu(torch.nn.functional.linear(h, p[f"ddf.map_w{i}"], p[f"ddf.map_b{i}"]), 0.2)
+    assert (hs[-1].cpu().double() - h).abs().max().item() < 1e-5 * max(1.0, h.abs().max().item())
+    assert all(torch.isfinite(t).all() for t in hs + zs + ys)
+    # y = sin(freq z + phase) is consistent with the saved z of the same layer
+    fo = torch.nn.functional.linear(h, p["ddf.map_wo"], p["ddf.map_bo"])
+    i = n_film - 1
+    freq, phase = fo[:, i * H:(i + 1) * H] * 15 + 30, fo[:, (n_film + i) * H:(n_film + i + 1) * H]
+    y_from_z = torch.sin(freq * zs[i].cpu().double() + phase)
+    assert (y_from_z - ys[i].cpu().double()).abs().max().item() < 2e-4
+
+
+def test_fused_forward_without_saves_and_large_batch():
+    """no-grad mode (render): only the hand-off buffers; M spans many workgroups; deterministic"""
+    net = _net(256, 5, 5, 35, 15, 1)
+    cond, x = _inputs(20000, 35, 15, seed=3)
+    res_a, _, _, _ = _run_fused(net, cond, x, save=False)
+    res_b, _, _, _ = _run_fused(net, cond, x, save=True)
+    assert torch.equal(res_a[:, 0], res_b[:, 0])
+    p = _oracle_params(net)
+    sub = slice(19000, 20000)
+    ref = O.film_siren(x[sub, :15].double(), cond[sub, :35].double(), p)[:, 0]
+    assert (res_a[sub, 0].cpu().double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())

@@ -172,9 +172,11 @@ def test_big_step_loss_terms(step_big):
 
 
 # per-tensor bars, as a fraction of the tensor's max |gradient| in the float64 oracle.  Measured on MI355X
-# (profiles/r02_grad_errors.txt); the bar is ~3x the measured error of the shipped arithmetic, and for every network it
-# is at or below the distance of the float32 ORACLE from the float64 one (the reference's own arithmetic).
-GRAD_BARS = {"field": 2e-3, "ddf.table": 2e-3, "ddf.map": 2e-2, "ddf.film": 3e-3, "ddf.out": 2e-3, "prop0": 2e-3, "prop1": 2e-3,
+# (profiles/r02_grad_errors.txt); the bar is ~3x the measured error of the shipped arithmetic.  The measured errors sit
+# at the distance of the float32 ORACLE from the float64 one (the reference's own arithmetic; same file, third column):
+# the DDF hash table (2.4e-3 in the fp32 oracle) and its mapping network (3e-3 .. 6.5e-3) are ill-conditioned in fp32
+# for ANY evaluator (SIREN frequencies ~30 x hash-grid scale 2047).
+GRAD_BARS = {"field": 2e-3, "ddf.table": 1e-2, "ddf.map": 2e-2, "ddf.film": 3e-3, "ddf.out": 2e-3, "prop0": 2e-3, "prop1": 2e-3,
              "train": 2e-3, "visibility": 2e-3}
 
 
