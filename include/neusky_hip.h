@@ -115,16 +115,23 @@ int nsky_weighted_colsum_f32(const float* X, int32_t M, int32_t N, int32_t ldx, 
  *   net: geometry + the fp32 parameter pointers in torch nn.Linear layout ([out, in], rows contiguous, leading dimensions
  *        in elements).  hidden = width of the FiLM layers AND of the mapping layers (128 or 256); cond_dim <= 320,
  *        x_dim <= 16, out_dim <= 4, at most NSKY_FILM_MAX_LAYERS layers each.
- *   nsky_film_stream_layout: bytes of the packed weight stream and number of 32-feature weight tiles (= tile_scales floats).
+ *   nsky_film_stream_layout: bytes of the packed weight stream and number of 32-feature weight tiles.
  *   nsky_film_pack: once per optimisation step: every weight tile -> power-of-two scaled fp16 hi + fp16 residual planes in
- *        MFMA-fragment order (direction 0 = forward stream), one reciprocal scale per tile.
+ *        MFMA-fragment order (direction 0 = forward stream, 1 = backward stream), plus `table` (NSKY_FILM_TABLE_FLOATS
+ *        floats, 16-byte aligned): every bias of the network followed by one reciprocal scale per tile.
  *   nsky_film_chain_fwd: cond [M, ldcond] (first cond_dim columns), x [M, ldx] -> res [M, ldres] (first out_dim columns,
- *        raw head output; columns out_dim..3 are written too).  Side outputs, each [M, hidden] contiguous:
- *        y_save[i] (FiLM layer outputs; REQUIRED: they are also the hand-off to the next layer), z_save[i] (FiLM
+ *        raw head output; columns out_dim..3 are written too).  Side outputs, each a TILE-NATIVE [ceil32(M), hidden] matrix
+ *        (below): y_save[i] (FiLM layer outputs; REQUIRED: they are also the hand-off to the next layer), z_save[i] (FiLM
  *        pre-activations W y + b; optional), h_save[l] (mapping activations after LeakyReLU(0.2); optional).
  *        Products are fp32-grade (three fp16 MFMAs on power-of-two pre-scaled hi / residual planes, fp32 accumulate).
+ *   Tile-native layout of a [rows, width] fp32 matrix (rows padded to a multiple of 32, width % 32 == 0): 32 x 32 blocks of
+ *        4 KB, block (R, t) at float offset (R * (width / 32) + t) * 1024; inside a block element (row c, feature f) at
+ *        (f / 8) * 256 + (c + 32 * ((f / 4) & 1)) * 4 + (f & 3) -- the accumulator layout of v_mfma_f32_32x32x16, so the
+ *        chain kernels move a tile with four 1 KB-contiguous wave instructions.  nsky_gemm_f32 reads such operands with
+ *        a_native_nt / b_native_nt = width / 32 (weight gradients).
  */
 #define NSKY_FILM_MAX_LAYERS 12
+#define NSKY_FILM_TABLE_FLOATS 6656
 typedef struct nsky_film_net {
   int32_t hidden, n_map, n_film;
   int32_t cond_dim, x_dim, out_dim;
@@ -134,8 +141,8 @@ typedef struct nsky_film_net {
   const float* out_w; const float* out_b; int32_t out_ld;  /* head [out_dim, hidden] */
 } nsky_film_net;
 int nsky_film_stream_layout(const nsky_film_net* net, int32_t direction, int64_t* stream_bytes, int32_t* n_tiles);
-int nsky_film_pack(const nsky_film_net* net, int32_t direction, void* stream_buf, float* tile_scales, nsky_stream_t stream);
-int nsky_film_chain_fwd(const nsky_film_net* net, const void* stream_buf, const float* tile_scales, const float* cond,
+int nsky_film_pack(const nsky_film_net* net, int32_t direction, void* stream_buf, float* table, nsky_stream_t stream);
+int nsky_film_chain_fwd(const nsky_film_net* net, const void* stream_buf, const float* table, const float* cond,
                         int32_t ldcond, const float* x, int32_t ldx, int32_t M, float* const* h_save, float* const* z_save,
                         float* const* y_save, float* res, int32_t ldres, nsky_stream_t stream);
 

@@ -32,9 +32,9 @@ constexpr int SLAB = 2048;
 constexpr int GSLABS = 8;
 constexpr int GROUP = SLAB * GSLABS;  // 16 KB
 constexpr int RING_GROUPS = 8;
-constexpr int LOOKAHEAD = 7;
 constexpr int RING_BYTES = GROUP * RING_GROUPS;  // 128 KB
 constexpr int BIAS_FLOATS = 6144;                // 24 KB: every bias of the network
+constexpr int SCALE_FLOATS = 512;                // reciprocal tile scales, stream order
 constexpr int MAXL = NSKY_FILM_MAX_LAYERS;
 constexpr float Y_SCALE = 16384.0f;              // sine outputs live in [-1, 1]: fixed power-of-two scale
 constexpr int PACK_KMAX = 320;
@@ -112,15 +112,33 @@ __device__ inline TileDesc fwd_tile(const nsky_film_net& n, const Layout& L, int
   return d;
 }
 
+// bias table: [mapping layer l: H][mapping head: 2 n_film H][FiLM layer i: H][head: 32]
+__device__ inline void write_bias_table(const nsky_film_net& n, float* bl, int tid) {
+  const int H = n.hidden;
+  int off = 0;
+  for (int l = 0; l < n.n_map; ++l, off += H)
+    for (int i = tid; i < H; i += 256) bl[off + i] = n.map_b[l] ? n.map_b[l][i] : 0.0f;
+  for (int i = tid; i < 2 * n.n_film * H; i += 256) bl[off + i] = n.mo_b ? n.mo_b[i] : 0.0f;
+  off += 2 * n.n_film * H;
+  for (int l = 0; l < n.n_film; ++l, off += H)
+    for (int i = tid; i < H; i += 256) bl[off + i] = n.film_b[l] ? n.film_b[l][i] : 0.0f;
+  for (int i = tid; i < 32; i += 256) bl[off + i] = (n.out_b && i < n.out_dim) ? n.out_b[i] : 0.0f;
+}
+
 // one block per tile: absmax -> power-of-two scale -> fp16 hi / residual planes in fragment order
 __global__ __launch_bounds__(256) void film_pack_kernel(nsky_film_net net, int direction, unsigned char* __restrict__ stream,
-                                                        float* __restrict__ scales) {
+                                                        float* __restrict__ table) {
   __shared__ float w[32][PACK_KMAX + 1];
   __shared__ float red[256];
   const Layout L = fwd_layout(net);
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x == L.n_tiles) {  // the extra block: every bias of the network, in the order the chain kernels index them
+    write_bias_table(net, table, tid);
+    return;
+  }
+  float* scales = table + BIAS_FLOATS;
   const TileDesc d = fwd_tile(net, L, blockIdx.x);
   (void)direction;
-  const int tid = threadIdx.x;
   const int Kp = ksteps_of(d.K) * 16;
   float m = 0.0f;
   for (int idx = tid; idx < 32 * Kp; idx += 256) {
@@ -171,49 +189,137 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-struct Ring {
+// Weight stream consumer.  Invariant while slabs of group g are being consumed: every piece of groups <= g + 1 has landed and
+// all four waves know it (barrier).  Fragment reads run TWO k-steps ahead of the MFMAs (three register buffers, rotated at
+// compile time inside a product) and one k-step ahead across a tile boundary, so an LDS round trip (~150-200 cycles under
+// load) hides behind 6 MFMAs; the waits are counted (lgkmcnt(2): only the youngest pair may still be in flight; LDS returns
+// in order, so a scalar load the compiler slips in can only make the wait stricter).
+// Transition g -> g + 1 (after this wave's last fragment of group g has arrived): wait for the wave's own pieces of group g + 2
+// (at most RING_GROUPS - 3 younger groups x 4 pieces outstanding; every other vector-memory operation of the wave only makes the
+// wait longer), barrier (all pieces of g + 2 landed; nobody reads group g any more), refill the slot of g with group g + 8.
+// LDS reads in flight across the barrier belong to group g + 1: never the slot being refilled.
+struct WStream {
   const unsigned char* src;  // this lane's source address inside group 0 (stream + wave * 4096 + lane * 16)
   uint32_t dst;              // this wave's destination inside ring slot 0 (lds0 + wave * 4096)
-  int g;                     // next group to consume
+  uint32_t lds_lane;         // lds0 + lane * 16
+  int g;                     // group of the slab whose fragments are carried in (ch, cl): slab 0 of the next tile
+  f16x8 ch, cl;              // fragments requested ahead of the next product (landed: every product settles them at its end)
 };
 
-__device__ __forceinline__ void ring_issue(const Ring& r, int group) {
-  const unsigned char* s = r.src + (long)group * GROUP;
-  const uint32_t d = r.dst + (uint32_t)(group & (RING_GROUPS - 1)) * GROUP;
+__device__ __forceinline__ void ws_issue(const WStream& w, int group) {
+  const unsigned char* s = w.src + (long)group * GROUP;
+  const uint32_t d = w.dst + (uint32_t)(group & (RING_GROUPS - 1)) * GROUP;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) glds16(s + p * 1024, d + p * 1024);
+  for (int p = 0; p < 4; ++p) {
+#ifndef FILM_LAB_NODMA
+    glds16(s + p * 1024, d + p * 1024);
+#endif
+  }
 }
 
-// Hand-shake before the first read of group r.g: this wave's own pieces of that group have landed (at most LOOKAHEAD - 1
-// younger groups x 4 pieces outstanding; every other vector-memory operation of the wave only makes the wait longer), every
-// LDS read of the previous group has returned, then the barrier: all four waves' pieces landed AND nobody still reads the slot
-// of group g - 1, which is refilled right away with group g + LOOKAHEAD.
-__device__ __forceinline__ const unsigned char* ring_advance(Ring& r, const unsigned char* smem) {
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 * (LOOKAHEAD - 1)) : "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  ring_issue(r, r.g + LOOKAHEAD);
-  const unsigned char* cur = smem + (r.g & (RING_GROUPS - 1)) * GROUP;
-  ++r.g;
-  return cur;
+// The two fragment registers are read-write operands of BOTH the request and the wait: the compiler sees one value that is
+// modified in place, so it neither renames it nor copies it while the LDS read is still in flight (a copy of a register whose
+// load has not landed would capture stale data; cdna_hip_programming.md section 5.7 item 1).
+__device__ __forceinline__ void frag_read(f16x8& h, f16x8& l, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "+v"(h), "+v"(l) : "v"(addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void frag_wait(f16x8& h, f16x8& l) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(h), "+v"(l) : "n"(N) : "memory");
 }
 
-// acc += W_tile X: KS k-steps (ksn <= KS of them real), B planes in registers
+__device__ __forceinline__ uint32_t ws_addr(const WStream& w, int group, int slab) {
+  return w.lds_lane + (uint32_t)(group & (RING_GROUPS - 1)) * GROUP + slab * SLAB;
+}
+
+__device__ __forceinline__ void ws_begin(WStream& w) {
+#pragma unroll
+  for (int g = 0; g < RING_GROUPS; ++g) ws_issue(w, g);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (RING_GROUPS - 2)) : "memory");  // groups 0 and 1 landed
+  w.g = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { w.ch[j] = (_Float16)0.0f; w.cl[j] = (_Float16)0.0f; }
+  frag_read(w.ch, w.cl, ws_addr(w, 0, 0));
+  frag_wait<0>(w.ch, w.cl);
+}
+
+__device__ __forceinline__ void ws_transition(WStream& w, int from_group) {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (RING_GROUPS - 3)) : "memory");
+  ws_issue(w, from_group + RING_GROUPS);
+}
+
+// acc += W_tile X over KS k-steps, B planes in registers.  One wave per SIMD issues in order, so everything that is not an
+// MFMA is placed in the shadow of one: the LDS requests of k-step ks + 2 (and a group transition: barrier + 4 DMA pieces) right
+// behind the first MFMA of k-step ks, the counted wait for the fragments of ks + 1 behind the third.
 template <int KS>
-__device__ __forceinline__ void product(Ring& r, const unsigned char* smem, int lane, int ksn, const f16x8 (&bh)[KS],
-                                        const f16x8 (&bl)[KS], f32x16& acc) {
-  const unsigned char* cur = nullptr;
+__device__ __forceinline__ void product(WStream& w, const f16x8 (&bh)[KS], const f16x8 (&bl)[KS], f32x16& acc) {
+  constexpr int NG = (KS + GSLABS - 1) / GSLABS;  // groups of this tile; slab index KS stands for slab 0 of the next tile
+  f16x8 fh[3], fl[3];
+  fh[0] = w.ch;
+  fl[0] = w.cl;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { fh[1][j] = fh[2][j] = fl[1][j] = fl[2][j] = (_Float16)0.0f; }
+  const int g0 = w.g;
+  auto request = [&](int s) {  // s static
+    if (s < KS) frag_read(fh[s % 3], fl[s % 3], ws_addr(w, g0 + s / GSLABS, s % GSLABS));
+    else frag_read(fh[s % 3], fl[s % 3], ws_addr(w, g0 + NG, 0));
+  };
+  request(1);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef FILM_LAB_NOMFMA
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks % 3], bl[ks], acc, 0, 0, 0);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 2 <= KS) request(ks + 2);  // into the buffer of k-step ks - 1, whose MFMAs have been issued
+    if ((ks & (GSLABS - 1)) == GSLABS - 1 || ks == KS - 1) ws_transition(w, g0 + ks / GSLABS);
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef FILM_LAB_NOMFMA
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks % 3], bh[ks], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks % 3], bh[ks], acc, 0, 0, 0);
+#else
+    asm volatile("" :: "v"(fh[ks % 3]), "v"(fl[ks % 3]), "v"(bh[ks]), "v"(bl[ks]));
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    // fragments of k-step ks + 1 (slab KS = first slab of the next tile): only the pair requested above may still be in flight
+    if (ks + 2 <= KS) frag_wait<2>(fh[(ks + 1) % 3], fl[(ks + 1) % 3]);
+    else frag_wait<0>(fh[(ks + 1) % 3], fl[(ks + 1) % 3]);
+  }
+  // nothing is in flight here (the last wait was lgkmcnt(0)): no load crosses a loop back-edge or a branch join, where the
+  // compiler is free to insert register copies
+  w.ch = fh[KS % 3];
+  w.cl = fl[KS % 3];
+  w.g = g0 + NG;
+}
+
+// the same over the first ksn (wave-uniform, run time; >= 1) of KS k-steps: the mapping network's first layer.  No read-ahead
+// inside the tile (every step sits in its own branch); 8 short tiles per row tile.
+template <int KS>
+__device__ __forceinline__ void product_dyn(WStream& w, int ksn, const f16x8 (&bh)[KS], const f16x8 (&bl)[KS], f32x16& acc) {
+  const int g0 = w.g;
+  const int ng = (ksn + GSLABS - 1) / GSLABS;
+  f16x8 ah = w.ch, al = w.cl;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     if (ks < ksn) {
-      if ((ks & (GSLABS - 1)) == 0) cur = ring_advance(r, smem);
-      const unsigned char* s = cur + (ks & (GSLABS - 1)) * SLAB + lane * 16;
-      const f16x8 ah = *reinterpret_cast<const f16x8*>(s);
-      const f16x8 al = *reinterpret_cast<const f16x8*>(s + 1024);
+      const bool last = ks == ksn - 1;
+      if ((ks & (GSLABS - 1)) == GSLABS - 1 || last) ws_transition(w, g0 + ks / GSLABS);
+      f16x8 nh = ah, nl = al;
+      frag_read(nh, nl, last ? ws_addr(w, g0 + ng, 0) : ws_addr(w, g0 + (ks + 1) / GSLABS, (ks + 1) % GSLABS));
+      __builtin_amdgcn_sched_barrier(0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_wait<0>(nh, nl);
+      ah = nh;
+      al = nl;
     }
   }
+  w.ch = ah;
+  w.cl = al;
+  w.g = g0 + ng;
 }
 
 __device__ __forceinline__ void split8(const float (&x)[8], f16x8& hi, f16x8& lo) {
@@ -296,61 +402,86 @@ __device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
   c = ((q + 1) & 2) ? -cc : cc;
 }
 
+#ifdef FILM_LAB_STAMP
+__device__ unsigned long long g_stamps[64];
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define STAMP(var) const unsigned long long var = stamp()
+#define ACCUM(slot, a, b) do { if (blockIdx.x == 300 && tid == 0) g_stamps[slot] += (b) - (a); } while (0)
+#else
+#define STAMP(var)
+#define ACCUM(slot, a, b)
+#endif
+
 struct FwdArgs {
   nsky_film_net net;
   const unsigned char* stream;
-  const float* scales;
+  const float* table;  // [BIAS_FLOATS biases | SCALE_FLOATS reciprocal tile scales] (film_pack_kernel)
   const float* cond; int ldcond;
   const float* x; int ldx;
   int M;
-  float* h_save[MAXL];  // mapping activations (after LeakyReLU), [M, H]; NULL = not kept
-  float* z_save[MAXL];  // FiLM pre-activations W y + b, [M, H]; NULL = not kept
-  float* y_save[MAXL];  // FiLM outputs, [M, H]; never NULL: also the hand-off to the next layer
+  float* h_save[MAXL];  // mapping activations (after LeakyReLU), native [ceil32(M), H]; NULL = not kept
+  float* z_save[MAXL];  // FiLM pre-activations W y + b, native [ceil32(M), H]; NULL = not kept
+  float* y_save[MAXL];  // FiLM outputs, native [ceil32(M), H]; never NULL: also the hand-off to the next layer
   float* res; int ldres;
 };
 
-// bias table in LDS: [mapping layer l: H][mapping head: 2 n_film H][FiLM layer i: H][head: 32]
-__device__ __forceinline__ void load_biases(const nsky_film_net& n, float* bl, int tid) {
-  const int H = n.hidden;
-  int off = 0;
-  for (int l = 0; l < n.n_map; ++l, off += H)
-    for (int i = tid; i < H; i += 256) bl[off + i] = n.map_b[l] ? n.map_b[l][i] : 0.0f;
-  for (int i = tid; i < 2 * n.n_film * H; i += 256) bl[off + i] = n.mo_b ? n.mo_b[i] : 0.0f;
-  off += 2 * n.n_film * H;
-  for (int l = 0; l < n.n_film; ++l, off += H)
-    for (int i = tid; i < H; i += 256) bl[off + i] = n.film_b[l] ? n.film_b[l][i] : 0.0f;
-  for (int i = tid; i < 32; i += 256) bl[off + i] = (n.out_b && i < n.out_dim) ? n.out_b[i] : 0.0f;
-}
-
-// accumulator layout: register 4 g + q of lane (c, h) = feature 8 g + 4 h + q of batch row c
-__device__ __forceinline__ void store_tile(float* rowp, int h, const float (&v)[16], bool live) {
-  if (!live) return;
+// Tile-native activation layout ("native"): the [rows, width] matrix is cut into 32-row x 32-feature blocks of 4 KB, block
+// (R, t) at float offset (R * (width / 32) + t) * 1024, and inside a block element (row c, feature f) sits at
+// (f / 8) * 256 + (c + 32 * ((f / 4) & 1)) * 4 + (f & 3): exactly the accumulator layout of v_mfma_f32_32x32x16 (register
+// 4 g + q of lane (c, h) = feature 8 g + 4 h + q of batch row c), so a wave stores / loads a tile with four 1 KB-contiguous
+// float4 instructions and the lane that stored a piece is the lane that reads it back.  Rows are padded to a multiple of 32.
+__device__ __forceinline__ void store_tile(float* blk, int lane, const float (&v)[16]) {
 #pragma unroll
-  for (int g = 0; g < 4; ++g) stg4(rowp + 8 * g + 4 * h, make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]));
+  for (int g = 0; g < 4; ++g) stg4(blk + g * 256 + lane * 4, make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]));
+}
+__device__ __forceinline__ void load_tile(const float* blk, int lane, float (&v)[16]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 q = ldg4(blk + g * 256 + lane * 4);
+    v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
+  }
 }
 
 template <int H, int KSC>
 __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
   constexpr int NT = H / 32, KS = H / 16;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + BIAS_FLOATS * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + (BIAS_FLOATS + SCALE_FLOATS) * 4];
   float* bl = reinterpret_cast<float*>(smem + RING_BYTES);
   const nsky_film_net& net = a.net;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5;
-  load_biases(net, bl, tid);
+  float* sl = bl + BIAS_FLOATS;  // reciprocal tile scales, stream order
+  {  // biases + tile scales: one table written by the pack kernel; all loads in flight at once
+    constexpr int N4 = (BIAS_FLOATS + SCALE_FLOATS) / 4;
+    float4 q[(N4 + 255) / 256];
+#pragma unroll
+    for (int i = 0; i < (N4 + 255) / 256; ++i)
+      if (i * 256 + tid < N4) q[i] = ldg4(a.table + 4 * (i * 256 + tid));
+#pragma unroll
+    for (int i = 0; i < (N4 + 255) / 256; ++i)
+      if (i * 256 + tid < N4) *reinterpret_cast<float4*>(bl + 4 * (i * 256 + tid)) = q[i];
+  }
   __syncthreads();
 
-  Ring ring;
-  ring.src = a.stream + wave * 4096 + lane * 16;
-  ring.dst = (uint32_t)(uintptr_t)smem + wave * 4096;
-  ring.g = 0;
-#pragma unroll
-  for (int g = 0; g < LOOKAHEAD; ++g) ring_issue(ring, g);
+  STAMP(t_begin);
+  WStream ws;
+  ws.src = a.stream + wave * 4096 + lane * 16;
+  ws.dst = (uint32_t)(uintptr_t)smem + wave * 4096;
+  ws.lds_lane = (uint32_t)(uintptr_t)smem + lane * 16;
+  ws_begin(ws);
 
-  const long row = (long)blockIdx.x * 128 + wave * 32 + c;
+  const long rt = (long)blockIdx.x * 4 + wave;  // 32-row tile of this wave
+  const long row = rt * 32 + c;
   const bool live = row < a.M;
   const long rowc = live ? row : a.M - 1;
+  const bool wave_live = rt * 32 < a.M;  // wave-uniform: the tile holds at least one real row (dead rows of it are stored too)
   const int n_map = net.n_map, n_film = net.n_film;
   int tile = 0;  // index into scales[], stream order
 
@@ -368,8 +499,8 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-      product<KSC>(ring, smem, lane, ksc, ch, cl, acc);
-      const float inv = c_inv * a.scales[tile++];
+      product_dyn<KSC>(ws, ksc, ch, cl, acc);
+      const float inv = c_inv * sl[tile++];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 b = *reinterpret_cast<const float4*>(bl + 32 * t + 8 * g + 4 * h);
@@ -382,7 +513,7 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
           m = fmaxf(m, fabsf(o));
         }
       }
-      if (a.h_save[0]) store_tile(a.h_save[0] + rowc * H + 32 * t, h, hn[t], live);
+      if (a.h_save[0] && wave_live) store_tile(a.h_save[0] + (rt * NT + t) * 1024, lane, hn[t]);
     }
     const float s = row_scale(m, h_inv);
 #pragma unroll
@@ -404,8 +535,8 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-      product<KS>(ring, smem, lane, KS, hh, hl, acc);
-      const float inv = h_inv * a.scales[tile++];
+      product<KS>(ws, hh, hl, acc);
+      const float inv = h_inv * sl[tile++];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 b = *reinterpret_cast<const float4*>(bias + 32 * t + 8 * g + 4 * h);
@@ -418,7 +549,7 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
           m = fmaxf(m, fabsf(o));
         }
       }
-      if (a.h_save[l]) store_tile(a.h_save[l] + rowc * H + 32 * t, h, hn[t], live);
+      if (a.h_save[l] && wave_live) store_tile(a.h_save[l] + (rt * NT + t) * 1024, lane, hn[t]);
     }
     const float s = row_scale(m, h_inv);
 #pragma unroll
@@ -432,6 +563,7 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
       }
   }
 
+  STAMP(t_map);
   // ------------------------------------------------------------------ FiLM layers
   f16x8 xh[1], xl[1];
   const float x_inv = load_planes<1>(a.x + rowc * a.ldx, (net.x_dim + 3) & ~3, 1, h, xh, xl);
@@ -446,23 +578,29 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
     const float* bF = bias_mo + i * H;
     const float* bP = bias_mo + (n_film + i) * H;
     const float* bZ = bias_film + i * H;
-    float* zrow = a.z_save[i] ? a.z_save[i] + rowc * H : nullptr;
-    float* yrow = a.y_save[i] + rowc * H;
+    // a wave whose tile lies wholly beyond M stores nothing and reads tile 0 back (in bounds; its results are never stored)
+    float* zblk = a.z_save[i] ? a.z_save[i] + (wave_live ? rt : 0) * NT * 1024 : nullptr;
+    float* yblk = a.y_save[i] + (wave_live ? rt : 0) * NT * 1024;
     for (int t = 0; t < NT; ++t) {
       f32x16 aF, aP, aZ;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { aF[r] = 0.0f; aP[r] = 0.0f; aZ[r] = 0.0f; }
-      product<KS>(ring, smem, lane, KS, hh, hl, aF);
-      product<KS>(ring, smem, lane, KS, hh, hl, aP);
+      STAMP(t0);
+      product<KS>(ws, hh, hl, aF);
+      STAMP(t1);
+      ACCUM(0, t0, t1);
+      product<KS>(ws, hh, hl, aP);
       float z_unscale;
       if (i == 0) {
-        product<1>(ring, smem, lane, 1, xh, xl, aZ);
+        product<1>(ws, xh, xl, aZ);
         z_unscale = x_inv;
       } else {
-        product<KS>(ring, smem, lane, KS, yh, yl, aZ);
+        product<KS>(ws, yh, yl, aZ);
         z_unscale = 1.0f / Y_SCALE;
       }
-      const float iF = h_inv * a.scales[tile], iP = h_inv * a.scales[tile + 1], iZ = z_unscale * a.scales[tile + 2];
+      STAMP(t2);
+      ACCUM(1, t1, t2);
+      const float iF = h_inv * sl[tile], iP = h_inv * sl[tile + 1], iZ = z_unscale * sl[tile + 2];
       tile += 3;
       float zz[16], yy[16];
 #pragma unroll
@@ -477,40 +615,57 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
           const int r = 4 * g + q;
           const float F = fmaf(aF[r], iF, bf[q]), P = fmaf(aP[r], iP, bp[q]), z = fmaf(aZ[r], iZ, bz[q]);
           float sn, cs;
+#ifndef FILM_LAB_NOSIN
           sincos_cw(fmaf(fmaf(15.0f, F, 30.0f), z, P), sn, cs);
+#else
+          sn = fmaf(fmaf(15.0f, F, 30.0f), z, P);
+#endif
           zz[r] = z;
           yy[r] = sn;
         }
       }
-      if (zrow) store_tile(zrow + 32 * t, h, zz, live);
-      store_tile(yrow + 32 * t, h, yy, live);
+      STAMP(t3);
+      ACCUM(2, t2, t3);
+      if (wave_live) {
+        if (zblk) store_tile(zblk + t * 1024, lane, zz);
+        store_tile(yblk + t * 1024, lane, yy);
+      }
+      STAMP(t4);
+      ACCUM(3, t3, t4);
     }
-    // hand-off: this lane reads back exactly the 16-byte pieces it stored (feature 16 ks + 8 u + 4 h of its own row)
+    STAMP(t5);
+    // hand-off: this lane reads back exactly the 16-byte pieces it stored (k-step ks, half u = register group 2 (ks & 1) + u of
+    // tile ks / 2)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       float x8[8];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const float4 q = ldg4_nt(yrow + 16 * ks + 8 * u + 4 * h);
+        const float4 q = ldg4_nt(yblk + (ks >> 1) * 1024 + (2 * (ks & 1) + u) * 256 + lane * 4);
         x8[4 * u] = q.x * Y_SCALE; x8[4 * u + 1] = q.y * Y_SCALE; x8[4 * u + 2] = q.z * Y_SCALE; x8[4 * u + 3] = q.w * Y_SCALE;
       }
       split8(x8, yh[ks], yl[ks]);
     }
+    STAMP(t6);
+    ACCUM(4, t5, t6);
   }
+  STAMP(t_end);
+  ACCUM(5, t_begin, t_end);
+  ACCUM(6, t_begin, t_map);
 
   // ------------------------------------------------------------------ head
   {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    product<KS>(ring, smem, lane, KS, yh, yl, acc);
-    const float inv = a.scales[tile] / Y_SCALE;
+    product<KS>(ws, yh, yl, acc);
+    const float inv = sl[tile] / Y_SCALE;
     const float* bO = bias_film + n_film * H;
     if (live && h == 0)
       stg4(a.res + row * a.ldres, make_float4(fmaf(acc[0], inv, bO[0]), fmaf(acc[1], inv, bO[1]), fmaf(acc[2], inv, bO[2]),
                                               fmaf(acc[3], inv, bO[3])));
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail groups of the ring are still landing
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the tail groups of the ring are still landing
 }
 
 int check_net(const nsky_film_net* n, const char* who) {
@@ -521,6 +676,7 @@ int check_net(const nsky_film_net* n, const char* who) {
                  "%s: cond_dim %d (<= %d), x_dim %d (<= 16), out_dim %d (<= 4)", who, n->cond_dim, PACK_KMAX, n->x_dim, n->out_dim);
   const int nb = n->n_map * n->hidden + 3 * n->n_film * n->hidden + 32;
   NSKY_CHECK_ARG(nb <= BIAS_FLOATS, "%s: %d bias values exceed the LDS table (%d)", who, nb, BIAS_FLOATS);
+  NSKY_CHECK_ARG(fwd_layout(*n).n_tiles <= SCALE_FLOATS, "%s: %d weight tiles exceed the LDS scale table (%d)", who, fwd_layout(*n).n_tiles, SCALE_FLOATS);
   for (int l = 0; l < n->n_map; ++l) NSKY_CHECK_ARG(n->map_w[l] && n->map_ld[l] >= (l == 0 ? n->cond_dim : n->hidden), "%s: mapping layer %d", who, l);
   for (int l = 0; l < n->n_film; ++l) NSKY_CHECK_ARG(n->film_w[l] && n->film_ld[l] >= (l == 0 ? n->x_dim : n->hidden), "%s: FiLM layer %d", who, l);
   NSKY_CHECK_ARG(n->mo_w && n->mo_ld >= n->hidden && n->out_w && n->out_ld >= n->hidden, "%s: head weights", who);
@@ -533,32 +689,32 @@ extern "C" int nsky_film_stream_layout(const nsky_film_net* net, int32_t directi
   if (int rc = check_net(net, "nsky_film_stream_layout")) return rc;
   NSKY_CHECK_ARG(direction == 0, "nsky_film_stream_layout: direction %d", direction);
   const Layout L = fwd_layout(*net);
-  if (stream_bytes) *stream_bytes = (L.total_groups + LOOKAHEAD + 1) * (int64_t)GROUP;
+  if (stream_bytes) *stream_bytes = (L.total_groups + RING_GROUPS + 2) * (int64_t)GROUP;
   if (n_tiles) *n_tiles = L.n_tiles;
   return NSKY_OK;
 }
 
-extern "C" int nsky_film_pack(const nsky_film_net* net, int32_t direction, void* stream_buf, float* tile_scales, nsky_stream_t stream) {
+extern "C" int nsky_film_pack(const nsky_film_net* net, int32_t direction, void* stream_buf, float* table, nsky_stream_t stream) {
   if (int rc = check_net(net, "nsky_film_pack")) return rc;
-  NSKY_CHECK_ARG(direction == 0 && stream_buf && tile_scales && ((uintptr_t)stream_buf % 16) == 0, "nsky_film_pack: bad arguments");
+  NSKY_CHECK_ARG(direction == 0 && stream_buf && table && ((uintptr_t)stream_buf % 16) == 0 && ((uintptr_t)table % 16) == 0, "nsky_film_pack: bad arguments");
   const Layout L = fwd_layout(*net);
-  hipLaunchKernelGGL(film_pack_kernel, dim3(L.n_tiles), dim3(256), 0, (hipStream_t)stream, *net, direction, (unsigned char*)stream_buf, tile_scales);
+  hipLaunchKernelGGL(film_pack_kernel, dim3(L.n_tiles + 1), dim3(256), 0, (hipStream_t)stream, *net, direction, (unsigned char*)stream_buf, table);
   NSKY_CHECK_LAUNCH("nsky_film_pack");
   return NSKY_OK;
 }
 
-extern "C" int nsky_film_chain_fwd(const nsky_film_net* net, const void* stream_buf, const float* tile_scales, const float* cond,
+extern "C" int nsky_film_chain_fwd(const nsky_film_net* net, const void* stream_buf, const float* table, const float* cond,
                                    int32_t ldcond, const float* x, int32_t ldx, int32_t M, float* const* h_save, float* const* z_save,
                                    float* const* y_save, float* res, int32_t ldres, nsky_stream_t stream) {
   if (int rc = check_net(net, "nsky_film_chain_fwd")) return rc;
-  NSKY_CHECK_ARG(stream_buf && tile_scales && cond && x && res && y_save && M > 0, "nsky_film_chain_fwd: null operand / empty batch");
+  NSKY_CHECK_ARG(stream_buf && table && cond && x && res && y_save && M > 0, "nsky_film_chain_fwd: null operand / empty batch");
   NSKY_CHECK_ARG(ldcond % 4 == 0 && ldcond >= ((net->cond_dim + 3) & ~3) && ldx % 4 == 0 && ldx >= ((net->x_dim + 3) & ~3) && ldres >= 4 && ldres % 4 == 0,
                  "nsky_film_chain_fwd: leading dimensions (cond %d, x %d, res %d) must be multiples of 4 covering the padded widths", ldcond, ldx, ldres);
-  NSKY_CHECK_ARG(((uintptr_t)cond % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)res % 16) == 0 && ((uintptr_t)stream_buf % 16) == 0,
+  NSKY_CHECK_ARG(((uintptr_t)cond % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)res % 16) == 0 && ((uintptr_t)stream_buf % 16) == 0 && ((uintptr_t)table % 16) == 0,
                  "nsky_film_chain_fwd: operands must be 16-byte aligned");
   FwdArgs a;
   a.net = *net;
-  a.stream = (const unsigned char*)stream_buf; a.scales = tile_scales;
+  a.stream = (const unsigned char*)stream_buf; a.table = table;
   a.cond = cond; a.ldcond = ldcond; a.x = x; a.ldx = ldx; a.M = M; a.res = res; a.ldres = ldres;
   for (int l = 0; l < MAXL; ++l) {
     a.h_save[l] = (h_save && l < net->n_map) ? h_save[l] : nullptr;
@@ -575,3 +731,13 @@ extern "C" int nsky_film_chain_fwd(const nsky_film_net* net, const void* stream_
   NSKY_CHECK_LAUNCH("nsky_film_chain_fwd");
   return NSKY_OK;
 }
+
+#ifdef FILM_LAB_STAMP
+extern "C" int nsky_film_lab_stamps(unsigned long long* host_out, int reset) {
+  if (reset) {
+    unsigned long long z[64] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) == hipSuccess ? 0 : -1;
+  }
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -419,6 +419,7 @@ def ddf_losses_bwd(desc: DDFLossesDesc, d_terms, d_expected, d_sdf, d_mv_expecte
 
 # ------------------------------------------------------------------------------------------ fused FiLM-SIREN chain
 FILM_MAX_LAYERS = 12
+FILM_TABLE_FLOATS = 6656  # biases + reciprocal tile scales written by nsky_film_pack
 
 
 class FilmNet(C.Structure):
@@ -479,3 +480,23 @@ def film_chain_fwd(net: FilmNet, stream_buf, scales, cond, x, M, h_save, z_save,
                     _ptr_array(h_save, net.n_map), _ptr_array(z_save, net.n_film), _ptr_array(y_save, net.n_film), ptr(res), ld(res),
                     stream_ptr()), "nsky_film_chain_fwd")
     return res
+
+
+def film_rows(M: int) -> int:
+    """rows of a tile-native activation matrix holding M batch rows"""
+    return (M + 31) // 32 * 32
+
+
+def film_native_to_rows(buf, M: int, width: int):
+    """tile-native [ceil32(M), width] -> row-major [M, width] (tests / fallbacks; torch ops)"""
+    R = film_rows(M) // 32
+    return buf.reshape(R, width // 32, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(R * 32, width)[:M]
+
+
+def film_rows_to_native(x, width: int):
+    """row-major [M, width] -> tile-native [ceil32(M), width] (zero padded rows)"""
+    M = x.shape[0]
+    R = film_rows(M) // 32
+    full = x.new_zeros(R * 32, width)
+    full[:M] = x[:, :width]
+    return full.reshape(R, 32, width // 32, 4, 2, 4).permute(0, 2, 3, 4, 1, 5).contiguous().reshape(R * 32, width)

@@ -159,6 +159,7 @@ _PLANES_MIN_K = int(_os.environ.get("NSKY_PLANES_MIN_K", "36"))  # below: the la
 
 def begin_step() -> None:
     _PLANES.clear()
+    _FILM_STREAMS.clear()
 
 
 def _planes(W, n_rows, n_k, transpose, precision):
@@ -294,6 +295,33 @@ class DenseFn(torch.autograd.Function):
 # =============================================================================================
 # FiLM-SIREN (DDF network, RENI-shaped illumination decoder)
 # =============================================================================================
+FUSED_FILM_MIN_ROWS = int(_os.environ.get("NSKY_FUSED_FILM_MIN_ROWS", "4096"))  # below: a few workgroups walking a ~0.3 ms chain
+_FILM_STREAMS: dict = {}
+
+
+def _film_fused_ok(M, H, Hm, n_map, n_film, mw, fw, ow, x, cond) -> bool:
+    return (FWD_PRECISION == hip.PREC_F16X2 and M >= FUSED_FILM_MIN_ROWS and x.is_cuda
+            and hip.film_supported(H, Hm, n_map, n_film, mw[0].shape[1], fw[0].shape[1], ow.shape[0])
+            and ld(x) >= fw[0].shape[1] and ld(cond) >= mw[0].shape[1])
+
+
+def _film_stream(wb, n_map, n_film, mw, mb, mwo, mbo, fw, fb, ow, ob):
+    """per-step cache of the packed weight stream of one network (dropped by begin_step: the optimiser changed the weights)"""
+    key = (wb[0].data_ptr(), wb[0]._version, wb[-2].data_ptr(), n_map, n_film)
+    hit = _FILM_STREAMS.get(key)
+    cur = torch.cuda.current_stream()
+    if hit is None:
+        net = hip.film_net(mw[0].shape[1], fw[0].shape[1], ow.shape[0], mw, mb, mwo, mbo, fw, fb, ow, ob)
+        nbytes, ntiles = hip.film_stream_layout(net)
+        # zero-filled: the pad slabs of partial groups are streamed through LDS but never multiplied
+        stream = torch.zeros(nbytes, dtype=torch.uint8, device=wb[0].device)
+        scales = torch.empty(hip.FILM_TABLE_FLOATS, device=wb[0].device)
+        hip.film_pack(net, stream, scales)
+        hit = _FILM_STREAMS[key] = (list(wb), net, stream, scales, cur)
+    elif hit[4] != cur:  # packed on another stream of the same step: order this stream after it
+        cur.wait_stream(hit[4])
+    return hit[1], hit[2], hit[3]
+
 class FilmSirenFn(torch.autograd.Function):
     """neusky/utils/siren.py:108-208 as a chain of fp32-MFMA layers with fused epilogues.
 
@@ -332,6 +360,23 @@ class FilmSirenFn(torch.autograd.Function):
         # nothing has to survive the call when no input needs a gradient (render / eval): two ping-pong activation
         # buffers, no pre-activation side output
         save = any(ctx.needs_input_grad)
+        if _film_fused_ok(M, H, Hm, n_map, n_film, mw, fw, ow, x, cond):
+            # one launch for the whole network (csrc/film_chain.hip): the [M, 2 n_film H] frequency / phase matrix is never
+            # formed and no activation makes a round trip through HBM between layers; kept for the backward: mapping
+            # activations, FiLM pre-activations and outputs
+            net, stream, scales = _film_stream(wb, n_map, n_film, mw, mb, mwo, mbo, fw, fb, ow, ob)
+            Mp = hip.film_rows(M)  # saved activations are tile-native [ceil32(M), H] matrices (include/neusky_hip.h)
+            ys = [torch.empty(Mp, H, device=dev) for _ in range(n_film if save else min(2, n_film))]
+            hs = [torch.empty(Mp, Hm, device=dev) for _ in range(n_map)] if save else None
+            zs = [torch.empty(Mp, H, device=dev) for _ in range(n_film)] if save else None
+            res = torch.empty(M, n_out_p, device=dev)
+            hip.film_chain_fwd(net, stream, scales, cond, x, M, hs, zs, ys if save else [ys[i % len(ys)] for i in range(n_film)], res)
+            if not save:
+                return res
+            ctx.save_for_backward(x, cond, x.new_empty(0), *hs, *ys, *zs, *wb)
+            ctx.cfg = (n_map, n_film, train_weights, need_dcond, M, H, Hm)
+            ctx.sinks = [w if getattr(w, "_nsky_grad_sink", False) else None for w in wb]
+            return res
         if save:
             hs = [torch.empty(M, Hm, device=dev) for _ in range(n_map)]
             ys = [torch.empty(M, H, device=dev) for _ in range(n_film)]
@@ -379,6 +424,12 @@ class FilmSirenFn(torch.autograd.Function):
         wb = sv[3 + n_map + 2 * n_film:]
         mw, mb, mwo, mbo, fw, fb, ow, ob, o = FilmSirenFn._unpack(wb, n_map, n_film)
         dev = x.device
+        if FP.numel() == 0:  # fused forward: frequencies / phases were never stored; re-form them from the last mapping activation
+            hs = [hip.film_native_to_rows(t, M, Hm) for t in hs]
+            ys = [hip.film_native_to_rows(t, M, H) for t in ys]
+            zs = [hip.film_native_to_rows(t, M, H) for t in zs]
+            FP = torch.empty(M, 2 * n_film * H, device=dev)
+            fgemm(hs[-1], mwo, FP, M, 2 * n_film * H, Hm, bias=mbo)
         grads: List[Optional[torch.Tensor]] = [None] * len(wb)
         d_res = d_res.contiguous()
         n_out_p = ow.shape[0]

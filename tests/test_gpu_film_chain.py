@@ -51,15 +51,16 @@ def _run_fused(net, cond, x, save=True):
                         net.final_layer.weight, net.final_layer.bias)
     nbytes, ntiles = hip.film_stream_layout(desc)
     stream = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
-    scales = torch.empty(ntiles, device=DEV)
+    scales = torch.empty(hip.FILM_TABLE_FLOATS, device=DEV)
     hip.film_pack(desc, stream, scales)
     M = cond.shape[0]
-    mk = lambda n: [torch.full((M, H), float("nan"), device=DEV) for _ in range(n)]  # noqa: E731
+    mk = lambda n: [torch.full((hip.film_rows(M), H), float("nan"), device=DEV) for _ in range(n)]  # noqa: E731
     hs, zs, ys = (mk(n_map), mk(n_film), mk(n_film)) if save else (None, None, mk(n_film))
     res = torch.full((M, 4), float("nan"), device=DEV)
     hip.film_chain_fwd(desc, stream, scales, cond.to(DEV), x.to(DEV), M, hs, zs, ys, res)
     torch.cuda.synchronize()
-    return res, hs, zs, ys
+    rows = lambda ts: None if ts is None else [hip.film_native_to_rows(t, M, H) for t in ts]  # noqa: E731  saved in tile-native layout
+    return res, rows(hs), rows(zs), rows(ys)
 
 
 @pytest.mark.parametrize("H,n_map,n_film,cond_dim,x_dim,out_dim,M", [

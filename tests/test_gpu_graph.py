@@ -62,10 +62,11 @@ def test_graph_replay_equals_eager_on_injected_randoms():
     opt.zero_grad_all()
     outs, ld, _ = pipe.get_train_loss_dict(step, ray_bundle=rb, batch=batch, randoms=rnd)
     total_loss(ld).backward()
-    eager_ld = {k: float(v) for k, v in ld.items()}
+    eager_ld = {k: float(v.detach()) for k, v in ld.items()}
     eager_rgb = outs["rgb"].detach().clone()
     eager_inds = [t.clone() for t in outs["pdf_inds_list"]]
     eager_g = opt.flat_g.clone()
+    del outs, ld  # the eager autograd graph (and its AccumulateGrad nodes, bound to the default stream) must be gone before the capture
     stepper = GraphedTrainStep(pipe, opt, rb, batch, warmup=2, start_step=step, randoms=rnd)
     pipe.model.set_step(step)
     for rep in range(2):
