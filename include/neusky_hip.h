@@ -145,6 +145,22 @@ int nsky_film_pack(const nsky_film_net* net, int32_t direction, void* stream_buf
 int nsky_film_chain_fwd(const nsky_film_net* net, const void* stream_buf, const float* table, const float* cond,
                         int32_t ldcond, const float* x, int32_t ldx, int32_t M, float* const* h_save, float* const* z_save,
                         float* const* y_save, float* res, int32_t ldres, nsky_stream_t stream);
+/* Backward of the chain (replaces the autograd-generated backward of siren.py:108-208; parameters' gradients are then plain
+ * weight-gradient GEMMs, nsky_gemm_f32 with a_native_nt / b_native_nt, over the tile-native matrices written here).
+ *   nsky_film_chain_bwd_film (stream / table packed with direction 1): d_res [M, ldres] -> for every FiLM layer i
+ *        dz_save[i] = dL/d(W y + b) (tile-native [ceil32(M), hidden]) and, in dfp (tile-native [ceil32(M), 2 n_film hidden]),
+ *        dL/dF_i in columns i hidden.. and dL/dphase_i in columns (n_film + i) hidden..; dfp_rowmax [ceil32(M)] = max |dfp| of each
+ *        batch row.  F and phase are re-formed from h_last (the last mapping activation), z_save[i] is read back.
+ *   nsky_film_chain_bwd_map (direction 2): dfp, dfp_rowmax, h_save[l] -> dpre_save[l] = dL/d(pre-activation of mapping layer l)
+ *        (tile-native) and d_cond [M, ldcond] (row-major, pad columns zeroed; optional).
+ * hidden must be a multiple of 128 for the backward streams.  The gradient w.r.t. x is not produced (the callers' x rows are
+ * constants of the geometry). */
+int nsky_film_chain_bwd_film(const nsky_film_net* net, const void* stream_buf, const float* table, int32_t M, const float* d_res,
+                             int32_t ldres, const float* h_last, const float* const* z_save, float* const* dz_save, float* dfp,
+                             float* dfp_rowmax, nsky_stream_t stream);
+int nsky_film_chain_bwd_map(const nsky_film_net* net, const void* stream_buf, const float* table, int32_t M, const float* dfp,
+                            const float* dfp_rowmax, const float* const* h_save, float* const* dpre_save, float* d_cond,
+                            int32_t ldcond, nsky_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multiresolution hash-grid encode (tiny-cuda-nn HashGrid semantics, fp32) fused with the rest of

@@ -112,6 +112,69 @@ __device__ inline TileDesc fwd_tile(const nsky_film_net& n, const Layout& L, int
   return d;
 }
 
+// direction 1 (FiLM backward): for i = n_film-1 .. 0: for t: F tile, phase tile; if i > 0: for u: transposed FiLM weight tile
+//   (rows = input features 32 u .., k = output features).
+// direction 2 (mapping backward): mapping head transposed, k-group outer: for kg: for u: tile (rows = hidden features 32 u ..,
+//   k = head rows 128 kg .. 128 kg + 127); layers n_map-1 .. 1 transposed: for u; layer 0 transposed: ceil(cond_dim / 32) tiles.
+__host__ __device__ inline void bwd_film_layout(const nsky_film_net& n, long& total_groups, int& n_tiles) {
+  const int NT = n.hidden / 32, Gh = groups_of(n.hidden);
+  n_tiles = n.n_film * NT * 2 + (n.n_film - 1) * NT;
+  total_groups = (long)n_tiles * Gh;
+}
+__host__ __device__ inline void bwd_map_layout(const nsky_film_net& n, long& total_groups, int& n_tiles) {
+  const int NT = n.hidden / 32, Gh = groups_of(n.hidden);
+  const int nkg = 2 * n.n_film * n.hidden / 128, ct = (n.cond_dim + 31) / 32;
+  n_tiles = nkg * NT + (n.n_map - 1) * NT + ct;
+  total_groups = (long)nkg * NT + (long)((n.n_map - 1) * NT + ct) * Gh;
+}
+
+__device__ inline TileDesc bwd_film_tile(const nsky_film_net& n, int idx) {
+  TileDesc d;
+  const int NT = n.hidden / 32, H = n.hidden, Gh = groups_of(H);
+  d.group = (long)idx * Gh;
+  d.nrows = 32; d.K = H; d.k0 = 0; d.transposed = 0;
+  // layers i = n_film-1 .. 1 own 3 NT tiles each, layer 0 owns 2 NT
+  int i = n.n_film - 1, rem = idx;
+  while (i > 0 && rem >= 3 * NT) { rem -= 3 * NT; --i; }
+  if (rem < 2 * NT) {
+    const int t = rem / 2, which = rem % 2;
+    d.W = n.mo_w; d.ld = n.mo_ld; d.row0 = (which == 0 ? i : n.n_film + i) * H + 32 * t;
+  } else {
+    const int u = rem - 2 * NT;
+    d.W = n.film_w[i]; d.ld = n.film_ld[i]; d.row0 = 32 * u; d.transposed = 1;
+  }
+  return d;
+}
+
+__device__ inline TileDesc bwd_map_tile(const nsky_film_net& n, int idx) {
+  TileDesc d;
+  const int NT = n.hidden / 32, H = n.hidden, Gh = groups_of(H);
+  const int nkg = 2 * n.n_film * H / 128;
+  d.nrows = 32; d.transposed = 1; d.k0 = 0;
+  if (idx < nkg * NT) {
+    const int kg = idx / NT, u = idx % NT;
+    d.W = n.mo_w; d.ld = n.mo_ld; d.row0 = 32 * u; d.K = 128; d.k0 = 128 * kg; d.group = idx;
+    return d;
+  }
+  idx -= nkg * NT;
+  d.group = (long)nkg * NT + (long)idx * Gh;
+  d.K = H;
+  if (idx < (n.n_map - 1) * NT) {
+    const int l = n.n_map - 1 - idx / NT, u = idx % NT;
+    d.W = n.map_w[l]; d.ld = n.map_ld[l]; d.row0 = 32 * u;
+    return d;
+  }
+  idx -= (n.n_map - 1) * NT;
+  d.W = n.map_w[0]; d.ld = n.map_ld[0]; d.row0 = 32 * idx; d.nrows = min(32, n.cond_dim - 32 * idx);
+  return d;
+}
+
+__host__ __device__ inline void dir_layout(const nsky_film_net& n, int direction, long& total_groups, int& n_tiles) {
+  if (direction == 0) { const Layout L = fwd_layout(n); total_groups = L.total_groups; n_tiles = L.n_tiles; }
+  else if (direction == 1) bwd_film_layout(n, total_groups, n_tiles);
+  else bwd_map_layout(n, total_groups, n_tiles);
+}
+
 // bias table: [mapping layer l: H][mapping head: 2 n_film H][FiLM layer i: H][head: 32]
 __device__ inline void write_bias_table(const nsky_film_net& n, float* bl, int tid) {
   const int H = n.hidden;
@@ -130,15 +193,17 @@ __global__ __launch_bounds__(256) void film_pack_kernel(nsky_film_net net, int d
                                                         float* __restrict__ table) {
   __shared__ float w[32][PACK_KMAX + 1];
   __shared__ float red[256];
-  const Layout L = fwd_layout(net);
   const int tid = threadIdx.x;
-  if ((int)blockIdx.x == L.n_tiles) {  // the extra block: every bias of the network, in the order the chain kernels index them
+  long total_groups;
+  int n_tiles;
+  dir_layout(net, direction, total_groups, n_tiles);
+  if ((int)blockIdx.x == n_tiles) {  // the extra block: every bias of the network, in the order the chain kernels index them
     write_bias_table(net, table, tid);
     return;
   }
   float* scales = table + BIAS_FLOATS;
-  const TileDesc d = fwd_tile(net, L, blockIdx.x);
-  (void)direction;
+  const TileDesc d = direction == 0 ? fwd_tile(net, fwd_layout(net), blockIdx.x)
+                                    : (direction == 1 ? bwd_film_tile(net, blockIdx.x) : bwd_map_tile(net, blockIdx.x));
   const int Kp = ksteps_of(d.K) * 16;
   float m = 0.0f;
   for (int idx = tid; idx < 32 * Kp; idx += 256) {
@@ -668,6 +733,365 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the tail groups of the ring are still landing
 }
 
+// =====================================================================================================================
+// Backward, FiLM part.  Per 32-row tile of a wave, walking the FiLM layers from the last to the first:
+//   F, phase of a 32-feature tile are RE-FORMED from the last mapping activation (two products, as in the forward: the
+//   frequency / phase matrix is never stored), z is read back (tile-native), then
+//     g = dY cos(arg), dz = g f, dF = 15 g z, dphase = g        (arg = f z + phase, f = 15 F + 30)
+//   dz (for the weight gradient), dF and dphase (for the mapping head) are stored tile-native; dz stays in registers, is
+//   pre-scaled per batch row (a per-lane scalar) and split into fp16 hi / residual planes, and dY of the layer below is
+//   W^T dz on the transposed weight tiles.  Gradients therefore get the same fp32-grade products as the forward.
+// A vector-memory load the compiler knows about would make it wait for every LDS-DMA piece issued before it (one in-order
+// counter), so z is fetched with hidden loads one tile ahead and waited for with a counted vmcnt.
+struct BwdFilmArgs {
+  nsky_film_net net;
+  const unsigned char* stream;
+  const float* table;
+  int M;
+  const float* d_res; int ldres;   // [M, ldres] gradient of the raw head output (first out_dim columns)
+  const float* h_last;             // native [ceil32(M), H]
+  const float* z_save[MAXL];       // native
+  float* dz_save[MAXL];            // native [ceil32(M), H]
+  float* dfp;                      // native [ceil32(M), 2 n_film H]: dF of layer i in columns i H .., dphase in (n_film + i) H ..
+  float* dfp_rowmax;               // [ceil32(M)] max |dfp| per batch row
+};
+
+__device__ __forceinline__ void hidden_load4(f32x4& q, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(q) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void hidden_wait(f32x4 (&q)[4]) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : "n"(N) : "memory");
+}
+
+template <int H>
+__global__ __launch_bounds__(256, 1) void film_bwd_kernel(const BwdFilmArgs a) {
+  constexpr int NT = H / 32, KS = H / 16, GH = (KS + GSLABS - 1) / GSLABS;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + (BIAS_FLOATS + SCALE_FLOATS) * 4 + 4 * H * 4];
+  float* bl = reinterpret_cast<float*>(smem + RING_BYTES);
+  float* sl = bl + BIAS_FLOATS;
+  float* wo = sl + SCALE_FLOATS;  // head weights [4][H] (rows >= out_dim zero)
+  const nsky_film_net& net = a.net;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  {
+    constexpr int N4 = (BIAS_FLOATS + SCALE_FLOATS) / 4;
+    float4 q[(N4 + 255) / 256];
+#pragma unroll
+    for (int i = 0; i < (N4 + 255) / 256; ++i)
+      if (i * 256 + tid < N4) q[i] = ldg4(a.table + 4 * (i * 256 + tid));
+#pragma unroll
+    for (int i = 0; i < (N4 + 255) / 256; ++i)
+      if (i * 256 + tid < N4) *reinterpret_cast<float4*>(bl + 4 * (i * 256 + tid)) = q[i];
+    for (int i = tid; i < 4 * H; i += 256) wo[i] = (i / H) < net.out_dim ? net.out_w[(long)(i / H) * net.out_ld + (i % H)] : 0.0f;
+  }
+  __syncthreads();
+  const long rt = (long)blockIdx.x * 4 + wave;
+  const long row = rt * 32 + c;
+  const bool live = row < a.M;
+  const long rowc = live ? row : a.M - 1;
+  const bool wave_live = rt * 32 < a.M;
+  const long rts = wave_live ? rt : 0;  // a wave wholly beyond M reads tile 0 (in bounds) and stores nothing
+  const int n_film = net.n_film;
+
+  // row scale of the last mapping activation (its planes are rebuilt at the top of every layer: they would otherwise sit in
+  // 128 registers through the W^T products, where the old and the new dY and the dz planes are live)
+  float h_inv, h_scale;
+  {
+    float m = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float hv[16];
+      load_tile(a.h_last + (rts * NT + t) * 1024, lane, hv);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(hv[r]));
+    }
+    h_scale = row_scale(m, h_inv);
+  }
+  // head gradient -> dY of the last FiLM layer
+  float dY[NT][16];
+  {
+    const float4 dr = ldg4(a.d_res + rowc * a.ldres);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int fo = 32 * t + 8 * g + 4 * h;
+        const float4 w0 = *reinterpret_cast<const float4*>(wo + fo), w1 = *reinterpret_cast<const float4*>(wo + H + fo);
+        const float4 w2 = *reinterpret_cast<const float4*>(wo + 2 * H + fo), w3 = *reinterpret_cast<const float4*>(wo + 3 * H + fo);
+        dY[t][4 * g] = dr.x * w0.x + dr.y * w1.x + dr.z * w2.x + dr.w * w3.x;
+        dY[t][4 * g + 1] = dr.x * w0.y + dr.y * w1.y + dr.z * w2.y + dr.w * w3.y;
+        dY[t][4 * g + 2] = dr.x * w0.z + dr.y * w1.z + dr.z * w2.z + dr.w * w3.z;
+        dY[t][4 * g + 3] = dr.x * w0.w + dr.y * w1.w + dr.z * w2.w + dr.w * w3.w;
+      }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every compiler-visible load has returned before the DMA stream starts
+  WStream ws;
+  ws.src = a.stream + wave * 4096 + lane * 16;
+  ws.dst = (uint32_t)(uintptr_t)smem + wave * 4096;
+  ws.lds_lane = (uint32_t)(uintptr_t)smem + lane * 16;
+  ws_begin(ws);
+
+  const float* bias_mo = bl + net.n_map * H;
+  float fp_max = 0.0f;
+  int tile = 0;
+  for (int i = n_film - 1; i >= 0; --i) {
+    const float* bF = bias_mo + i * H;
+    const float* bP = bias_mo + (n_film + i) * H;
+    const float* zblk = a.z_save[i] + rts * NT * 1024;
+    float* dzblk = a.dz_save[i] + rt * NT * 1024;
+    float* dFblk = a.dfp + (rt * (2 * n_film * NT) + (long)i * NT) * 1024;
+    float* dPblk = a.dfp + (rt * (2 * n_film * NT) + (long)(n_film + i) * NT) * 1024;
+    float dz_max = 0.0f;
+    f16x8 hh[KS], hl[KS];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float hv[16];
+      load_tile(a.h_last + (rts * NT + t) * 1024, lane, hv);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float x8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x8[j] = hv[8 * u + j] * h_scale;
+        split8(x8, hh[2 * t + u], hl[2 * t + u]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // compiler-visible loads: none pending when the hidden z loads are counted
+    f32x4 zq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) zq[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) hidden_load4(zq[g], zblk + g * 256 + lane * 4);  // z of tile 0
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x16 aF, aP;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { aF[r] = 0.0f; aP[r] = 0.0f; }
+      product<KS>(ws, hh, hl, aF);
+      product<KS>(ws, hh, hl, aP);
+      // z of this tile was requested just before the two products: only their 2 GH transitions x 4 DMA pieces are younger
+      hidden_wait<8 * GH>(zq);
+      const float iF = h_inv * sl[tile], iP = h_inv * sl[tile + 1];
+      tile += 2;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int fo = 32 * t + 8 * g + 4 * h;
+        const float4 b4F = *reinterpret_cast<const float4*>(bF + fo);
+        const float4 b4P = *reinterpret_cast<const float4*>(bP + fo);
+        const float bf[4] = {b4F.x, b4F.y, b4F.z, b4F.w}, bp[4] = {b4P.x, b4P.y, b4P.z, b4P.w};
+        float dFv[4], dPv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 4 * g + q;
+          const float F = fmaf(aF[r], iF, bf[q]), P = fmaf(aP[r], iP, bp[q]), z = zq[g][q];
+          const float f = fmaf(15.0f, F, 30.0f);
+          float sn, cs;
+          sincos_cw(fmaf(f, z, P), sn, cs);
+          const float gc = dY[t][r] * cs;
+          const float dz = gc * f;
+          dFv[q] = 15.0f * gc * z;
+          dPv[q] = gc;
+          dz_max = fmaxf(dz_max, fabsf(dz));
+          fp_max = fmaxf(fp_max, fmaxf(fabsf(dFv[q]), fabsf(gc)));
+          dY[t][r] = dz;
+        }
+        if (wave_live) {  // the three pieces of register group g: 1 KB-contiguous per wave instruction
+          stg4(dzblk + t * 1024 + g * 256 + lane * 4, make_float4(dY[t][4 * g], dY[t][4 * g + 1], dY[t][4 * g + 2], dY[t][4 * g + 3]));
+          stg4(dFblk + t * 1024 + g * 256 + lane * 4, make_float4(dFv[0], dFv[1], dFv[2], dFv[3]));
+          stg4(dPblk + t * 1024 + g * 256 + lane * 4, make_float4(dPv[0], dPv[1], dPv[2], dPv[3]));
+        }
+      }
+      if (t + 1 < NT) {  // z of the next tile, behind this tile's stores
+#pragma unroll
+        for (int g = 0; g < 4; ++g) hidden_load4(zq[g], zblk + (t + 1) * 1024 + g * 256 + lane * 4);
+      }
+    }
+    if (i > 0) {
+      // dY of the layer below = W_i^T dz
+      float dz_inv;
+      const float s = row_scale(dz_max, dz_inv);
+      f16x8 dh_[KS], dl_[KS];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float x8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x8[j] = dY[t][8 * u + j] * s;
+          split8(x8, dh_[2 * t + u], dl_[2 * t + u]);
+        }
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        product<KS>(ws, dh_, dl_, acc);
+        const float inv = dz_inv * sl[tile++];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dY[u][r] = acc[r] * inv;
+      }
+    }
+  }
+  fp_max = fmaxf(fp_max, __shfl_xor(fp_max, 32, 64));
+  if (wave_live && h == 0) a.dfp_rowmax[row] = fp_max;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+// =====================================================================================================================
+// Backward, mapping network.  dh = sum over the 2 n_film H head rows of Wmo^T dfp (k-group outer: 128 head rows of dfp are
+// fetched tile-native one group ahead with hidden loads, pre-scaled by the row's maximum over ALL of dfp and split), then the
+// mapping layers backwards, hidden state in registers as in the forward: dpre = dh * leaky'(h) is stored tile-native (weight
+// gradients), split, and multiplied by the transposed weight tiles; the last product yields d_cond (row-major).
+struct BwdMapArgs {
+  nsky_film_net net;
+  const unsigned char* stream;
+  const float* table;
+  int M;
+  const float* dfp;          // native [ceil32(M), 2 n_film H]
+  const float* dfp_rowmax;   // [ceil32(M)]
+  const float* h_save[MAXL]; // native
+  float* dpre_save[MAXL];    // native [ceil32(M), H]
+  float* d_cond; int ldcond; // [M, ldcond] or NULL
+};
+
+template <int H>
+__global__ __launch_bounds__(256, 1) void film_bwd_map_kernel(const BwdMapArgs a) {
+  constexpr int NT = H / 32, KS = H / 16;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + SCALE_FLOATS * 4];
+  float* sl = reinterpret_cast<float*>(smem + RING_BYTES);
+  const nsky_film_net& net = a.net;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  for (int i = tid; i < SCALE_FLOATS; i += 256) sl[i] = a.table[BIAS_FLOATS + i];
+  const long rt = (long)blockIdx.x * 4 + wave;
+  const long row = rt * 32 + c;
+  const bool live = row < a.M;
+  const bool wave_live = rt * 32 < a.M;
+  const long rts = wave_live ? rt : 0;
+  const int nkg = 2 * net.n_film * H / 128, ntot = 2 * net.n_film * NT;
+  float f_inv;
+  const float f_scale = row_scale(a.dfp_rowmax[rts * 32 + c], f_inv);  // both lane halves read the same row: the shuffle is a no-op
+  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WStream ws;
+  ws.src = a.stream + wave * 4096 + lane * 16;
+  ws.dst = (uint32_t)(uintptr_t)smem + wave * 4096;
+  ws.lds_lane = (uint32_t)(uintptr_t)smem + lane * 16;
+  ws_begin(ws);
+
+  float dh[NT][16];
+#pragma unroll
+  for (int u = 0; u < NT; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dh[u][r] = 0.0f;
+  int tile = 0;
+  const float* fblk = a.dfp + rts * ntot * 1024;
+  f32x4 fq[16];  // 128 head rows = 4 native tiles x 4 pieces, one k-group ahead
+#pragma unroll
+  for (int j = 0; j < 16; ++j) fq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define NSKY_FQ_WAIT(N)                                                                                                         \
+  asm volatile("s_waitcnt vmcnt(%16)"                                                                                           \
+               : "+v"(fq[0]), "+v"(fq[1]), "+v"(fq[2]), "+v"(fq[3]), "+v"(fq[4]), "+v"(fq[5]), "+v"(fq[6]), "+v"(fq[7]), "+v"(fq[8]), \
+                 "+v"(fq[9]), "+v"(fq[10]), "+v"(fq[11]), "+v"(fq[12]), "+v"(fq[13]), "+v"(fq[14]), "+v"(fq[15])                \
+               : "n"(N)                                                                                                         \
+               : "memory")
+#pragma unroll
+  for (int j = 0; j < 16; ++j) hidden_load4(fq[j], fblk + (j >> 2) * 1024 + (j & 3) * 256 + lane * 4);
+  NSKY_FQ_WAIT(0);  // first group (the ring's first pieces are older and land with it)
+  for (int kg = 0; kg < nkg; ++kg) {
+    f16x8 ph[8], pl[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      float x8[8];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f32x4 q = fq[(ks >> 1) * 4 + 2 * (ks & 1) + u];
+        x8[4 * u] = q[0] * f_scale; x8[4 * u + 1] = q[1] * f_scale; x8[4 * u + 2] = q[2] * f_scale; x8[4 * u + 3] = q[3] * f_scale;
+      }
+      split8(x8, ph[ks], pl[ks]);
+    }
+    {
+      const int kn = kg + 1 < nkg ? kg + 1 : kg;  // the last group re-requests itself (same count of operations in flight)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) hidden_load4(fq[j], fblk + (long)(4 * kn + (j >> 2)) * 1024 + (j & 3) * 256 + lane * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      product<8>(ws, ph, pl, acc);
+      const float inv = f_inv * sl[tile++];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dh[u][r] = fmaf(acc[r], inv, dh[u][r]);
+    }
+    // the next group's 16 pieces were requested before this group's NT products (NT transitions x 4 DMA pieces)
+    NSKY_FQ_WAIT(4 * NT);
+  }
+#undef NSKY_FQ_WAIT
+
+  for (int l = net.n_map - 1; l >= 0; --l) {
+    // dpre = dh * leaky'(h_l): the activation keeps the sign of the pre-activation
+    float m = 0.0f;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      float hv[16];
+      load_tile(a.h_save[l] + (rts * NT + u) * 1024, lane, hv);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dh[u][r] = hv[r] > 0.0f ? dh[u][r] : 0.2f * dh[u][r];
+        m = fmaxf(m, fabsf(dh[u][r]));
+      }
+      if (wave_live) store_tile(a.dpre_save[l] + (rt * NT + u) * 1024, lane, dh[u]);
+    }
+    float d_inv;
+    const float s = row_scale(m, d_inv);
+    f16x8 ph[KS], pl[KS];
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        float x8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x8[j] = dh[u][8 * v + j] * s;
+        split8(x8, ph[2 * u + v], pl[2 * u + v]);
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the h_l loads: compiler-visible, none may be pending across the products
+    if (l > 0) {
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        product<KS>(ws, ph, pl, acc);
+        const float inv = d_inv * sl[tile++];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[u][r] = acc[r] * inv;
+      }
+    } else {
+      const int ct = (net.cond_dim + 31) / 32;
+      for (int u = 0; u < ct; ++u) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        product<KS>(ws, ph, pl, acc);
+        const float inv = d_inv * sl[tile++];
+        if (a.d_cond && live) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int fo = 32 * u + 8 * g + 4 * h;
+            if (fo < a.ldcond)
+              stg4(a.d_cond + row * a.ldcond + fo, make_float4(acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv, acc[4 * g + 3] * inv));
+          }
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
 int check_net(const nsky_film_net* n, const char* who) {
   NSKY_CHECK_ARG(n, "%s: null network", who);
   NSKY_CHECK_ARG(n->hidden == 128 || n->hidden == 256, "%s: hidden width %d (128 or 256)", who, n->hidden);
@@ -687,18 +1111,25 @@ int check_net(const nsky_film_net* n, const char* who) {
 
 extern "C" int nsky_film_stream_layout(const nsky_film_net* net, int32_t direction, int64_t* stream_bytes, int32_t* n_tiles) {
   if (int rc = check_net(net, "nsky_film_stream_layout")) return rc;
-  NSKY_CHECK_ARG(direction == 0, "nsky_film_stream_layout: direction %d", direction);
-  const Layout L = fwd_layout(*net);
-  if (stream_bytes) *stream_bytes = (L.total_groups + RING_GROUPS + 2) * (int64_t)GROUP;
-  if (n_tiles) *n_tiles = L.n_tiles;
+  NSKY_CHECK_ARG(direction >= 0 && direction <= 2, "nsky_film_stream_layout: direction %d", direction);
+  long groups;
+  int tiles;
+  dir_layout(*net, direction, groups, tiles);
+  NSKY_CHECK_ARG(tiles <= SCALE_FLOATS, "nsky_film_stream_layout: %d weight tiles exceed the scale table (%d)", tiles, SCALE_FLOATS);
+  if (stream_bytes) *stream_bytes = (groups + RING_GROUPS + 2) * (int64_t)GROUP;
+  if (n_tiles) *n_tiles = tiles;
   return NSKY_OK;
 }
 
 extern "C" int nsky_film_pack(const nsky_film_net* net, int32_t direction, void* stream_buf, float* table, nsky_stream_t stream) {
   if (int rc = check_net(net, "nsky_film_pack")) return rc;
-  NSKY_CHECK_ARG(direction == 0 && stream_buf && table && ((uintptr_t)stream_buf % 16) == 0 && ((uintptr_t)table % 16) == 0, "nsky_film_pack: bad arguments");
-  const Layout L = fwd_layout(*net);
-  hipLaunchKernelGGL(film_pack_kernel, dim3(L.n_tiles + 1), dim3(256), 0, (hipStream_t)stream, *net, direction, (unsigned char*)stream_buf, table);
+  NSKY_CHECK_ARG(direction >= 0 && direction <= 2 && stream_buf && table && ((uintptr_t)stream_buf % 16) == 0 && ((uintptr_t)table % 16) == 0, "nsky_film_pack: bad arguments");
+  long groups;
+  int tiles;
+  dir_layout(*net, direction, groups, tiles);
+  NSKY_CHECK_ARG(tiles <= SCALE_FLOATS, "nsky_film_pack: %d weight tiles exceed the scale table (%d)", tiles, SCALE_FLOATS);
+  if (direction != 0) NSKY_CHECK_ARG(net->hidden % 128 == 0, "nsky_film_pack: backward streams need hidden %% 128 == 0");
+  hipLaunchKernelGGL(film_pack_kernel, dim3(tiles + 1), dim3(256), 0, (hipStream_t)stream, *net, direction, (unsigned char*)stream_buf, table);
   NSKY_CHECK_LAUNCH("nsky_film_pack");
   return NSKY_OK;
 }
@@ -741,3 +1172,49 @@ extern "C" int nsky_film_lab_stamps(unsigned long long* host_out, int reset) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
+
+extern "C" int nsky_film_chain_bwd_film(const nsky_film_net* net, const void* stream_buf, const float* table, int32_t M, const float* d_res,
+                                        int32_t ldres, const float* h_last, const float* const* z_save, float* const* dz_save, float* dfp,
+                                        float* dfp_rowmax, nsky_stream_t stream) {
+  if (int rc = check_net(net, "nsky_film_chain_bwd_film")) return rc;
+  NSKY_CHECK_ARG(stream_buf && table && d_res && h_last && z_save && dz_save && dfp && dfp_rowmax && M > 0, "nsky_film_chain_bwd_film: null operand / empty batch");
+  NSKY_CHECK_ARG(ldres >= 4 && ldres % 4 == 0 && ((uintptr_t)d_res % 16) == 0 && ((uintptr_t)h_last % 16) == 0 && ((uintptr_t)dfp % 16) == 0 &&
+                     ((uintptr_t)stream_buf % 16) == 0 && ((uintptr_t)table % 16) == 0, "nsky_film_chain_bwd_film: alignment / ldres");
+  NSKY_CHECK_ARG(net->hidden % 128 == 0, "nsky_film_chain_bwd_film: hidden %% 128");
+  BwdFilmArgs a;
+  a.net = *net; a.stream = (const unsigned char*)stream_buf; a.table = table; a.M = M; a.d_res = d_res; a.ldres = ldres; a.h_last = h_last;
+  a.dfp = dfp; a.dfp_rowmax = dfp_rowmax;
+  for (int l = 0; l < MAXL; ++l) {
+    a.z_save[l] = l < net->n_film ? z_save[l] : nullptr;
+    a.dz_save[l] = l < net->n_film ? dz_save[l] : nullptr;
+    if (l < net->n_film) NSKY_CHECK_ARG(a.z_save[l] && a.dz_save[l] && ((uintptr_t)a.z_save[l] % 16) == 0 && ((uintptr_t)a.dz_save[l] % 16) == 0, "nsky_film_chain_bwd_film: z_save / dz_save[%d]", l);
+  }
+  const dim3 grid(ceil_div(M, 128));
+  if (net->hidden == 256) hipLaunchKernelGGL((film_bwd_kernel<256>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((film_bwd_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  NSKY_CHECK_LAUNCH("nsky_film_chain_bwd_film");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_film_chain_bwd_map(const nsky_film_net* net, const void* stream_buf, const float* table, int32_t M, const float* dfp,
+                                       const float* dfp_rowmax, const float* const* h_save, float* const* dpre_save, float* d_cond,
+                                       int32_t ldcond, nsky_stream_t stream) {
+  if (int rc = check_net(net, "nsky_film_chain_bwd_map")) return rc;
+  NSKY_CHECK_ARG(stream_buf && table && dfp && dfp_rowmax && h_save && dpre_save && M > 0, "nsky_film_chain_bwd_map: null operand / empty batch");
+  NSKY_CHECK_ARG(((uintptr_t)dfp % 16) == 0 && ((uintptr_t)stream_buf % 16) == 0 && ((uintptr_t)table % 16) == 0, "nsky_film_chain_bwd_map: alignment");
+  if (d_cond) NSKY_CHECK_ARG(ldcond % 4 == 0 && ldcond >= ((net->cond_dim + 3) & ~3) && ((uintptr_t)d_cond % 16) == 0, "nsky_film_chain_bwd_map: d_cond layout");
+  NSKY_CHECK_ARG(net->hidden % 128 == 0, "nsky_film_chain_bwd_map: hidden %% 128");
+  BwdMapArgs a;
+  a.net = *net; a.stream = (const unsigned char*)stream_buf; a.table = table; a.M = M; a.dfp = dfp; a.dfp_rowmax = dfp_rowmax;
+  a.d_cond = d_cond; a.ldcond = ldcond;
+  for (int l = 0; l < MAXL; ++l) {
+    a.h_save[l] = l < net->n_map ? h_save[l] : nullptr;
+    a.dpre_save[l] = l < net->n_map ? dpre_save[l] : nullptr;
+    if (l < net->n_map) NSKY_CHECK_ARG(a.h_save[l] && a.dpre_save[l] && ((uintptr_t)a.h_save[l] % 16) == 0 && ((uintptr_t)a.dpre_save[l] % 16) == 0, "nsky_film_chain_bwd_map: h_save / dpre_save[%d]", l);
+  }
+  const dim3 grid(ceil_div(M, 128));
+  if (net->hidden == 256) hipLaunchKernelGGL((film_bwd_map_kernel<256>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((film_bwd_map_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  NSKY_CHECK_LAUNCH("nsky_film_chain_bwd_map");
+  return NSKY_OK;
+}

@@ -437,6 +437,12 @@ _film_fwd = _sig("nsky_film_chain_fwd", C.POINTER(FilmNet), C.c_void_p, C.c_void
                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
 
 
+_film_bwd_film = _sig("nsky_film_chain_bwd_film", C.POINTER(FilmNet), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_film_bwd_map = _sig("nsky_film_chain_bwd_map", C.POINTER(FilmNet), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                     C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
+
+
 def film_supported(hidden, map_hidden, n_map, n_film, cond_dim, x_dim, out_dim) -> bool:
     """shapes the fused chain kernels are built for (anything else runs the per-layer dense kernels)"""
     return (hidden in (128, 256) and map_hidden == hidden and 1 <= n_map <= FILM_MAX_LAYERS and 1 <= n_film <= FILM_MAX_LAYERS
@@ -500,3 +506,14 @@ def film_rows_to_native(x, width: int):
     full = x.new_zeros(R * 32, width)
     full[:M] = x[:, :width]
     return full.reshape(R, 32, width // 32, 4, 2, 4).permute(0, 2, 3, 4, 1, 5).contiguous().reshape(R * 32, width)
+
+
+def film_chain_bwd_film(net: FilmNet, stream_buf, table, M, d_res, h_last, z_save, dz_save, dfp, dfp_rowmax):
+    check(_film_bwd_film(C.byref(net), ptr(stream_buf), ptr(table), M, ptr(d_res), ld(d_res), ptr(h_last), _ptr_array(z_save, net.n_film),
+                         _ptr_array(dz_save, net.n_film), ptr(dfp), ptr(dfp_rowmax), stream_ptr()), "nsky_film_chain_bwd_film")
+
+
+def film_chain_bwd_map(net: FilmNet, stream_buf, table, M, dfp, dfp_rowmax, h_save, dpre_save, d_cond):
+    check(_film_bwd_map(C.byref(net), ptr(stream_buf), ptr(table), M, ptr(dfp), ptr(dfp_rowmax), _ptr_array(h_save, net.n_map),
+                        _ptr_array(dpre_save, net.n_map), ptr(d_cond), ld(d_cond) if d_cond is not None else 0, stream_ptr()),
+          "nsky_film_chain_bwd_map")

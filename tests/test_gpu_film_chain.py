@@ -108,3 +108,69 @@ def test_fused_forward_without_saves_and_large_batch():
     sub = slice(19000, 20000)
     ref = O.film_siren(x[sub, :15].double(), cond[sub, :35].double(), p)[:, 0]
     assert (res_a[sub, 0].cpu().double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def _pack(desc, direction):
+    from neusky_amd import hip
+    nbytes, _ = hip.film_stream_layout(desc, direction)
+    stream = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    table = torch.empty(hip.FILM_TABLE_FLOATS, device=DEV)
+    hip.film_pack(desc, stream, table, direction)
+    return stream, table
+
+
+@pytest.mark.parametrize("H,n_map,n_film,cond_dim,x_dim,out_dim,M", [
+    (256, 5, 5, 35, 15, 1, 300),
+    (128, 5, 9, 300, 10, 3, 257),
+    (128, 2, 3, 24, 10, 3, 64),
+])
+def test_fused_backward_matches_float64_autograd(H, n_map, n_film, cond_dim, x_dim, out_dim, M):
+    """nsky_film_chain_bwd_film + _bwd_map against torch autograd of the float64 siren restatement: d_cond directly, and every
+    parameter gradient formed (in float64, on the host) from the tile-native gradient matrices the kernels store"""
+    from neusky_amd import hip
+    net = _net(H, n_map, n_film, cond_dim, x_dim, out_dim)
+    cond, x = _inputs(M, cond_dim, x_dim)
+    lins = net.mapping_network.linears()
+    desc = hip.film_net(cond_dim, x_dim, out_dim, [l.weight for l in lins[:-1]], [l.bias for l in lins[:-1]], lins[-1].weight, lins[-1].bias,
+                        [l.layer.weight for l in net.net], [l.layer.bias for l in net.net], net.final_layer.weight, net.final_layer.bias)
+    s0, t0 = _pack(desc, 0)
+    s1, t1 = _pack(desc, 1)
+    s2, t2 = _pack(desc, 2)
+    Mp = hip.film_rows(M)
+    mk = lambda n, w=H: [torch.full((Mp, w), float("nan"), device=DEV) for _ in range(n)]  # noqa: E731
+    hs, zs, ys = mk(n_map), mk(n_film), mk(n_film)
+    res = torch.empty(M, 4, device=DEV)
+    hip.film_chain_fwd(desc, s0, t0, cond.to(DEV), x.to(DEV), M, hs, zs, ys, res)
+    g = torch.Generator().manual_seed(5)
+    d_res = torch.zeros(M, 4); d_res[:, :out_dim] = torch.randn(M, out_dim, generator=g)
+    dzs, dpres = mk(n_film), mk(n_map)
+    dfp = torch.full((Mp, 2 * n_film * H), float("nan"), device=DEV)
+    rowmax = torch.full((Mp,), float("nan"), device=DEV)
+    d_cond = torch.full((M, cond.shape[1]), float("nan"), device=DEV)
+    hip.film_chain_bwd_film(desc, s1, t1, M, d_res.to(DEV), hs[-1], zs, dzs, dfp, rowmax)
+    hip.film_chain_bwd_map(desc, s2, t2, M, dfp, rowmax, hs, dpres, d_cond)
+    torch.cuda.synchronize()
+    # ---- float64 reference
+    p = {k: v.clone().requires_grad_(True) for k, v in _oracle_params(net).items()}
+    c64 = cond[:, :cond_dim].double().requires_grad_(True)
+    out = O.film_siren(x[:, :x_dim].double(), c64, p)
+    out.backward(d_res[:, :out_dim].double())
+    rel = lambda a, b: (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)  # noqa: E731
+    e = rel(d_cond[:, :cond_dim].cpu().double(), c64.grad)
+    assert e < 2e-4, ("d_cond", e)
+    assert float(d_cond[:, cond_dim:].abs().max()) == 0.0 if d_cond.shape[1] > cond_dim else True
+    rows = lambda t, w=H: hip.film_native_to_rows(t, M, w).cpu().double()  # noqa: E731
+    y_prev = [x[:, :x_dim].double()] + [rows(t) for t in ys[:-1]]
+    for i in range(n_film):
+        dz = rows(dzs[i])
+        assert rel(dz.t() @ y_prev[i], p[f"ddf.film_w{i}"].grad) < 3e-4, ("film_w", i)
+        assert rel(dz.sum(0), p[f"ddf.film_b{i}"].grad) < 3e-4, ("film_b", i)
+    h_prev = [cond[:, :cond_dim].double()] + [rows(t) for t in hs[:-1]]
+    for l in range(n_map):
+        dp = rows(dpres[l])
+        assert rel(dp.t() @ h_prev[l], p[f"ddf.map_w{l}"].grad) < 3e-4, ("map_w", l)
+        assert rel(dp.sum(0), p[f"ddf.map_b{l}"].grad) < 3e-4, ("map_b", l)
+    dF = rows(dfp, 2 * n_film * H)
+    assert rel(dF.t() @ rows(hs[-1]), p["ddf.map_wo"].grad) < 3e-4
+    assert rel(dF.sum(0), p["ddf.map_bo"].grad) < 3e-4
+    assert rel(rowmax[:M].cpu().double(), dF.abs().max(1).values) < 1e-6
