@@ -27,7 +27,7 @@ extern "C" {
 typedef void* nsky_stream_t; /* hipStream_t */
 
 const char* nsky_last_error(void);
-int nsky_abi_version(void); /* 2 (bumped when a struct layout or an entry point's signature changes) */
+int nsky_abi_version(void); /* 3 (bumped when a struct layout or an entry point's signature changes) */
 
 /* ------------------------------------------------------------------------------------------
  * Dense layer on the matrix cores: C[M,N] = epilogue( sum_k A(m,k) * B(n,k) + bias[n] )
@@ -82,6 +82,11 @@ typedef struct nsky_gemm_desc {
   int32_t precision; /* NSKY_PREC_*: arithmetic of the contraction (operands and result stay fp32 in memory) */
   int32_t rowsum_k_limit; /* a_rowsum sums only k < rowsum_k_limit (multiple of 32; 0 = all of K): the value rows of a stacked
                              [value; tangent] gradient matrix carry the bias, the tangent rows do not */
+  int32_t a_native_nt, b_native_nt; /* > 0: that operand (a_kcontig / b_kcontig must be 0) is a TILE-NATIVE matrix with this many
+                             32-feature tiles per row, as the FiLM chain kernels store activations and gradients (below) */
+  const float* a_scale_max; /* optional device scalar = largest |A| (NSKY_PREC_F16X2, N > 64): A is staged times the power of two
+                             that brings it to ~2^14, so the fp16 split keeps fp32-grade products for gradients of any
+                             magnitude; C and a_rowsum are scaled back */
 } nsky_gemm_desc;
 
 int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream);
@@ -153,14 +158,16 @@ int nsky_film_chain_fwd(const nsky_film_net* net, const void* stream_buf, const 
  *        batch row.  F and phase are re-formed from h_last (the last mapping activation), z_save[i] is read back.
  *   nsky_film_chain_bwd_map (direction 2): dfp, dfp_rowmax, h_save[l] -> dpre_save[l] = dL/d(pre-activation of mapping layer l)
  *        (tile-native) and d_cond [M, ldcond] (row-major, pad columns zeroed; optional).
- * hidden must be a multiple of 128 for the backward streams.  The gradient w.r.t. x is not produced (the callers' x rows are
- * constants of the geometry). */
+ * gmax (caller zero-fills): largest magnitude of each gradient matrix, for nsky_gemm_f32's a_scale_max -- bwd_film writes
+ *        [i] = max |dz_save[i]| (i < n_film) and [n_film] = max |dfp|; bwd_map writes [l] = max |dpre_save[l]| (l < n_map).
+ * hidden must be a multiple of 128 for the backward streams.  d_x (optional, [M, ldx], ldx <= 16): gradient w.r.t. the FiLM input
+ * rows (the DDF's multi-view rays differentiate through their direction rows, neusky/models/ddf_model.py:297-322). */
 int nsky_film_chain_bwd_film(const nsky_film_net* net, const void* stream_buf, const float* table, int32_t M, const float* d_res,
                              int32_t ldres, const float* h_last, const float* const* z_save, float* const* dz_save, float* dfp,
-                             float* dfp_rowmax, nsky_stream_t stream);
+                             float* dfp_rowmax, float* gmax, float* d_x, int32_t ldx, nsky_stream_t stream);
 int nsky_film_chain_bwd_map(const nsky_film_net* net, const void* stream_buf, const float* table, int32_t M, const float* dfp,
                             const float* dfp_rowmax, const float* const* h_save, float* const* dpre_save, float* d_cond,
-                            int32_t ldcond, nsky_stream_t stream);
+                            int32_t ldcond, float* gmax, nsky_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multiresolution hash-grid encode (tiny-cuda-nn HashGrid semantics, fp32) fused with the rest of

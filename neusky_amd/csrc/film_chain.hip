@@ -118,7 +118,7 @@ __device__ inline TileDesc fwd_tile(const nsky_film_net& n, const Layout& L, int
 //   k = head rows 128 kg .. 128 kg + 127); layers n_map-1 .. 1 transposed: for u; layer 0 transposed: ceil(cond_dim / 32) tiles.
 __host__ __device__ inline void bwd_film_layout(const nsky_film_net& n, long& total_groups, int& n_tiles) {
   const int NT = n.hidden / 32, Gh = groups_of(n.hidden);
-  n_tiles = n.n_film * NT * 2 + (n.n_film - 1) * NT;
+  n_tiles = n.n_film * NT * 2 + (n.n_film - 1) * NT + 1;  // last: first FiLM layer transposed (rows = x features) -> d_x
   total_groups = (long)n_tiles * Gh;
 }
 __host__ __device__ inline void bwd_map_layout(const nsky_film_net& n, long& total_groups, int& n_tiles) {
@@ -133,6 +133,10 @@ __device__ inline TileDesc bwd_film_tile(const nsky_film_net& n, int idx) {
   const int NT = n.hidden / 32, H = n.hidden, Gh = groups_of(H);
   d.group = (long)idx * Gh;
   d.nrows = 32; d.K = H; d.k0 = 0; d.transposed = 0;
+  if (idx == n.n_film * NT * 2 + (n.n_film - 1) * NT) {
+    d.W = n.film_w[0]; d.ld = n.film_ld[0]; d.row0 = 0; d.nrows = n.x_dim; d.transposed = 1;
+    return d;
+  }
   // layers i = n_film-1 .. 1 own 3 NT tiles each, layer 0 owns 2 NT
   int i = n.n_film - 1, rem = idx;
   while (i > 0 && rem >= 3 * NT) { rem -= 3 * NT; --i; }
@@ -743,6 +747,14 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
 //   W^T dz on the transposed weight tiles.  Gradients therefore get the same fp32-grade products as the forward.
 // A vector-memory load the compiler knows about would make it wait for every LDS-DMA piece issued before it (one in-order
 // counter), so z is fetched with hidden loads one tile ahead and waited for with a counted vmcnt.
+// largest magnitude of a gradient matrix -> device scalar (the weight-gradient GEMM pre-scales its fp16 split with it)
+__device__ __forceinline__ void publish_max(float* slot, float v, bool live_row, bool wave_live, int lane) {
+  v = live_row ? v : 0.0f;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  if (wave_live && lane == 0 && v > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(v));
+}
+
 struct BwdFilmArgs {
   nsky_film_net net;
   const unsigned char* stream;
@@ -754,6 +766,8 @@ struct BwdFilmArgs {
   float* dz_save[MAXL];            // native [ceil32(M), H]
   float* dfp;                      // native [ceil32(M), 2 n_film H]: dF of layer i in columns i H .., dphase in (n_film + i) H ..
   float* dfp_rowmax;               // [ceil32(M)] max |dfp| per batch row
+  float* gmax;                     // zero-initialised by the caller: [i] = max |dz_save[i]|, [n_film] = max |dfp|
+  float* d_x; int ldx;             // optional [M, ldx]: gradient w.r.t. the FiLM input rows (pad columns zeroed)
 };
 
 __device__ __forceinline__ void hidden_load4(f32x4& q, const float* p) {
@@ -907,8 +921,9 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(const BwdFilmArgs a) {
         for (int g = 0; g < 4; ++g) hidden_load4(zq[g], zblk + (t + 1) * 1024 + g * 256 + lane * 4);
       }
     }
-    if (i > 0) {
-      // dY of the layer below = W_i^T dz
+    publish_max(a.gmax + i, dz_max, live, wave_live, lane);
+    {
+      // dY of the layer below = W_i^T dz (i = 0: the gradient w.r.t. the input rows, one tile)
       float dz_inv;
       const float s = row_scale(dz_max, dz_inv);
       f16x8 dh_[KS], dl_[KS];
@@ -921,20 +936,35 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(const BwdFilmArgs a) {
           for (int j = 0; j < 8; ++j) x8[j] = dY[t][8 * u + j] * s;
           split8(x8, dh_[2 * t + u], dl_[2 * t + u]);
         }
+      if (i > 0) {
 #pragma unroll
-      for (int u = 0; u < NT; ++u) {
+        for (int u = 0; u < NT; ++u) {
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+          product<KS>(ws, dh_, dl_, acc);
+          const float inv = dz_inv * sl[tile++];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dY[u][r] = acc[r] * inv;
+        }
+      } else {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         product<KS>(ws, dh_, dl_, acc);
         const float inv = dz_inv * sl[tile++];
+        if (a.d_x && live) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dY[u][r] = acc[r] * inv;
+          for (int g = 0; g < 2; ++g)
+            if (8 * g + 4 * h < a.ldx)
+              stg4(a.d_x + row * a.ldx + 8 * g + 4 * h, make_float4(acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv, acc[4 * g + 3] * inv));
+        }
       }
     }
   }
   fp_max = fmaxf(fp_max, __shfl_xor(fp_max, 32, 64));
   if (wave_live && h == 0) a.dfp_rowmax[row] = fp_max;
+  publish_max(a.gmax + n_film, fp_max, live, wave_live, lane);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
@@ -953,6 +983,7 @@ struct BwdMapArgs {
   const float* h_save[MAXL]; // native
   float* dpre_save[MAXL];    // native [ceil32(M), H]
   float* d_cond; int ldcond; // [M, ldcond] or NULL
+  float* gmax;               // zero-initialised by the caller: [l] = max |dpre_save[l]|
 };
 
 template <int H>
@@ -1046,6 +1077,7 @@ __global__ __launch_bounds__(256, 1) void film_bwd_map_kernel(const BwdMapArgs a
       }
       if (wave_live) store_tile(a.dpre_save[l] + (rt * NT + u) * 1024, lane, dh[u]);
     }
+    publish_max(a.gmax + l, m, live, wave_live, lane);
     float d_inv;
     const float s = row_scale(m, d_inv);
     f16x8 ph[KS], pl[KS];
@@ -1175,15 +1207,16 @@ extern "C" int nsky_film_lab_stamps(unsigned long long* host_out, int reset) {
 
 extern "C" int nsky_film_chain_bwd_film(const nsky_film_net* net, const void* stream_buf, const float* table, int32_t M, const float* d_res,
                                         int32_t ldres, const float* h_last, const float* const* z_save, float* const* dz_save, float* dfp,
-                                        float* dfp_rowmax, nsky_stream_t stream) {
+                                        float* dfp_rowmax, float* gmax, float* d_x, int32_t ldx, nsky_stream_t stream) {
   if (int rc = check_net(net, "nsky_film_chain_bwd_film")) return rc;
-  NSKY_CHECK_ARG(stream_buf && table && d_res && h_last && z_save && dz_save && dfp && dfp_rowmax && M > 0, "nsky_film_chain_bwd_film: null operand / empty batch");
+  NSKY_CHECK_ARG(stream_buf && table && d_res && h_last && z_save && dz_save && dfp && dfp_rowmax && gmax && M > 0, "nsky_film_chain_bwd_film: null operand / empty batch");
   NSKY_CHECK_ARG(ldres >= 4 && ldres % 4 == 0 && ((uintptr_t)d_res % 16) == 0 && ((uintptr_t)h_last % 16) == 0 && ((uintptr_t)dfp % 16) == 0 &&
                      ((uintptr_t)stream_buf % 16) == 0 && ((uintptr_t)table % 16) == 0, "nsky_film_chain_bwd_film: alignment / ldres");
   NSKY_CHECK_ARG(net->hidden % 128 == 0, "nsky_film_chain_bwd_film: hidden %% 128");
   BwdFilmArgs a;
   a.net = *net; a.stream = (const unsigned char*)stream_buf; a.table = table; a.M = M; a.d_res = d_res; a.ldres = ldres; a.h_last = h_last;
-  a.dfp = dfp; a.dfp_rowmax = dfp_rowmax;
+  a.dfp = dfp; a.dfp_rowmax = dfp_rowmax; a.gmax = gmax; a.d_x = d_x; a.ldx = ldx;
+  if (d_x) NSKY_CHECK_ARG(ldx % 4 == 0 && ldx >= ((net->x_dim + 3) & ~3) && ldx <= 16 && ((uintptr_t)d_x % 16) == 0, "nsky_film_chain_bwd_film: d_x layout (ldx %d)", ldx);
   for (int l = 0; l < MAXL; ++l) {
     a.z_save[l] = l < net->n_film ? z_save[l] : nullptr;
     a.dz_save[l] = l < net->n_film ? dz_save[l] : nullptr;
@@ -1198,15 +1231,15 @@ extern "C" int nsky_film_chain_bwd_film(const nsky_film_net* net, const void* st
 
 extern "C" int nsky_film_chain_bwd_map(const nsky_film_net* net, const void* stream_buf, const float* table, int32_t M, const float* dfp,
                                        const float* dfp_rowmax, const float* const* h_save, float* const* dpre_save, float* d_cond,
-                                       int32_t ldcond, nsky_stream_t stream) {
+                                       int32_t ldcond, float* gmax, nsky_stream_t stream) {
   if (int rc = check_net(net, "nsky_film_chain_bwd_map")) return rc;
-  NSKY_CHECK_ARG(stream_buf && table && dfp && dfp_rowmax && h_save && dpre_save && M > 0, "nsky_film_chain_bwd_map: null operand / empty batch");
+  NSKY_CHECK_ARG(stream_buf && table && dfp && dfp_rowmax && h_save && dpre_save && gmax && M > 0, "nsky_film_chain_bwd_map: null operand / empty batch");
   NSKY_CHECK_ARG(((uintptr_t)dfp % 16) == 0 && ((uintptr_t)stream_buf % 16) == 0 && ((uintptr_t)table % 16) == 0, "nsky_film_chain_bwd_map: alignment");
   if (d_cond) NSKY_CHECK_ARG(ldcond % 4 == 0 && ldcond >= ((net->cond_dim + 3) & ~3) && ((uintptr_t)d_cond % 16) == 0, "nsky_film_chain_bwd_map: d_cond layout");
   NSKY_CHECK_ARG(net->hidden % 128 == 0, "nsky_film_chain_bwd_map: hidden %% 128");
   BwdMapArgs a;
   a.net = *net; a.stream = (const unsigned char*)stream_buf; a.table = table; a.M = M; a.dfp = dfp; a.dfp_rowmax = dfp_rowmax;
-  a.d_cond = d_cond; a.ldcond = ldcond;
+  a.d_cond = d_cond; a.ldcond = ldcond; a.gmax = gmax;
   for (int l = 0; l < MAXL; ++l) {
     a.h_save[l] = l < net->n_map ? h_save[l] : nullptr;
     a.dpre_save[l] = l < net->n_map ? dpre_save[l] : nullptr;

@@ -33,7 +33,23 @@ struct EpiCtx {
   int row_mod;
   float beta;
   int rs_limit;  // a_rowsum: only k < rs_limit contribute (whole 32-deep k-tiles)
+  int a_nnt, b_nnt;            // > 0: the (m-contiguous) operand is a tile-native matrix with that many 32-feature tiles per row
+  const float* a_scale_max;    // device scalar: largest |A| (A is multiplied by a power of two that brings it to ~2^14; undone on C)
 };
+
+// float offset of element (row k, feature t), t % 4 == 0, of a tile-native matrix with nnt 32-feature tiles per row
+// (include/neusky_hip.h: 32 x 32 blocks in v_mfma_f32_32x32x16 accumulator order)
+__device__ __forceinline__ long native_offset(int k, int t, int nnt) {
+  return ((long)(k >> 5) * nnt + (t >> 5)) * 1024 + ((t & 31) >> 3) * 256 + ((k & 31) + 32 * ((t >> 2) & 1)) * 4;
+}
+__device__ __forceinline__ float pow2_scale_for(float m, float& inv) {  // m s < 2^15
+  if (!(m > 0.0f) || !(m < 3.0e38f)) { inv = 1.0f; return 1.0f; }
+  int e;
+  (void)frexpf(m, &e);
+  e = max(-100, min(100, e));
+  inv = ldexpf(1.0f, e - 15);
+  return ldexpf(1.0f, 15 - e);
+}
 
 // sin/cos with Cody-Waite reduction to [-pi/4, pi/4] and minimax polynomials (|err| < 2e-7 for |x| < 1e4):
 // ~20 VALU ops instead of the ocml slow path; used by the FiLM epilogues where |x| = |freq * z + phase| ~ 1e2.
@@ -214,7 +230,7 @@ struct TileLoader {
   static constexpr int KQ = BK / 4;  // float4 per row (k-contiguous layout)
   float4 v[F4];
 
-  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int t0, int T, int k0, int kend, int tid) {
+  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int t0, int T, int k0, int kend, int tid, int nnt = 0) {
 #pragma unroll
     for (int it = 0; it < F4; ++it) {
       int f = it * 256 + tid;
@@ -226,7 +242,7 @@ struct TileLoader {
       } else {
         int krow = f / (BT / 4), t4 = f % (BT / 4);
         int k = k0 + krow, t = t0 + t4 * 4;
-        if (k < kend && t < T) x = *reinterpret_cast<const float4*>(P + (long)k * ld + t);
+        if (k < kend && t < T) x = *reinterpret_cast<const float4*>(P + (nnt > 0 ? native_offset(k, t, nnt) : (long)k * ld + t));
       }
       v[it] = x;
     }
@@ -316,8 +332,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const float* __restr
   TileLoader<BM, AK, BK> la;
   TileLoader<BN, BKC, BK> lb;
   if (ntiles > 0) {
-    la.load(A, lda, m0, M, kbeg, kend, tid);
-    lb.load(B, ldb, n0, N, kbeg, kend, tid);
+    la.load(A, lda, m0, M, kbeg, kend, tid, e.a_nnt);
+    lb.load(B, ldb, n0, N, kbeg, kend, tid, e.b_nnt);
     la.store(As, tid);
     lb.store(Bs, tid);
   }
@@ -328,8 +344,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const float* __restr
   for (int t = 0; t < ntiles; ++t) {
     const bool more = (t + 1 < ntiles);
     if (more) {
-      la.load(A, lda, m0, M, kbeg + (t + 1) * BK, kend, tid);
-      lb.load(B, ldb, n0, N, kbeg + (t + 1) * BK, kend, tid);
+      la.load(A, lda, m0, M, kbeg + (t + 1) * BK, kend, tid, e.a_nnt);
+      lb.load(B, ldb, n0, N, kbeg + (t + 1) * BK, kend, tid, e.b_nnt);
     }
     if (a_rowsum != nullptr && n_tile == 0 && tid < BM && kbeg + t * BK < e.rs_limit) {
       // bias gradient for free: sum_k A(m,k) of this K tile (A = dZ^T in the weight-gradient GEMM)
@@ -503,7 +519,7 @@ __device__ __forceinline__ void split4(const float x[4], uint2 out[NS]) {
 template <bool H, int BN = 128, int TMX, int TNX>
 __device__ __forceinline__ void tile_epilogue(float* Cs, f32x16 (&acc)[2][2], f32x16 (&accx)[TMX][TNX], int wm, int wn, int lane,
                                               int tid, int m0, int n0, int M, int N, float* __restrict__ C, int ldc, int vec4,
-                                              bool atomic, const EpiCtx& e) {
+                                              bool atomic, const EpiCtx& e, float out_scale = 1.0f) {
   constexpr int WM = 64, WN = 64, NT = 2 * BN;  // BN / 64 wave columns x 2 wave rows x 64 lanes
 #ifdef NSKY_LAB_NOEPI  // timing experiment only: no output unless an accumulator is NaN
   if (!(acc[0][0][0] != acc[0][0][0] || acc[1][1][5] != acc[1][1][5] || acc[0][1][3] != acc[0][1][3] || acc[1][0][9] != acc[1][0][9])) return;
@@ -520,7 +536,7 @@ __device__ __forceinline__ void tile_epilogue(float* Cs, f32x16 (&acc)[2][2], f3
           for (int r = 0; r < 16; ++r) {
             const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const int cl = wn * WN + j * 32 + (lane & 31);
-            Cs[rl * BN + cl] = H ? fmaf(accx[H ? i : 0][H ? j : 0][r], 1.0f / F16_RES_SCALE, acc[i][j][r]) : acc[i][j][r];
+            Cs[rl * BN + cl] = (H ? fmaf(accx[H ? i : 0][H ? j : 0][r], 1.0f / F16_RES_SCALE, acc[i][j][r]) : acc[i][j][r]) * out_scale;
           }
     }
     __syncthreads();
@@ -552,6 +568,8 @@ template <int NS, bool KCONTIG, bool H = false, int ROWS = 128>
 struct SplitLoader {  // ROWS x 32 fp32 tile -> NS bf16 images [ROWS][SROW]; ROWS = threads / 2 (non-k-contiguous form: any 8 x ROWS/4 threads)
   float4 v[4];
   float rs[4] = {0.f, 0.f, 0.f, 0.f};  // running row sums (every thread stages the same 4 tile rows on every k-tile)
+  int nnt = 0;        // > 0: tile-native operand (non-k-contiguous form only)
+  float scale = 1.0f; // power of two applied to every element as it is staged
   __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int t0, int T, int k0, int kend, int tid) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -564,9 +582,9 @@ struct SplitLoader {  // ROWS x 32 fp32 tile -> NS bf16 images [ROWS][SROW]; ROW
       } else {  // 4(k) x 4(t) block per thread: kb = tid % 8, mb = tid / 8; load row k0 + 4 kb + it
         const int kb = tid & 7, mb = tid >> 3;
         const int k = k0 + 4 * kb + it, t = t0 + 4 * mb;
-        if (k < kend && t < T) x = *reinterpret_cast<const float4*>(P + (long)k * ld + t);
+        if (k < kend && t < T) x = *reinterpret_cast<const float4*>(P + (nnt > 0 ? native_offset(k, t, nnt) : (long)k * ld + t));
       }
-      v[it] = x;
+      v[it] = make_float4(x.x * scale, x.y * scale, x.z * scale, x.w * scale);
     }
   }
   // images: S + term * (128 * SROW) bf16 ; rowsum: also accumulate sum_k of the staged tile rows into rs[]
@@ -654,6 +672,10 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : NSKY_LAB_OCC) void gemm_
   }
   SplitLoader<NS, AK, H> la;
   SplitLoader<NS, BKC, H> lb;
+  la.nnt = e.a_nnt;
+  lb.nnt = e.b_nnt;
+  float a_inv = 1.0f;
+  if (e.a_scale_max) la.scale = pow2_scale_for(*e.a_scale_max, a_inv);
   const int frow = lane & 31, fh = lane >> 5;
 
   auto compute = [&](const __bf16* As, const __bf16* Bs) {
@@ -778,10 +800,10 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : NSKY_LAB_OCC) void gemm_
   }
   if (want_rs) la.flush_rowsum(rsum, tid);
   __syncthreads();
-  if (want_rs && tid < 128 && m0 + tid < M) atomicAdd(a_rowsum + m0 + tid, rsum[tid]);
+  if (want_rs && tid < 128 && m0 + tid < M) atomicAdd(a_rowsum + m0 + tid, rsum[tid] * a_inv);
   __syncthreads();
 
-  tile_epilogue<H>(reinterpret_cast<float*>(smem_raw), acc, accx, wm, wn, lane, tid, m0, n0, M, N, C, ldc, vec4, k_split_len < K, e);
+  tile_epilogue<H>(reinterpret_cast<float*>(smem_raw), acc, accx, wm, wn, lane, tid, m0, n0, M, N, C, ldc, vec4, k_split_len < K, e, a_inv);
 }
 
 // =================================================================================================
@@ -1159,8 +1181,8 @@ extern "C" int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream) {
   NSKY_CHECK_ARG(d->lda % 4 == 0 && d->ldb % 4 == 0, "nsky_gemm_f32: lda/ldb must be multiples of 4 (got %d,%d)", d->lda, d->ldb);
   NSKY_CHECK_ARG(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0, "nsky_gemm_f32: A/B must be 16-byte aligned");
   if (d->a_kcontig || d->b_kcontig) NSKY_CHECK_ARG(d->K % 4 == 0, "nsky_gemm_f32: K=%d must be a multiple of 4 for k-contiguous operands", d->K);
-  if (d->a_kcontig) NSKY_CHECK_ARG(d->lda >= d->K, "nsky_gemm_f32: lda < K"); else NSKY_CHECK_ARG(d->lda >= d->M, "nsky_gemm_f32: lda < M");
-  if (d->b_kcontig) NSKY_CHECK_ARG(d->ldb >= d->K, "nsky_gemm_f32: ldb < K"); else NSKY_CHECK_ARG(d->ldb >= d->N, "nsky_gemm_f32: ldb < N");
+  if (d->a_kcontig) NSKY_CHECK_ARG(d->lda >= d->K, "nsky_gemm_f32: lda < K"); else NSKY_CHECK_ARG(d->a_native_nt > 0 || d->lda >= d->M, "nsky_gemm_f32: lda < M");
+  if (d->b_kcontig) NSKY_CHECK_ARG(d->ldb >= d->K, "nsky_gemm_f32: ldb < K"); else NSKY_CHECK_ARG(d->b_native_nt > 0 || d->ldb >= d->N, "nsky_gemm_f32: ldb < N");
   NSKY_CHECK_ARG(d->ldc >= d->N, "nsky_gemm_f32: ldc < N");
   int splits = d->k_splits > 1 ? d->k_splits : 1;
   int k_split_len = d->K;
@@ -1182,6 +1204,10 @@ extern "C" int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream) {
   e.row_mod = d->row_mod > 0 ? d->row_mod : d->M;
   e.beta = d->beta;
   e.rs_limit = d->rowsum_k_limit > 0 ? d->rowsum_k_limit : 0x7fffffff;
+  e.a_nnt = d->a_native_nt; e.b_nnt = d->b_native_nt; e.a_scale_max = d->a_scale_max;
+  if (d->a_native_nt > 0) NSKY_CHECK_ARG(!d->a_kcontig && d->M <= 32 * d->a_native_nt, "nsky_gemm_f32: a tile-native A is the m-contiguous (a_kcontig = 0) operand of a weight gradient");
+  if (d->b_native_nt > 0) NSKY_CHECK_ARG(!d->b_kcontig && d->N <= 32 * d->b_native_nt, "nsky_gemm_f32: a tile-native B is the n-contiguous (b_kcontig = 0) operand of a weight gradient");
+  if (d->a_scale_max) NSKY_CHECK_ARG(d->precision == NSKY_PREC_F16X2 && d->N > 64, "nsky_gemm_f32: a_scale_max is for the fp16-split contraction (N > 64)");
   if (d->a_rowsum && d->rowsum_k_limit > 0) NSKY_CHECK_ARG(d->rowsum_k_limit % 32 == 0, "nsky_gemm_f32: rowsum_k_limit=%d must be a multiple of 32", d->rowsum_k_limit);
   hipStream_t s = (hipStream_t)stream;
   // float4 epilogue when every row operand is 16-byte aligned with ld % 4 == 0 and N % 4 == 0
@@ -1253,6 +1279,8 @@ extern "C" int nsky_gemm_f32_planes(const nsky_gemm_desc* d, const uint16_t* B_h
   e.row_mod = d->row_mod > 0 ? d->row_mod : d->M;
   e.beta = d->beta;
   e.rs_limit = 0x7fffffff;
+  e.a_nnt = 0; e.b_nnt = 0; e.a_scale_max = nullptr;
+  NSKY_CHECK_ARG(d->a_native_nt == 0 && d->b_native_nt == 0 && d->a_scale_max == nullptr, "nsky_gemm_f32_planes: row-major operands only");
   auto ok = [](const void* p, int ld) { return p == nullptr || ((((uintptr_t)p) % 16 == 0) && (ld % 4 == 0)); };
   const int vec4 = (d->N % 4 == 0) && ok(d->C, d->ldc) && ok(d->bias, 4) && ok(d->aux0, d->ldaux0) && ok(d->aux1, d->ldaux1) &&
                    ok(d->aux2, d->ldaux2) && ok(d->out1, d->ldout1) && ok(d->out2, d->ldout2);

@@ -46,12 +46,13 @@ class GemmDesc(C.Structure):
         ("out2", C.c_void_p), ("ldout2", C.c_int32),
         ("row_mod", C.c_int32), ("k_splits", C.c_int32), ("beta", C.c_float), ("a_rowsum", C.c_void_p), ("precision", C.c_int32),
         ("rowsum_k_limit", C.c_int32),
+        ("a_native_nt", C.c_int32), ("b_native_nt", C.c_int32), ("a_scale_max", C.c_void_p),
     ]
 
 
 _lib.nsky_last_error.restype = C.c_char_p
 _lib.nsky_abi_version.restype = C.c_int
-ABI_VERSION = 2  # the ctypes structures below mirror this version of include/neusky_hip.h
+ABI_VERSION = 3  # the ctypes structures below mirror this version of include/neusky_hip.h
 if _lib.nsky_abi_version() != ABI_VERSION:
     raise NeuSkyHipError(f"libneusky_hip.so has ABI version {_lib.nsky_abi_version()}, this package binds version {ABI_VERSION}: rebuild (build.sh)")
 
@@ -92,14 +93,16 @@ _colsum = _sig("nsky_colsum_f32", C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C
 
 def gemm(A, B, Cout, M, N, K, *, a_kcontig=True, b_kcontig=True, bias=None, epi=EPI_NONE, p0=0.0, p1=0.0,
          aux0=None, aux1=None, aux2=None, out1=None, out2=None, row_mod=0, k_splits=0, beta=0.0, a_rowsum=None, precision=0,
-         rowsum_k_limit=0):
-    """C[M,N] = epi(sum_k A(m,k) B(n,k) + bias).  A/B/C are 2-D row-major views (rows contiguous)."""
+         rowsum_k_limit=0, a_native_nt=0, b_native_nt=0, a_scale_max=None):
+    """C[M,N] = epi(sum_k A(m,k) B(n,k) + bias).  A/B/C are 2-D row-major views (rows contiguous); a_native_nt / b_native_nt:
+    that operand is a tile-native matrix (include/neusky_hip.h) with this many 32-feature tiles per row."""
     d = GemmDesc(
         A=ptr(A), B=ptr(B), C=ptr(Cout), M=M, N=N, K=K, lda=ld(A), ldb=ld(B), ldc=ld(Cout),
         a_kcontig=int(a_kcontig), b_kcontig=int(b_kcontig), bias=ptr(bias), epi=epi, p0=p0, p1=p1,
         aux0=ptr(aux0), ldaux0=ld(aux0), aux1=ptr(aux1), ldaux1=ld(aux1), aux2=ptr(aux2), ldaux2=ld(aux2),
         out1=ptr(out1), ldout1=ld(out1), out2=ptr(out2), ldout2=ld(out2), row_mod=row_mod, k_splits=k_splits, beta=beta,
         a_rowsum=ptr(a_rowsum), precision=precision, rowsum_k_limit=rowsum_k_limit,
+        a_native_nt=a_native_nt, b_native_nt=b_native_nt, a_scale_max=ptr(a_scale_max),
     )
     check(_gemm(C.byref(d), stream_ptr()), "nsky_gemm_f32")
     return Cout
@@ -438,9 +441,9 @@ _film_fwd = _sig("nsky_film_chain_fwd", C.POINTER(FilmNet), C.c_void_p, C.c_void
 
 
 _film_bwd_film = _sig("nsky_film_chain_bwd_film", C.POINTER(FilmNet), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
-                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
 _film_bwd_map = _sig("nsky_film_chain_bwd_map", C.POINTER(FilmNet), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                     C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
+                     C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p)
 
 
 def film_supported(hidden, map_hidden, n_map, n_film, cond_dim, x_dim, out_dim) -> bool:
@@ -508,12 +511,15 @@ def film_rows_to_native(x, width: int):
     return full.reshape(R, 32, width // 32, 4, 2, 4).permute(0, 2, 3, 4, 1, 5).contiguous().reshape(R * 32, width)
 
 
-def film_chain_bwd_film(net: FilmNet, stream_buf, table, M, d_res, h_last, z_save, dz_save, dfp, dfp_rowmax):
+def film_chain_bwd_film(net: FilmNet, stream_buf, table, M, d_res, h_last, z_save, dz_save, dfp, dfp_rowmax, gmax, d_x=None):
+    """gmax: zero-filled float tensor [n_film + 1]; d_x: optional [M, ldx] output; see include/neusky_hip.h"""
     check(_film_bwd_film(C.byref(net), ptr(stream_buf), ptr(table), M, ptr(d_res), ld(d_res), ptr(h_last), _ptr_array(z_save, net.n_film),
-                         _ptr_array(dz_save, net.n_film), ptr(dfp), ptr(dfp_rowmax), stream_ptr()), "nsky_film_chain_bwd_film")
+                         _ptr_array(dz_save, net.n_film), ptr(dfp), ptr(dfp_rowmax), ptr(gmax), ptr(d_x), ld(d_x) if d_x is not None else 0,
+                         stream_ptr()), "nsky_film_chain_bwd_film")
 
 
-def film_chain_bwd_map(net: FilmNet, stream_buf, table, M, dfp, dfp_rowmax, h_save, dpre_save, d_cond):
+def film_chain_bwd_map(net: FilmNet, stream_buf, table, M, dfp, dfp_rowmax, h_save, dpre_save, d_cond, gmax):
+    """gmax: zero-filled float tensor [n_map]"""
     check(_film_bwd_map(C.byref(net), ptr(stream_buf), ptr(table), M, ptr(dfp), ptr(dfp_rowmax), _ptr_array(h_save, net.n_map),
-                        _ptr_array(dpre_save, net.n_map), ptr(d_cond), ld(d_cond) if d_cond is not None else 0, stream_ptr()),
+                        _ptr_array(dpre_save, net.n_map), ptr(d_cond), ld(d_cond) if d_cond is not None else 0, ptr(gmax), stream_ptr()),
           "nsky_film_chain_bwd_map")

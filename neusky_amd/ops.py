@@ -85,7 +85,7 @@ def _splits(M: int, n_out: int = 256, k_in: int = 256) -> int:
     return max(1, min((512 * waves) // tiles, M // 128))
 
 
-def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None, acc=None):
+def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None, acc=None, a_native_nt=0, b_native_nt=0, a_scale_max=None):
     """dW[n_out, k_in] = dZ[:M, :n_out]^T @ X[:M, :k_in] (split-K over M, atomically reduced).
     With bias_like, also returns db[n_out] = column sums of dZ (over the first `bias_rows` rows when the tail rows are
     tangent rows that carry no bias) from the same pass over dZ.  acc=(dW, db): accumulate into existing buffers
@@ -100,7 +100,9 @@ def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None, acc
         else:
             dW, db = torch.zeros_like(like), None
     splits = _splits(M, n_out, k_in)
-    kw = dict(a_kcontig=False, b_kcontig=False, k_splits=splits, precision=BWD_PRECISION)
+    kw = dict(a_kcontig=False, b_kcontig=False, k_splits=splits, precision=BWD_PRECISION, a_native_nt=a_native_nt, b_native_nt=b_native_nt)
+    if a_scale_max is not None and k_in > 64:  # fp32-grade products: fp16 hi + scaled residual, the gradient pre-scaled by its maximum
+        kw.update(precision=hip.PREC_F16X2, a_scale_max=a_scale_max)
     if acc is not None and splits <= 1:
         kw["beta"] = 1.0  # single-pass epilogue: add to what the previous chunks left
     if db is None:
@@ -300,27 +302,29 @@ _FILM_STREAMS: dict = {}
 
 
 def _film_fused_ok(M, H, Hm, n_map, n_film, mw, fw, ow, x, cond) -> bool:
-    return (FWD_PRECISION == hip.PREC_F16X2 and M >= FUSED_FILM_MIN_ROWS and x.is_cuda
+    return (FWD_PRECISION == hip.PREC_F16X2 and M >= FUSED_FILM_MIN_ROWS and x.is_cuda and ld(x) <= 16
             and hip.film_supported(H, Hm, n_map, n_film, mw[0].shape[1], fw[0].shape[1], ow.shape[0])
             and ld(x) >= fw[0].shape[1] and ld(cond) >= mw[0].shape[1])
 
 
-def _film_stream(wb, n_map, n_film, mw, mb, mwo, mbo, fw, fb, ow, ob):
-    """per-step cache of the packed weight stream of one network (dropped by begin_step: the optimiser changed the weights)"""
-    key = (wb[0].data_ptr(), wb[0]._version, wb[-2].data_ptr(), n_map, n_film)
+def _film_stream(wb, n_map, n_film, mw, mb, mwo, mbo, fw, fb, ow, ob, direction=0):
+    """per-step cache of one packed weight stream of a network (direction 0 forward, 1 FiLM backward, 2 mapping backward;
+    dropped by begin_step: the optimiser changed the weights) -> (descriptor, stream bytes, bias / scale table)"""
+    key = (wb[0].data_ptr(), wb[0]._version, wb[-2].data_ptr(), n_map, n_film, direction)
     hit = _FILM_STREAMS.get(key)
     cur = torch.cuda.current_stream()
     if hit is None:
         net = hip.film_net(mw[0].shape[1], fw[0].shape[1], ow.shape[0], mw, mb, mwo, mbo, fw, fb, ow, ob)
-        nbytes, ntiles = hip.film_stream_layout(net)
+        nbytes, _ = hip.film_stream_layout(net, direction)
         # zero-filled: the pad slabs of partial groups are streamed through LDS but never multiplied
         stream = torch.zeros(nbytes, dtype=torch.uint8, device=wb[0].device)
-        scales = torch.empty(hip.FILM_TABLE_FLOATS, device=wb[0].device)
-        hip.film_pack(net, stream, scales)
-        hit = _FILM_STREAMS[key] = (list(wb), net, stream, scales, cur)
+        table = torch.empty(hip.FILM_TABLE_FLOATS, device=wb[0].device)
+        hip.film_pack(net, stream, table, direction)
+        hit = _FILM_STREAMS[key] = (list(wb), net, stream, table, cur)
     elif hit[4] != cur:  # packed on another stream of the same step: order this stream after it
         cur.wait_stream(hit[4])
     return hit[1], hit[2], hit[3]
+
 
 class FilmSirenFn(torch.autograd.Function):
     """neusky/utils/siren.py:108-208 as a chain of fp32-MFMA layers with fused epilogues.
@@ -414,6 +418,60 @@ class FilmSirenFn(torch.autograd.Function):
         return res
 
     @staticmethod
+    def _backward_fused(ctx, d_res, x, cond, hs, ys, zs, wb, mw, mb, mwo, mbo, fw, fb, ow, ob, o):
+        """backward of the fused forward: two chain kernels (csrc/film_chain.hip) produce every pre-activation gradient as a
+        tile-native matrix (F / phase are re-formed in registers: no [M, 2 n_film H] matrix is read or recomputed through HBM)
+        and d_cond; the parameter gradients are weight-gradient GEMMs straight over those matrices."""
+        n_map, n_film, train_w, need_dcond, M, H, Hm = ctx.cfg
+        dev = x.device
+        Mp = hip.film_rows(M)
+        d_res = d_res.contiguous()
+        net1, s1, t1 = _film_stream(wb, n_map, n_film, mw, mb, mwo, mbo, fw, fb, ow, ob, 1)
+        net2, s2, t2 = _film_stream(wb, n_map, n_film, mw, mb, mwo, mbo, fw, fb, ow, ob, 2)
+        dzs = [torch.empty(Mp, H, device=dev) for _ in range(n_film)]
+        dfp = torch.empty(Mp, 2 * n_film * H, device=dev)
+        rowmax = torch.empty(Mp, device=dev)
+        gmax = torch.zeros(n_film + 1 + n_map, device=dev)
+        d_x = torch.empty(M, ld(x), device=dev) if ctx.need_dx else None  # the DDF's multi-view rays (ddf_model.py:297-322)
+        hip.film_chain_bwd_film(net1, s1, t1, M, d_res, hs[-1], zs, dzs, dfp, rowmax, gmax[:n_film + 1], d_x)
+        d_cond = torch.empty(M, ld(cond), device=dev) if need_dcond else None
+        want_map = need_dcond or train_w
+        dpres = [torch.empty(Mp, Hm, device=dev) for _ in range(n_map)] if want_map else None
+        if want_map:
+            hip.film_chain_bwd_map(net2, s2, t2, M, dfp, rowmax, hs, dpres, d_cond, gmax[n_film + 1:])
+        grads: List[Optional[torch.Tensor]] = [None] * len(wb)
+        sunk = [False] * len(wb)
+        if train_w:
+            for idx, t in enumerate(wb):
+                sk = ctx.sinks[idx]
+                if sk is not None and sk.grad is not None and sk.grad.shape == t.shape and sk.grad.is_contiguous():
+                    grads[idx], sunk[idx] = sk.grad, True
+            sizes = [0 if sunk[idx] else (t.numel() + 3) // 4 * 4 for idx, t in enumerate(wb)]
+            flat = torch.zeros(max(sum(sizes), 4), device=dev)
+            off = 0
+            for idx, t in enumerate(wb):
+                if not sunk[idx]:
+                    grads[idx] = flat[off:off + t.numel()].view_as(t)
+                    off += sizes[idx]
+            acc = lambda iw: (grads[iw], grads[iw + 1])  # noqa: E731
+            nt, ntm = H // 32, Hm // 32
+            # head and FiLM layers
+            grad_weight(d_res, ys[-1], M, ow.shape[0], H, ow, ob, acc=acc(o + 2 * n_film), b_native_nt=nt)
+            for i in range(n_film - 1, 0, -1):
+                grad_weight(dzs[i], ys[i - 1], M, H, H, fw[i], fb[i], acc=acc(o + 2 * i), a_native_nt=nt, b_native_nt=nt, a_scale_max=gmax[i:i + 1])
+            grad_weight(dzs[0], x, M, H, fw[0].shape[1], fw[0], fb[0], acc=acc(o), a_native_nt=nt)
+            # mapping head and layers
+            grad_weight(dfp, hs[-1], M, 2 * n_film * H, Hm, mwo, mbo, acc=acc(2 * n_map), a_native_nt=2 * n_film * nt, b_native_nt=ntm,
+                        a_scale_max=gmax[n_film:n_film + 1])
+            for l in range(n_map - 1, 0, -1):
+                grad_weight(dpres[l], hs[l - 1], M, Hm, Hm, mw[l], mb[l], acc=acc(2 * l), a_native_nt=ntm, b_native_nt=ntm,
+                            a_scale_max=gmax[n_film + 1 + l:n_film + 2 + l])
+            k0 = mw[0].shape[1]
+            grad_weight(dpres[0], cond, M, Hm, k0, mw[0], mb[0], acc=acc(0), a_native_nt=ntm,
+                        a_scale_max=gmax[n_film + 1:n_film + 2] if k0 > 64 else None)
+        return (d_x, d_cond, None, None, None, None, *[None if sunk[i] else g for i, g in enumerate(grads)])
+
+    @staticmethod
     def backward(ctx, d_res):
         n_map, n_film, train_w, need_dcond, M, H, Hm = ctx.cfg
         sv = ctx.saved_tensors
@@ -424,12 +482,8 @@ class FilmSirenFn(torch.autograd.Function):
         wb = sv[3 + n_map + 2 * n_film:]
         mw, mb, mwo, mbo, fw, fb, ow, ob, o = FilmSirenFn._unpack(wb, n_map, n_film)
         dev = x.device
-        if FP.numel() == 0:  # fused forward: frequencies / phases were never stored; re-form them from the last mapping activation
-            hs = [hip.film_native_to_rows(t, M, Hm) for t in hs]
-            ys = [hip.film_native_to_rows(t, M, H) for t in ys]
-            zs = [hip.film_native_to_rows(t, M, H) for t in zs]
-            FP = torch.empty(M, 2 * n_film * H, device=dev)
-            fgemm(hs[-1], mwo, FP, M, 2 * n_film * H, Hm, bias=mbo)
+        if FP.numel() == 0:
+            return FilmSirenFn._backward_fused(ctx, d_res, x, cond, hs, ys, zs, wb, mw, mb, mwo, mbo, fw, fb, ow, ob, o)
         grads: List[Optional[torch.Tensor]] = [None] * len(wb)
         d_res = d_res.contiguous()
         n_out_p = ow.shape[0]

@@ -147,17 +147,21 @@ def test_fused_backward_matches_float64_autograd(H, n_map, n_film, cond_dim, x_d
     dfp = torch.full((Mp, 2 * n_film * H), float("nan"), device=DEV)
     rowmax = torch.full((Mp,), float("nan"), device=DEV)
     d_cond = torch.full((M, cond.shape[1]), float("nan"), device=DEV)
-    hip.film_chain_bwd_film(desc, s1, t1, M, d_res.to(DEV), hs[-1], zs, dzs, dfp, rowmax)
-    hip.film_chain_bwd_map(desc, s2, t2, M, dfp, rowmax, hs, dpres, d_cond)
+    gmax = torch.zeros(n_film + 1 + n_map, device=DEV)
+    d_x = torch.full((M, x.shape[1]), float("nan"), device=DEV)
+    hip.film_chain_bwd_film(desc, s1, t1, M, d_res.to(DEV), hs[-1], zs, dzs, dfp, rowmax, gmax[:n_film + 1], d_x)
+    hip.film_chain_bwd_map(desc, s2, t2, M, dfp, rowmax, hs, dpres, d_cond, gmax[n_film + 1:])
     torch.cuda.synchronize()
     # ---- float64 reference
     p = {k: v.clone().requires_grad_(True) for k, v in _oracle_params(net).items()}
     c64 = cond[:, :cond_dim].double().requires_grad_(True)
-    out = O.film_siren(x[:, :x_dim].double(), c64, p)
+    x64 = x[:, :x_dim].double().requires_grad_(True)
+    out = O.film_siren(x64, c64, p)
     out.backward(d_res[:, :out_dim].double())
     rel = lambda a, b: (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)  # noqa: E731
     e = rel(d_cond[:, :cond_dim].cpu().double(), c64.grad)
     assert e < 2e-4, ("d_cond", e)
+    assert rel(d_x[:, :x_dim].cpu().double(), x64.grad) < 2e-4 and float(d_x[:, x_dim:].abs().max() if d_x.shape[1] > x_dim else 0.0) == 0.0
     assert float(d_cond[:, cond_dim:].abs().max()) == 0.0 if d_cond.shape[1] > cond_dim else True
     rows = lambda t, w=H: hip.film_native_to_rows(t, M, w).cpu().double()  # noqa: E731
     y_prev = [x[:, :x_dim].double()] + [rows(t) for t in ys[:-1]]
@@ -174,3 +178,21 @@ def test_fused_backward_matches_float64_autograd(H, n_map, n_film, cond_dim, x_d
     assert rel(dF.t() @ rows(hs[-1]), p["ddf.map_wo"].grad) < 3e-4
     assert rel(dF.sum(0), p["ddf.map_bo"].grad) < 3e-4
     assert rel(rowmax[:M].cpu().double(), dF.abs().max(1).values) < 1e-6
+    # published maxima of the gradient matrices (pre-scaling of the weight-gradient GEMMs)
+    want = [rows(t).abs().max().item() for t in dzs] + [dF.abs().max().item()] + [rows(t).abs().max().item() for t in dpres]
+    assert rel(gmax.cpu().double(), torch.tensor(want, dtype=torch.float64)) < 1e-6
+    # ---- weight gradients by the GEMM kernel straight from the tile-native matrices (fp16 split pre-scaled by the published max)
+    from neusky_amd import ops
+    for i in range(1, n_film):
+        like = net.net[i].layer.weight
+        dW, db = ops.grad_weight(dzs[i], ys[i - 1], M, H, H, like, net.net[i].layer.bias, a_native_nt=H // 32, b_native_nt=H // 32, a_scale_max=gmax[i:i + 1])
+        assert rel(dW.cpu().double(), p[f"ddf.film_w{i}"].grad) < 3e-4 and rel(db.cpu().double(), p[f"ddf.film_b{i}"].grad) < 3e-4, ("gemm film", i)
+    lins_ = net.mapping_network.linears()
+    dW, db = ops.grad_weight(dfp, hs[-1], M, 2 * n_film * H, H, lins_[-1].weight, lins_[-1].bias, a_native_nt=2 * n_film * H // 32, b_native_nt=H // 32,
+                             a_scale_max=gmax[n_film:n_film + 1])
+    assert rel(dW.cpu().double(), p["ddf.map_wo"].grad) < 3e-4 and rel(db.cpu().double(), p["ddf.map_bo"].grad) < 3e-4
+    # first layers: native gradient against a row-major input (N <= 64: exact fp32 MFMA kernel)
+    xp = x.to(DEV)
+    w0 = ops.pad_weight(net.net[0].layer.weight)
+    dW, db = ops.grad_weight(dzs[0], xp, M, H, xp.shape[1], w0, net.net[0].layer.bias, a_native_nt=H // 32)
+    assert rel(dW[:, :x_dim].cpu().double(), p["ddf.film_w0"].grad) < 3e-4 and rel(db.cpu().double(), p["ddf.film_b0"].grad) < 3e-4

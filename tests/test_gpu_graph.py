@@ -68,6 +68,7 @@ def test_graph_replay_equals_eager_on_injected_randoms():
     eager_g = opt.flat_g.clone()
     del outs, ld  # the eager autograd graph (and its AccumulateGrad nodes, bound to the default stream) must be gone before the capture
     stepper = GraphedTrainStep(pipe, opt, rb, batch, warmup=2, start_step=step, randoms=rnd)
+    stepper.load(rb, batch, sky=rnd["sky_ray_bundle"])  # the graph owns its sky-ray buffers: same sky rays as the eager step
     pipe.model.set_step(step)
     for rep in range(2):
         stepper.graph.replay()
@@ -88,6 +89,7 @@ def test_proposal_anneal_follows_the_step_under_graph_replay():
     pipe, opt, rb, batch, rnd = _setup()
     sampler = pipe.model.proposal_sampler
     stepper = GraphedTrainStep(pipe, opt, rb, batch, warmup=2, start_step=500, randoms=rnd)
+    stepper.load(rb, batch, sky=rnd["sky_ray_bundle"])
     seen = {}
     for s in (5, 2000):
         pipe.model.set_step(s)
