@@ -32,7 +32,8 @@ class _Dataset:
 
 class DeviceImageDataManager:
     def __init__(self, images: torch.Tensor, masks: torch.Tensor, c2w: torch.Tensor, fx, fy, cx, cy,
-                 train_num_rays_per_batch: int = 1024, device="cuda:0", scene_scale: float = 1.0, num_eval: int = 0, seed: int = 0):
+                 train_num_rays_per_batch: int = 1024, device="cuda:0", scene_scale: float = 1.0, num_eval: int = 0, seed: int = 0,
+                 image_idx: Optional[torch.Tensor] = None):
         """images [N,H,W,3] float, masks [N,H,W,4] bool, c2w [N,3,4] camera-to-world (nerfstudio/OpenGL convention);
         fx, fy, cx, cy: one pinhole for every image (floats) or per-image tensors [N]"""
         assert images.shape[:3] == masks.shape[:3] and masks.shape[-1] == 4 and c2w.shape[1:] == (3, 4)
@@ -42,6 +43,8 @@ class DeviceImageDataManager:
         per_image = lambda v: torch.as_tensor(v, dtype=torch.float32).reshape(-1).expand(self.N).contiguous().to(device)  # noqa: E731
         self.fx, self.fy, self.cx, self.cy = per_image(fx), per_image(fy), per_image(cx), per_image(cy)
         self.train_num_rays_per_batch = train_num_rays_per_batch
+        # dataset index of every stacked image: `indices[:, 0] = batch["image_idx"][c]` (neusky_pixel_sampler.py:76,155)
+        self.image_idx = (torch.arange(self.N) if image_idx is None else torch.as_tensor(image_idx)).to(device).long()
         scene_box = {"aabb": torch.tensor([[-scene_scale] * 3, [scene_scale] * 3])}
         self.train_dataset = _Dataset(self.N, scene_box)
         self.eval_dataset = _Dataset(max(num_eval, 1), scene_box)
@@ -83,11 +86,27 @@ class DeviceImageDataManager:
         pick = torch.randint(0, pixels.shape[0], (n,), device=pixels.device, generator=self.gen)
         return pixels[pick]
 
+    def collate(self, idx: torch.Tensor) -> Dict:
+        """batch of the stacked pixels idx [R,3] = (stack position, y, x): values gathered by [c, y, x], first index column
+        remapped to the dataset's image index (neusky_pixel_sampler.py:71-77)"""
+        c, y, x = idx[:, 0], idx[:, 1], idx[:, 2]
+        out = idx.clone()
+        out[:, 0] = self.image_idx[c]
+        return {"image": self.images[c, y, x], "mask": self.masks[c, y, x], "indices": out}
+
+    def half_pixels(self, sample_region: str = "full_image", image_index: Optional[int] = None) -> torch.Tensor:
+        """pixels admissible for eval-latent fitting: static mask (channel 0) restricted to an image half
+        (neusky_pixel_sampler.py:128-146); all stacked images, or one"""
+        sel = self.static_pixels if image_index is None else self.static_pixels[self.static_pixels[:, 0] == image_index]
+        if sample_region == "left_image_half":
+            sel = sel[sel[:, 2] < self.W // 2]
+        elif sample_region == "right_image_half":
+            sel = sel[sel[:, 2] >= self.W // 2]
+        return sel
+
     def next_train(self, step: int) -> Tuple[RayBundle, Dict]:
         idx = self._draw(self.static_pixels, self.train_num_rays_per_batch)
-        c, y, x = idx[:, 0], idx[:, 1], idx[:, 2]
-        batch = {"image": self.images[c, y, x], "mask": self.masks[c, y, x], "indices": idx}
-        return self.generate_rays(idx), batch
+        return self.generate_rays(idx), self.collate(idx)
 
     def get_sky_ray_bundle(self, number_of_rays: int) -> RayBundle:
         pool = self.sky_pixels if self.sky_pixels.shape[0] > 0 else self.static_pixels
@@ -96,11 +115,5 @@ class DeviceImageDataManager:
     def get_eval_image_half_bundle(self, sample_region: str = "full_image", image_index: int = 0, num_rays: Optional[int] = None):
         """rays of ONE image restricted to an image half and to the static mask (datamanager :288-333), for eval-latent fitting"""
         n = num_rays or self.train_num_rays_per_batch
-        sel = self.static_pixels[self.static_pixels[:, 0] == image_index]
-        if sample_region == "left_image_half":
-            sel = sel[sel[:, 2] < self.W // 2]
-        elif sample_region == "right_image_half":
-            sel = sel[sel[:, 2] >= self.W // 2]
-        idx = self._draw(sel, n)
-        c, y, x = idx[:, 0], idx[:, 1], idx[:, 2]
-        return self.generate_rays(idx), {"image": self.images[c, y, x], "mask": self.masks[c, y, x], "indices": idx}
+        idx = self._draw(self.half_pixels(sample_region, image_index), n)
+        return self.generate_rays(idx), self.collate(idx)

@@ -26,6 +26,9 @@ class SyntheticDataManagerConfig:
     image_height: int = 823
     image_width: int = 1280
     focal: float = 1100.0
+    eval_image_height: int = 24   # synthetic eval frames are small: a full 823 x 1280 frame is BASELINE config 5's job
+    eval_image_width: int = 32
+    eval_num_rays_per_batch: int = 1024
     seed: int = 0
     camera_optimizer = None
 
@@ -97,3 +100,73 @@ class SyntheticDataManager:
         d[:, 2] = d[:, 2].abs() + 0.2  # sky rays point upwards (device-side ops, no host round trip)
         rb.directions = d / d.norm(dim=-1, keepdim=True)
         return rb
+
+    # ------------------------------------------------------------------ evaluation side (NeuSkyDataManager.next_eval /
+    # next_eval_image / get_eval_image_half_bundle, neusky/data/datamanagers/neusky_datamanager.py:236-333)
+    class _EvalLoader:
+        def __init__(self, n):
+            self.image_indices = list(range(n))
+
+        def __len__(self):
+            return len(self.image_indices)
+
+    @property
+    def eval_dataloader(self):
+        return SyntheticDataManager._EvalLoader(self.config.num_eval_images)
+
+    def _eval_frame(self, image_idx: int):
+        """synthetic eval frame `image_idx`: pinhole rays of train camera `image_idx % num_train`, seeded pixel colours / masks"""
+        c = self.config
+        H, W = c.eval_image_height, c.eval_image_width
+        cam = image_idx % c.num_train_images
+        g = torch.Generator().manual_seed(c.seed + 7919 * (image_idx + 1))
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+        f = c.focal * W / c.image_width
+        d_cam = torch.stack([(xs + 0.5 - W / 2) / f, (ys + 0.5 - H / 2) / f, torch.ones(H, W)], -1)
+        d = torch.einsum("ij,hwj->hwi", self.cam_R[cam], d_cam)
+        norm = d.norm(dim=-1, keepdim=True)
+        image = torch.rand(H, W, 3, generator=g)
+        u = torch.rand(H, W, 4, generator=g)
+        mask = torch.stack([u[..., 0] < 0.9, u[..., 1] < 0.6, u[..., 2] < 0.15, u[..., 3] < 0.3], -1)
+        mask[..., 1] &= ~mask[..., 3]
+        return cam, d / norm, norm, image, mask
+
+    def next_eval_image(self, idx: int):
+        """-> (image_idx, camera_ray_bundle [H,W], batch{image [H,W,3], mask [H,W,4], image_idx})"""
+        image_idx = int(idx) % self.config.num_eval_images
+        cam, d, norm, image, mask = self._eval_frame(image_idx)
+        H, W = d.shape[:2]
+        dev = self.device
+        rb = RayBundle(origins=to_device_async(self.cam_pos[cam].expand(H, W, 3).contiguous(), dev), directions=to_device_async(d.contiguous(), dev),
+                       pixel_area=torch.ones(H, W, 1, device=dev), camera_indices=torch.full((H, W, 1), image_idx, dtype=torch.long, device=dev),
+                       metadata={"directions_norm": to_device_async(norm.contiguous(), dev)})
+        return image_idx, rb, {"image": to_device_async(image, dev), "mask": to_device_async(mask, dev), "image_idx": image_idx}
+
+    def _eval_rays(self, image_idx: int, sample_region: str, n: int, g: torch.Generator):
+        cam, d, norm, image, mask = self._eval_frame(image_idx)
+        H, W = d.shape[:2]
+        ok = mask[..., 0].clone()  # static mask, restricted to an image half (neusky_pixel_sampler.py:128-146)
+        if sample_region == "left_image_half":
+            ok[:, W // 2:] = False
+        elif sample_region == "right_image_half":
+            ok[:, :W // 2] = False
+        pix = torch.nonzero(ok)
+        pick = pix[torch.randint(0, pix.shape[0], (n,), generator=g)]
+        y, x = pick[:, 0], pick[:, 1]
+        dev = self.device
+        rb = RayBundle(origins=to_device_async(self.cam_pos[cam].expand(n, 3).contiguous(), dev), directions=to_device_async(d[y, x].contiguous(), dev),
+                       pixel_area=torch.ones(n, 1, device=dev), camera_indices=torch.full((n, 1), image_idx, dtype=torch.long, device=dev),
+                       metadata={"directions_norm": to_device_async(norm[y, x].contiguous(), dev)})
+        batch = {"image": to_device_async(image[y, x], dev), "mask": to_device_async(mask[y, x], dev),
+                 "indices": torch.stack([torch.full_like(y, image_idx), y, x], 1)}
+        return rb, batch
+
+    def next_eval(self, step: int):
+        self._eval_cursor = (getattr(self, "_eval_cursor", -1) + 1) % self.config.num_eval_images
+        return self._eval_rays(self._eval_cursor, "full_image", self.config.eval_num_rays_per_batch, self._gen)
+
+    def get_eval_image_half_bundle(self, sample_region: str = "full_image", image_index=None, num_rays=None):
+        if image_index is None:  # the reference cycles its eval image dataloader (:288-291)
+            self._half_cursor = (getattr(self, "_half_cursor", -1) + 1) % self.config.num_eval_images
+            image_index = self._half_cursor
+        return self._eval_rays(int(image_index), sample_region, num_rays or self.config.eval_num_rays_per_batch, self._gen)

@@ -19,6 +19,7 @@ from ..encoding import HashGridGeometry
 from ..field_components.neusky_fieldheadnames import NeuSkyFieldHeadNames
 from ..utils.siren import FiLMSiren
 from .sdf_albedo_field import HashEncoding
+from ..plugin import FieldBase
 
 
 def nerf_encoding(x: torch.Tensor, num_freq: int, max_exp: float, include_input: bool = False) -> torch.Tensor:
@@ -56,11 +57,11 @@ class DirectionalDistanceFieldConfig:
         return self._target(self, **kwargs)
 
 
-class DirectionalDistanceField(nn.Module):
+class DirectionalDistanceField(FieldBase):
     config: DirectionalDistanceFieldConfig
 
     def __init__(self, config: DirectionalDistanceFieldConfig, ddf_radius: float = 1.0) -> None:
-        super().__init__()
+        nn.Module.__init__(self)  # not the nerfstudio base's constructor (neusky_amd/plugin.py)
         c = self.config = config
         self.ddf_radius = ddf_radius
         if c.conditioning != "FiLM" or c.ddf_type != "ddf" or c.position_encoding_type != "hash" or \

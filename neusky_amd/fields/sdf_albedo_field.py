@@ -25,6 +25,7 @@ from .. import hip, ops
 from ..cameras.rays import RaySamples
 from ..encoding import HashGridGeometry
 from ..field_components.neusky_fieldheadnames import FieldHeadNames, NeuSkyFieldHeadNames
+from ..plugin import FieldBase
 
 
 class HashEncoding(nn.Module):
@@ -104,12 +105,12 @@ class SDFAlbedoFieldConfig:
         return self._target(self, **kwargs)
 
 
-class SDFAlbedoField(nn.Module):
+class SDFAlbedoField(FieldBase):
     config: SDFAlbedoFieldConfig
 
     def __init__(self, config: SDFAlbedoFieldConfig, aabb: torch.Tensor, num_images: int,
                  use_average_appearance_embedding: bool = False, spatial_distortion=None) -> None:
-        super().__init__()
+        nn.Module.__init__(self)  # not the nerfstudio base's constructor (neusky_amd/plugin.py)
         c = self.config = config
         if c.predict_shininess:
             raise NotImplementedError("predict_shininess (Blinn-Phong) is outside the neusky config (neusky_config.py:76)")
@@ -235,6 +236,23 @@ class SDFAlbedoField(nn.Module):
         colour net is skipped each way and albedo comes back as zeros (geometry-only passes: DDF-fit ground truth, grid probe)."""
         ET = self._encode(positions_flat.detach(), True, False)
         return ops.SDFAlbedoFn.apply(ET, *self._geo_weights(), *self._colour_weights(), self.softplus_beta, want_albedo)
+
+    def get_colors(self, points: torch.Tensor, geo_features: torch.Tensor) -> torch.Tensor:
+        """sdf_albedo_field.py:185-209: albedo of the colour network at `points` given their geometric features:
+        [x | PE6(x) | feat] -> Linear+ReLU -> Linear+ReLU... -> sigmoid.  (The training step reaches the same three dense
+        layers fused behind the geo network inside ops.SDFAlbedoFn; this entry point serves callers written against the reference.)"""
+        from .directional_distance_field import nerf_encoding
+        x = points.reshape(-1, 3)
+        feat = geo_features.reshape(x.shape[0], -1)
+        Wc0p, bc0, Wc1, bc1, Wc2p, bc2 = self._colour_weights()
+        GF = feat.shape[1]
+        cin = x.new_zeros(x.shape[0], Wc0p.shape[1])  # columns [feat | 0 0 0 0 | x PE | 0] (see _colour_weights_uncached)
+        cin[:, :GF] = feat
+        cin[:, GF + 4:GF + 4 + 39] = torch.cat([x, nerf_encoding(x, 6, 5.0)], -1)
+        h0 = ops.DenseFn.apply(cin, Wc0p, bc0, Wc0p.shape[0], "relu", True)
+        h1 = ops.DenseFn.apply(h0, Wc1, bc1, Wc1.shape[0], "relu", True)
+        out = ops.DenseFn.apply(h1, Wc2p, bc2, 3, "none", True)
+        return torch.sigmoid(out[:, :3]).reshape(*points.shape[:-1], 3)
 
     def get_alpha(self, ray_samples: RaySamples, sdf: Optional[torch.Tensor] = None, gradients: Optional[torch.Tensor] = None):
         """nerfstudio SDFField.get_alpha for isolated samples (used by the hash-grid density probe,

@@ -20,6 +20,7 @@ from ..model_components.losses import LossDict, scale_dict
 
 _COEF_VECTORS: Dict[tuple, torch.Tensor] = {}
 from ..utils.utils import ray_sphere_intersection
+from ..plugin import ModelBase
 
 
 @dataclass
@@ -47,11 +48,11 @@ class DDFModelConfig:
         return self._target(self, **kwargs)
 
 
-class DDFModel(nn.Module):
+class DDFModel(ModelBase):
     config: DDFModelConfig
 
     def __init__(self, config: DDFModelConfig, ddf_radius: float, **kwargs) -> None:
-        super().__init__()
+        nn.Module.__init__(self)  # not the nerfstudio base's constructor (neusky_amd/plugin.py)
         self.config = config
         self.ddf_radius = ddf_radius
         if config.compute_normals:

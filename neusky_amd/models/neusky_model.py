@@ -34,6 +34,7 @@ from ..model_components.losses import LossDict, RENISkyPixelLoss, interlevel_los
 from ..model_components.ray_samplers import HashMLPDensityField, ProposalNetworkSampler
 from ..model_components.renderers import RGBLambertianRendererWithVisibility
 from ..utils.utils import linear_to_sRGB, to_device_async
+from ..plugin import ModelBase
 
 
 def _default_loss_inclusions() -> Dict[str, Any]:  # neusky/configs/neusky_config.py:102-126
@@ -96,12 +97,12 @@ class NeuSkyFactoModelConfig:
         return self._target(self, **kwargs)
 
 
-class NeuSkyFactoModel(nn.Module):
+class NeuSkyFactoModel(ModelBase):
     config: NeuSkyFactoModelConfig
 
     def __init__(self, config: NeuSkyFactoModelConfig, scene_box, num_train_data: int, num_val_data: int, num_test_data: int,
                  visibility_field, test_mode: str, **kwargs) -> None:
-        super().__init__()
+        nn.Module.__init__(self)  # not the nerfstudio base's constructor (neusky_amd/plugin.py)
         self.config = config
         self.scene_box = scene_box
         self.num_train_data, self.num_val_data, self.num_test_data = num_train_data, num_val_data, num_test_data
@@ -231,8 +232,19 @@ class NeuSkyFactoModel(nn.Module):
                         spacing_starts=sbins[:, :-1, None], spacing_ends=sbins[:, 1:, None])
         return rs, weights_list, sbins_list, sbins, inds_list
 
-    def sample_illumination(self, camera_indices: torch.Tensor, ray_directions: torch.Tensor,
-                            rotation: Optional[torch.Tensor] = None, randoms: Optional[Dict] = None):
+    def sample_illumination(self, ray_samples: RaySamples, rotation: Optional[torch.Tensor] = None):
+        """neusky_model.py:445-551 with the reference's signature and return layout: (hdr illumination colours [R*S, D, 3],
+        illumination directions [R*S, D, 3], hdr background colours [R, 3]).  The broadcast tensors are materialised HERE
+        only, for callers written against the reference; the step itself runs sample_illumination_compact."""
+        cam = ray_samples.camera_indices[:, 0, 0] if ray_samples.camera_indices.dim() == 3 else ray_samples.camera_indices.reshape(-1)
+        R, S = ray_samples.frustums.origins.shape[:2]
+        dirs, cols, cam_of_ray, bg = self.sample_illumination_compact(cam, ray_samples.frustums.directions[:, 0].contiguous(), rotation)
+        D = dirs.shape[0]
+        colours = cols[cam_of_ray.long()][:, None].expand(R, S, D, 3).reshape(R * S, D, 3)
+        return colours, dirs[None].expand(R * S, D, 3), bg
+
+    def sample_illumination_compact(self, camera_indices: torch.Tensor, ray_directions: torch.Tensor,
+                                    rotation: Optional[torch.Tensor] = None, randoms: Optional[Dict] = None):
         """neusky_model.py:445-551 on compact data: camera_indices [R], ray_directions [R,3] ->
         directions [D,3], cam_colours [U,D,3], cam_of_ray [R] (int32 row of cam_colours), hdr_background [R,3]."""
         latents, scales = self.get_illumination_field()
@@ -288,7 +300,7 @@ class NeuSkyFactoModel(nn.Module):
         side = self._illumination_stream()
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            self._illumination_pending = self.sample_illumination(cam, ray_bundle.directions, rotation, randoms)
+            self._illumination_pending = self.sample_illumination_compact(cam, ray_bundle.directions, rotation, randoms)
 
     def _illumination_stream(self):
         s = getattr(self, "_illum_stream", None)
@@ -302,9 +314,23 @@ class NeuSkyFactoModel(nn.Module):
         depth = torch.sum(weights * steps, dim=-2) / (torch.sum(weights, -2) + 1e-10)
         return torch.clip(depth, steps.min(), steps.max())
 
-    def compute_visibility(self, origins: torch.Tensor, ray_directions: torch.Tensor, depth: torch.Tensor,
-                           illumination_directions: torch.Tensor, threshold_distance: torch.Tensor, sigmoid_scale: float,
-                           compute_shadow_map: bool = False, sel: Optional[torch.Tensor] = None) -> Dict[str, Any]:
+    def compute_visibility(self, ray_samples: RaySamples, depth: torch.Tensor, illumination_directions: torch.Tensor,
+                           threshold_distance: torch.Tensor, sigmoid_scale: float, compute_shadow_map: bool = False) -> Dict[str, Any]:
+        """neusky_model.py:1624-1778 with the reference's signature: ray_samples [R,S] (sample 0 of each ray is used, :1667-1668),
+        illumination_directions [R*S, D, 3] (row 0 is used, :1648) or [D, 3]; `visibility` comes back in the reference layout
+        [R*S, D, 1] (repeated over the samples, :1755-1759).  The step itself runs compute_visibility_compact ([R, D])."""
+        fr = ray_samples.frustums
+        R, S = fr.origins.shape[:2]
+        dirs = illumination_directions[0] if illumination_directions.dim() == 3 else illumination_directions
+        out = self.compute_visibility_compact(fr.origins[:, 0].contiguous(), fr.directions[:, 0].contiguous(), depth, dirs.contiguous(),
+                                              threshold_distance, sigmoid_scale, compute_shadow_map)
+        D = dirs.shape[0]
+        out["visibility"] = out["visibility"][:, None, :, None].expand(R, S, D, 1).reshape(R * S, D, 1)
+        return out
+
+    def compute_visibility_compact(self, origins: torch.Tensor, ray_directions: torch.Tensor, depth: torch.Tensor,
+                                   illumination_directions: torch.Tensor, threshold_distance: torch.Tensor, sigmoid_scale: float,
+                                   compute_shadow_map: bool = False, sel: Optional[torch.Tensor] = None) -> Dict[str, Any]:
         """neusky_model.py:1624-1778 on compact data: origins / ray_directions [R,3] (= sample 0 of each ray,
         :1667-1668), depth [R,1], illumination_directions [D,3] (= row 0 of the broadcast, :1648).
         Returns visibility [R,D] (the reference repeats it over S, :1755-1759)."""
@@ -387,7 +413,7 @@ class NeuSkyFactoModel(nn.Module):
             side = self._illumination_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                dirs, cam_colours, cam_of_ray, hdr_bg = self.sample_illumination(cam, ray_bundle.directions, rotation, randoms)
+                dirs, cam_colours, cam_of_ray, hdr_bg = self.sample_illumination_compact(cam, ray_bundle.directions, rotation, randoms)
         ray_samples, weights_list, sbins_list, sbins, inds_list = self._sample(ray_bundle, randoms, want_inds=randoms is not None)
         field_outputs = self.field(ray_samples, return_alphas=True)
         weights = field_outputs["weights"]
@@ -399,7 +425,7 @@ class NeuSkyFactoModel(nn.Module):
                 if isinstance(t, torch.Tensor):
                     t.record_stream(main)  # allocated on the side stream, consumed on this one from here on
         else:
-            dirs, cam_colours, cam_of_ray, hdr_bg = self.sample_illumination(cam, ray_bundle.directions, rotation, randoms)
+            dirs, cam_colours, cam_of_ray, hdr_bg = self.sample_illumination_compact(cam, ray_bundle.directions, rotation, randoms)
         out: Dict[str, Any] = {
             "ray_samples": ray_samples, "field_outputs": field_outputs, "weights": weights,
             "bg_transmittance": field_outputs["bg_transmittance"], "weights_list": weights_list, "sbins_list": sbins_list,
@@ -413,7 +439,7 @@ class NeuSkyFactoModel(nn.Module):
             p2p_vis = p2p_dist.detach() if self.config.sdf_to_visibility_stop_gradients in ["depth", "both"] else p2p_dist
             if p2p_vis.requires_grad:
                 raise NotImplementedError("visibility geometry is differentiated only in 'depth'/'both' mode (neusky_config.py:156)")
-            out["visibility_dict"] = self.compute_visibility(ray_bundle.origins, ray_bundle.directions, p2p_vis, dirs,
+            out["visibility_dict"] = self.compute_visibility_compact(ray_bundle.origins, ray_bundle.directions, p2p_vis, dirs,
                                                              self.visibility_threshold, self.sigmoid_scale,
                                                              sel=getattr(self, "_upper_sel", None))
             out.update(p2p_dist=p2p_dist, depth=depth, accumulation=accumulation)
@@ -594,7 +620,63 @@ class NeuSkyFactoModel(nn.Module):
                 m["visibility_threshold"] = self.visibility_threshold.detach()
         return m
 
-    def generate_ddf_ground_truth(self, ray_bundle: RayBundle, mask_threshold: float = 0.5, randoms=None) -> Dict[str, Any]:
+    def get_image_metrics_and_images(self, outputs: Dict[str, Any], batch: Dict[str, Any]):
+        """neusky_model.py:1079-1335: per-image metrics + the image dict for the viewer / logger.  PSNR, SSIM (torchmetrics'
+        structural_similarity_index_measure restated in utils/image_metrics.py) and MSE are computed; LPIPS needs torchmetrics'
+        pretrained VGG weights, absent here, and is reported as NaN.  Colour-mapped panels use a plain grey ramp (nerfstudio's
+        `colormaps` is not vendored by the reference).  Ground-truth material panels (:1184-1254) need the synthetic EXR layers
+        and are produced when the batch carries them."""
+        from ..utils.image_metrics import grey_ramp, psnr, ssim
+        dev = self.device
+        image = batch["image"].to(dev)
+        rgb = outputs["rgb"]
+        acc = grey_ramp(outputs["accumulation"])
+        gt_acc = grey_ramp(batch["mask"][..., 1:2].float().to(dev))  # fg mask (:1088)
+        normal = (outputs["normal"] + 1.0) / 2.0
+        depth = grey_ramp(outputs["depth"] / outputs["depth"].max().clamp_min(1e-8))
+        squared_error = (rgb - image) ** 2
+        normalised_error = (squared_error - squared_error.min()) / (squared_error.max() - squared_error.min()).clamp_min(1e-12)
+        images_dict = {
+            "img": torch.cat([image, rgb], dim=1), "accumulation": torch.cat([gt_acc, acc], dim=1), "depth": depth,
+            "normal": torch.cat([(batch["normal"].to(dev) + 1.0) / 2.0, normal], dim=1) if "normal" in batch else normal,
+            "normalised_error": grey_ramp(normalised_error.mean(dim=-1, keepdim=True)),
+        }
+        method = getattr(self.config, "eval_latent_optimise_method", "per_image")
+        if method in ["nerf_osr_holdout", "nerf_osr_envmap"]:  # metrics inside the provided test mask only (:1135-1140)
+            m = batch["mask"][..., 0:1].float().to(dev)
+            rgb, image = rgb * m, image * m
+        im4, rgb4 = torch.moveaxis(image, -1, 0)[None], torch.moveaxis(rgb, -1, 0)[None]
+        metrics_dict = {"psnr": float(psnr(im4, rgb4)), "ssim": float(ssim(im4, rgb4)), "lpips": float("nan"),
+                        "mse": float(torch.mean((im4 - rgb4) ** 2))}
+        images_dict["albedo"] = outputs["albedo"]
+        if "hdr_background_colours" in outputs:
+            images_dict["envmap_from_camera"] = linear_to_sRGB(outputs["hdr_background_colours"])
+        fg = batch["mask"][..., 1:2].float().to(dev)
+        if "gt_albedo" in batch:  # :1184-1208 (NeRFactor convention: per-channel least-squares rescale on the foreground)
+            gt_srgb, pred_srgb = linear_to_sRGB(batch["gt_albedo"].to(dev)), linear_to_sRGB(outputs["albedo"]).clone()
+            sel = fg[..., 0] > 0.5
+            for ch in range(3):
+                g_, p_ = gt_srgb[..., ch][sel], pred_srgb[..., ch][sel]
+                if p_.sum() > 1e-8:
+                    pred_srgb[..., ch] *= (g_ * p_).sum() / (p_ * p_).sum().clamp(min=1e-8)
+            g4, p4 = torch.moveaxis(gt_srgb * fg, -1, 0)[None], torch.moveaxis(pred_srgb * fg, -1, 0)[None]
+            metrics_dict["albedo_psnr"], metrics_dict["albedo_ssim"] = float(psnr(g4, p4)), float(ssim(g4, p4))
+            images_dict["gt_vs_pred_albedo"] = torch.cat([gt_srgb, pred_srgb], dim=1)
+        if "gt_normal" in batch:  # :1210-1236
+            gt_n = batch["gt_normal"].to(dev)
+            if self.eval_metadata is not None and "orientation_rotation" in self.eval_metadata:
+                Rm = self.eval_metadata["orientation_rotation"].to(dev).float()
+                gt_n = (Rm @ gt_n.reshape(-1, 3).T).T.reshape(gt_n.shape)
+            gn, pn = F.normalize(gt_n, dim=-1), F.normalize(outputs["normal"], dim=-1)
+            sel = fg[..., 0] > 0.5
+            if sel.any():
+                cos = (gn[sel] * pn[sel]).sum(dim=-1).clamp(-1.0, 1.0)
+                metrics_dict["normal_mae"] = float((torch.acos(cos) * (180.0 / math.pi)).mean())
+            images_dict["gt_vs_pred_normal"] = torch.cat([(gn + 1.0) / 2.0, (pn + 1.0) / 2.0], dim=1)
+        return metrics_dict, images_dict
+
+    def generate_ddf_ground_truth(self, ray_bundle: RayBundle, mask_threshold: float = 0.5, log_depth: bool = False,
+                                  randoms=None) -> Dict[str, Any]:
         """neusky_model.py:1337-1367: second sampler + field pass on the DDF-fit rays"""
         ray_bundle = self.collider(ray_bundle)
         sub = None if randoms is None or "ddf_jitters" not in randoms else {"jitters": randoms["ddf_jitters"]}
@@ -606,6 +688,8 @@ class NeuSkyFactoModel(nn.Module):
         p2p = self.render_depth(weights, ray_samples).reshape(-1, 1)
         if self.visibility_field is not None:
             p2p = torch.clamp(p2p, max=2 * self.visibility_field.ddf_radius)
+        if log_depth:  # :1354-1355
+            p2p = torch.log(p2p + 1e-6)
         normals = torch.sum(weights * fo[FieldHeadNames.NORMALS], dim=-2).reshape(-1, 3)
         return {"ray_bundle": ray_bundle, "accumulations": accumulations, "mask": mask, "termination_dist": p2p, "normals": normals}
 

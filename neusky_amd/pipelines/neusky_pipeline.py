@@ -22,6 +22,7 @@ from ..model_components.ddf_sampler import VMFDDFSamplerConfig
 from ..model_components.losses import merge_loss_dicts
 from ..models.ddf_model import DDFModelConfig
 from ..models.neusky_model import NeuSkyFactoModelConfig
+from ..plugin import PipelineBase
 
 
 @dataclass
@@ -38,15 +39,16 @@ class NeuSkyPipelineConfig:
     num_sky_rays: int = 256
     test_mode: Optional[str] = None
     stop_sdf_gradients: bool = False
+    least_squares_global_scale: bool = False
 
     def setup(self, **kwargs):
         return self._target(self, **kwargs)
 
 
-class NeuSkyPipeline(nn.Module):
+class NeuSkyPipeline(PipelineBase):
     def __init__(self, config: NeuSkyPipelineConfig, device: str, test_mode: str = "val", world_size: int = 1,
                  local_rank: int = 0, grad_scaler=None):
-        super().__init__()
+        nn.Module.__init__(self)  # not the nerfstudio base's constructor (neusky_amd/plugin.py)
         self.config = config
         self.test_mode = test_mode if config.test_mode is None else config.test_mode
         self.datamanager = config.datamanager.setup(device=device, test_mode=self.test_mode, world_size=world_size,
@@ -68,6 +70,9 @@ class NeuSkyPipeline(nn.Module):
             grad_scaler=grad_scaler)
         self._model.to(device)
         self.world_size, self.local_rank = world_size, local_rank
+        self.step_of_last_latent_optimisation = 0  # neusky_pipeline.py:202
+        self.eval_image_num = 0
+        self.max_eval_num = max(int(self.num_val_data if self.test_mode == "val" else self.num_test_data), 1)
         self.grad_sync = None
         if world_size > 1:
             from ..distributed import GradientAllReduce
@@ -106,7 +111,7 @@ class NeuSkyPipeline(nn.Module):
                            metadata={"directions_norm": torch.ones(o.shape[0], 1, device=dev)})
         else:
             rb = self.visibility_train_sampler()
-        data = self.model.generate_ddf_ground_truth(rb, self.config.visibility_accumulation_mask_threshold, randoms)
+        data = self.model.generate_ddf_ground_truth(rb, self.config.visibility_accumulation_mask_threshold, randoms=randoms)
         data["sky_ray_bundle"] = randoms["sky_ray_bundle"] if randoms is not None and "sky_ray_bundle" in randoms else \
             self.datamanager.get_sky_ray_bundle(self.config.num_sky_rays)
         if self.config.stop_sdf_gradients:
@@ -161,3 +166,108 @@ class NeuSkyPipeline(nn.Module):
         """all-reduce (mean) of every trainable gradient; no-op on one GPU"""
         if self.grad_sync is not None:
             self.grad_sync.all_reduce()
+
+    # ------------------------------------------------------------------ evaluation (neusky_pipeline.py:204-444)
+    def _optimise_evaluation_latents(self, step) -> None:
+        """:204-210: fit the eval illumination latents once per eval step"""
+        if self.step_of_last_latent_optimisation != step:
+            self.model.fit_latent_codes_for_eval(datamanager=self.datamanager, global_step=step)
+            self.step_of_last_latent_optimisation = step
+
+    def global_scale(self, pred_img: torch.Tensor, gt_img: torch.Tensor) -> torch.Tensor:
+        """:212-225: least-squares optimal scalar alpha = <gt, pred> / <pred, pred>"""
+        p, g = pred_img.reshape(-1), gt_img.reshape(-1).to(pred_img.device)
+        return torch.dot(g, p) / torch.dot(p, p) * pred_img
+
+    def _eval_mode(self, on: bool) -> None:
+        m = self.model
+        if on:
+            m.eval()
+            if m.visibility_field is not None:
+                m.visibility_field.eval()
+        else:
+            m.train()
+            if m.visibility_field is not None and m.config.fit_visibility_field:
+                m.visibility_field.train()
+
+    def get_eval_loss_dict(self, step: int):
+        """:294-313"""
+        self._optimise_evaluation_latents(step)
+        self._eval_mode(True)
+        try:
+            ray_bundle, batch = self.datamanager.next_eval(step)
+            with torch.no_grad():
+                model_outputs = self.model(ray_bundle, step=step)
+                metrics_dict = self.model.get_metrics_dict(model_outputs, batch)
+                loss_dict = self.model.get_loss_dict(model_outputs, batch, metrics_dict)
+        finally:
+            self._eval_mode(False)
+        return model_outputs, loss_dict, metrics_dict
+
+    def get_eval_image_metrics_and_images(self, step: int):
+        """:316-390.  The DDF depth-grid visualisation (:330-377: twelve look-at cameras on the sphere rendered through the DDF) is
+        viewer output and is not produced (viewer / visualisation out of scope)."""
+        self._optimise_evaluation_latents(step)
+        self._eval_mode(True)
+        try:
+            self.eval_image_num = self.eval_image_num % self.max_eval_num
+            image_idx, camera_ray_bundle, batch = self.datamanager.next_eval_image(self.eval_image_num)
+            outputs = self.model.get_outputs_for_camera_ray_bundle(camera_ray_bundle, show_progress=True, step=step)
+            if self.config.least_squares_global_scale:
+                outputs["rgb"] = self.global_scale(outputs["rgb"], batch["image"])
+            metrics_dict, images_dict = self.model.get_image_metrics_and_images(outputs, batch)
+            assert "image_idx" not in metrics_dict
+            metrics_dict["image_idx"] = image_idx
+            assert "num_rays" not in metrics_dict
+            metrics_dict["num_rays"] = int(camera_ray_bundle.origins.shape[0] * camera_ray_bundle.origins.shape[1]) \
+                if camera_ray_bundle.origins.dim() == 3 else int(camera_ray_bundle.origins.shape[0])
+        finally:
+            self._eval_mode(False)
+        self.eval_image_num += 1
+        return metrics_dict, images_dict
+
+    def get_average_eval_image_metrics(self, step: Optional[int] = None):
+        """:393-444: every eval image once, metrics averaged; adds num_rays_per_sec and fps like the reference"""
+        from time import time
+        self._optimise_evaluation_latents(step)
+        self._eval_mode(True)
+        metrics_dict_list = []
+        try:
+            loader = getattr(self.datamanager, "eval_dataloader", None)
+            num_images = len(loader.image_indices) if hasattr(loader, "image_indices") else (len(loader) if loader is not None else self.max_eval_num)
+            for eval_image_num in range(num_images):
+                image_idx, camera_ray_bundle, batch = self.datamanager.next_eval_image(eval_image_num)
+                inner_start = time()
+                height, width = camera_ray_bundle.origins.shape[:2]
+                num_rays = height * width
+                outputs = self.model.get_outputs_for_camera_ray_bundle(camera_ray_bundle, step=step)
+                if self.config.least_squares_global_scale:
+                    outputs["rgb"] = self.global_scale(outputs["rgb"], batch["image"])
+                metrics_dict, _ = self.model.get_image_metrics_and_images(outputs, batch)
+                if outputs["rgb"].is_cuda:
+                    torch.cuda.synchronize()
+                assert "num_rays_per_sec" not in metrics_dict
+                metrics_dict["num_rays_per_sec"] = num_rays / (time() - inner_start)
+                assert "fps" not in metrics_dict
+                metrics_dict["fps"] = metrics_dict["num_rays_per_sec"] / (height * width)
+                metrics_dict_list.append(metrics_dict)
+        finally:
+            self._eval_mode(False)
+        return {key: float(torch.mean(torch.tensor([float(m[key]) for m in metrics_dict_list]))) for key in metrics_dict_list[0].keys()}
+
+    # ------------------------------------------------------------------ trainer hooks (nerfstudio VanillaPipeline surface)
+    def get_training_callbacks(self, training_callback_attributes=None) -> List:
+        """nerfstudio's Trainer asks the pipeline for per-iteration callbacks; the proposal-weight anneal is applied by
+        `get_train_loss_dict` itself (model.set_step), so there is nothing to register."""
+        return []
+
+    def load_pipeline(self, loaded_state: Dict[str, Any], step: int) -> None:
+        """nerfstudio Trainer._load_checkpoint: {"pipeline": state_dict} with or without the DDP `module.` prefix"""
+        state = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in loaded_state.items()}
+        self.load_state_dict(state, strict=True)
+        self.model.set_step(step)
+        self.model.begin_step()
+
+    @property
+    def device(self):
+        return self.model.device

@@ -52,3 +52,36 @@ def test_eval_half_bundle_and_uniformity():
     share = (b["indices"][:, 0] == 0).float().mean().item()
     want = masks[0, ..., 0].sum().item() / masks[..., 0].sum().item()
     assert abs(share - want) < 0.04
+
+
+def test_pixel_sets_and_collation_match_the_reference_sampler():
+    """golden from the reference's own NeuSkyPixelSampler (tests/golden/make_golden_sampler.py; nerfstudio's random draw replaced
+    by an enumeration of the admissible pixels): the pixels THIS datamanager may draw in each mode are exactly the reference's,
+    and a batch is collated the same way (values by [c, y, x], indices[:, 0] remapped through image_idx)"""
+    import os
+    import numpy as np
+    from neusky_amd.data.image_datamanager import DeviceImageDataManager
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pixel_sampler.npz"))
+    N, H, W = g["image"].shape[:3]
+    c2w = torch.eye(4)[:3][None].repeat(N, 1, 1)
+    dm = DeviceImageDataManager(torch.from_numpy(g["image"]), torch.from_numpy(g["mask"]), c2w, 10.0, 10.0, W / 2, H / 2, device="cpu",
+                                train_num_rays_per_batch=16, image_idx=torch.from_numpy(g["image_idx"]))
+    key = lambda a: sorted(map(tuple, np.asarray(a).tolist()))  # noqa: E731
+    remap = lambda p: torch.stack([dm.image_idx[p[:, 0]], p[:, 1], p[:, 2]], 1).numpy()  # noqa: E731
+    assert key(dm.static_pixels.numpy()) == key(g["train_pixels"])                      # neusky_pixel_sampler.py:36-46
+    assert key(remap(dm.sky_pixels)) == key(g["sky_pixels_remapped"])                   # :58-62
+    for region in ("left_image_half", "right_image_half", "full_image"):                # :128-146
+        assert key(remap(dm.half_pixels(region))) == key(g[f"{region}_pixels_remapped"]), region
+    # collation of the very pixels the reference collated (un-remap the first column to stack positions)
+    pos = {int(v): i for i, v in enumerate(g["image_idx"].tolist())}
+    for name in ("sky", "left_image_half", "full_image"):
+        ref_idx = g[f"{name}_batch_indices"]
+        stack = torch.from_numpy(np.stack([[pos[int(r[0])] for r in ref_idx], ref_idx[:, 1], ref_idx[:, 2]], 1))
+        b = dm.collate(stack)
+        assert torch.equal(b["indices"], torch.from_numpy(ref_idx)) and torch.equal(b["image"], torch.from_numpy(g[f"{name}_batch_image"]))
+        assert torch.equal(b["mask"].float(), torch.from_numpy(g[f"{name}_batch_mask"]))
+    # and what the manager actually draws stays inside those sets
+    rb, batch = dm.next_train(0)
+    assert set(map(tuple, batch["indices"].tolist())) <= set(key(remap(dm.static_pixels)))
+    sky = dm._draw(dm.sky_pixels, 64)
+    assert set(map(tuple, remap(sky).tolist())) <= set(key(g["sky_pixels_remapped"]))
