@@ -92,6 +92,11 @@ class NeuSkyFactoModelConfig:
     near_plane: float = 0.05
     visibility_threshold: Union[str, float] = "learnable"
     render_ambient_light: bool = False
+    # eval-latent fitting (neusky_model.py:151-168, values of neusky_config.py:142-149)
+    eval_latent_optimise_method: str = "per_image"      # per_image | nerf_osr_holdout | nerf_osr_envmap
+    eval_latent_sample_region: str = "full_image"       # left_image_half | right_image_half | full_image
+    optimise_compare_eval_scale: bool = False
+    eval_latent_optimizer: Dict[str, Any] = field(default_factory=lambda: {"lr": 1e-1, "eps": 1e-15, "lr_final": 1e-7, "max_steps": 250})
 
     def setup(self, **kwargs):
         return self._target(self, **kwargs)
@@ -143,6 +148,7 @@ class NeuSkyFactoModel(ModelBase):
         self.train_scale = Parameter(torch.ones(self.num_train_data))
         self.eval_illumination_latents = Parameter(torch.zeros((max(self.num_eval_data, 1), L, 3)))
         self.eval_scale = Parameter(torch.ones(max(self.num_eval_data, 1)))
+        self.eval_rotation = Parameter(torch.ones(max(self.num_eval_data, 1)))  # :259 (nerf_osr_envmap: z-rotation per eval session)
         self.illumination_sampler = c.illumination_sampler.setup()
         self.lambertian_renderer = RGBLambertianRendererWithVisibility()
         li = c.loss_inclusions
@@ -264,9 +270,10 @@ class NeuSkyFactoModel(ModelBase):
             dirs, sel = self.illumination_sampler.on_device(self.device)  # :456-458, drawn on the device
         self._upper_sel = sel  # upper-hemisphere subset (:1650-1657): static size D/2 for the antipodal direction set
         D = dirs.shape[0]
-        if self.training and not self.fitting_eval_latents and self.num_train_data <= max(1024, camera_indices.shape[0]):
-            # every training camera is decoded (U = num_train_data, static shape, no torch.unique host sync); rows of
-            # cameras absent from the batch are never read by the renderer and receive zero gradient
+        if self.training and latents.shape[0] <= max(1024, camera_indices.shape[0]):
+            # every camera of the active latent set is decoded (U = num_train_data, or num_eval_data while the eval latents
+            # are being fitted: static shape, no torch.unique host sync, hipGraph-safe); rows of cameras absent from the
+            # batch are never read by the renderer and receive zero gradient
             inverse = camera_indices
             cols = self.illumination_field.forward_grid(dirs, latents, scales) if rotation is None else None
             unique = torch.arange(latents.shape[0], device=dirs.device)
@@ -693,44 +700,130 @@ class NeuSkyFactoModel(ModelBase):
         normals = torch.sum(weights * fo[FieldHeadNames.NORMALS], dim=-2).reshape(-1, 3)
         return {"ray_bundle": ray_bundle, "accumulations": accumulations, "mask": mask, "termination_dist": p2p, "normals": normals}
 
-    def fit_latent_codes_for_eval(self, datamanager, global_step: int, steps: int = 250, lr: float = 1e-1, lr_final: float = 1e-7,
-                                  eps: float = 1e-15, sample_region: str = "full_image", image_indices=None, log_every: int = 0):
-        """neusky_model.py:1503-1588 (`eval_latent_optimise_method="per_image"`): optimise the per-eval-image illumination
-        latents + scale with the decoder held fixed; 250 Adam steps, exponential decay 1e-1 -> 1e-7
-        (neusky_config.py:142-147).  Loss = rgb + sky-pixel terms of the eval branch (:1036-1059).  Returns the loss trace."""
+    def _eval_fit_bundle(self, datamanager):
+        """:1544-1575: the rays of one fitting step and, for nerf_osr_envmap, the per-session z-rotations"""
+        method = self.config.eval_latent_optimise_method
+        if method == "per_image":
+            rb, batch = datamanager.get_eval_image_half_bundle(sample_region=self.config.eval_latent_sample_region)
+            return rb, batch, None
+        if method == "nerf_osr_holdout":
+            rb, batch = datamanager.get_nerfosr_lighting_eval_bundle("compare" if self.config.optimise_compare_eval_scale else "optimise")
+            return rb, batch, None
+        if method == "nerf_osr_envmap":
+            rb, batch = datamanager.get_nerfosr_lighting_eval_bundle("compare")
+            gamma = torch.sigmoid(self.eval_rotation) * 2 * math.pi
+            cg, sg = torch.cos(gamma), torch.sin(gamma)
+            rot = torch.zeros(gamma.shape[0], 3, 3, dtype=gamma.dtype, device=gamma.device)
+            rot[:, 0, 0], rot[:, 0, 1], rot[:, 1, 0], rot[:, 1, 1], rot[:, 2, 2] = cg, -sg, sg, cg, 1.0
+            return rb, batch, rot
+        raise NotImplementedError(method)
+
+    def fit_latent_codes_for_eval(self, datamanager, global_step: int, steps: Optional[int] = None, lr: Optional[float] = None,
+                                  lr_final: Optional[float] = None, eps: Optional[float] = None, log_every: int = 0,
+                                  bundles=None, randoms_per_step=None, use_graph: Optional[bool] = None):
+        """neusky_model.py:1503-1588: optimise the evaluation illumination (per-image latents + scale; scale only with
+        `optimise_compare_eval_scale`; scale + z-rotation for nerf_osr_envmap) with every other parameter held fixed: Adam,
+        exponential decay lr -> lr_final over `steps` iterations (neusky_config.py:142-147: 1e-1 -> 1e-7, 250 steps, eps 1e-15).
+        Loss = the eval branch of get_loss_dict (:1036-1059).  Returns the loss trace (device scalars, every `log_every` steps).
+
+        One iteration (zero the gradients, forward, loss, backward) is captured in a HIP graph and replayed: the step's inputs
+        are copied into static buffers, the random draws happen on the device inside the graph, and only the Adam update (whose
+        learning rate changes every step) is launched from the host.  `bundles` / `randoms_per_step` (tests) inject the ray
+        bundles and random draws of every step; injected randoms run eagerly."""
         from ..engine import ExponentialDecaySchedulerConfig
+        oc = self.config.eval_latent_optimizer
+        steps = int(oc["max_steps"]) if steps is None else steps
+        lr = float(oc["lr"]) if lr is None else lr
+        lr_final = float(oc["lr_final"]) if lr_final is None else lr_final
+        eps = float(oc["eps"]) if eps is None else eps
+        method = self.config.eval_latent_optimise_method
         self.fitting_eval_latents = True  # forward() now reads the eval latents (:1506-1507)
-        params = [self.eval_illumination_latents, self.eval_scale]
+        if method == "nerf_osr_envmap":  # :1509-1518
+            params = [self.eval_scale, self.eval_rotation]
+        elif self.config.optimise_compare_eval_scale:
+            params = [self.eval_scale]
+        else:
+            params = [self.eval_illumination_latents, self.eval_scale]
         with torch.no_grad():  # :1536-1540
-            self.eval_illumination_latents.zero_()
+            if method != "nerf_osr_envmap":
+                self.eval_illumination_latents.zero_()
             self.eval_scale.fill_(1.0)
         for p in params:
             p.requires_grad_(True)
         frozen = [p for p in self.parameters() if p.requires_grad and all(p is not q for q in params)]
         for p in frozen:
             p.requires_grad_(False)
+        old_grads = [p.grad for p in params]
+        for p in params:
+            p.grad = torch.zeros_like(p)
         state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in params]
         sched = ExponentialDecaySchedulerConfig(lr_final=lr_final, max_steps=steps, lr_init=lr)
-        image_indices = list(range(self.num_eval_data)) if image_indices is None else list(image_indices)
         trace = []
+
+        def next_bundle(it):
+            if bundles is not None:
+                rb, batch = bundles[it % len(bundles)]
+                return rb, batch, None
+            return self._eval_fit_bundle(datamanager)
+
+        def iteration(rb, batch, rot, randoms):
+            for p in params:
+                p.grad.zero_()
+            self.begin_step()
+            outputs = self.forward(ray_bundle=rb, step=global_step, rotation=rot, randoms=randoms)
+            loss = total_loss(self.get_loss_dict(outputs, batch))
+            loss.backward()
+            return loss.detach()
+
         try:
+            rb0, batch0, rot0 = next_bundle(0)
+            if use_graph is None:
+                use_graph = rb0.origins.is_cuda and randoms_per_step is None and method != "nerf_osr_envmap"
+            graph = None
+            if use_graph:
+                c = lambda t: t.detach().clone()  # noqa: E731
+                srb = RayBundle(origins=c(rb0.origins), directions=c(rb0.directions), pixel_area=c(rb0.pixel_area),
+                                camera_indices=c(rb0.camera_indices), metadata={k: c(v) for k, v in rb0.metadata.items()})
+                sbatch = {"image": c(batch0["image"]), "mask": c(batch0["mask"])}
+                srnd = None
+                if randoms_per_step is not None:  # injected draws live in static buffers the graph reads
+                    keys = ("jitters", "light_rotation", "grid_perturb", "grid_dirs")
+                    srnd = {k: ([c(t) for t in v] if isinstance(v, (list, tuple)) else c(v)) for k, v in randoms_per_step[0].items() if k in keys}
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):  # eager warm-up (allocator pools, per-step caches); no parameter is updated by it
+                    iteration(srb, sbatch, None, srnd)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    gloss = iteration(srb, sbatch, None, srnd)
             for it in range(steps):
-                ray_bundle, batch = datamanager.get_eval_image_half_bundle(sample_region=sample_region,
-                                                                           image_index=image_indices[it % len(image_indices)])
-                for p in params:
-                    p.grad = None
-                self.begin_step()
-                outputs = self.forward(ray_bundle=ray_bundle, step=global_step)
-                loss = total_loss(self.get_loss_dict(outputs, batch))
-                loss.backward()
+                rb, batch, rot = (rb0, batch0, rot0) if it == 0 else next_bundle(it)
+                if graph is not None:
+                    srb.origins.copy_(rb.origins, non_blocking=True); srb.directions.copy_(rb.directions, non_blocking=True)
+                    srb.camera_indices.copy_(rb.camera_indices, non_blocking=True)
+                    for k, v in rb.metadata.items():
+                        srb.metadata[k].copy_(v, non_blocking=True)
+                    sbatch["image"].copy_(batch["image"], non_blocking=True); sbatch["mask"].copy_(batch["mask"], non_blocking=True)
+                    if srnd is not None:
+                        for k, v in srnd.items():
+                            src = randoms_per_step[it][k]
+                            for dst_t, src_t in (zip(v, src) if isinstance(v, list) else ((v, src),)):
+                                dst_t.copy_(src_t, non_blocking=True)
+                    graph.replay()
+                    loss = gloss
+                else:
+                    loss = iteration(rb, batch, rot, None if randoms_per_step is None else randoms_per_step[it])
                 for p, (m_, v_) in zip(params, state):
-                    if p.grad is not None:
-                        hip.adam_step(p.data, p.grad.contiguous(), m_, v_, lr * sched.factor(it), 0.9, 0.999, eps, it + 1)
+                    hip.adam_step(p.data, p.grad, m_, v_, lr * sched.factor(it), 0.9, 0.999, eps, it + 1)
                 if log_every and it % log_every == 0:
-                    trace.append(loss.detach())
+                    trace.append(loss.clone())
         finally:
             for p in frozen:
                 p.requires_grad_(True)
+            for p, g in zip(params, old_grads):
+                p.grad = g
             self.fitting_eval_latents = False  # :1588
         return trace
 

@@ -851,3 +851,57 @@ def neusky_render(p: Dict[str, Tensor], cfg: StepCfg, origins: Tensor, direction
     return {"rgb": rgb, "p2p_dist": p2p, "accumulation": weights.sum(-1, keepdim=True),
             "normal": (weights[..., None] * fo["normals"]).sum(-2), "albedo": (weights[..., None] * fo["albedo"]).sum(-2) + (1 - weights.sum(-1, keepdim=True)),
             "visibility": vis["visibility"]}
+
+
+# =====================================================================================
+# (f)2  eval-latent fitting: neusky/models/neusky_model.py:1503-1588 (per_image), loss = eval branch of get_loss_dict
+#       (:1036-1059): sky-masked rgb L1 + RENISkyPixelLoss, both with coefficient 1 (neusky_config.py:127-141)
+# =====================================================================================
+def neusky_eval_fit_loss(p: Dict[str, Tensor], cfg: StepCfg, origins: Tensor, directions: Tensor, cam_idx: Tensor, image: Tensor,
+                         mask: Tensor, rnd: Dict[str, Tensor], light_dirs: Tensor, latents: Tensor, scales: Tensor) -> Tensor:
+    """forward of one fitting step (the model is in training mode: jittered samplers, rotated light directions) with the
+    EVAL latents / scales as the only variables; everything that does not depend on them is evaluated without a graph"""
+    with torch.no_grad():
+        nears, fars = sphere_collider(origins, directions, cfg.radius)
+        samp = proposal_sample(origins, directions, nears, fars, p, cfg.prop_grids, cfg.num_prop, cfg.num_final, rnd["jitters"], cfg.anneal)
+    ebins = samp["ebins"]
+    pc = {k: v.detach() for k, v in p.items()}
+    fo = field_pass(pc, cfg, origins, directions, ebins)
+    fo = {k: v.detach() for k, v in fo.items()}
+    weights = fo["weights"]
+    decode = lambda lat, dd, sc: reni_decode(lat, dd, sc, pc)
+    cols, inverse, bg = sample_illumination(cam_idx, directions, light_dirs, latents, scales, decode)
+    p2p = render_depth(weights, ebins)
+    with torch.no_grad():
+        vis = compute_visibility(origins, directions, p2p, light_dirs, pc["visibility_threshold"], cfg.sigmoid_scale, cfg.radius,
+                                 lambda sp, dd: {"expected_termination_dist": ddf_query(sp, dd, pc, cfg.ddf_grid, cfg.radius)}, True, True)
+    rgb = lambertian_render(fo["albedo"], fo["normals"], light_dirs, cols, inverse, vis["visibility"], bg, weights)
+    sky = mask[:, 3].to(rgb.dtype)
+    keep = (1 - sky)[:, None]
+    loss = F.l1_loss(image * keep, rgb * keep)  # :1038-1043
+    loss = loss + sky_pixel_loss(linear_to_srgb(bg), image, sky[:, None].expand(-1, 3), 0.1)  # :1051-1058, cosine_weight 0.1
+    return loss
+
+
+def adam_fit(params, loss_fn, steps: int, lr: float, lr_final: float, eps: float = 1e-15, betas=(0.9, 0.999)):
+    """torch.optim.Adam + nerfstudio ExponentialDecayScheduler (no warm-up): lr_t = exp(log lr (1 - t) + log lr_final t), t = it / steps.
+    loss_fn(it) -> scalar.  Updates `params` (leaf tensors requiring grad) in place; returns the loss trace."""
+    import math
+    m = [torch.zeros_like(q) for q in params]
+    v = [torch.zeros_like(q) for q in params]
+    trace = []
+    for it in range(steps):
+        loss = loss_fn(it)
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        t = min(max(it / steps, 0.0), 1.0)
+        lr_t = math.exp(math.log(lr) * (1 - t) + math.log(lr_final) * t)
+        with torch.no_grad():
+            for q, g, mm, vv in zip(params, grads, m, v):
+                if g is None:
+                    g = torch.zeros_like(q)
+                mm.mul_(betas[0]).add_(g, alpha=1 - betas[0])
+                vv.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+                mhat, vhat = mm / (1 - betas[0] ** (it + 1)), vv / (1 - betas[1] ** (it + 1))
+                q.sub_(lr_t * mhat / (vhat.sqrt() + eps))
+        trace.append(float(loss))
+    return trace

@@ -33,3 +33,77 @@ def test_fit_latent_codes_for_eval():
     moved = [n for n, p in pipe.named_parameters() if not torch.equal(p.detach(), before[n])]
     assert sorted(moved) == ["_model.eval_illumination_latents", "_model.eval_scale"], moved
     assert not m.fitting_eval_latents and m.field.glin0.weight_v.requires_grad and m.field.encoding.params.requires_grad
+
+
+def test_fit_matches_the_oracle_adam_steps():
+    """N Adam steps of fit_latent_codes_for_eval on injected bundles and random draws against the float64
+    restatement (oracle.neusky_eval_fit_loss + oracle.adam_fit): the fitted latents and scales agree"""
+    from oracle import neusky_oracle as O
+    from util_step import make_randoms, oracle_params, oracle_randoms, oracle_step_cfg, randoms_to
+    torch.manual_seed(0)
+    R, steps = 32, 6
+    pipe = small_pipeline_config(R=R, num_prop=(24, 12), S=8, D=24, images=4).setup(device=DEV)
+    pipe.train()
+    randomise(pipe)
+    m = pipe.model
+    dm = pipe.datamanager
+    bundles = [dm.get_eval_image_half_bundle("full_image", image_index=i % 2, num_rays=R) for i in range(steps)]
+    rnds = [make_randoms(pipe, R, seed=10 + i) for i in range(steps)]
+    dev_rnds = []
+    for r in rnds:
+        d = randoms_to(r, DEV)
+        for k in ("light_rotation", "grid_perturb", "grid_dirs"):
+            d[k] = d[k].to(DEV)
+        dev_rnds.append(d)
+    m.set_step(10_000)
+    trace = m.fit_latent_codes_for_eval(dm, global_step=10_000, steps=steps, bundles=bundles, randoms_per_step=dev_rnds, log_every=1)
+    got_lat, got_scale = m.eval_illumination_latents.detach().cpu().double(), m.eval_scale.detach().cpu().double()
+    # ---- oracle
+    p = oracle_params(pipe)
+    cfg = oracle_step_cfg(pipe)
+    lat = torch.zeros_like(got_lat).requires_grad_(True)
+    sc = torch.ones_like(got_scale).requires_grad_(True)
+
+    def loss_fn(it):
+        rb, batch = bundles[it]
+        light = m.illumination_sampler(rotation=rnds[it]["light_rotation"]).double()
+        return O.neusky_eval_fit_loss(p, cfg, rb.origins.cpu().double(), rb.directions.cpu().double(), rb.camera_indices.cpu().reshape(-1),
+                                      batch["image"].cpu().double(), batch["mask"].cpu(), oracle_randoms(rnds[it], light), light, lat, sc)
+
+    ref_trace = O.adam_fit([lat, sc], loss_fn, steps, lr=1e-1, lr_final=1e-7)
+    got_trace = [float(t) for t in trace]
+    for a, b in zip(got_trace, ref_trace):
+        assert abs(a - b) < 2e-4 * max(abs(b), 1e-3), (got_trace, ref_trace)
+    used = sorted({int(b[0].camera_indices.reshape(-1)[0]) for b in bundles})
+    assert (got_lat[used] - lat.detach()[used]).abs().max() < 2e-3 * max(lat.detach()[used].abs().max().item(), 1e-3)
+    assert (got_scale[used] - sc.detach()[used]).abs().max() < 2e-3
+
+
+def test_fit_graph_replay_equals_eager():
+    """the captured fitting iteration (one HIP graph replay per step + the Adam launches) reproduces the eager loop on the same
+    injected bundles and random draws: loss trace and fitted latents agree to fp32 reduction-order noise"""
+    from util_step import make_randoms, randoms_to
+    torch.manual_seed(0)
+    R, steps = 64, 12
+    pipe = small_pipeline_config(R=R, num_prop=(32, 16), S=12, D=32, images=4).setup(device=DEV)
+    pipe.train()
+    randomise(pipe)
+    m = pipe.model
+    bundles = [pipe.datamanager.get_eval_image_half_bundle("full_image", image_index=i % 2, num_rays=R) for i in range(3)]
+    rnds = []
+    for i in range(steps):
+        d = randoms_to(make_randoms(pipe, R, seed=20 + i), DEV)
+        for k in ("light_rotation", "grid_perturb", "grid_dirs"):
+            d[k] = d[k].to(DEV)
+        rnds.append(d)
+    t_graph = m.fit_latent_codes_for_eval(pipe.datamanager, 10_000, steps=steps, bundles=bundles, randoms_per_step=rnds, log_every=1, use_graph=True)
+    lat_graph, sc_graph = m.eval_illumination_latents.detach().clone(), m.eval_scale.detach().clone()
+    t_eager = m.fit_latent_codes_for_eval(pipe.datamanager, 10_000, steps=steps, bundles=bundles, randoms_per_step=rnds, log_every=1, use_graph=False)
+    g, e = torch.stack(t_graph).cpu(), torch.stack(t_eager).cpu()
+    assert torch.isfinite(g).all() and float((g - e).abs().max()) < 1e-4 * float(e.abs().max()), (g, e)
+    assert float((lat_graph - m.eval_illumination_latents.detach()).abs().max()) < 5e-3
+    assert float((sc_graph - m.eval_scale.detach()).abs().max()) < 5e-3
+    # and without injected draws the default path IS the graph path, and the loss goes down
+    t = m.fit_latent_codes_for_eval(pipe.datamanager, 10_000, steps=40, bundles=bundles, log_every=1)
+    t = torch.stack(t).cpu()
+    assert torch.isfinite(t).all() and t[-5:].mean() < t[:3].mean()

@@ -1,0 +1,46 @@
+"""The evaluation half of the pipeline surface (neusky_pipeline.py:294-444, neusky_model.py:1079-1335): the methods run on the
+HIP path, keep the reference's return contracts and restore train mode."""
+import pytest
+import torch
+
+from util_step import randomise, small_pipeline_config
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_eval_methods_run_and_keep_their_contracts():
+    torch.manual_seed(0)
+    cfg = small_pipeline_config(R=64, num_prop=(32, 16), S=12, D=32, images=4)
+    cfg.model.eval_latent_optimizer = {"lr": 1e-1, "eps": 1e-15, "lr_final": 1e-7, "max_steps": 4}
+    cfg.datamanager.eval_num_rays_per_batch = 64
+    cfg.datamanager.eval_image_height, cfg.datamanager.eval_image_width = 12, 16
+    pipe = cfg.setup(device=DEV)
+    pipe.train()
+    randomise(pipe)
+    outs, loss_dict, metrics = pipe.get_eval_loss_dict(step=7)
+    assert pipe.step_of_last_latent_optimisation == 7 and pipe.model.training and not pipe.model.fitting_eval_latents
+    assert set(loss_dict) == {"rgb_l1_loss", "sky_pixel_loss"} and all(torch.isfinite(v) for v in loss_dict.values())
+    assert "psnr" in metrics and outs["rgb"].shape == (64, 3)
+    moved = float((pipe.model.eval_illumination_latents.detach()).abs().max())
+    assert moved > 0.0  # the eval latents were fitted (they start at zero)
+    m, images = pipe.get_eval_image_metrics_and_images(step=7)  # same step: no second fit
+    assert {"psnr", "ssim", "lpips", "mse", "image_idx", "num_rays"} <= set(m) and m["num_rays"] == 12 * 16
+    assert images["img"].shape == (12, 32, 3) and images["accumulation"].shape == (12, 32, 3) and images["albedo"].shape == (12, 16, 3)
+    assert pipe.eval_image_num == 1 and pipe.model.training
+    avg = pipe.get_average_eval_image_metrics(step=7)
+    assert {"psnr", "ssim", "mse", "num_rays_per_sec", "fps"} <= set(avg) and avg["psnr"] == avg["psnr"]
+    # reference-signature adapters (materialised layouts)
+    rb, batch = pipe.datamanager.next_train(0)
+    rb = pipe.model.collider(rb)
+    pipe.model.begin_step()
+    rs, _, _, _, _ = pipe.model._sample(rb, None)
+    cols, dirs, bg = pipe.model.sample_illumination(rs)
+    N, D = rs.frustums.origins.shape[0] * rs.frustums.origins.shape[1], dirs.shape[1]
+    assert cols.shape == (N, D, 3) and dirs.shape == (N, D, 3) and bg.shape == (rs.frustums.origins.shape[0], 3)
+    vis = pipe.model.compute_visibility(rs, torch.full((rs.frustums.origins.shape[0], 1), 0.5, device=DEV), dirs, pipe.model.visibility_threshold,
+                                        pipe.model.sigmoid_scale)
+    assert vis["visibility"].shape == (N, D, 1)
+    feat = torch.randn(10, 256, device=DEV)
+    alb = pipe.model.field.get_colors(torch.rand(10, 3, device=DEV) - 0.5, feat)
+    assert alb.shape == (10, 3) and bool(((alb > 0) & (alb < 1)).all())
