@@ -44,50 +44,85 @@ def build_pipeline(device, world_size, local_rank, rays=RAYS, samples=SAMPLES, d
     return pipe
 
 
-class GemmTimer:
-    """HIP-event timing of every launch of ONE gemm kernel (the dominant one) on torch's current stream: either a variant of
-    the register-staged kernel behind hip.gemm, or the LDS-DMA kernel behind hip.gemm_planes at one precision."""
+class KernelTimer:
+    """HIP-event timing of every launch of the step's heavy kernel families on torch's current stream (the stream the C-ABI
+    launches on), during ONE eager iteration: the fused FiLM-SIREN chain kernels (forward / FiLM backward / mapping backward,
+    per hidden width) and the dense-layer kernels (LDS-DMA planes kernel, register-staged split kernel, by precision).
+    Each record carries the ALGORITHMIC FLOPs of the launch (2 M N K of the contraction the layer needs; for the chain
+    kernels the products of the layers they replace) and, for the FiLM backward, the FLOPs it actually executes (it re-forms
+    the frequency / phase tiles instead of reading a [M, 2 n H] matrix back)."""
 
-    def __init__(self, variant, planes=False):
-        self.variant = variant  # (a_kcontig, b_kcontig, wide, precision)
-        self.planes = planes
-        self.records = []
+    def __init__(self):
+        self.records = {}
 
-    def _timed_call(self, fn, flops, *a, **kw):
+    def _timed(self, key, fn, flops, executed, *a, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = fn(*a, **kw)
         e1.record()
-        self.records.append((e0, e1, flops))
+        self.records.setdefault(key, []).append((e0, e1, flops, executed))
         return out
 
     def install(self):
         from neusky_amd import hip
-        self._orig, self._orig_planes = hip.gemm, hip.gemm_planes
-        timer = self
+        self._orig = {n: getattr(hip, n) for n in ("gemm", "gemm_planes", "film_chain_fwd", "film_chain_bwd_film", "film_chain_bwd_map")}
+        o, t = self._orig, self
 
-        def timed(A, B, Cout, M, N, K, **kw):
-            v = (bool(kw.get("a_kcontig", True)), bool(kw.get("b_kcontig", True)), N > 64, int(kw.get("precision", 0)))
-            if timer.planes or v != timer.variant:
-                return timer._orig(A, B, Cout, M, N, K, **kw)
-            return timer._timed_call(timer._orig, 2.0 * M * N * K, A, B, Cout, M, N, K, **kw)
+        def gemm(A, B, Cout, M, N, K, **kw):
+            prec = int(kw.get("precision", 0))
+            kind = "weight-gradient" if not kw.get("a_kcontig", True) else "layer"
+            key = f"gemm_bf16s_kernel ({kind}, precision {prec})" if (prec and N > 64) else f"gemm_f32_kernel ({kind})"
+            return t._timed(key, o["gemm"], 2.0 * M * N * K, 2.0 * M * N * K, A, B, Cout, M, N, K, **kw)
 
-        def timed_planes(A, planes, Cout, M, N, K, **kw):
-            if not timer.planes or int(kw.get("precision", 0)) != timer.variant[3]:
-                return timer._orig_planes(A, planes, Cout, M, N, K, **kw)
-            return timer._timed_call(timer._orig_planes, 2.0 * M * N * K, A, planes, Cout, M, N, K, **kw)
+        def gemm_planes(A, planes, Cout, M, N, K, **kw):
+            key = f"gemm_planes_kernel (precision {int(kw.get('precision', 0))})"
+            return t._timed(key, o["gemm_planes"], 2.0 * M * N * K, 2.0 * M * N * K, A, planes, Cout, M, N, K, **kw)
 
-        hip.gemm, hip.gemm_planes = timed, timed_planes
+        def dims(net):
+            return net.hidden, net.n_map, net.n_film, net.cond_dim, net.x_dim, net.out_dim
+
+        def fwd(net, stream, table, cond, x, M, *a, **kw):
+            H, nm, nf, cd, xd, od = dims(net)
+            fl = 2.0 * M * (cd * H + (nm - 1) * H * H + H * 2 * nf * H + xd * H + (nf - 1) * H * H + H * od)
+            return t._timed(f"film_fwd_kernel<{H}>", o["film_chain_fwd"], fl, fl, net, stream, table, cond, x, M, *a, **kw)
+
+        def bwd_film(net, stream, table, M, *a, **kw):
+            H, nm, nf, cd, xd, od = dims(net)
+            fl = 2.0 * M * ((nf - 1) * H * H + H * xd)
+            return t._timed(f"film_bwd_kernel<{H}>", o["film_chain_bwd_film"], fl, fl + 2.0 * M * 2 * nf * H * H, net, stream, table, M, *a, **kw)
+
+        def bwd_map(net, stream, table, M, *a, **kw):
+            H, nm, nf, cd, xd, od = dims(net)
+            fl = 2.0 * M * (2 * nf * H * H + (nm - 1) * H * H + H * cd)
+            return t._timed(f"film_bwd_map_kernel<{H}>", o["film_chain_bwd_map"], fl, fl, net, stream, table, M, *a, **kw)
+
+        hip.gemm, hip.gemm_planes, hip.film_chain_fwd, hip.film_chain_bwd_film, hip.film_chain_bwd_map = gemm, gemm_planes, fwd, bwd_film, bwd_map
 
     def uninstall(self):
         from neusky_amd import hip
-        hip.gemm, hip.gemm_planes = self._orig, self._orig_planes
+        for n, f in self._orig.items():
+            setattr(hip, n, f)
 
     def summary(self):
-        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
-        fl = sum(f for _, _, f in self.records)
-        n = len(self.records)
-        return n, ms, fl
+        out = []
+        for key, recs in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _, _ in recs)
+            out.append({"kernel": key, "launches": len(recs), "total_ms": ms, "avg_launch_ms": ms / len(recs),
+                        "algorithmic_flops_per_launch": sum(r[2] for r in recs) / len(recs),
+                        "executed_flops_per_launch": sum(r[3] for r in recs) / len(recs),
+                        "achieved_tflops": sum(r[2] for r in recs) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0})
+        return sorted(out, key=lambda d: -d["total_ms"])
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -136,7 +171,7 @@ def cpu_baseline(seconds_budget=25.0):
         for _ in range(reps):
             one()
         dt = (time.time() - t0) / reps
-    return {"value": rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+    return {"value": rays / dt, "unit": "rays/s", "cores": cores, "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{reps} full train steps (fwd+bwd via torch autograd, fp32) of {rays} rays x {SAMPLES} samples x "
                       f"{DIRECTIONS} directions + 16 DDF-fit + 8 sky rays; Adam excluded; {dt:.2f} s/step"}
 
@@ -148,6 +183,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured HIP graph")
+    ap.add_argument("--no-exact-f32", action="store_true", help="skip the three extra eager steps under the exact-fp32 policy")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -180,10 +216,7 @@ def main():
 
     import neusky_amd.ops as ops
     from neusky_amd import hip as _hip
-    # dominant kernel of the step = the forward (NT layout) dense-layer kernel of the active precision policy
-    # (the LDS-DMA kernel when the policy routes the forward layers to it, i.e. the default fp16-split policy)
-    fwd_planes = ops.USE_PLANES_FWD and ops.FWD_PRECISION == _hip.PREC_F16X2
-    timer = GemmTimer((True, True, True, ops.FWD_PRECISION), planes=fwd_planes)
+    timer = KernelTimer()
     use_graph = not args.no_graph
     skies = [pipe.datamanager.get_sky_ray_bundle(pipe.config.num_sky_rays) for _ in range(args.steps + args.warmup)]
     graph_note = ""
@@ -205,8 +238,8 @@ def main():
             loss, _, _ = stepper.step(2000 + i, batches[j][0], batches[j][1], skies[j])
         barrier()
         dt = time.perf_counter() - t0
-        # HIP events cannot be read back from inside a replayed graph: the dominant kernel's launches are timed with
-        # events on one extra EAGER iteration of the same step (same kernels, shapes and stream) right after the timed region
+        # HIP events cannot be read back from inside a replayed graph: the heavy kernels' launches are timed with events on
+        # one extra EAGER iteration of the same step (same kernels, shapes and stream) right after the timed region
         timer.install()
         train_iteration(pipe, opt, 3000, ray_bundle=batches[-1][0], batch=batches[-1][1])
         torch.cuda.synchronize()
@@ -215,7 +248,6 @@ def main():
         for i in range(args.warmup):
             rb, b = batches[i]
             train_iteration(pipe, opt, 1000 + i, ray_bundle=rb, batch=b)
-        timer.install()
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -223,57 +255,70 @@ def main():
             loss, _, _ = train_iteration(pipe, opt, 2000 + i, ray_bundle=rb, batch=b)
         barrier()
         dt = time.perf_counter() - t0
+        timer.install()
+        train_iteration(pipe, opt, 3000, ray_bundle=batches[-1][0], batch=batches[-1][1])
+        torch.cuda.synchronize()
         timer.uninstall()
     t = torch.tensor([dt], device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    n_launch, k_ms, k_flops = timer.summary()
+    final_loss = float(loss)
+
+    # the same step with EXACT fp32 products everywhere (v_mfma_f32_32x32x2_f32, per-layer kernels): a few eager steps, rank 0
+    exact = None
+    if rank == 0 and not args.no_exact_f32 and ops._POLICY != "f32":
+        policy = ops._POLICY
+        ops.set_precision_policy("f32")
+        try:
+            for i in range(2):
+                train_iteration(pipe, opt, 4000 + i, ray_bundle=batches[i][0], batch=batches[i][1])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(3):
+                train_iteration(pipe, opt, 4002 + i, ray_bundle=batches[i][0], batch=batches[i][1])
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t1) / 3 * 1e3
+            exact = {"ms_per_step": ms, "rays_per_s": RAYS / (ms * 1e-3), "launch": "eager",
+                     "note": "NSKY_PRECISION=f32: every product of the step on the exact-fp32 MFMA (157.3 TFLOP/s peak); per-layer dense kernels, no fused chains"}
+        finally:
+            ops.set_precision_policy(policy)
 
     if rank == 0:
         rays_total = RAYS * world * args.steps
-        achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        if ops.FWD_PRECISION == _hip.PREC_F32:
-            kernel = "gemm_f32_kernel<128,128,2,2,true,true,32,2> (exact fp32 MFMA v_mfma_f32_32x32x2_f32, forward NT layout)"
-            peak, dtype = PEAK_F32_MFMA_TFLOPS, "f32"
-            peak_note = "fp32 matrix peak 157.3 TFLOP/s (MI355X_MICROARCH.md)"
-        elif ops.FWD_PRECISION == _hip.PREC_F16X2:
-            kernel = ("gemm_planes_kernel<true> (weights pre-split once per step into fp16 hi + 2^11-scaled fp16 residual planes, activations "
-                      "split in LDS after LDS-DMA; " if fwd_planes else
-                      "gemm_bf16s_kernel<2,true,true,false,true> (fp32 operands split on the fly into fp16 hi + 2^11-scaled fp16 residual, ")
-            kernel += "3 x v_mfma_f32_32x32x16_f16 per product into two fp32 accumulators)"
-            peak, dtype = PEAK_BF16_MFMA_TFLOPS / 3.0, "f32 (fp16 hi + scaled-residual split on the matrix cores, ~2^-21 per product)"
-            peak_note = "fp16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-equivalent product = 833.3 TFLOP/s of algorithmic FLOPs"
-        else:
-            n_terms = 3 if ops.FWD_PRECISION == _hip.PREC_BF16X3 else 2
-            n_mfma = 6 if n_terms == 3 else 3
-            kernel = (f"gemm_bf16s_kernel<{n_terms},true,true> (fp32 operands split on the fly into {n_terms} bf16 terms, "
-                      f"{n_mfma} x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate)")
-            peak, dtype = PEAK_BF16_MFMA_TFLOPS / n_mfma, f"f32 ({n_terms}-term bf16 split on the matrix cores)"
-            peak_note = (f"bf16 dense MFMA peak 2500 TFLOP/s / {n_mfma} MFMAs per fp32-equivalent product = "
-                         f"{PEAK_BF16_MFMA_TFLOPS / n_mfma:.1f} TFLOP/s of algorithmic FLOPs")
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (not re-collected live)
-            tj = json.load(open(tpath))
-            if tj.get("precision_policy") == ops._POLICY:
-                traffic = tj["traffic_bytes_per_launch"]
+        kernels = timer.summary()
+        peak = PEAK_BF16_MFMA_TFLOPS / 3.0
+        for k in kernels:
+            k["frac_of_833_tflops"] = k["achieved_tflops"] / peak
+        traffic, tsrc = None, os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        dom = kernels[0]
+        if os.path.exists(tsrc):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_bench.sh; not re-collected live)
+            tj = json.load(open(tsrc))
+            traffic = tj.get("bytes_per_launch", {}).get(dom["kernel"].split(" ")[0])
+        fwd = "fp16 hi + residual split, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate (~2^-22; chains: power-of-two pre-scaled operands, one accumulator; field layers: 2^11-scaled residual, two accumulators)"
+        bwd = ("FiLM-SIREN chains (83 % of the step's FLOPs) and their weight gradients: the same fp16 split on per-row / per-matrix pre-scaled gradients (fp32-grade); "
+               "SDF / colour layers: 2-term bf16 split (2^-16 per product); proposal layers and all N <= 64 heads: exact fp32 MFMA")
         line = {
             "metric": "train rays/sec on NeRF-OSR lk2 @1024 rays x 96 samples",
             "value": rays_total / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": dtype, "data": "synthetic",
+            "dtype": f"f32 in memory; forward products: {fwd}; backward products: {bwd}", "data": "synthetic",
             "config": {"workload": "full NeuSky train step (BASELINE configs[2]): 1024 rays/GPU x 96 samples, proposal 256+96, "
                                    "512 illumination directions (256 upper-hemisphere DDF queries/ray), latent 100x3, "
                                    "hash L16 F2 T2^19 x2, 256-wide MLPs; fwd + losses + bwd + all-reduce + 5 Adam groups",
                        "rays_per_gpu": RAYS, "samples_per_ray": SAMPLES, "illumination_directions": DIRECTIONS,
-                       "parallelism": f"ray-sharded dp{world}", "final_loss": float(loss),
+                       "parallelism": f"ray-sharded dp{world}", "final_loss": final_loss,
                        "launch": "HIP graph replay (1 graph/step + all-reduce + 5 Adam launches)" if use_graph else "eager (host launches every kernel)" + graph_note},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic.json)", "kernel": kernel, "peak_note": peak_note,
-                         "precision_policy": ops._POLICY,
-                         "launches_timed": n_launch, "avg_launch_ms": k_ms / max(n_launch, 1),
-                         "algorithmic_flops_per_launch": k_flops / max(n_launch, 1)},
+            "roofline": {"bound": "mfma", "achieved": dom["achieved_tflops"], "peak": peak, "unit": "TFLOP/s",
+                         "frac": dom["achieved_tflops"] / peak, "traffic": traffic,
+                         "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r02_pmc_traffic.json)",
+                         "kernel": dom["kernel"] + " = the kernel family with the largest total time in the eager timing iteration",
+                         "peak_note": "fp16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-grade product = 833.3 TFLOP/s of algorithmic FLOPs",
+                         "precision_policy": ops._POLICY, "launches_timed": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
+                         "algorithmic_flops_per_launch": dom["algorithmic_flops_per_launch"],
+                         "executed_flops_per_launch": dom["executed_flops_per_launch"]},
+            "kernels": kernels[:8],
+            "fp32_exact": exact,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

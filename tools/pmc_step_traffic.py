@@ -21,5 +21,16 @@ total = sum(r[0] for r in rows) / iters
 print(f"whole step: {total/1e9:.2f} GB/iteration (fetch x2 {sum(2*r[2][0] for r in rows)/iters/1e9:.2f} + write {sum(r[2][1] for r in rows)/iters/1e9:.2f})")
 for b, k, v in rows[:18]:
     print(f"{k:72s} {v[2]/iters:6.1f} launches/it {b/iters/1e9:8.2f} GB/it")
-json.dump({"GB_per_iteration": total / 1e9, "iterations": iters, "top": [(k, b / iters / 1e9) for b, k, v in rows[:25]]},
-          open(os.path.join(ROOT, "gpurun_out", "pmc_step_traffic.json"), "w"), indent=1)
+# per launch, by kernel family (template arguments of the dense-layer kernels folded together; the chain kernels by hidden width)
+fam = collections.defaultdict(lambda: [0.0, 0])
+for b, k, v in rows:
+    name = k.split("(")[0].strip()
+    key = re.sub(r"<(\d+)[^>]*>", r"<\1>", name) if name.startswith("film_") else name.split("<")[0]
+    fam[key][0] += b
+    fam[key][1] += v[2]
+out = {"command": "tools/pmc_bench.sh: rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-exact-f32 (two passes)",
+       "units": "bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE): counters are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads)",
+       "whole_step_GB": total / 1e9, "iterations": iters,
+       "bytes_per_launch": {k: v[0] / max(v[1], 1) for k, v in fam.items() if v[1] > 0 and v[0] / iters > 5e7},
+       "GB_per_iteration": {k: v[0] / iters / 1e9 for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:20]}}
+json.dump(out, open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"), "w"), indent=1)
