@@ -275,11 +275,13 @@ struct WStream {
   f16x8 ch, cl;              // fragments requested ahead of the next product (landed: every product settles them at its end)
 };
 
+// PW = 1 KB pieces of a 16 KB group this wave moves: 4 with four waves per workgroup, 2 with eight
+template <int PW = 4>
 __device__ __forceinline__ void ws_issue(const WStream& w, int group) {
   const unsigned char* s = w.src + (long)group * GROUP;
   const uint32_t d = w.dst + (uint32_t)(group & (RING_GROUPS - 1)) * GROUP;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < PW; ++p) {
 #ifndef FILM_LAB_NODMA
     glds16(s + p * 1024, d + p * 1024);
 #endif
@@ -301,10 +303,11 @@ __device__ __forceinline__ uint32_t ws_addr(const WStream& w, int group, int sla
   return w.lds_lane + (uint32_t)(group & (RING_GROUPS - 1)) * GROUP + slab * SLAB;
 }
 
+template <int PW = 4>
 __device__ __forceinline__ void ws_begin(WStream& w) {
 #pragma unroll
-  for (int g = 0; g < RING_GROUPS; ++g) ws_issue(w, g);
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (RING_GROUPS - 2)) : "memory");  // groups 0 and 1 landed
+  for (int g = 0; g < RING_GROUPS; ++g) ws_issue<PW>(w, g);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PW * (RING_GROUPS - 2)) : "memory");  // groups 0 and 1 landed
   w.g = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) { w.ch[j] = (_Float16)0.0f; w.cl[j] = (_Float16)0.0f; }
@@ -312,15 +315,16 @@ __device__ __forceinline__ void ws_begin(WStream& w) {
   frag_wait<0>(w.ch, w.cl);
 }
 
+template <int PW = 4>
 __device__ __forceinline__ void ws_transition(WStream& w, int from_group) {
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (RING_GROUPS - 3)) : "memory");
-  ws_issue(w, from_group + RING_GROUPS);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PW * (RING_GROUPS - 3)) : "memory");
+  ws_issue<PW>(w, from_group + RING_GROUPS);
 }
 
 // acc += W_tile X over KS k-steps, B planes in registers.  One wave per SIMD issues in order, so everything that is not an
 // MFMA is placed in the shadow of one: the LDS requests of k-step ks + 2 (and a group transition: barrier + 4 DMA pieces) right
 // behind the first MFMA of k-step ks, the counted wait for the fragments of ks + 1 behind the third.
-template <int KS>
+template <int KS, int PW = 4>
 __device__ __forceinline__ void product(WStream& w, const f16x8 (&bh)[KS], const f16x8 (&bl)[KS], f32x16& acc) {
   constexpr int NG = (KS + GSLABS - 1) / GSLABS;  // groups of this tile; slab index KS stands for slab 0 of the next tile
   f16x8 fh[3], fl[3];
@@ -342,7 +346,7 @@ __device__ __forceinline__ void product(WStream& w, const f16x8 (&bh)[KS], const
 #endif
     __builtin_amdgcn_sched_barrier(0);
     if (ks + 2 <= KS) request(ks + 2);  // into the buffer of k-step ks - 1, whose MFMAs have been issued
-    if ((ks & (GSLABS - 1)) == GSLABS - 1 || ks == KS - 1) ws_transition(w, g0 + ks / GSLABS);
+    if ((ks & (GSLABS - 1)) == GSLABS - 1 || ks == KS - 1) ws_transition<PW>(w, g0 + ks / GSLABS);
     __builtin_amdgcn_sched_barrier(0);
 #ifndef FILM_LAB_NOMFMA
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks % 3], bh[ks], acc, 0, 0, 0);
@@ -778,9 +782,23 @@ __device__ __forceinline__ void hidden_wait(f32x4 (&q)[4]) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : "n"(N) : "memory");
 }
 
+template <int N>
+__device__ __forceinline__ void hidden_wait8(f32x4 (&p)[4], f32x4 (&q)[4]) {
+  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : "n"(N) : "memory");
+}
+// a load of data THIS lane stored earlier in the launch: bypass the CU's vector L1 (nt), served by the XCD's L2
+__device__ __forceinline__ void hidden_load4_nt(f32x4& q, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "+v"(q) : "v"(p) : "memory");
+}
+
+// Eight waves per workgroup (two per SIMD: the matrix pipe of one wave's products overlaps the epilogue arithmetic of the
+// other; 256 batch rows share one weight stream, half the L2 -> LDS traffic per row of the four-wave forward), 256 registers
+// each.  That budget is met by keeping NO per-layer matrix in registers across the tile loop: the incoming gradient dY of a
+// layer waits, tile-native, in that layer's dz buffer (written by the layer above, overwritten tile by tile with dz), and the
+// W^T products of the layer read the finished dz tiles back (the lane that stored a piece loads it).
 template <int H>
-__global__ __launch_bounds__(256, 1) void film_bwd_kernel(const BwdFilmArgs a) {
-  constexpr int NT = H / 32, KS = H / 16, GH = (KS + GSLABS - 1) / GSLABS;
+__global__ __launch_bounds__(512, 2) void film_bwd_kernel(const BwdFilmArgs a) {
+  constexpr int NT = H / 32, KS = H / 16, GH = (KS + GSLABS - 1) / GSLABS, PW = 2;
   __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + (BIAS_FLOATS + SCALE_FLOATS) * 4 + 4 * H * 4];
   float* bl = reinterpret_cast<float*>(smem + RING_BYTES);
   float* sl = bl + BIAS_FLOATS;
@@ -791,30 +809,28 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(const BwdFilmArgs a) {
   const int c = lane & 31, h = lane >> 5;
   {
     constexpr int N4 = (BIAS_FLOATS + SCALE_FLOATS) / 4;
-    float4 q[(N4 + 255) / 256];
+    float4 q[(N4 + 511) / 512];
 #pragma unroll
-    for (int i = 0; i < (N4 + 255) / 256; ++i)
-      if (i * 256 + tid < N4) q[i] = ldg4(a.table + 4 * (i * 256 + tid));
+    for (int i = 0; i < (N4 + 511) / 512; ++i)
+      if (i * 512 + tid < N4) q[i] = ldg4(a.table + 4 * (i * 512 + tid));
 #pragma unroll
-    for (int i = 0; i < (N4 + 255) / 256; ++i)
-      if (i * 256 + tid < N4) *reinterpret_cast<float4*>(bl + 4 * (i * 256 + tid)) = q[i];
-    for (int i = tid; i < 4 * H; i += 256) wo[i] = (i / H) < net.out_dim ? net.out_w[(long)(i / H) * net.out_ld + (i % H)] : 0.0f;
+    for (int i = 0; i < (N4 + 511) / 512; ++i)
+      if (i * 512 + tid < N4) *reinterpret_cast<float4*>(bl + 4 * (i * 512 + tid)) = q[i];
+    for (int i = tid; i < 4 * H; i += 512) wo[i] = (i / H) < net.out_dim ? net.out_w[(long)(i / H) * net.out_ld + (i % H)] : 0.0f;
   }
   __syncthreads();
-  const long rt = (long)blockIdx.x * 4 + wave;
+  const long rt = (long)blockIdx.x * 8 + wave;
   const long row = rt * 32 + c;
   const bool live = row < a.M;
   const long rowc = live ? row : a.M - 1;
   const bool wave_live = rt * 32 < a.M;
-  const long rts = wave_live ? rt : 0;  // a wave wholly beyond M reads tile 0 (in bounds) and stores nothing
+  const long rts = wave_live ? rt : 0;  // a wave wholly beyond M works on tile 0's data (in bounds) and stores nothing
   const int n_film = net.n_film;
 
-  // row scale of the last mapping activation (its planes are rebuilt at the top of every layer: they would otherwise sit in
-  // 128 registers through the W^T products, where the old and the new dY and the dz planes are live)
+  // row scale of the last mapping activation
   float h_inv, h_scale;
   {
     float m = 0.0f;
-#pragma unroll
     for (int t = 0; t < NT; ++t) {
       float hv[16];
       load_tile(a.h_last + (rts * NT + t) * 1024, lane, hv);
@@ -823,29 +839,27 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(const BwdFilmArgs a) {
     }
     h_scale = row_scale(m, h_inv);
   }
-  // head gradient -> dY of the last FiLM layer
-  float dY[NT][16];
+  // head gradient -> dY of the last FiLM layer, parked in its dz buffer
   {
     const float4 dr = ldg4(a.d_res + rowc * a.ldres);
-#pragma unroll
+    float* dst = a.dz_save[n_film - 1] + rt * NT * 1024 + lane * 4;
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int fo = 32 * t + 8 * g + 4 * h;
         const float4 w0 = *reinterpret_cast<const float4*>(wo + fo), w1 = *reinterpret_cast<const float4*>(wo + H + fo);
         const float4 w2 = *reinterpret_cast<const float4*>(wo + 2 * H + fo), w3 = *reinterpret_cast<const float4*>(wo + 3 * H + fo);
-        dY[t][4 * g] = dr.x * w0.x + dr.y * w1.x + dr.z * w2.x + dr.w * w3.x;
-        dY[t][4 * g + 1] = dr.x * w0.y + dr.y * w1.y + dr.z * w2.y + dr.w * w3.y;
-        dY[t][4 * g + 2] = dr.x * w0.z + dr.y * w1.z + dr.z * w2.z + dr.w * w3.z;
-        dY[t][4 * g + 3] = dr.x * w0.w + dr.y * w1.w + dr.z * w2.w + dr.w * w3.w;
+        if (wave_live)
+          stg4(dst + t * 1024 + g * 256, make_float4(dr.x * w0.x + dr.y * w1.x + dr.z * w2.x + dr.w * w3.x, dr.x * w0.y + dr.y * w1.y + dr.z * w2.y + dr.w * w3.y,
+                                                      dr.x * w0.z + dr.y * w1.z + dr.z * w2.z + dr.w * w3.z, dr.x * w0.w + dr.y * w1.w + dr.z * w2.w + dr.w * w3.w));
       }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every compiler-visible load has returned before the DMA stream starts
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every compiler-visible memory operation is done before the DMA stream starts
   WStream ws;
-  ws.src = a.stream + wave * 4096 + lane * 16;
-  ws.dst = (uint32_t)(uintptr_t)smem + wave * 4096;
+  ws.src = a.stream + wave * (PW * 1024) + lane * 16;
+  ws.dst = (uint32_t)(uintptr_t)smem + wave * (PW * 1024);
   ws.lds_lane = (uint32_t)(uintptr_t)smem + lane * 16;
-  ws_begin(ws);
+  ws_begin<PW>(ws);
 
   const float* bias_mo = bl + net.n_map * H;
   float fp_max = 0.0f;
@@ -853,10 +867,10 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(const BwdFilmArgs a) {
   for (int i = n_film - 1; i >= 0; --i) {
     const float* bF = bias_mo + i * H;
     const float* bP = bias_mo + (n_film + i) * H;
-    const float* zblk = a.z_save[i] + rts * NT * 1024;
-    float* dzblk = a.dz_save[i] + rt * NT * 1024;
-    float* dFblk = a.dfp + (rt * (2 * n_film * NT) + (long)i * NT) * 1024;
-    float* dPblk = a.dfp + (rt * (2 * n_film * NT) + (long)(n_film + i) * NT) * 1024;
+    const float* zp = a.z_save[i] + rts * NT * 1024 + lane * 4;
+    float* dzp = a.dz_save[i] + rts * NT * 1024 + lane * 4;   // holds dY on entry
+    float* dFp = a.dfp + (rts * (2 * n_film * NT) + (long)i * NT) * 1024 + lane * 4;
+    float* dPp = a.dfp + (rts * (2 * n_film * NT) + (long)(n_film + i) * NT) * 1024 + lane * 4;
     float dz_max = 0.0f;
     f16x8 hh[KS], hl[KS];
 #pragma unroll
@@ -871,21 +885,22 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(const BwdFilmArgs a) {
         split8(x8, hh[2 * t + u], hl[2 * t + u]);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // compiler-visible loads: none pending when the hidden z loads are counted
-    f32x4 zq[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) zq[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int g = 0; g < 4; ++g) hidden_load4(zq[g], zblk + g * 256 + lane * 4);  // z of tile 0
-#pragma unroll
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // compiler-visible loads: none pending when the hidden loads are counted
+    // ---- pass 1: dz, dF, dphase tile by tile
     for (int t = 0; t < NT; ++t) {
+      f32x4 zq[4], yq[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { zq[g] = f32x4{0.f, 0.f, 0.f, 0.f}; yq[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) hidden_load4(zq[g], zp + t * 1024 + g * 256);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) hidden_load4_nt(yq[g], dzp + t * 1024 + g * 256);
       f32x16 aF, aP;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { aF[r] = 0.0f; aP[r] = 0.0f; }
-      product<KS>(ws, hh, hl, aF);
-      product<KS>(ws, hh, hl, aP);
-      // z of this tile was requested just before the two products: only their 2 GH transitions x 4 DMA pieces are younger
-      hidden_wait<8 * GH>(zq);
+      product<KS, PW>(ws, hh, hl, aF);
+      product<KS, PW>(ws, hh, hl, aP);
+      hidden_wait8<2 * GH * PW>(zq, yq);  // requested just before the two products: only their 2 GH transitions x PW pieces are younger
       const float iF = h_inv * sl[tile], iP = h_inv * sl[tile + 1];
       tile += 2;
 #pragma unroll
@@ -894,7 +909,7 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(const BwdFilmArgs a) {
         const float4 b4F = *reinterpret_cast<const float4*>(bF + fo);
         const float4 b4P = *reinterpret_cast<const float4*>(bP + fo);
         const float bf[4] = {b4F.x, b4F.y, b4F.z, b4F.w}, bp[4] = {b4P.x, b4P.y, b4P.z, b4P.w};
-        float dFv[4], dPv[4];
+        float dzv[4], dFv[4], dPv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int r = 4 * g + q;
@@ -902,56 +917,57 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(const BwdFilmArgs a) {
           const float f = fmaf(15.0f, F, 30.0f);
           float sn, cs;
           sincos_cw(fmaf(f, z, P), sn, cs);
-          const float gc = dY[t][r] * cs;
-          const float dz = gc * f;
+          const float gc = yq[g][q] * cs;
+          dzv[q] = gc * f;
           dFv[q] = 15.0f * gc * z;
           dPv[q] = gc;
-          dz_max = fmaxf(dz_max, fabsf(dz));
+          dz_max = fmaxf(dz_max, fabsf(dzv[q]));
           fp_max = fmaxf(fp_max, fmaxf(fabsf(dFv[q]), fabsf(gc)));
-          dY[t][r] = dz;
         }
-        if (wave_live) {  // the three pieces of register group g: 1 KB-contiguous per wave instruction
-          stg4(dzblk + t * 1024 + g * 256 + lane * 4, make_float4(dY[t][4 * g], dY[t][4 * g + 1], dY[t][4 * g + 2], dY[t][4 * g + 3]));
-          stg4(dFblk + t * 1024 + g * 256 + lane * 4, make_float4(dFv[0], dFv[1], dFv[2], dFv[3]));
-          stg4(dPblk + t * 1024 + g * 256 + lane * 4, make_float4(dPv[0], dPv[1], dPv[2], dPv[3]));
+        if (wave_live) {  // 1 KB-contiguous per wave instruction
+          stg4(dzp + t * 1024 + g * 256, make_float4(dzv[0], dzv[1], dzv[2], dzv[3]));
+          stg4(dFp + t * 1024 + g * 256, make_float4(dFv[0], dFv[1], dFv[2], dFv[3]));
+          stg4(dPp + t * 1024 + g * 256, make_float4(dPv[0], dPv[1], dPv[2], dPv[3]));
         }
-      }
-      if (t + 1 < NT) {  // z of the next tile, behind this tile's stores
-#pragma unroll
-        for (int g = 0; g < 4; ++g) hidden_load4(zq[g], zblk + (t + 1) * 1024 + g * 256 + lane * 4);
       }
     }
     publish_max(a.gmax + i, dz_max, live, wave_live, lane);
+    // ---- pass 2: dY of the layer below = W_i^T dz (i = 0: the gradient w.r.t. the input rows, one tile)
     {
-      // dY of the layer below = W_i^T dz (i = 0: the gradient w.r.t. the input rows, one tile)
       float dz_inv;
       const float s = row_scale(dz_max, dz_inv);
       f16x8 dh_[KS], dl_[KS];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's dz stores have left before it reads them back
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int ks = 0; ks < KS; ++ks) {
+        float x8[8];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          float x8[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) x8[j] = dY[t][8 * u + j] * s;
-          split8(x8, dh_[2 * t + u], dl_[2 * t + u]);
+          const float4 q = ldg4_nt(dzp + (ks >> 1) * 1024 + (2 * (ks & 1) + u) * 256);
+          x8[4 * u] = q.x * s; x8[4 * u + 1] = q.y * s; x8[4 * u + 2] = q.z * s; x8[4 * u + 3] = q.w * s;
         }
+        split8(x8, dh_[ks], dl_[ks]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (i > 0) {
-#pragma unroll
+        float* nxt = a.dz_save[i - 1] + rts * NT * 1024 + lane * 4;
         for (int u = 0; u < NT; ++u) {
           f32x16 acc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-          product<KS>(ws, dh_, dl_, acc);
+          product<KS, PW>(ws, dh_, dl_, acc);
           const float inv = dz_inv * sl[tile++];
+          if (wave_live) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) dY[u][r] = acc[r] * inv;
+            for (int g = 0; g < 4; ++g)
+              stg4(nxt + u * 1024 + g * 256, make_float4(acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv, acc[4 * g + 3] * inv));
+          }
         }
       } else {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        product<KS>(ws, dh_, dl_, acc);
+        product<KS, PW>(ws, dh_, dl_, acc);
         const float inv = dz_inv * sl[tile++];
         if (a.d_x && live) {
 #pragma unroll
@@ -960,6 +976,7 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(const BwdFilmArgs a) {
               stg4(a.d_x + row * a.ldx + 8 * g + 4 * h, make_float4(acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv, acc[4 * g + 3] * inv));
         }
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next layer's hidden loads read what was just stored
     }
   }
   fp_max = fmaxf(fp_max, __shfl_xor(fp_max, 32, 64));
@@ -1222,9 +1239,9 @@ extern "C" int nsky_film_chain_bwd_film(const nsky_film_net* net, const void* st
     a.dz_save[l] = l < net->n_film ? dz_save[l] : nullptr;
     if (l < net->n_film) NSKY_CHECK_ARG(a.z_save[l] && a.dz_save[l] && ((uintptr_t)a.z_save[l] % 16) == 0 && ((uintptr_t)a.dz_save[l] % 16) == 0, "nsky_film_chain_bwd_film: z_save / dz_save[%d]", l);
   }
-  const dim3 grid(ceil_div(M, 128));
-  if (net->hidden == 256) hipLaunchKernelGGL((film_bwd_kernel<256>), grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((film_bwd_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid(ceil_div(M, 256));
+  if (net->hidden == 256) hipLaunchKernelGGL((film_bwd_kernel<256>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((film_bwd_kernel<128>), grid, dim3(512), 0, (hipStream_t)stream, a);
   NSKY_CHECK_LAUNCH("nsky_film_chain_bwd_film");
   return NSKY_OK;
 }
