@@ -282,9 +282,7 @@ __device__ __forceinline__ void ws_issue(const WStream& w, int group) {
   const uint32_t d = w.dst + (uint32_t)(group & (RING_GROUPS - 1)) * GROUP;
 #pragma unroll
   for (int p = 0; p < PW; ++p) {
-#ifndef FILM_LAB_NODMA
     glds16(s + p * 1024, d + p * 1024);
-#endif
   }
 }
 
@@ -341,19 +339,13 @@ __device__ __forceinline__ void product(WStream& w, const f16x8 (&bh)[KS], const
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     __builtin_amdgcn_sched_barrier(0);
-#ifndef FILM_LAB_NOMFMA
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks % 3], bl[ks], acc, 0, 0, 0);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     if (ks + 2 <= KS) request(ks + 2);  // into the buffer of k-step ks - 1, whose MFMAs have been issued
     if ((ks & (GSLABS - 1)) == GSLABS - 1 || ks == KS - 1) ws_transition<PW>(w, g0 + ks / GSLABS);
     __builtin_amdgcn_sched_barrier(0);
-#ifndef FILM_LAB_NOMFMA
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks % 3], bh[ks], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks % 3], bh[ks], acc, 0, 0, 0);
-#else
-    asm volatile("" :: "v"(fh[ks % 3]), "v"(fl[ks % 3]), "v"(bh[ks]), "v"(bl[ks]));
-#endif
     __builtin_amdgcn_sched_barrier(0);
     // fragments of k-step ks + 1 (slab KS = first slab of the next tile): only the pair requested above may still be in flight
     if (ks + 2 <= KS) frag_wait<2>(fh[(ks + 1) % 3], fl[(ks + 1) % 3]);
@@ -475,21 +467,6 @@ __device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
   c = ((q + 1) & 2) ? -cc : cc;
 }
 
-#ifdef FILM_LAB_STAMP
-__device__ unsigned long long g_stamps[64];
-__device__ __forceinline__ unsigned long long stamp() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-#define STAMP(var) const unsigned long long var = stamp()
-#define ACCUM(slot, a, b) do { if (blockIdx.x == 300 && tid == 0) g_stamps[slot] += (b) - (a); } while (0)
-#else
-#define STAMP(var)
-#define ACCUM(slot, a, b)
-#endif
 
 struct FwdArgs {
   nsky_film_net net;
@@ -542,8 +519,6 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
       if (i * 256 + tid < N4) *reinterpret_cast<float4*>(bl + 4 * (i * 256 + tid)) = q[i];
   }
   __syncthreads();
-
-  STAMP(t_begin);
   WStream ws;
   ws.src = a.stream + wave * 4096 + lane * 16;
   ws.dst = (uint32_t)(uintptr_t)smem + wave * 4096;
@@ -635,8 +610,6 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
         split8(x8, hh[2 * t + u], hl[2 * t + u]);
       }
   }
-
-  STAMP(t_map);
   // ------------------------------------------------------------------ FiLM layers
   f16x8 xh[1], xl[1];
   const float x_inv = load_planes<1>(a.x + rowc * a.ldx, (net.x_dim + 3) & ~3, 1, h, xh, xl);
@@ -658,10 +631,7 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
       f32x16 aF, aP, aZ;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { aF[r] = 0.0f; aP[r] = 0.0f; aZ[r] = 0.0f; }
-      STAMP(t0);
       product<KS>(ws, hh, hl, aF);
-      STAMP(t1);
-      ACCUM(0, t0, t1);
       product<KS>(ws, hh, hl, aP);
       float z_unscale;
       if (i == 0) {
@@ -671,8 +641,6 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
         product<KS>(ws, yh, yl, aZ);
         z_unscale = 1.0f / Y_SCALE;
       }
-      STAMP(t2);
-      ACCUM(1, t1, t2);
       const float iF = h_inv * sl[tile], iP = h_inv * sl[tile + 1], iZ = z_unscale * sl[tile + 2];
       tile += 3;
       float zz[16], yy[16];
@@ -688,25 +656,16 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
           const int r = 4 * g + q;
           const float F = fmaf(aF[r], iF, bf[q]), P = fmaf(aP[r], iP, bp[q]), z = fmaf(aZ[r], iZ, bz[q]);
           float sn, cs;
-#ifndef FILM_LAB_NOSIN
           sincos_cw(fmaf(fmaf(15.0f, F, 30.0f), z, P), sn, cs);
-#else
-          sn = fmaf(fmaf(15.0f, F, 30.0f), z, P);
-#endif
           zz[r] = z;
           yy[r] = sn;
         }
       }
-      STAMP(t3);
-      ACCUM(2, t2, t3);
       if (wave_live) {
         if (zblk) store_tile(zblk + t * 1024, lane, zz);
         store_tile(yblk + t * 1024, lane, yy);
       }
-      STAMP(t4);
-      ACCUM(3, t3, t4);
     }
-    STAMP(t5);
     // hand-off: this lane reads back exactly the 16-byte pieces it stored (k-step ks, half u = register group 2 (ks & 1) + u of
     // tile ks / 2)
 #pragma unroll
@@ -719,12 +678,7 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
       }
       split8(x8, yh[ks], yl[ks]);
     }
-    STAMP(t6);
-    ACCUM(4, t5, t6);
   }
-  STAMP(t_end);
-  ACCUM(5, t_begin, t_end);
-  ACCUM(6, t_begin, t_map);
 
   // ------------------------------------------------------------------ head
   {
@@ -1212,15 +1166,6 @@ extern "C" int nsky_film_chain_fwd(const nsky_film_net* net, const void* stream_
   return NSKY_OK;
 }
 
-#ifdef FILM_LAB_STAMP
-extern "C" int nsky_film_lab_stamps(unsigned long long* host_out, int reset) {
-  if (reset) {
-    unsigned long long z[64] = {0};
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) == hipSuccess ? 0 : -1;
-  }
-  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
-}
-#endif
 
 extern "C" int nsky_film_chain_bwd_film(const nsky_film_net* net, const void* stream_buf, const float* table, int32_t M, const float* d_res,
                                         int32_t ldres, const float* h_last, const float* const* z_save, float* const* dz_save, float* dfp,

@@ -487,10 +487,6 @@ __device__ __forceinline__ void split4h(const float x[4], uint2 out[2]) {
   unpack2h(h01, h[0], h[1]);
   unpack2h(h23, h[2], h[3]);
   out[0] = make_uint2(h01, h23);
-#ifdef NSKY_FAKE_SPLIT
-  out[1] = out[0];
-  return;
-#endif
   out[1] = make_uint2(pack2h((c[0] - h[0]) * F16_RES_SCALE, (c[1] - h[1]) * F16_RES_SCALE),
                       pack2h((c[2] - h[2]) * F16_RES_SCALE, (c[3] - h[3]) * F16_RES_SCALE));
 }
@@ -503,9 +499,6 @@ __device__ __forceinline__ void split4(const float x[4], uint2 out[NS]) {
   for (int t = 0; t < NS; ++t) {
     const uint32_t p01 = pack2(r[0], r[1]), p23 = pack2(r[2], r[3]);
     out[t] = make_uint2(p01, p23);
-#ifdef NSKY_FAKE_SPLIT  // timing experiment only: skip the residual arithmetic (wrong numerics)
-    continue;
-#endif
     if (t + 1 < NS) {
       r[0] -= bf16_hi_as_f32(p01); r[1] -= bf16_lo_as_f32(p01);
       r[2] -= bf16_hi_as_f32(p23); r[3] -= bf16_lo_as_f32(p23);
@@ -521,9 +514,6 @@ __device__ __forceinline__ void tile_epilogue(float* Cs, f32x16 (&acc)[2][2], f3
                                               int tid, int m0, int n0, int M, int N, float* __restrict__ C, int ldc, int vec4,
                                               bool atomic, const EpiCtx& e, float out_scale = 1.0f) {
   constexpr int WM = 64, WN = 64, NT = 2 * BN;  // BN / 64 wave columns x 2 wave rows x 64 lanes
-#ifdef NSKY_LAB_NOEPI  // timing experiment only: no output unless an accumulator is NaN
-  if (!(acc[0][0][0] != acc[0][0][0] || acc[1][1][5] != acc[1][1][5] || acc[0][1][3] != acc[0][1][3] || acc[1][0][9] != acc[1][0][9])) return;
-#endif
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     if (pass > 0) __syncthreads();
@@ -622,24 +612,17 @@ struct SplitLoader {  // ROWS x 32 fp32 tile -> NS bf16 images [ROWS][SROW]; ROW
   }
 };
 
-#ifndef NSKY_LAB_PF2
-#define NSKY_LAB_PF2 false
-#endif
-template <int NS, bool AK, bool BKC, bool DBUF, bool H = false, bool PF2 = NSKY_LAB_PF2>
-#ifndef NSKY_LAB_OCC
-#define NSKY_LAB_OCC 2
-#endif
-__global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : NSKY_LAB_OCC) void gemm_bf16s_kernel(
+template <int NS, bool AK, bool BKC, bool H = false>
+__global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K, int lda, int ldb,
     int ldc, int k_split_len, int vec4, float* __restrict__ a_rowsum, EpiCtx e) {
   constexpr int BM = 128, BN = 128, BKT = 32, WM = 64, WN = 64, TM = 2, TN = 2;
   constexpr int IMG = 128 * SROW;  // bf16 elements per image
-  constexpr int NBUF = DBUF ? 2 : 1;
-  constexpr int STAGE = 2 * NS * IMG;  // bf16 elements per pipeline stage (A images then B images)
-  constexpr int SMEM_MAIN = NBUF * STAGE * 2 + 128 * 4, SMEM_EPI = WM * BN * 4;
+  constexpr int STAGE = 2 * NS * IMG;  // bf16 elements of the stage (A images then B images)
+  constexpr int SMEM_MAIN = STAGE * 2 + 128 * 4, SMEM_EPI = WM * BN * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
   __bf16* S0 = reinterpret_cast<__bf16*>(smem_raw);
-  float* rsum = reinterpret_cast<float*>(smem_raw + NBUF * STAGE * 2);
+  float* rsum = reinterpret_cast<float*>(smem_raw + STAGE * 2);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -718,85 +701,18 @@ __global__ __launch_bounds__(256, DBUF && NS == 3 ? 1 : NSKY_LAB_OCC) void gemm_
     la.load(A, lda, m0, M, kbeg, kend, tid);
     lb.load(B, ldb, n0, N, kbeg, kend, tid);
   }
-  if (DBUF) {
-    // two LDS stages: tile t+1 is split and written (VALU + LDS pipes) in the same instruction stream as the bf16
-    // MFMAs of tile t (matrix pipe); tile t+2's global loads are issued right after and land during the next tile
-    if (ntiles > 0) {
-      __syncthreads();
-      la.store(S0, tid, want_rs && kbeg < e.rs_limit);
-      lb.store(S0 + NS * IMG, tid, false);
-      if (ntiles > 1) {
-        la.load(A, lda, m0, M, kbeg + BKT, kend, tid);
-        lb.load(B, ldb, n0, N, kbeg + BKT, kend, tid);
-      }
-    }
+  // one LDS stage, two workgroups per CU: tile t+1 is fetched to registers while tile t is multiplied (a two-stage variant,
+  // a prefetch distance of two and a 256-wide tile were measured slower or neutral in round 1 and are gone)
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();  // previous tile's fragment reads are done
+    la.store(S0, tid, want_rs && kbeg + t * BKT < e.rs_limit);
+    lb.store(S0 + NS * IMG, tid, false);
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-      const __bf16* cur = S0 + (t & 1) * STAGE;
-      __bf16* nxt = S0 + ((t + 1) & 1) * STAGE;
-      compute(cur, cur + NS * IMG);
-      if (t + 1 < ntiles) {
-        la.store(nxt, tid, want_rs && kbeg + (t + 1) * BKT < e.rs_limit);
-        lb.store(nxt + NS * IMG, tid, false);
-        if (t + 2 < ntiles) {
-          la.load(A, lda, m0, M, kbeg + (t + 2) * BKT, kend, tid);
-          lb.load(B, ldb, n0, N, kbeg + (t + 2) * BKT, kend, tid);
-        }
-      }
-      __syncthreads();
+    if (t + 1 < ntiles) {
+      la.load(A, lda, m0, M, kbeg + (t + 1) * BKT, kend, tid);
+      lb.load(B, ldb, n0, N, kbeg + (t + 1) * BKT, kend, tid);
     }
-  } else if (PF2) {
-    // prefetch distance 2: a second register set holds tile t+1 while tile t+2 is requested, so a tile's HBM round trip is
-    // covered by two MFMA phases and one split/store phase instead of one MFMA phase (lab: the loads, not the MFMAs or the
-    // split, set the k-loop time at distance 1)
-    SplitLoader<NS, AK, H> la1;
-    SplitLoader<NS, BKC, H> lb1;
-    if (ntiles > 1) {
-      la1.load(A, lda, m0, M, kbeg + BKT, kend, tid);
-      lb1.load(B, ldb, n0, N, kbeg + BKT, kend, tid);
-    }
-    for (int t = 0; t < ntiles; t += 2) {
-      __syncthreads();
-      la.store(S0, tid, want_rs && kbeg + t * BKT < e.rs_limit);
-      lb.store(S0 + NS * IMG, tid, false);
-      __syncthreads();
-      if (t + 2 < ntiles) {
-        la.load(A, lda, m0, M, kbeg + (t + 2) * BKT, kend, tid);
-        lb.load(B, ldb, n0, N, kbeg + (t + 2) * BKT, kend, tid);
-      }
-      compute(S0, S0 + NS * IMG);
-      if (t + 1 < ntiles) {
-        __syncthreads();
-        la1.store(S0, tid, want_rs && kbeg + (t + 1) * BKT < e.rs_limit);
-        lb1.store(S0 + NS * IMG, tid, false);
-        __syncthreads();
-        if (t + 3 < ntiles) {
-          la1.load(A, lda, m0, M, kbeg + (t + 3) * BKT, kend, tid);
-          lb1.load(B, ldb, n0, N, kbeg + (t + 3) * BKT, kend, tid);
-        }
-        compute(S0, S0 + NS * IMG);
-      }
-    }
-    if (want_rs) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) la.rs[i] += la1.rs[i];
-    }
-  } else {
-    for (int t = 0; t < ntiles; ++t) {
-      __syncthreads();  // previous tile's fragment reads are done
-      la.store(S0, tid, want_rs && kbeg + t * BKT < e.rs_limit);
-      lb.store(S0 + NS * IMG, tid, false);
-      __syncthreads();
-#ifndef NSKY_LAB_NOLOAD
-      if (t + 1 < ntiles) {
-        la.load(A, lda, m0, M, kbeg + (t + 1) * BKT, kend, tid);
-        lb.load(B, ldb, n0, N, kbeg + (t + 1) * BKT, kend, tid);
-      }
-#endif
-#ifndef NSKY_LAB_NOMFMA
-      compute(S0, S0 + NS * IMG);
-#endif
-    }
+    compute(S0, S0 + NS * IMG);
   }
   if (want_rs) la.flush_rowsum(rsum, tid);
   __syncthreads();
@@ -837,25 +753,20 @@ __device__ __forceinline__ void vmcnt_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <bool H, int BN>
-__global__ __launch_bounds__(2 * BN, BN == 128 ? 2 : 1) void gemm_planes_kernel(const float* __restrict__ A, const uint16_t* __restrict__ Bhi,
+template <bool H>
+__global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const float* __restrict__ A, const uint16_t* __restrict__ Bhi,
                                                              const uint16_t* __restrict__ Blo, float* __restrict__ C, int M, int N,
                                                              int K, int lda, int ldp, int ldc, int vec4, EpiCtx e) {
-  // BN = 128: 4 waves (2 x 2), two workgroups per CU, every wave streams its share of A and of B (A ring of 3 stages).
-  // BN = 256: 8 waves (2 x 4), one workgroup per CU covering a whole 256-wide layer (A fetched and split once per row tile),
-  //   with the streaming SPLIT BY WAVE: waves 0-3 stream and split A, waves 4-7 stream B.  vmcnt is one in-order counter per
-  //   wave, so a wave that waits for its newest B tile also drains every older A tile; with the roles on different waves the
-  //   A ring runs 2 tiles and the B ring 2 tiles (64 KB) ahead of the MFMAs, each waited by its own counter.
-  constexpr bool SPEC = BN == 256;
-  constexpr int NW = BN / 32, WCOLS = BN / 64;
-  constexpr int STAGE = 16384, A_STAGES = SPEC ? 4 : 3, PD = A_STAGES - 1, B_STAGES = SPEC ? 3 : 2, B_OFF = A_STAGES * STAGE, B_STAGE = BN * 128;
-  constexpr int NA = SPEC ? 4 : 16 / NW, NB = SPEC ? 8 : 4;  // LDS-DMA instructions per streaming wave and tile
+  // 128 x 128 tile, 4 waves (2 x 2), two workgroups per CU, every wave streams its share of A and of B (A ring of 3 stages,
+  // B ring of 2).  (A 256-wide, wave-specialised variant measured 0.5 % slower on the step in round 1 and is gone.)
+  constexpr int BN = 128, NW = BN / 32, WCOLS = BN / 64;
+  constexpr int STAGE = 16384, A_STAGES = 3, B_STAGES = 2, B_OFF = A_STAGES * STAGE, B_STAGE = BN * 128;
+  constexpr int NA = 16 / NW, NB = 4;  // LDS-DMA instructions per wave and tile
   __shared__ __attribute__((aligned(16))) unsigned char smem[B_OFF + B_STAGES * B_STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WCOLS, wn = wave % WCOLS;
-  const bool a_wave = !SPEC || wave < 4, b_wave = !SPEC || wave >= 4;
-  const int aw = wave & 3, bw = SPEC ? (wave & 3) : wave;
+  const int aw = wave, bw = wave;
   int m_tile, n_tile;
   tile_of_block((N + BN - 1) / BN, m_tile, n_tile);
   const int m0 = m_tile * 128, n0 = n_tile * BN;
@@ -892,16 +803,6 @@ __global__ __launch_bounds__(2 * BN, BN == 128 ? 2 : 1) void gemm_planes_kernel(
     const uint32_t dst = lds0 + B_OFF + (t % B_STAGES) * B_STAGE + bw * (NB * 1024);
 #pragma unroll
     for (int j = 0; j < NB; ++j) glds16(b_src[j] + t * 32, dst + j * 1024);
-  };
-  // wait until at most `younger` A tiles issued after the wanted one are still in flight (SPEC A waves: only A in the queue)
-  auto wait_a_tiles = [&](int younger) {
-    switch (younger) {
-      case 0: vmcnt_wait<0>(); break;
-      case 1: vmcnt_wait<NA>(); break;
-      case 2: vmcnt_wait<2 * NA>(); break;
-      case 3: vmcnt_wait<3 * NA>(); break;
-      default: vmcnt_wait<4 * NA>(); break;
-    }
   };
   // in-place split of the chunks this lane's DMAs delivered (tile t): raw_load reads them (before the MFMAs of the current
   // tile are issued), split_store converts and writes the two 8-byte halves (after them, so the VALU work can be scheduled
@@ -951,21 +852,13 @@ __global__ __launch_bounds__(2 * BN, BN == 128 ? 2 : 1) void gemm_planes_kernel(
       const int q = 2 * ks + fh;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-#ifdef NSKY_LABP_BCAST  // timing experiment: every lane reads the same row (broadcast, no bank conflicts possible)
-        const int r = wm * 64 + i * 32, sw = (r >> 1) & 7;
-#else
         const int r = wm * 64 + i * 32 + frow, sw = (r >> 1) & 7;
-#endif
         af[0][i] = *reinterpret_cast<const bf16x8*>(As + r * 128 + (((2 * q) ^ sw) * 16));
         af[1][i] = *reinterpret_cast<const bf16x8*>(As + r * 128 + (((2 * q + 1) ^ sw) * 16));
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-#ifdef NSKY_LABP_BCAST
-        const int r = wn * 64 + j * 32, sw = (r >> 1) & 7;
-#else
         const int r = wn * 64 + j * 32 + frow, sw = (r >> 1) & 7;
-#endif
         bfr[0][j] = *reinterpret_cast<const bf16x8*>(Bs + r * 128 + ((q ^ sw) * 16));
         bfr[1][j] = *reinterpret_cast<const bf16x8*>(Bs + r * 128 + (((4 + q) ^ sw) * 16));
       }
@@ -987,39 +880,7 @@ __global__ __launch_bounds__(2 * BN, BN == 128 ? 2 : 1) void gemm_planes_kernel(
     }
   };
 
-  if (SPEC) {
-    if (a_wave) {  // queue of an A wave: A tiles only, oldest first
-      const int n0t = min(PD, T);
-      for (int i = 0; i < n0t; ++i) issue_a(i);
-      wait_a_tiles(n0t - 1);
-      raw_load(0);
-      split_store(0);
-    } else {  // queue of a B wave: B tiles only; two tiles ahead of the MFMAs
-      issue_b(0);
-      if (T > 1) { issue_b(1); vmcnt_wait<NB>(); } else { vmcnt_wait<0>(); }
-    }
-    __syncthreads();
-    for (int t = 0; t < T; ++t) {
-      const bool n1 = t + 1 < T;
-      if (a_wave) {
-        // A stage (t+PD) % A_STAGES = (t-1) % A_STAGES and B stage (t+1)&1 were last read by the MFMAs of tile t-1 (barrier passed)
-        if (t + PD < T) issue_a(t + PD);
-        if (n1) {
-          wait_a_tiles(min(T, t + PD + 1) - (t + 2));
-          raw_load(t + 1);
-        }
-      } else if (t + 2 < T) {
-        issue_b(t + 2);  // B stage (t+2) % 3 = (t-1) % 3: free since the barrier that closed tile t-1
-      }
-      compute(t);
-      if (n1) {
-        if (a_wave) split_store(t + 1);
-        else if (t + 2 < T) vmcnt_wait<NB>();
-        else vmcnt_wait<0>();
-      }
-      __syncthreads();
-    }
-  } else {
+  {
     // prologue: queue = B0, A0, A1
     issue_b(0);
     issue_a(0);
@@ -1029,21 +890,15 @@ __global__ __launch_bounds__(2 * BN, BN == 128 ? 2 : 1) void gemm_planes_kernel(
     __syncthreads();
     for (int t = 0; t < T; ++t) {
       const bool n1 = t + 1 < T, n2 = t + 2 < T;
-#ifndef NSKY_LABP_NOGLDS
       if (n1) issue_b(t + 1);  // B stage (t+1)&1 and A stage (t+2)%3 were last read by the MFMAs of tile t-1 (barrier passed)
       if (n2) issue_a(t + 2);
-#endif
       if (n1) {  // queue (oldest first): A(t+1), B(t+1), A(t+2); A(t+1) has been in flight for a whole tile
         if (n2) vmcnt_wait<NB + NA>(); else vmcnt_wait<NB>();
         raw_load(t + 1);
       }
-#ifndef NSKY_LABP_NOMFMA
       compute(t);
-#endif
       if (n1) {
-#ifndef NSKY_LABP_NOCONV
         split_store(t + 1);
-#endif
         if (n2) vmcnt_wait<NA>(); else vmcnt_wait<0>();
       }
       __syncthreads();
@@ -1099,11 +954,11 @@ __global__ void split_planes_kernel(const float* __restrict__ W, int n_rows, int
   }
 }
 
-template <int NS, bool DBUF, bool H = false>
+template <int NS, bool H = false>
 void launch_split(const nsky_gemm_desc* d, const EpiCtx& e, int splits, int k_split_len, int vec4, hipStream_t s) {
   dim3 grid(ceil_div(d->M, 128) * ceil_div(d->N, 128) * splits);
 #define NSKY_SGEMM_LAUNCH(AK, BKC)                                                                          \
-  hipLaunchKernelGGL((gemm_bf16s_kernel<NS, AK, BKC, DBUF, H>), grid, dim3(256), 0, s, d->A, d->B, d->C, d->M, d->N, \
+  hipLaunchKernelGGL((gemm_bf16s_kernel<NS, AK, BKC, H>), grid, dim3(256), 0, s, d->A, d->B, d->C, d->M, d->N, \
                      d->K, d->lda, d->ldb, d->ldc, k_split_len, vec4, d->a_rowsum, e)
   if (d->a_kcontig && d->b_kcontig) NSKY_SGEMM_LAUNCH(true, true);
   else if (d->a_kcontig && !d->b_kcontig) NSKY_SGEMM_LAUNCH(true, false);
@@ -1214,16 +1069,12 @@ extern "C" int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream) {
   auto ok = [](const void* p, int ld) { return p == nullptr || ((((uintptr_t)p) % 16 == 0) && (ld % 4 == 0)); };
   const int vec4 = (d->N % 4 == 0) && ok(d->C, d->ldc) && ok(d->bias, 4) && ok(d->aux0, d->ldaux0) && ok(d->aux1, d->ldaux1) &&
                    ok(d->aux2, d->ldaux2) && ok(d->out1, d->ldout1) && ok(d->out2, d->ldout2);
-  static const int variant = getenv("NSKY_GEMM_VARIANT") ? atoi(getenv("NSKY_GEMM_VARIANT")) : 0;
   if (d->precision != NSKY_PREC_F32 && d->N > 64) {
     NSKY_CHECK_ARG(d->precision == NSKY_PREC_BF16X2 || d->precision == NSKY_PREC_BF16X3 || d->precision == NSKY_PREC_F16X2,
                    "nsky_gemm_f32: unknown precision %d", d->precision);
-    // the two-stage LDS variant needs 80-120 KB per workgroup (one workgroup per CU) and measured 1.4-2.5x SLOWER than
-    // the single-stage kernel at 2 workgroups per CU; kept selectable (NSKY_GEMM_VARIANT=4) for experiments only
-    const bool dbuf = (variant & 4) != 0;
-    if (d->precision == NSKY_PREC_F16X2) launch_split<2, false, true>(d, e, splits, k_split_len, vec4, s);
-    else if (d->precision == NSKY_PREC_BF16X2) { if (dbuf) launch_split<2, true>(d, e, splits, k_split_len, vec4, s); else launch_split<2, false>(d, e, splits, k_split_len, vec4, s); }
-    else { if (dbuf) launch_split<3, true>(d, e, splits, k_split_len, vec4, s); else launch_split<3, false>(d, e, splits, k_split_len, vec4, s); }
+    if (d->precision == NSKY_PREC_F16X2) launch_split<2, true>(d, e, splits, k_split_len, vec4, s);
+    else if (d->precision == NSKY_PREC_BF16X2) launch_split<2>(d, e, splits, k_split_len, vec4, s);
+    else launch_split<3>(d, e, splits, k_split_len, vec4, s);
     NSKY_CHECK_LAUNCH("nsky_gemm_f32(split-bf16)");
     return NSKY_OK;
   }
@@ -1231,12 +1082,6 @@ extern "C" int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream) {
     launch<128, 32, 4, 1, 32, 2>(d, e, splits, k_split_len, vec4, s);
   else if (d->N <= 64)
     launch<128, 64, 2, 2, 32, 2>(d, e, splits, k_split_len, vec4, s);
-  else if (variant == 1)
-    launch<128, 128, 2, 2, 16, 3>(d, e, splits, k_split_len, vec4, s);
-  else if (variant == 2)
-    launch<128, 128, 2, 2, 16, 4>(d, e, splits, k_split_len, vec4, s);
-  else if (variant == 3)
-    launch<128, 128, 2, 2, 32, 1>(d, e, splits, k_split_len, vec4, s);
   else
     launch<128, 128, 2, 2, 32, 2>(d, e, splits, k_split_len, vec4, s);
   NSKY_CHECK_LAUNCH("nsky_gemm_f32");
@@ -1284,18 +1129,11 @@ extern "C" int nsky_gemm_f32_planes(const nsky_gemm_desc* d, const uint16_t* B_h
   auto ok = [](const void* p, int ld) { return p == nullptr || ((((uintptr_t)p) % 16 == 0) && (ld % 4 == 0)); };
   const int vec4 = (d->N % 4 == 0) && ok(d->C, d->ldc) && ok(d->bias, 4) && ok(d->aux0, d->ldaux0) && ok(d->aux1, d->ldaux1) &&
                    ok(d->aux2, d->ldaux2) && ok(d->out1, d->ldout1) && ok(d->out2, d->ldout2);
-  // 128-wide tiles, two workgroups per CU, by default: the 256-wide wave-specialised variant (A fetched and split once per
-  // row tile, one 8-wave workgroup per CU) measured 0.5 % slower on the train step (36.7 vs 36.5 ms); NSKY_PLANES_BN=256
-  // selects it for experiments
-  static const int force_bn = getenv("NSKY_PLANES_BN") ? atoi(getenv("NSKY_PLANES_BN")) : 0;
-  const bool wide = force_bn == 256 && d->N > 128;
-  const bool h = d->precision == NSKY_PREC_F16X2;
-#define NSKY_PLANES_LAUNCH(HH, BNN)                                                                                          \
-  hipLaunchKernelGGL((gemm_planes_kernel<HH, BNN>), dim3(ceil_div(d->M, 128) * ceil_div(d->N, BNN)), dim3(2 * BNN), 0,      \
-                     (hipStream_t)stream, d->A, B_hi, B_lo, d->C, d->M, d->N, d->K, d->lda, ldp, d->ldc, vec4, e)
-  if (wide) { if (h) NSKY_PLANES_LAUNCH(true, 256); else NSKY_PLANES_LAUNCH(false, 256); }
-  else { if (h) NSKY_PLANES_LAUNCH(true, 128); else NSKY_PLANES_LAUNCH(false, 128); }
-#undef NSKY_PLANES_LAUNCH
+  const dim3 grid(ceil_div(d->M, 128) * ceil_div(d->N, 128));
+  if (d->precision == NSKY_PREC_F16X2)
+    hipLaunchKernelGGL((gemm_planes_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, d->A, B_hi, B_lo, d->C, d->M, d->N, d->K, d->lda, ldp, d->ldc, vec4, e);
+  else
+    hipLaunchKernelGGL((gemm_planes_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, d->A, B_hi, B_lo, d->C, d->M, d->N, d->K, d->lda, ldp, d->ldc, vec4, e);
   NSKY_CHECK_LAUNCH("nsky_gemm_f32_planes");
   return NSKY_OK;
 }

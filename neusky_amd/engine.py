@@ -18,9 +18,6 @@ import torch.distributed as dist
 from . import hip
 from .model_components.losses import total_loss
 
-import os as _os
-
-_GRAD_SINK = _os.environ.get("NSKY_GRAD_SINK", "1") != "0"
 
 
 @dataclass
@@ -95,7 +92,7 @@ class _Group:
             self.flat_p[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat_p[off:off + k].view_as(p)
             p.grad = self.flat_g[off:off + k].view_as(p)
-            p._nsky_grad_sink = _GRAD_SINK  # custom backward passes may accumulate into p.grad directly (zeroed by zero_grad_all)
+            p._nsky_grad_sink = True  # custom backward passes may accumulate into p.grad directly (zeroed by zero_grad_all)
             off += (k + 3) // 4 * 4
         if isinstance(self.sched, ExponentialDecaySchedulerConfig):
             self.sched.lr_init = self.opt.lr

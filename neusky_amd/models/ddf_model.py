@@ -169,55 +169,28 @@ class DDFModel(ModelBase):
         loss_dict: Dict[str, torch.Tensor] = {}
         li = c.loss_inclusions
         exp_d = outputs["expected_termination_dist"]
-        if (exp_d.is_cuda and os.environ.get("NSKY_FUSED_LOSSES", "1") in ("1", "ddf")
-                and (c.include_depth_loss_scene_center_weight or not c.inverse_depth_weight)):
-            # one launch each way for the five closed-form terms (ops.DDFLossesFn; same formulas, keys and scaling)
-            want_sdf = (li["sdf_l2_loss"] or li["sdf_l1_loss"])
-            mv = li["multi_view_loss"]
-            sky = li["sky_ray_loss"]
-            flags = dict(want_depth=int(li["depth_l1_loss"]), want_sdf_l2=int(li["sdf_l2_loss"]), want_sdf_l1=int(li["sdf_l1_loss"]),
-                         mask_to_circumference=int(c.mask_to_circumference), inverse_depth_weight=int(c.inverse_depth_weight),
-                         radius=float(self.ddf_radius))
-            terms = ops.DDFLossesFn.apply(
-                exp_d, batch["termination_dist"], batch["mask"],
-                outputs["distance_weight"] if c.include_depth_loss_scene_center_weight else None,
-                outputs["sdf_at_termination"] if want_sdf else None,
-                outputs["multi_view_expected_termination_dist"] if mv else None, outputs["multi_view_termintation_dist"] if mv else None,
-                outputs["sky_ray_expected_termination_dist"] if sky else None, outputs["sky_ray_termination_dist"] if sky else None, flags)
-            names = ("depth_l1_loss", "sdf_l2_loss", "sdf_l1_loss", "multi_view_loss", "sky_ray_loss")
-            present = (li["depth_l1_loss"], li["sdf_l2_loss"], li["sdf_l1_loss"], mv, sky)
-            key = (tuple(float(c.loss_coefficients.get(k, 1.0)) if p else 0.0 for k, p in zip(names, present)), str(terms.device))
-            cv = _COEF_VECTORS.get(key)
-            if cv is None:
-                cv = _COEF_VECTORS[key] = torch.tensor(key[0], dtype=torch.float32).to(terms.device)
-            scaled = terms * cv
-            out = LossDict({k: scaled[i] for i, (k, p) in enumerate(zip(names, present)) if p})
-            out.total = scaled.sum()
-            return out
-        if c.mask_to_circumference:
-            expected = outputs["expected_termination_dist"].unsqueeze(1)
-            gt = batch["termination_dist"].clone()
-            gt[batch["mask"] == 0] = self.ddf_radius * 2
-        else:
-            expected = outputs["expected_termination_dist"].unsqueeze(1) * batch["mask"]
-            gt = batch["termination_dist"] * batch["mask"]
-        inv_w = 1.0 / (gt + 1e-6) if c.inverse_depth_weight else 1.0
-        if c.loss_inclusions["depth_l1_loss"]:
-            l = torch.abs(expected - gt)
-            if c.include_depth_loss_scene_center_weight:
-                loss_dict["depth_l1_loss"] = torch.mean(l * outputs["distance_weight"].unsqueeze(-1) * inv_w)
-            else:
-                loss_dict["depth_l1_loss"] = torch.mean(l.mean() * inv_w)
-        if c.loss_inclusions["sdf_l2_loss"]:
-            loss_dict["sdf_l2_loss"] = F.mse_loss(outputs["sdf_at_termination"] * batch["mask"],
-                                                  torch.zeros_like(outputs["sdf_at_termination"]) * batch["mask"])
-        if c.loss_inclusions["sdf_l1_loss"]:
-            loss_dict["sdf_l1_loss"] = F.l1_loss(outputs["sdf_at_termination"] * batch["mask"],
-                                                 torch.zeros_like(outputs["sdf_at_termination"]) * batch["mask"])
-        if c.loss_inclusions["multi_view_loss"]:
-            # (sic) [M] - [M,1] broadcasts to [M,M] in the reference (:478-483); reproduced
-            loss_dict["multi_view_loss"] = torch.mean(F.relu(outputs["multi_view_expected_termination_dist"] -
-                                                             outputs["multi_view_termintation_dist"]) ** 2)
-        if c.loss_inclusions["sky_ray_loss"]:
-            loss_dict["sky_ray_loss"] = F.l1_loss(outputs["sky_ray_expected_termination_dist"], outputs["sky_ray_termination_dist"])
-        return scale_dict(loss_dict, c.loss_coefficients)
+        if c.inverse_depth_weight and not c.include_depth_loss_scene_center_weight:
+            raise NotImplementedError("inverse_depth_weight without the scene-centre weight (ddf_model.py:434-436) is outside the `neusky` method")
+        # one launch each way for the five closed-form terms (ops.DDFLossesFn; same formulas, keys and scaling)
+        want_sdf = (li["sdf_l2_loss"] or li["sdf_l1_loss"])
+        mv = li["multi_view_loss"]
+        sky = li["sky_ray_loss"]
+        flags = dict(want_depth=int(li["depth_l1_loss"]), want_sdf_l2=int(li["sdf_l2_loss"]), want_sdf_l1=int(li["sdf_l1_loss"]),
+                     mask_to_circumference=int(c.mask_to_circumference), inverse_depth_weight=int(c.inverse_depth_weight),
+                     radius=float(self.ddf_radius))
+        terms = ops.DDFLossesFn.apply(
+            exp_d, batch["termination_dist"], batch["mask"],
+            outputs["distance_weight"] if c.include_depth_loss_scene_center_weight else None,
+            outputs["sdf_at_termination"] if want_sdf else None,
+            outputs["multi_view_expected_termination_dist"] if mv else None, outputs["multi_view_termintation_dist"] if mv else None,
+            outputs["sky_ray_expected_termination_dist"] if sky else None, outputs["sky_ray_termination_dist"] if sky else None, flags)
+        names = ("depth_l1_loss", "sdf_l2_loss", "sdf_l1_loss", "multi_view_loss", "sky_ray_loss")
+        present = (li["depth_l1_loss"], li["sdf_l2_loss"], li["sdf_l1_loss"], mv, sky)
+        key = (tuple(float(c.loss_coefficients.get(k, 1.0)) if p else 0.0 for k, p in zip(names, present)), str(terms.device))
+        cv = _COEF_VECTORS.get(key)
+        if cv is None:
+            cv = _COEF_VECTORS[key] = torch.tensor(key[0], dtype=torch.float32).to(terms.device)
+        scaled = terms * cv
+        out = LossDict({k: scaled[i] for i, (k, p) in enumerate(zip(names, present)) if p})
+        out.total = scaled.sum()
+        return out

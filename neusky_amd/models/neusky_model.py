@@ -300,8 +300,7 @@ class NeuSkyFactoModel(ModelBase):
         before the DDF-fit ground-truth pass, whose sampler geometry is a run of ~180 small launches that leave the chip
         idle, so the decode's dense layers fill it."""
         cam = ray_bundle.camera_indices.reshape(-1)
-        if not (self.training and cam.is_cuda and os.environ.get("NSKY_PARALLEL_ILLUMINATION", "1") != "0"
-                and os.environ.get("NSKY_EARLY_ILLUMINATION", "1") != "0"):
+        if not (self.training and cam.is_cuda):
             return
         main = torch.cuda.current_stream()
         side = self._illumination_stream()
@@ -409,7 +408,7 @@ class NeuSkyFactoModel(ModelBase):
         # The illumination decode (big dense layers, nothing but the camera indices as input) runs on a second HIP stream
         # beside the proposal sampler + field pass (hundreds of small launches): a fork/join that the HIP graph keeps as
         # two parallel branches, forward and backward (autograd replays each node on its forward stream).
-        fork = self.training and cam.is_cuda and os.environ.get("NSKY_PARALLEL_ILLUMINATION", "1") != "0"
+        fork = self.training and cam.is_cuda
         pending = getattr(self, "_illumination_pending", None)
         self._illumination_pending = None
         if fork and pending is not None:  # started by start_illumination (the pipeline, before the DDF-fit ground truth pass)
@@ -527,68 +526,30 @@ class NeuSkyFactoModel(ModelBase):
         return outputs
 
     def get_loss_dict(self, outputs: Dict[str, Any], batch: Dict[str, Any], metrics_dict=None) -> Dict[str, torch.Tensor]:
-        """neusky_model.py:933-1062"""
-        dev = self.device
-        mask = batch["mask"].to(dev)
-        fg_mask, ground_mask, sky_mask = mask[..., 1], mask[..., 2], mask[..., 3]
+        """neusky_model.py:933-1062, both branches, through ONE fused kernel each way (ops.MainLossesFn): the train branch's eight
+        closed-form terms + the interlevel kernel, or - while the eval latents are fitted and in eval mode - the sky-masked rgb L1
+        and the sky-pixel term (:1036-1059).  The two colour-loss options the `neusky` method does not use (rgb_l2_loss,
+        cosine_colour_loss, neusky_config.py:104-105) are not built."""
         li = self.config.loss_inclusions
-        ld: Dict[str, torch.Tensor] = {}
-        image = batch["image"].to(dev)
-        if (image.is_cuda and self.training and not self.fitting_eval_latents and not li["rgb_l2_loss"] and not li["cosine_colour_loss"]
-                and os.environ.get("NSKY_FUSED_LOSSES", "1") in ("1", "main")):
-            return self._fused_loss_dict(outputs, image, mask)
-        keep = (1 - sky_mask.float()).unsqueeze(1)
-        img, pred = image * keep, outputs["rgb"] * keep  # :947-948
-        if li["rgb_l1_loss"]:
-            ld["rgb_l1_loss"] = F.l1_loss(img, pred)
-        if li["rgb_l2_loss"]:
-            ld["rgb_l2_loss"] = F.mse_loss(img, pred)
-        if li["cosine_colour_loss"]:
-            ld["cosine_colour_loss"] = torch.mean(1 - F.cosine_similarity(img, pred, dim=1))
-        if self.training and not self.fitting_eval_latents:
-            if li["eikonal loss"]:
-                ld["eikonal_loss"] = ((outputs["eik_grad"].norm(2, dim=-1) - 1) ** 2).mean()  # :958-960
-            if li["fg_mask_loss"]:
-                ws = torch.nan_to_num(outputs["weights"].sum(dim=1).clip(1e-3, 1.0 - 1e-3), nan=0.5)  # :964-965
-                ld["fg_mask_loss"] = F.binary_cross_entropy(ws, fg_mask.float().unsqueeze(1))
-            if li["interlevel_loss"]:
-                ld["interlevel_loss"] = interlevel_loss(outputs["weights_list"], outputs["sbins_list"])  # :987-988
-            if li["hashgrid_density_loss"]["enabled"]:
-                ld["hashgrid_density_loss"] = outputs["grid_density"].abs().mean()  # :990-993
-            if li["ground_plane_loss"]:
-                npred = outputs["normal"]
-                ngt = torch.zeros_like(npred)
-                ngt[:, 2] = 1.0
-                gm = ground_mask.unsqueeze(1).expand_as(npred)
-                ld["ground_plane_loss"] = monosdf_normal_loss(npred * gm, ngt * gm)  # :995-1000
-            if li["sky_pixel_loss"]["enabled"]:
-                sm = sky_mask.float().unsqueeze(1).expand(-1, 3)
-                ld["sky_pixel_loss"] = self.sky_pixel_loss(inputs=linear_to_sRGB(outputs["hdr_background_colours"]),
-                                                           targets=image, mask=sm)  # :1002-1009
-            if self.visibility_field is not None and self.visibility_threshold_method == "learnable":
-                tgt = li["visibility_sigmoid_loss"]["target_min_bias"]
-                ld["visibility_sigmoid_loss"] = (self.visibility_threshold[0] - tgt) ** 2  # MSE of two scalars, :1011-1030
-            if li["sdf_level_set_visibility_loss"] and outputs.get("sdf_at_termination") is not None:
-                ld["sdf_level_set_visibility_loss"] = (outputs["sdf_at_termination"] ** 2).mean()  # :1032-1035
-        elif li["sky_pixel_loss"]["enabled"]:
-            sm = sky_mask.float().unsqueeze(1).expand(-1, 3)
-            ld["sky_pixel_loss"] = self.sky_pixel_loss(inputs=linear_to_sRGB(outputs["hdr_background_colours"]), targets=image, mask=sm)
-        return scale_dict(ld, self.config.loss_coefficients)
+        if li["rgb_l2_loss"] or li["cosine_colour_loss"]:
+            raise NotImplementedError("rgb_l2_loss / cosine_colour_loss are outside the `neusky` method (neusky_config.py:104-105)")
+        dev = self.device
+        return self._fused_loss_dict(outputs, batch["image"].to(dev), batch["mask"].to(dev),
+                                     train_branch=self.training and not self.fitting_eval_latents)
 
     _FUSED_TERMS = ("rgb_l1_loss", "eikonal_loss", "fg_mask_loss", "hashgrid_density_loss", "ground_plane_loss", "sky_pixel_loss",
                     "visibility_sigmoid_loss", "sdf_level_set_visibility_loss")
 
-    def _fused_loss_dict(self, outputs: Dict[str, Any], image: torch.Tensor, mask: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """the train branch of get_loss_dict (:933-1035) through ops.MainLossesFn: one launch each way for the eight
-        closed-form terms (same formulas, same keys, same scale_dict semantics); the interlevel term keeps its own kernel"""
+    def _fused_loss_dict(self, outputs: Dict[str, Any], image: torch.Tensor, mask: torch.Tensor, train_branch: bool = True) -> Dict[str, torch.Tensor]:
+        """same formulas, same keys, same scale_dict semantics as the reference; a term whose input is absent stays out of the dict"""
         li = self.config.loss_inclusions
         learn = self.visibility_field is not None and self.visibility_threshold_method == "learnable"
-        sdf_t = outputs.get("sdf_at_termination") if li["sdf_level_set_visibility_loss"] else None
+        sdf_t = outputs.get("sdf_at_termination") if (train_branch and li["sdf_level_set_visibility_loss"]) else None
+        sky_ok = li["sky_pixel_loss"]["enabled"] and (train_branch or self.config.eval_latent_optimise_method != "nerf_osr_envmap")  # :1051
         present = {
-            "rgb_l1_loss": li["rgb_l1_loss"], "eikonal_loss": li["eikonal loss"], "fg_mask_loss": li["fg_mask_loss"],
-            "hashgrid_density_loss": li["hashgrid_density_loss"]["enabled"], "ground_plane_loss": li["ground_plane_loss"],
-            "sky_pixel_loss": li["sky_pixel_loss"]["enabled"], "visibility_sigmoid_loss": learn,
-            "sdf_level_set_visibility_loss": sdf_t is not None,
+            "rgb_l1_loss": li["rgb_l1_loss"], "eikonal_loss": train_branch and li["eikonal loss"], "fg_mask_loss": train_branch and li["fg_mask_loss"],
+            "hashgrid_density_loss": train_branch and li["hashgrid_density_loss"]["enabled"], "ground_plane_loss": train_branch and li["ground_plane_loss"],
+            "sky_pixel_loss": sky_ok, "visibility_sigmoid_loss": train_branch and learn, "sdf_level_set_visibility_loss": sdf_t is not None,
         }
         w = outputs["weights"]
         terms = ops.MainLossesFn.apply(
@@ -598,8 +559,8 @@ class NeuSkyFactoModel(ModelBase):
             outputs["normal"] if present["ground_plane_loss"] else None,
             outputs["hdr_background_colours"] if present["sky_pixel_loss"] else None,
             outputs["grid_density"] if present["hashgrid_density_loss"] else None,
-            sdf_t, self.visibility_threshold if learn else None,
-            self.sky_pixel_loss.alpha, li["visibility_sigmoid_loss"]["target_min_bias"])
+            sdf_t, self.visibility_threshold if present["visibility_sigmoid_loss"] else None,
+            self.sky_pixel_loss.alpha if li["sky_pixel_loss"]["enabled"] else 0.0, li["visibility_sigmoid_loss"]["target_min_bias"])
         coefs = self.config.loss_coefficients
         key = (tuple(float(coefs.get(k, 1.0)) if present[k] else 0.0 for k in self._FUSED_TERMS), str(terms.device))
         cv = _COEF_VECTORS.get(key)
@@ -608,7 +569,7 @@ class NeuSkyFactoModel(ModelBase):
         scaled = terms * cv  # nerfstudio scale_dict: keys missing from the coefficient table ('eikonal_loss') stay unscaled
         ld = LossDict({k: scaled[i] for i, k in enumerate(self._FUSED_TERMS) if present[k]})
         total = scaled.sum()
-        if li["interlevel_loss"]:
+        if train_branch and li["interlevel_loss"]:
             il = interlevel_loss(outputs["weights_list"], outputs["sbins_list"]) * float(coefs.get("interlevel_loss", 1.0))  # :987-988
             ld["interlevel_loss"] = il
             total = total + il

@@ -44,14 +44,9 @@ def set_precision_policy(policy: str) -> None:
     BWD_PRECISION = hip.PREC_F32 if policy == "f32" else hip.PREC_BF16X2
 
 
-# row-chunking of the FiLM-SIREN chain (keeps layer hand-offs inside the Infinity Cache): measured no gain on MI355X
-# (50.8 ms/step un-chunked, 51.1 @65536, 54.2 @32768, 65.2 @16384 rows) -> off by default
-FILM_ROW_CHUNK = int(_os.environ.get("NSKY_FILM_ROW_CHUNK", "0"))
-
-
 def fgemm(A, W, Cout, M, N, K, **k):
     """forward-pass dense layer (W = [out, in] weight, k-contiguous)"""
-    if USE_PLANES_FWD and FWD_PRECISION == hip.PREC_F16X2 and K % _PLANES_K_STEP == 0 and K >= _PLANES_MIN_K and N > 64 and M >= 4096:
+    if FWD_PRECISION == hip.PREC_F16X2 and K % _PLANES_K_STEP == 0 and K >= _PLANES_MIN_K and N > 64 and M >= 4096:
         return hip.gemm_planes(A, _planes(W, N, K, False, FWD_PRECISION), Cout, M, N, K, precision=FWD_PRECISION, **k)
     return hip.gemm(A, W, Cout, M, N, K, precision=FWD_PRECISION, **k)
 
@@ -153,10 +148,8 @@ def grad_bias(dZ, M, n_out, like):
 # storage; the weight tensor itself is held so its address cannot be recycled inside the step.  Dropped by begin_step()
 # (the optimiser has changed the weights) -- models call it from their own begin_step.
 _PLANES: dict = {}
-USE_PLANES = _os.environ.get("NSKY_GEMM_PLANES", "1") != "0"
-USE_PLANES_FWD = _os.environ.get("NSKY_GEMM_PLANES_FWD", "1") != "0"
-_PLANES_K_STEP = 4 if _os.environ.get("NSKY_PLANES_KTAIL", "1") != "0" else 32
-_PLANES_MIN_K = int(_os.environ.get("NSKY_PLANES_MIN_K", "36"))  # below: the layer is all epilogue, the 32-deep k-tile mostly padding
+_PLANES_K_STEP = 4   # the LDS-DMA kernel takes any K % 4 == 0 (a partial last k-tile multiplies the planes' zero padding)
+_PLANES_MIN_K = 36   # below: the layer is all epilogue, the 32-deep k-tile mostly padding
 
 
 def begin_step() -> None:
@@ -181,7 +174,7 @@ def ld(t):
 
 def grad_input(dZ, W, M, k_in, n_red, out, **epi):
     """dX[M, k_in] = dZ[M, n_red] @ W[n_red, k_in]   (W stored [out, in] = [n_red, k_in])."""
-    if USE_PLANES and BWD_PRECISION == hip.PREC_BF16X2 and n_red % _PLANES_K_STEP == 0 and n_red >= _PLANES_MIN_K and k_in > 64 and M >= 4096:
+    if BWD_PRECISION == hip.PREC_BF16X2 and n_red % _PLANES_K_STEP == 0 and n_red >= _PLANES_MIN_K and k_in > 64 and M >= 4096:
         return hip.gemm_planes(dZ, _planes(W, k_in, n_red, True, BWD_PRECISION), out, M, k_in, n_red, precision=BWD_PRECISION, **epi)
     return hip.gemm(dZ, W, out, M, k_in, n_red, a_kcontig=True, b_kcontig=False, precision=BWD_PRECISION, **epi)
 
@@ -297,7 +290,7 @@ class DenseFn(torch.autograd.Function):
 # =============================================================================================
 # FiLM-SIREN (DDF network, RENI-shaped illumination decoder)
 # =============================================================================================
-FUSED_FILM_MIN_ROWS = int(_os.environ.get("NSKY_FUSED_FILM_MIN_ROWS", "4096"))  # below: a few workgroups walking a ~0.3 ms chain
+FUSED_FILM_MIN_ROWS = 4096  # below: a handful of workgroups each walking a ~0.3 ms serial chain; the per-layer kernels are faster
 _FILM_STREAMS: dict = {}
 
 
@@ -344,16 +337,6 @@ class FilmSirenFn(torch.autograd.Function):
         return mw, mb, mwo, mbo, fw, fb, wb[o + 2 * n_film], wb[o + 2 * n_film + 1], o
 
     @staticmethod
-    def _chunks(M):
-        """Row chunks.  A chunk of 32768 rows keeps every producer -> consumer hand-off of the layer chain (33.5 MB per
-        [chunk, 256] matrix) inside the 256 MiB Infinity Cache, so the next layer's operand and aux reads are served
-        on-die instead of from HBM; the un-chunked chain streams 268 MB matrices through HBM between launches."""
-        ch = FILM_ROW_CHUNK
-        if ch <= 0 or M < 2 * ch:
-            return [(0, M)]
-        return [(r, min(M, r + ch)) for r in range(0, M, ch)]
-
-    @staticmethod
     def forward(ctx, x, cond, n_map, n_film, train_weights, need_dcond, *wb):
         M = x.shape[0]
         ctx.need_dx = x.requires_grad
@@ -392,7 +375,7 @@ class FilmSirenFn(torch.autograd.Function):
             zs = [None] * n_film
         FP = torch.empty(M, 2 * n_film * H, device=dev)
         res = torch.zeros(M, n_out_p, device=dev)
-        for r0, r1 in FilmSirenFn._chunks(M):
+        for r0, r1 in [(0, M)]:
             m = r1 - r0
             # mapping network: (Linear, LeakyReLU(0.2)) * n  -> Linear to 2*n_film*H  (siren.py:114-119)
             h = cond[r0:r1]
@@ -505,7 +488,7 @@ class FilmSirenFn(torch.autograd.Function):
         acc = (lambda iw: (grads[iw], grads[iw + 1])) if train_w else (lambda iw: None)
         d_x = torch.empty(M, fw[0].shape[1], device=dev) if ctx.need_dx else None
         d_cond = torch.empty(M, mw[0].shape[1], device=dev) if need_dcond else None
-        chunks = FilmSirenFn._chunks(M)
+        chunks = [(0, M)]
         mc = max(r1 - r0 for r0, r1 in chunks)
         dFP_buf = torch.empty(mc, NF, device=dev)
         dZa, dZb = torch.empty(mc, H, device=dev), torch.empty(mc, H, device=dev)

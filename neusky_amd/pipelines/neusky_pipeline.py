@@ -129,7 +129,7 @@ class NeuSkyPipeline(PipelineBase):
         model.set_step(step)
         model.begin_step()  # prepared-weight caches are per optimisation step
         fit = model.config.fit_visibility_field and model.visibility_field is not None
-        fuse = fit and model.config.use_visibility and model.training and os.environ.get("NSKY_FUSE_DDF_FIT", "1") != "0"
+        fuse = fit and model.config.use_visibility and model.training
         vis_batch = None
         if model.training:
             model.start_illumination(ray_bundle, randoms=randoms)  # second stream; joined inside the model's forward

@@ -13,9 +13,42 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, out_q):
+class _RendezvousError(RuntimeError):
+    pass
+
+
+def _init(rank, world, port, out_q) -> bool:
+    """rendezvous; a failure HERE (the port found free a moment ago was taken) is reported as such, so that only it is retried"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import datetime
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+        return True
+    except Exception as exc:  # noqa: BLE001
+        out_q.put(("rendezvous_error", rank, f"{type(exc).__name__}: {exc}"))
+        return False
+
+
+def _collect(q, procs, timeout):
+    res = []
+    try:
+        for _ in procs:
+            item = q.get(timeout=timeout)
+            if item and item[0] == "rendezvous_error":
+                raise _RendezvousError(item[2])
+            res.append(item)
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return sorted(res, key=lambda t: t[0])
+
+
+def _worker(rank, world, port, out_q):
+    if not _init(rank, world, port, out_q):
+        return
     from neusky_amd.distributed import GradientAllReduce
     torch.manual_seed(100 + rank)  # deliberately different initial replicas
     w = torch.nn.Parameter(torch.randn(5, 3))
@@ -45,7 +78,8 @@ def _worker(rank, world, port, out_q):
     opt.all_reduce_gradients()
     slab_ok = (torch.allclose(wa.grad, w.grad, atol=1e-7) and torch.allclose(ba.grad, b.grad, atol=1e-7)
                and torch.equal(ua.grad, torch.zeros(3)) and wa.grad.data_ptr() == opt.flat_g.data_ptr())
-    out_q.put((rank, w.detach().clone(), w.grad.clone(), b.grad.clone(), unused.grad.clone(), w2.grad.clone(), b2.grad.clone(), slab_ok))
+    # numpy, not tensors: a tensor crosses the queue as a shared-memory handle that dies with this process
+    out_q.put((rank,) + tuple(t.detach().numpy().copy() for t in (w, w.grad, b.grad, unused.grad, w2.grad, b2.grad)) + (bool(slab_ok),))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,39 +91,23 @@ def _run_two_ranks():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    try:
-        res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
-    finally:
-        for p in procs:
-            p.join(timeout=60)
-            if p.is_alive():
-                p.kill()
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    return res
-
-
-def _is_rendezvous_error(exc: BaseException) -> bool:
-    text = f"{type(exc).__name__}: {exc}".lower()
-    return any(k in text for k in ("address already in use", "eaddrinuse", "connection refused", "timed out", "timeout", "rendezvous", "empty"))
+    return _collect(q, procs, 120)
 
 
 def _run_with_one_rendezvous_retry(fn):
-    """the rendezvous port found free a moment ago can be taken by the time rank 0 binds it: ONE retry, for that failure only
-    (a crashed rank or a wrong result is never retried)"""
+    """the rendezvous port found free a moment ago can be taken by the time rank 0 binds it: ONE retry, for exactly that failure
+    (reported by the worker itself); a crashed rank, a hang or a wrong result is never retried"""
     try:
         return fn()
-    except AssertionError:
-        raise
-    except Exception as exc:  # noqa: BLE001
-        if not _is_rendezvous_error(exc):
-            raise
+    except _RendezvousError:
         return fn()
 
 
 def test_two_rank_gradient_allreduce_equals_single_process():
     os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")  # two freshly spawned interpreters must not race on __pycache__
     res = _run_with_one_rendezvous_retry(_run_two_ranks)
-    (_, w0, gw0, gb0, gu0, rw0, rb0, ok0), (_, w1, gw1, gb1, gu1, _, _, ok1) = res
+    (_, w0, gw0, gb0, gu0, rw0, rb0, ok0), (_, w1, gw1, gb1, gu1, _, _, ok1) = [
+        tuple(torch.from_numpy(v) if hasattr(v, "dtype") else v for v in item) for item in res]
     assert ok0 and ok1, "engine.Optimizers: single-slab all-reduce differs from the per-parameter one"
     assert torch.equal(w0, w1), "replicas differ after the parameter broadcast"
     assert torch.allclose(gw0, gw1) and torch.allclose(gb0, gb1), "ranks disagree after the all-reduce"
@@ -100,8 +118,8 @@ def test_two_rank_gradient_allreduce_equals_single_process():
 # ---------------------------------------------------------------------------------------------------------------------
 # the train loop's reduce path with the REAL parameter-group layout
 def _pipeline_worker(rank, world, port, out_q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if not _init(rank, world, port, out_q):
+        return
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from util_step import small_pipeline_config
@@ -158,15 +176,7 @@ def _run_pipeline_ranks():
     procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    try:
-        res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
-    finally:
-        for p in procs:
-            p.join(timeout=60)
-            if p.is_alive():
-                p.kill()
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    return res
+    return _collect(q, procs, 300)
 
 
 def test_two_rank_pipeline_groups_slab_and_replicas():

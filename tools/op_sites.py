@@ -8,7 +8,7 @@ import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 import bench
 from neusky_amd.engine import Optimizers, neusky_optimizers, train_iteration
-from util_step import randomise
+from neusky_amd.utils.randomise import randomise
 
 pipe = bench.build_pipeline("cuda:0", 1, 0)
 randomise(pipe)
