@@ -28,6 +28,7 @@ import torch.distributed as dist
 # fp32 matrix-core peak and HBM peak from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
 RAYS, SAMPLES, DIRECTIONS, PROPOSAL = 1024, 96, 512, (256, 96)
 
 
@@ -55,17 +56,18 @@ class KernelTimer:
     def __init__(self):
         self.records = {}
 
-    def _timed(self, key, fn, flops, executed, *a, **kw):
+    def _timed(self, key, fn, flops, executed, *a, nbytes=None, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = fn(*a, **kw)
         e1.record()
-        self.records.setdefault(key, []).append((e0, e1, flops, executed))
+        self.records.setdefault(key, []).append((e0, e1, flops, executed, nbytes))
         return out
 
     def install(self):
         from neusky_amd import hip
-        self._orig = {n: getattr(hip, n) for n in ("gemm", "gemm_planes", "film_chain_fwd", "film_chain_bwd_film", "film_chain_bwd_map")}
+        self._orig = {n: getattr(hip, n) for n in ("gemm", "gemm_planes", "film_chain_fwd", "film_chain_bwd_film", "film_chain_bwd_map",
+                                                   "wgrad_native_batch")}
         o, t = self._orig, self
 
         def gemm(A, B, Cout, M, N, K, **kw):
@@ -96,7 +98,20 @@ class KernelTimer:
             fl = 2.0 * M * (2 * nf * H * H + (nm - 1) * H * H + H * cd)
             return t._timed(f"film_bwd_map_kernel<{H}>", o["film_chain_bwd_map"], fl, fl, net, stream, table, M, *a, **kw)
 
+        def wgrad(problems, rows):
+            fl = sum(2.0 * rows * 32 * q.nnt_a * 32 * q.nnt_b for q in problems)
+            # algorithmic bytes: every operand matrix once (the layer input shared by the blocks of a wide layer counts once)
+            seen, by = set(), 0.0
+            for q in problems:
+                for p_, nt in ((q.dZ, q.nnt_a), (q.X, q.nnt_b)):
+                    if p_ not in seen:
+                        seen.add(p_)
+                        by += 4.0 * rows * 32 * nt
+            widths = sorted({32 * q.nnt_b for q in problems})
+            return t._timed(f"wgrad_native_kernel<{widths[-1]}>", o["wgrad_native_batch"], fl, fl, problems, rows, nbytes=by)
+
         hip.gemm, hip.gemm_planes, hip.film_chain_fwd, hip.film_chain_bwd_film, hip.film_chain_bwd_map = gemm, gemm_planes, fwd, bwd_film, bwd_map
+        hip.wgrad_native_batch = wgrad
 
     def uninstall(self):
         from neusky_amd import hip
@@ -106,11 +121,15 @@ class KernelTimer:
     def summary(self):
         out = []
         for key, recs in self.records.items():
-            ms = sum(a.elapsed_time(b) for a, b, _, _ in recs)
-            out.append({"kernel": key, "launches": len(recs), "total_ms": ms, "avg_launch_ms": ms / len(recs),
-                        "algorithmic_flops_per_launch": sum(r[2] for r in recs) / len(recs),
-                        "executed_flops_per_launch": sum(r[3] for r in recs) / len(recs),
-                        "achieved_tflops": sum(r[2] for r in recs) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0})
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            d = {"kernel": key, "launches": len(recs), "total_ms": ms, "avg_launch_ms": ms / len(recs),
+                 "algorithmic_flops_per_launch": sum(r[2] for r in recs) / len(recs),
+                 "executed_flops_per_launch": sum(r[3] for r in recs) / len(recs),
+                 "achieved_tflops": sum(r[2] for r in recs) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+            if all(r[4] is not None for r in recs):  # a streaming kernel: its HBM roofline beside the MFMA one
+                d["algorithmic_bytes_per_launch"] = sum(r[4] for r in recs) / len(recs)
+                d["achieved_GBs"] = sum(r[4] for r in recs) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            out.append(d)
         return sorted(out, key=lambda d: -d["total_ms"])
 
 
@@ -241,8 +260,10 @@ def main():
         # HIP events cannot be read back from inside a replayed graph: the heavy kernels' launches are timed with events on
         # one extra EAGER iteration of the same step (same kernels, shapes and stream) right after the timed region
         timer.install()
+        pipe.model.second_stream = False  # one stream: every timed kernel has the chip to itself
         train_iteration(pipe, opt, 3000, ray_bundle=batches[-1][0], batch=batches[-1][1])
         torch.cuda.synchronize()
+        pipe.model.second_stream = True
         timer.uninstall()
     else:
         for i in range(args.warmup):
@@ -256,8 +277,10 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         timer.install()
+        pipe.model.second_stream = False
         train_iteration(pipe, opt, 3000, ray_bundle=batches[-1][0], batch=batches[-1][1])
         torch.cuda.synchronize()
+        pipe.model.second_stream = True
         timer.uninstall()
     t = torch.tensor([dt], device=device)
     if world > 1:
@@ -295,6 +318,9 @@ def main():
         if os.path.exists(tsrc):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_bench.sh; not re-collected live)
             tj = json.load(open(tsrc))
             traffic = tj.get("bytes_per_launch", {}).get(dom["kernel"].split(" ")[0])
+        roof = {"bound": "mfma", "achieved": dom["achieved_tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["achieved_tflops"] / peak}
+        if "algorithmic_bytes_per_launch" in dom and dom["algorithmic_bytes_per_launch"] / (HBM_PEAK_GBS * 1e9) > dom["algorithmic_flops_per_launch"] / (peak * 1e12):
+            roof = {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["achieved_GBs"] / HBM_PEAK_GBS}
         fwd = "fp16 hi + residual split, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate (~2^-22; chains: power-of-two pre-scaled operands, one accumulator; field layers: 2^11-scaled residual, two accumulators)"
         bwd = ("FiLM-SIREN chains (83 % of the step's FLOPs) and their weight gradients: the same fp16 split on per-row / per-matrix pre-scaled gradients (fp32-grade); "
                "SDF / colour layers: 2-term bf16 split (2^-16 per product); proposal layers and all N <= 64 heads: exact fp32 MFMA")
@@ -309,8 +335,7 @@ def main():
                        "rays_per_gpu": RAYS, "samples_per_ray": SAMPLES, "illumination_directions": DIRECTIONS,
                        "parallelism": f"ray-sharded dp{world}", "final_loss": final_loss,
                        "launch": "HIP graph replay (1 graph/step + all-reduce + 5 Adam launches)" if use_graph else "eager (host launches every kernel)" + graph_note},
-            "roofline": {"bound": "mfma", "achieved": dom["achieved_tflops"], "peak": peak, "unit": "TFLOP/s",
-                         "frac": dom["achieved_tflops"] / peak, "traffic": traffic,
+            "roofline": {**roof, "traffic": traffic,
                          "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r02_pmc_traffic.json)",
                          "kernel": dom["kernel"] + " = the kernel family with the largest total time in the eager timing iteration",
                          "peak_note": "fp16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-grade product = 833.3 TFLOP/s of algorithmic FLOPs",

@@ -27,7 +27,7 @@ extern "C" {
 typedef void* nsky_stream_t; /* hipStream_t */
 
 const char* nsky_last_error(void);
-int nsky_abi_version(void); /* 3 (bumped when a struct layout or an entry point's signature changes) */
+int nsky_abi_version(void); /* 4 (bumped when a struct layout or an entry point's signature changes) */
 
 /* ------------------------------------------------------------------------------------------
  * Dense layer on the matrix cores: C[M,N] = epilogue( sum_k A(m,k) * B(n,k) + bias[n] )
@@ -168,6 +168,28 @@ int nsky_film_chain_bwd_film(const nsky_film_net* net, const void* stream_buf, c
 int nsky_film_chain_bwd_map(const nsky_film_net* net, const void* stream_buf, const float* table, int32_t M, const float* dfp,
                             const float* dfp_rowmax, const float* const* h_save, float* const* dpre_save, float* d_cond,
                             int32_t ldcond, float* gmax, nsky_stream_t stream);
+/* Weight and bias gradient of one dense layer of the chain straight over two tile-native matrices (what autograd's
+ * AddmmBackward / the MmBackward pair of nn.Linear computes for siren.py:59-66, :167-172 and the mapping network's layers):
+ *     dW[n, k] += sum_rows dZ[row, n] X[row, k]   (n < 32 nnt_a, k < 32 nnt_b; dW row-major, leading dimension ldw)
+ *     db[n]    += sum_rows dZ[row, n]             (db optional)
+ * dW / db are ACCUMULATED into (float atomics over a batch split): the caller zero-fills them or passes a gradient slab.
+ * nnt_a and nnt_b must be multiples of 4 (128 features).  a_scale_max: device scalar holding max |dZ| (gmax above), or null;
+ * b_scale: power of two applied to X before the fp16 hi + residual split (2^6 suits activations up to ~500).  Products are
+ * fp32-grade (three fp16 MFMAs per product, fp32 accumulation). */
+int nsky_wgrad_native(const float* dZ, int32_t nnt_a, const float* X, int32_t nnt_b, int32_t rows, float* dW, int32_t ldw,
+                      float* db, const float* a_scale_max, float b_scale, nsky_stream_t stream);
+/* The same for up to NSKY_WGRAD_MAX_PROBLEMS layers that share the batch (every layer of a chain's backward) in ONE launch:
+ * the batch split is shared, so the reduction traffic and the launch cost are paid once instead of per layer. */
+#define NSKY_WGRAD_MAX_PROBLEMS 16
+typedef struct {
+  const float* dZ; int32_t nnt_a;
+  const float* X;  int32_t nnt_b;
+  float* dW;       int32_t ldw;
+  float* db;                 /* may be null */
+  const float* a_scale_max;  /* may be null */
+  float b_scale;
+} nsky_wgrad_problem;
+int nsky_wgrad_native_batch(const nsky_wgrad_problem* problems, int32_t n_problems, int32_t rows, nsky_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multiresolution hash-grid encode (tiny-cuda-nn HashGrid semantics, fp32) fused with the rest of

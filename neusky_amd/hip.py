@@ -52,7 +52,7 @@ class GemmDesc(C.Structure):
 
 _lib.nsky_last_error.restype = C.c_char_p
 _lib.nsky_abi_version.restype = C.c_int
-ABI_VERSION = 3  # the ctypes structures below mirror this version of include/neusky_hip.h
+ABI_VERSION = 4  # the ctypes structures below mirror this version of include/neusky_hip.h
 if _lib.nsky_abi_version() != ABI_VERSION:
     raise NeuSkyHipError(f"libneusky_hip.so has ABI version {_lib.nsky_abi_version()}, this package binds version {ABI_VERSION}: rebuild (build.sh)")
 
@@ -444,6 +444,43 @@ _film_bwd_film = _sig("nsky_film_chain_bwd_film", C.POINTER(FilmNet), C.c_void_p
                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
 _film_bwd_map = _sig("nsky_film_chain_bwd_map", C.POINTER(FilmNet), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                      C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p)
+
+
+_wgrad_native = _sig("nsky_wgrad_native", C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                     C.c_void_p, C.c_float, C.c_void_p)
+
+
+class WgradProblem(C.Structure):
+    _fields_ = [("dZ", C.c_void_p), ("nnt_a", C.c_int32), ("X", C.c_void_p), ("nnt_b", C.c_int32), ("dW", C.c_void_p), ("ldw", C.c_int32),
+                ("db", C.c_void_p), ("a_scale_max", C.c_void_p), ("b_scale", C.c_float)]
+
+
+WGRAD_MAX_PROBLEMS = 16
+_wgrad_native_batch = _sig("nsky_wgrad_native_batch", C.POINTER(WgradProblem), C.c_int32, C.c_int32, C.c_void_p)
+
+
+def wgrad_problem(dZ, nnt_a, X, nnt_b, rows, dW, db=None, a_scale_max=None, b_scale=64.0) -> WgradProblem:
+    assert dW.stride(1) == 1 and dW.shape[0] >= 32 * nnt_a and dW.shape[1] >= 32 * nnt_b
+    assert dZ.numel() >= film_rows(rows) * 32 * nnt_a and X.numel() >= film_rows(rows) * 32 * nnt_b
+    return WgradProblem(ptr(dZ), nnt_a, ptr(X), nnt_b, ptr(dW), ld(dW), ptr(db), ptr(a_scale_max), float(b_scale))
+
+
+def wgrad_native_batch(problems, rows):
+    """every problem: dW += dZ^T X, db += column sums of dZ over tile-native matrices sharing the batch `rows`; ONE launch
+    (csrc/wgrad_native.hip).  problems: list of wgrad_problem(...), at most WGRAD_MAX_PROBLEMS."""
+    for i in range(0, len(problems), WGRAD_MAX_PROBLEMS):
+        chunk = problems[i:i + WGRAD_MAX_PROBLEMS]
+        arr = (WgradProblem * len(chunk))(*chunk)
+        check(_wgrad_native_batch(arr, len(chunk), rows, stream_ptr()), "nsky_wgrad_native_batch")
+
+
+def wgrad_native(dZ, nnt_a, X, nnt_b, rows, dW, db=None, a_scale_max=None, b_scale=64.0):
+    """dW[32 nnt_a, 32 nnt_b] += dZ^T X and db += column sums of dZ over two tile-native matrices (csrc/wgrad_native.hip);
+    dW / db are accumulated into.  nnt_a, nnt_b: multiples of 4."""
+    wgrad_problem(dZ, nnt_a, X, nnt_b, rows, dW, db, a_scale_max, b_scale)  # shape checks
+    check(_wgrad_native(ptr(dZ), nnt_a, ptr(X), nnt_b, rows, ptr(dW), ld(dW), ptr(db), ptr(a_scale_max), float(b_scale), stream_ptr()),
+          "nsky_wgrad_native")
+    return dW
 
 
 def film_supported(hidden, map_hidden, n_map, n_film, cond_dim, x_dim, out_dim) -> bool:

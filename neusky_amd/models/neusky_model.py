@@ -300,13 +300,17 @@ class NeuSkyFactoModel(ModelBase):
         before the DDF-fit ground-truth pass, whose sampler geometry is a run of ~180 small launches that leave the chip
         idle, so the decode's dense layers fill it."""
         cam = ray_bundle.camera_indices.reshape(-1)
-        if not (self.training and cam.is_cuda):
+        if not (self.training and cam.is_cuda and self.second_stream):
             return
         main = torch.cuda.current_stream()
         side = self._illumination_stream()
         side.wait_stream(main)
         with torch.cuda.stream(side):
             self._illumination_pending = self.sample_illumination_compact(cam, ray_bundle.directions, rotation, randoms)
+
+    # False: the illumination decode runs in line on the caller's stream (bench.py's per-kernel timing iteration, where a kernel
+    # sharing the chip with the other stream's work would be timed with that work's share of the CUs missing)
+    second_stream: bool = True
 
     def _illumination_stream(self):
         s = getattr(self, "_illum_stream", None)
@@ -408,7 +412,7 @@ class NeuSkyFactoModel(ModelBase):
         # The illumination decode (big dense layers, nothing but the camera indices as input) runs on a second HIP stream
         # beside the proposal sampler + field pass (hundreds of small launches): a fork/join that the HIP graph keeps as
         # two parallel branches, forward and backward (autograd replays each node on its forward stream).
-        fork = self.training and cam.is_cuda
+        fork = self.training and cam.is_cuda and self.second_stream
         pending = getattr(self, "_illumination_pending", None)
         self._illumination_pending = None
         if fork and pending is not None:  # started by start_illumination (the pipeline, before the DDF-fit ground truth pass)

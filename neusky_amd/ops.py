@@ -438,20 +438,27 @@ class FilmSirenFn(torch.autograd.Function):
                     off += sizes[idx]
             acc = lambda iw: (grads[iw], grads[iw + 1])  # noqa: E731
             nt, ntm = H // 32, Hm // 32
-            # head and FiLM layers
-            grad_weight(d_res, ys[-1], M, ow.shape[0], H, ow, ob, acc=acc(o + 2 * n_film), b_native_nt=nt)
+            # layers whose two operands are tile-native (FiLM layers 1.., the mapping head, mapping layers 1..): ONE launch of the
+            # streaming weight-gradient kernel for all of them; the rest (row-major d_res / x / cond operands) per layer
+            native = []
+
+            def wgrad(dZ, X, n_out, k_in, like, bias_like, iw, a_nt, b_nt, smax):
+                if a_nt > 0 and b_nt > 0 and a_nt % 4 == 0 and b_nt % 4 == 0 and smax is not None:
+                    native.append(hip.wgrad_problem(dZ, a_nt, X, b_nt, M, grads[iw], grads[iw + 1], smax))
+                else:
+                    grad_weight(dZ, X, M, n_out, k_in, like, bias_like, acc=acc(iw), a_native_nt=a_nt, b_native_nt=b_nt, a_scale_max=smax)
+
+            wgrad(d_res, ys[-1], ow.shape[0], H, ow, ob, o + 2 * n_film, 0, nt, None)
             for i in range(n_film - 1, 0, -1):
-                grad_weight(dzs[i], ys[i - 1], M, H, H, fw[i], fb[i], acc=acc(o + 2 * i), a_native_nt=nt, b_native_nt=nt, a_scale_max=gmax[i:i + 1])
-            grad_weight(dzs[0], x, M, H, fw[0].shape[1], fw[0], fb[0], acc=acc(o), a_native_nt=nt)
-            # mapping head and layers
-            grad_weight(dfp, hs[-1], M, 2 * n_film * H, Hm, mwo, mbo, acc=acc(2 * n_map), a_native_nt=2 * n_film * nt, b_native_nt=ntm,
-                        a_scale_max=gmax[n_film:n_film + 1])
+                wgrad(dzs[i], ys[i - 1], H, H, fw[i], fb[i], o + 2 * i, nt, nt, gmax[i:i + 1])
+            wgrad(dzs[0], x, H, fw[0].shape[1], fw[0], fb[0], o, nt, 0, None)
+            wgrad(dfp, hs[-1], 2 * n_film * H, Hm, mwo, mbo, 2 * n_map, 2 * n_film * nt, ntm, gmax[n_film:n_film + 1])
             for l in range(n_map - 1, 0, -1):
-                grad_weight(dpres[l], hs[l - 1], M, Hm, Hm, mw[l], mb[l], acc=acc(2 * l), a_native_nt=ntm, b_native_nt=ntm,
-                            a_scale_max=gmax[n_film + 1 + l:n_film + 2 + l])
+                wgrad(dpres[l], hs[l - 1], Hm, Hm, mw[l], mb[l], 2 * l, ntm, ntm, gmax[n_film + 1 + l:n_film + 2 + l])
             k0 = mw[0].shape[1]
-            grad_weight(dpres[0], cond, M, Hm, k0, mw[0], mb[0], acc=acc(0), a_native_nt=ntm,
-                        a_scale_max=gmax[n_film + 1:n_film + 2] if k0 > 64 else None)
+            wgrad(dpres[0], cond, Hm, k0, mw[0], mb[0], 0, ntm, 0, gmax[n_film + 1:n_film + 2] if k0 > 64 else None)
+            if native:
+                hip.wgrad_native_batch(native, M)
         return (d_x, d_cond, None, None, None, None, *[None if sunk[i] else g for i, g in enumerate(grads)])
 
     @staticmethod
