@@ -401,6 +401,221 @@ __global__ __launch_bounds__(256) void encode_bwd_coarse_kernel(Grid g, const fl
   }
 }
 
+// ---- table gradient, owner-computes form --------------------------------------------------------------------------------
+// The scatter above is bound by the L2 atomic units: one request per touched 64-B line and wave instruction, ~3.4e10 requests
+// per second chip-wide, and a hashed level sends every corner of every point to a different line.  Here a workgroup OWNS a
+// 16384-entry chunk of one level's slab (128 KB of float2 accumulators in LDS) and adds every corner that lands in it with
+// ds_add_f32; the chunk is written back once, as whole lines.  Three things keep the owners cheap:
+//   * a pre-pass writes ONE 32-bit key per (level, point): for a hashed level the chunk numbers of its four (y, z) corner pairs
+//     (x and x + 1 differ below bit 14, the chunk bits start there: the two x-corners of a pair share a chunk), for a dense level
+//     the index of corner 0.  An owner's walk over all points is then a coalesced key load and a few compares per point;
+//   * the points that pass (1/8 of them on a hashed level) are queued in LDS and worked through by full waves -- positions,
+//     weights and the exact corner indices are recomputed only for those;
+//   * ds_add_f32 retires about one lane per clock and CU, so a level's adds must be spread over ~32 workgroups: levels with
+//     few chunks (the dense ones) split their POINTS over several workgroups per chunk, whose write-backs are then atomic.
+constexpr int OWN_CH = 16384;            // entries per chunk (a power of two: chunk number = index >> 14)
+constexpr int OWN_SHIFT = 14;
+constexpr int OWN_THREADS = 1024;
+constexpr int OWN_U = 12;                // keys per thread and trip (the queue of a trip: 12288 x 2 B beside the 128 KB chunk)
+constexpr int OWN_TRIP = OWN_THREADS * OWN_U;
+constexpr int OWN_WG_PER_LEVEL = 32;
+constexpr uint32_t KEY_ALWAYS = 0xFFFFFFFFu;  // dense level, point outside the grid: every owner looks at it
+
+struct OwnerArgs {
+  Grid g;
+  const float* x;
+  const float* dY;
+  const float* dT;
+  float* dtable;
+  uint32_t* keys;          // [n_levels_owned][P]
+  int P, mode, feat0, lddy;
+  int n_levels_owned;      // scatter levels
+  int level[16];           // their level numbers
+  int splits[16];          // workgroups sharing a chunk of that level (each takes 1/splits of the points; > 1: atomic write-back)
+  int wg0[17];             // prefix sums of workgroups per owned level
+};
+
+__host__ __device__ __forceinline__ bool level_is_dense(uint32_t size, uint32_t res) {
+  return (unsigned long long)res * res * res <= (unsigned long long)size;
+}
+
+struct F3 { float v[3]; };
+constexpr uint32_t HASH_P1 = 2654435761u, HASH_P2 = 805459861u;
+
+__global__ __launch_bounds__(256) void owner_keys_kernel(OwnerArgs a) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.P) return;
+  const F3 xv = reinterpret_cast<const F3*>(a.x)[p];
+  float pos[3], J[3][3];
+  grid_position(xv.v, a.mode, pos, J);
+  for (int li = 0; li < a.n_levels_owned; ++li) {
+    const int level = a.level[li];
+    const float scale = a.g.scale[level];
+    const uint32_t res = (uint32_t)a.g.resolution[level];
+    const uint32_t size = a.g.offset[level + 1] - a.g.offset[level];
+    uint32_t pg[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) pg[d] = (uint32_t)(int)floorf(fmaf(scale, pos[d], 0.5f));
+    uint32_t key;
+    if (level_is_dense(size, res)) {
+      // corner 0's index; a point whose cell is not inside the grid (index arithmetic wraps, grid_index's modulo bites) is rare
+      const bool inside = pg[0] < res - 1u && pg[1] < res - 1u && pg[2] < res - 1u;  // (a negative cell is a huge unsigned number)
+      key = inside ? pg[0] + pg[1] * res + pg[2] * res * res : KEY_ALWAYS;
+    } else {
+      const uint32_t smask = size - 1, Y0 = pg[1] * HASH_P1, Z0 = pg[2] * HASH_P2;
+      const uint32_t yz[4] = {Y0 ^ Z0, (Y0 + HASH_P1) ^ Z0, Y0 ^ (Z0 + HASH_P2), (Y0 + HASH_P1) ^ (Z0 + HASH_P2)};
+      // x and x + 1 agree above bit 13 unless x ends in fourteen ones (cell -1 is the common case): their shared high bits are
+      // folded into the pair's chunk number; the rare carry case is flagged and looked at by every owner of the level
+      const uint32_t xhi = pg[0] & ~(uint32_t)(OWN_CH - 1);
+      key = 0;
+#pragma unroll
+      for (int bc = 0; bc < 4; ++bc) key |= (((yz[bc] ^ xhi) & smask) >> OWN_SHIFT) << (5 * bc);
+      if ((pg[0] & (uint32_t)(OWN_CH - 1)) == (uint32_t)(OWN_CH - 1)) key |= 0x80000000u;
+    }
+    a.keys[(long)li * a.P + p] = key;
+  }
+}
+
+template <bool TANGENTS>
+__global__ __launch_bounds__(OWN_THREADS) void encode_bwd_owner_kernel(OwnerArgs a) {
+  extern __shared__ float acc[];  // 2 * OWN_CH accumulators, then the queue of one trip (point number - trip start) and its counter
+  uint16_t* queue = reinterpret_cast<uint16_t*>(acc + 2 * OWN_CH);
+  uint32_t* qn = reinterpret_cast<uint32_t*>(queue + OWN_TRIP);
+  const int tid = threadIdx.x, lane = tid & 63;
+  int li = 0;
+  while (li + 1 < a.n_levels_owned && (int)blockIdx.x >= a.wg0[li + 1]) ++li;
+  const int level = a.level[li], splits = a.splits[li];
+  const int item = (int)blockIdx.x - a.wg0[li];
+  const uint32_t chunk = (uint32_t)(item / splits);
+  const int ps = item % splits;
+  const Grid& g = a.g;
+  const float scale = g.scale[level];
+  const uint32_t res = (uint32_t)g.resolution[level];
+  const uint32_t size = g.offset[level + 1] - g.offset[level];
+  const bool dense = level_is_dense(size, res);
+  const uint32_t smask = size - 1;  // hashed: size is a power of two (checked on the host), grid_index's modulo is this mask
+  const uint32_t c_beg = chunk * OWN_CH;
+  const int n_own = (int)min((uint32_t)OWN_CH, size - c_beg);
+  const uint32_t span = 1u + res + res * res;  // dense: corner 7's index minus corner 0's
+  for (int i = tid; i < 2 * OWN_CH; i += OWN_THREADS) acc[i] = 0.0f;
+  if (tid == 0) *qn = 0;
+  __syncthreads();
+
+  const int per = (a.P + splits - 1) / splits;
+  const int p_beg = ps * per, p_end = min(a.P, p_beg + per);
+  const int col = a.feat0 + 2 * level;
+  const bool smooth = g.smoothstep != 0;
+  const uint32_t* keys = a.keys + (long)li * a.P;
+  const F3* xs = reinterpret_cast<const F3*>(a.x);
+  // The walk is latency bound (keys from L2, then per queued point a 12-byte position gather and its dY row): the next trip's
+  // keys are requested before this trip's queue is worked through, and a queued point's two loads are issued together.
+  uint32_t key[OWN_U];
+  auto fetch_keys = [&](int p0) {
+#pragma unroll
+    for (int u = 0; u < OWN_U; ++u) key[u] = keys[min(p0 + u * OWN_THREADS + tid, p_end - 1)];
+  };
+  if (p_beg < p_end) fetch_keys(p_beg);
+  for (int p0 = p_beg; p0 < p_end; p0 += OWN_TRIP) {
+    // ---- walk: one key per point; candidates go to the queue (wave-aggregated reservation)
+#pragma unroll
+    for (int u = 0; u < OWN_U; ++u) {
+      const int p = p0 + u * OWN_THREADS + tid;
+      bool cand;
+      if (dense) {
+        cand = key[u] == KEY_ALWAYS || (key[u] + span >= c_beg && key[u] < c_beg + (uint32_t)OWN_CH);
+      } else {
+        cand = (key[u] >> 31) != 0u;
+#pragma unroll
+        for (int bc = 0; bc < 4; ++bc) cand = cand || (((key[u] >> (5 * bc)) & 31u) == chunk);
+      }
+      cand = cand && p < p_end;
+      const unsigned long long bal = __ballot(cand);
+      if (bal) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(qn, (uint32_t)__popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (cand) queue[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)(p - p0);
+      }
+    }
+    if (p0 + OWN_TRIP < p_end) fetch_keys(p0 + OWN_TRIP);
+    __syncthreads();
+    // ---- the queued points, by full waves: exact corner indices, weights, adds
+    const int nq = (int)*qn;
+    for (int e = tid; e < nq; e += OWN_THREADS) {
+      const int p = p0 + (int)queue[e];
+      const F3 xv = xs[p];
+      const float2 gy = *reinterpret_cast<const float2*>(a.dY + (long)p * a.lddy + col);
+      float2 gt[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+      if (TANGENTS)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gt[k] = *reinterpret_cast<const float2*>(a.dT + ((long)k * a.P + p) * a.lddy + col);
+      float pos[3], J[3][3];
+      grid_position(xv.v, a.mode, pos, J);
+      uint32_t pg[3];
+      float w[3], dw[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const float q = fmaf(scale, pos[d], 0.5f);
+        const float fl = floorf(q);
+        pg[d] = (uint32_t)(int)fl;
+        const float td = q - fl;
+        w[d] = smooth ? td * td * (3.0f - 2.0f * td) : td;
+        dw[d] = smooth ? 6.0f * td * (1.0f - td) * scale : scale;
+      }
+      float2 gpa[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};  // gradient w.r.t. d feat / d pos_a, pulled back through J
+      if (TANGENTS)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int d = 0; d < 3; ++d) { gpa[d].x = fmaf(gt[k].x, J[d][k], gpa[d].x); gpa[d].y = fmaf(gt[k].y, J[d][k], gpa[d].y); }
+      // y / z terms of the index in wrapping 32-bit arithmetic, as grid_index forms them: hashed y P1 ^ z P2, dense y res + z res^2
+      const uint32_t YM = dense ? res : HASH_P1, ZM = dense ? res * res : HASH_P2;
+      const uint32_t Y0 = pg[1] * YM, Z0 = pg[2] * ZM;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t xk = pg[0] + (k & 1), yk = Y0 + ((k & 2) ? YM : 0u), zk = Z0 + ((k & 4) ? ZM : 0u);
+        uint32_t idx;
+        if (dense) {
+          idx = xk + yk + zk;
+          if (idx >= size) idx %= size;
+        } else {
+          idx = (xk ^ yk ^ zk) & smask;
+        }
+        if ((idx >> OWN_SHIFT) != chunk) continue;
+        const float wx = (k & 1) ? w[0] : 1.0f - w[0];
+        const float wy = (k & 2) ? w[1] : 1.0f - w[1];
+        const float wz = (k & 4) ? w[2] : 1.0f - w[2];
+        float a0 = wx * wy * wz * gy.x, a1 = wx * wy * wz * gy.y;
+        if (TANGENTS) {
+          const float cx = ((k & 1) ? dw[0] : -dw[0]) * wy * wz;
+          const float cy = ((k & 2) ? dw[1] : -dw[1]) * wx * wz;
+          const float cz = ((k & 4) ? dw[2] : -dw[2]) * wx * wy;
+          a0 += cx * gpa[0].x + cy * gpa[1].x + cz * gpa[2].x;
+          a1 += cx * gpa[0].y + cy * gpa[1].y + cz * gpa[2].y;
+        }
+        const int loc = (int)(idx - c_beg);
+        atomicAdd(acc + 2 * loc, a0);      // ds_add_f32
+        atomicAdd(acc + 2 * loc + 1, a1);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) *qn = 0;
+    __syncthreads();
+  }
+  float* out = a.dtable + 2l * (g.offset[level] + c_beg);
+  if (splits == 1) {
+    for (int i = tid; i < 2 * n_own; i += OWN_THREADS) {
+      const float v = acc[i];
+      if (v != 0.0f) out[i] += v;  // this workgroup is the only writer of these entries in the launch
+    }
+  } else {
+    for (int i = tid; i < 2 * n_own; i += OWN_THREADS) {
+      const float v = acc[i];
+      if (v != 0.0f) atomicAdd(out + i, v);
+    }
+  }
+}
+
 __global__ void hash_indices_kernel(Grid g, const float* __restrict__ x, int P, int mode, uint32_t* __restrict__ out) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long)P * g.n_levels) return;
@@ -445,9 +660,21 @@ extern "C" int nsky_encode_fwd(const nsky_hashgrid_desc* d, const float* x, int3
   return NSKY_OK;
 }
 
+static int fine_levels(const Grid& g) {  // levels that do not fit the LDS-privatised coarse pass
+  int n_coarse = 0;
+  while (n_coarse < g.n_levels && (size_t)g.offset[n_coarse + 1] * 2 * sizeof(float) <= 144 * 1024) ++n_coarse;
+  return g.n_levels - n_coarse;
+}
+
+extern "C" int64_t nsky_encode_bwd_workspace_bytes(const nsky_hashgrid_desc* d, int32_t P) {
+  Grid g;
+  if (make_grid(d, g, "nsky_encode_bwd_workspace_bytes") != NSKY_OK || P < NSKY_ENCODE_BWD_OWNER_MIN_POINTS) return 0;
+  return (int64_t)fine_levels(g) * P * (int64_t)sizeof(uint32_t);
+}
+
 extern "C" int nsky_encode_bwd(const nsky_hashgrid_desc* d, const float* x, int32_t P, int32_t mode, int32_t include_x,
                                int32_t pe_freqs, float pe_max_exp, const float* dY, int32_t lddy, const float* dT, float* dtable,
-                               float* dx, nsky_stream_t stream) {
+                               float* dx, void* workspace, nsky_stream_t stream) {
   Grid g;
   if (int rc = make_grid(d, g, "nsky_encode_bwd")) return rc;
   if (P == 0) return NSKY_OK;
@@ -465,8 +692,8 @@ extern "C" int nsky_encode_bwd(const nsky_hashgrid_desc* d, const float* x, int3
     dim3 grid(ceil_div(P, ppb));
     // raise the dynamic-LDS ceiling once per process (not a stream operation; kept out of captured regions)
     static bool attr_set = [] {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_coarse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_coarse_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_coarse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_coarse_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       return true;
     }();
     (void)attr_set;
@@ -478,12 +705,53 @@ extern "C" int nsky_encode_bwd(const nsky_hashgrid_desc* d, const float* x, int3
     NSKY_CHECK_LAUNCH("nsky_encode_bwd(coarse)");
   }
   if (n_coarse < g.n_levels) {
-    dim3 grid(ceil_div(P, 16), g.n_levels - n_coarse);
-    if (dT)
-      hipLaunchKernelGGL(encode_bwd_scatter_kernel<true>, grid, dim3(256), 0, s, g, x, P, mode, feat0, dY, lddy, dT, dtable, n_coarse);
-    else
-      hipLaunchKernelGGL(encode_bwd_scatter_kernel<false>, grid, dim3(256), 0, s, g, x, P, mode, feat0, dY, lddy, dT, dtable, n_coarse);
-    NSKY_CHECK_LAUNCH("nsky_encode_bwd(scatter)");
+    // fine / hashed levels.  Many points: chunk owners (LDS accumulation, above); few points: the direct scatter (an owner walks
+    // every point for each of its ~10^2..10^3 chunks, which only pays once the atomics it replaces outnumber that walk)
+    bool own_ok = workspace != nullptr;  // hashed slabs of 2^T <= 2^19 entries (what tcnn's geometry produces): 5-bit chunk numbers
+    for (int l = n_coarse; l < g.n_levels; ++l) {
+      const uint32_t sz = g.offset[l + 1] - g.offset[l];
+      if (!level_is_dense(sz, (uint32_t)g.resolution[l]) && ((sz & (sz - 1)) != 0 || sz > 32u * OWN_CH)) own_ok = false;
+    }
+    if (P >= NSKY_ENCODE_BWD_OWNER_MIN_POINTS && own_ok) {
+      OwnerArgs oa;
+      oa.g = g; oa.x = x; oa.dY = dY; oa.dT = dT; oa.dtable = dtable; oa.P = P; oa.mode = mode; oa.feat0 = feat0; oa.lddy = lddy;
+      oa.keys = reinterpret_cast<uint32_t*>(workspace);
+      oa.n_levels_owned = 0;
+      int wgs = 0;
+      for (int l = n_coarse; l < g.n_levels; ++l) {
+        const int nch = ceil_div((long)(g.offset[l + 1] - g.offset[l]), OWN_CH);
+        // hashed: the hash spreads a level's adds evenly over its 32 chunks; dense: the points' spatial distribution decides,
+        // and a scene's points crowd a few slabs -- twice the workgroups per level, split over the points
+        const bool dense_l = level_is_dense(g.offset[l + 1] - g.offset[l], (uint32_t)g.resolution[l]);
+        int sp = (dense_l ? 2 * OWN_WG_PER_LEVEL : OWN_WG_PER_LEVEL) / nch;
+        if (sp < 1) sp = 1;
+        oa.level[oa.n_levels_owned] = l;
+        oa.splits[oa.n_levels_owned] = sp;
+        oa.wg0[oa.n_levels_owned++] = wgs;
+        wgs += nch * sp;
+      }
+      oa.wg0[oa.n_levels_owned] = wgs;
+      static bool own_attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_owner_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_owner_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true;
+      }();
+      (void)own_attr;
+      hipLaunchKernelGGL(owner_keys_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, s, oa);
+      const size_t smem = 2 * OWN_CH * sizeof(float) + OWN_TRIP * sizeof(uint16_t) + 16;
+      if (dT)
+        hipLaunchKernelGGL(encode_bwd_owner_kernel<true>, dim3(wgs), dim3(OWN_THREADS), smem, s, oa);
+      else
+        hipLaunchKernelGGL(encode_bwd_owner_kernel<false>, dim3(wgs), dim3(OWN_THREADS), smem, s, oa);
+      NSKY_CHECK_LAUNCH("nsky_encode_bwd(owner)");
+    } else {
+      dim3 grid(ceil_div(P, 16), g.n_levels - n_coarse);
+      if (dT)
+        hipLaunchKernelGGL(encode_bwd_scatter_kernel<true>, grid, dim3(256), 0, s, g, x, P, mode, feat0, dY, lddy, dT, dtable, n_coarse);
+      else
+        hipLaunchKernelGGL(encode_bwd_scatter_kernel<false>, grid, dim3(256), 0, s, g, x, P, mode, feat0, dY, lddy, dT, dtable, n_coarse);
+      NSKY_CHECK_LAUNCH("nsky_encode_bwd(scatter)");
+    }
   }
   if (dx) {  // first-order input gradient (lane = point kernel, no table traffic)
     dim3 grid(ceil_div(P, PB));

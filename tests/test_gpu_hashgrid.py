@@ -71,12 +71,13 @@ def test_forward_rows_and_tangents(smooth, mode):
     assert (tn - jac).abs().max().item() < 5e-4 * scale, ((tn - jac).abs().max().item(), scale)
 
 
-@pytest.mark.parametrize("smooth,mode,with_t", [(True, 1, True), (False, 0, False)])
-def test_backward_table_and_input(smooth, mode, with_t):
+# P = 777: direct scatter of the fine levels; P = 33000: chunk-owner kernel (>= 32768 points; T = 2^15 -> two chunks per hashed level)
+@pytest.mark.parametrize("smooth,mode,with_t,P,log2T", [(True, 1, True, 777, 14), (False, 0, False, 777, 14),
+                                                        (True, 1, True, 33000, 15), (False, 0, False, 33000, 15)])
+def test_backward_table_and_input(smooth, mode, with_t, P, log2T):
     from neusky_amd import hip
-    geom, cfg, table = _setup(smooth, n_levels=8, log2T=14, max_res=256)
+    geom, cfg, table = _setup(smooth, n_levels=8, log2T=log2T, max_res=256)
     g = torch.Generator().manual_seed(3)
-    P = 777
     x = (torch.rand(P, 3, generator=g) * 2 - 1) * (1.2 if mode == 1 else 1.0)
     pe = 6 if mode == 1 else 0
     width = 3 + 6 * pe + 2 * geom.n_levels
@@ -111,6 +112,39 @@ def test_backward_table_and_input(smooth, mode, with_t):
     assert (dtab.cpu().double() - gt_ref).abs().max().item() < 5e-4 * scale
     sx = gx_ref.abs().max().item()
     assert (dx.cpu().double() - gx_ref).abs().max().item() < 5e-4 * sx
+
+
+@pytest.mark.parametrize("smooth,mode,with_t,P", [(False, 0, False, 262144 + 1312), (True, 1, True, 98304), (True, 1, False, 263168)])
+def test_owner_kernel_equals_direct_scatter_at_full_size(smooth, mode, with_t, P):
+    """the step's grids (L = 16, T = 2^19, 16 -> 2048): table gradient from the chunk-owner kernel (one call, P >= 32768) against
+    the direct scatter (no workspace handed in), accumulated into a table that is not zero"""
+    from neusky_amd import hip
+    from neusky_amd.encoding import HashGridGeometry
+    geom = HashGridGeometry(smoothstep=smooth)
+    g = torch.Generator().manual_seed(11)
+    table = ((torch.rand(geom.n_params, 2, generator=g) * 2 - 1) * 1e-2).to(DEV)
+    x = torch.rand(P, 3, generator=g) * 2 - 1
+    x = torch.nn.functional.normalize(x, dim=-1) if mode == 0 else x * 1.3  # sphere points (DDF) / contracted scene points
+    x = x.to(DEV).contiguous()
+    pe = 6 if mode == 1 else 0
+    width = 3 + 6 * pe + 2 * geom.n_levels
+    ldy = (width + 3) // 4 * 4
+    dY = torch.randn(P, ldy, generator=g).to(DEV)
+    dT = torch.randn(3, P, ldy, generator=g).to(DEV) if with_t else None
+    base = torch.randn(geom.n_params, 2, generator=g).to(DEV) * 1e-3
+    a = base.clone()
+    hip.encode_bwd(geom, table, x, mode, True, pe, 5.0, dY, dT, a, None)
+    b = base.clone()
+    hip.encode_bwd(geom, table, x, mode, True, pe, 5.0, dY, dT, b, None, workspace=None)  # no scratch: the direct scatter
+    torch.cuda.synchronize()
+    scale = float((b - base).abs().max())
+    assert scale > 0
+    err = float((a - b).abs().max())
+    assert err < 2e-5 * scale, (err, scale)
+    # every level received gradient through both paths
+    for lvl in range(geom.n_levels):
+        sl = slice(geom.offsets[lvl], geom.offsets[lvl + 1])
+        assert float((a[sl] - base[sl]).abs().max()) > 0
 
 
 def test_empty_and_bad_args():

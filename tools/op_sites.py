@@ -58,8 +58,8 @@ byfile = collections.Counter()
 for s, n in sites.items():
     byfile[s.split(":")[0]] += n
 print("by file:", dict(byfile.most_common()))
-for s, n in sites.most_common(110):
-    top = ", ".join(f"{k.replace('aten.', '')}x{v}" for k, v in ops_at[s].most_common(5))
+for s, n in sites.most_common(400):
+    top = ", ".join(f"{k.replace('aten.', '')}x{v}" for k, v in ops_at[s].most_common(8))
     print(f"{n:5d}  {s:60s} {top}")
 print("---- slices / selects / index of tensors that require grad (each costs a zeros + copy pair in backward)")
 for s_, n in views.most_common(40):
