@@ -192,6 +192,33 @@ typedef struct {
 int nsky_wgrad_native_batch(const nsky_wgrad_problem* problems, int32_t n_problems, int32_t rows, nsky_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Sample generators (replace host-side torch RNG + upload in the reference).  Counter-based RNG (Philox4x32-10) keyed by
+ * (seed, *counter); every call advances *counter (a device uint64 the caller owns) by one, so a replayed HIP graph draws
+ * fresh numbers.  Distributions follow the reference, RNG streams do not.
+ *
+ * nsky_ddf_vmf_samples: VMFDDFSampler.generate_ddf_samples (neusky/model_components/ddf_sampler.py:249-286 with
+ *   random_vmf :205-247): n_positions points on the unit sphere (z >= 0 when upper_hemisphere), each with n_directions
+ *   directions from the vMF lobe (concentration kappa) about its inward normal.  origins [n_positions * n_directions, 3] =
+ *   point * radius (repeated), directions likewise. */
+int nsky_ddf_vmf_samples(int32_t n_positions, int32_t n_directions, float kappa, float radius, int32_t upper_hemisphere,
+                         uint64_t seed, uint64_t* counter, float* origins, float* directions, nsky_stream_t stream);
+
+/* nsky_ddf_fit_rows_fwd: the DDF evaluations of DDFModel.get_outputs (neusky/models/ddf_model.py:193-219 the fit rays,
+ *   :279-321 one multi-view ray per fit ray, :324-360 the sky rays), as rows for the DDF network: E = N + (want_mv ? N : 0) + Ns
+ *   rows of q_pos [E,3] (sphere positions) and xrow [E,ldx] = [d_loc | NeRF2(d_loc) | 0] (get_localised_transforms :158-181 +
+ *   directional_distance_field.py:188-191,270-271).  mv_points_in null: the multi-view points are drawn here (seed, *counter,
+ *   advanced by one); mv_points_out [N,3] receives the points used (z folded to >= 0).  sky_gt [Ns] = |o - sphere exit| (:343);
+ *   distance_weight [N] (optional) = 1 - (|p| / radius)^weight_exp (:224-238).
+ * nsky_ddf_fit_rows_bwd: d_term_dist [N] from d_xrow_mv = gradient of the N multi-view rows (the only differentiable input is the
+ *   fit rays' termination distance, :287). */
+int nsky_ddf_fit_rows_fwd(const float* positions, const float* directions, const float* term_dist, int32_t N,
+                          const float* mv_points_in, uint64_t seed, uint64_t* counter, const float* sky_o, const float* sky_d,
+                          int32_t Ns, float radius, int32_t want_mv, float weight_exp, int32_t weight_include_z, float* q_pos,
+                          float* xrow, int32_t ldx, float* mv_points_out, float* sky_gt, float* distance_weight, nsky_stream_t stream);
+int nsky_ddf_fit_rows_bwd(const float* positions, const float* directions, const float* term_dist, const float* mv_points,
+                          int32_t N, const float* d_xrow_mv, int32_t ldx, float* d_term_dist, nsky_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Multiresolution hash-grid encode (tiny-cuda-nn HashGrid semantics, fp32) fused with the rest of
  * the MLP input row.  Replaces tcnn.Encoding + NeRFEncoding + torch.cat at
  *   neusky/fields/sdf_albedo_field.py:119-130 (+ inherited forward_geonetwork, called :172,180,233)

@@ -1,0 +1,274 @@
+// Sample generators of the train step that the reference draws on the host with torch's RNG (and uploads): here each is ONE
+// kernel with a counter-based generator (Philox4x32-10, Salmon et al. 2011), keyed by (seed, call number) so that a
+// replayed HIP graph draws fresh numbers: the call number lives in device memory and is advanced by a one-thread kernel
+// behind every draw.  The RNG streams are not the reference's (they are not portable anyway): the DISTRIBUTIONS are, and
+// the tests check those.
+#include "common.h"
+#include "../../include/neusky_hip.h"
+
+namespace {
+
+constexpr float TWO_PI = 6.283185307179586f;
+
+struct Philox {
+  uint32_t k0, k1;
+  __device__ __forceinline__ static void round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  }
+  // four 32-bit words for counter (a, b, call number)
+  __device__ __forceinline__ void draw(uint32_t a, uint32_t b, uint64_t call, uint32_t (&out)[4]) const {
+    uint32_t c[4] = {a, b, (uint32_t)call, (uint32_t)(call >> 32)};
+    uint32_t x = k0, y = k1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      round(c, x, y);
+      x += 0x9E3779B9u;
+      y += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = c[i];
+  }
+};
+
+__device__ __forceinline__ float u01(uint32_t w) { return ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // in (0, 1)
+
+__global__ void advance_counter_kernel(uint64_t* counter) { *counter += 1; }
+
+// VMFDDFSampler (neusky/model_components/ddf_sampler.py:205-286): num_positions points on the unit sphere (upper hemisphere),
+// per point num_directions directions from a von Mises-Fisher-like lobe around the inward normal (Wood's rejection sampler with
+// the reference's acceptance test `>= -e`, :220), flipped into the inward half space.  One thread per (position, direction).
+__global__ __launch_bounds__(256) void ddf_vmf_samples_kernel(int n_pos, int n_dir, float kappa, float radius, int upper, uint64_t seed,
+                                                              const uint64_t* __restrict__ counter, float* __restrict__ origins,
+                                                              float* __restrict__ directions) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pos * n_dir) return;
+  const int n = i / n_dir;
+  const uint64_t call = *counter;
+  Philox rng{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t w[4];
+  // the position of sample n: the same words in every thread of that position (stream 0)
+  rng.draw((uint32_t)n, 0u, call, w);
+  const float theta = TWO_PI * u01(w[0]);
+  const float cphi = 2.0f * u01(w[1]) - 1.0f;
+  const float sphi = sqrtf(fmaxf(0.0f, 1.0f - cphi * cphi));
+  float p[3] = {sphi * cosf(theta), sphi * sinf(theta), cphi};
+  if (upper && p[2] < 0.0f) { p[0] = -p[0]; p[1] = -p[1]; p[2] = -p[2]; }
+  const float nrm[3] = {-p[0], -p[1], -p[2]};
+  // tangent direction: a normal 3-vector, projected off the normal (stream 1, counter = sample)
+  rng.draw((uint32_t)i, 1u, call, w);
+  const float r0 = sqrtf(-2.0f * logf(u01(w[0]))), r1 = sqrtf(-2.0f * logf(u01(w[2])));
+  float z[3] = {r0 * cosf(TWO_PI * u01(w[1])), r0 * sinf(TWO_PI * u01(w[1])), r1 * cosf(TWO_PI * u01(w[3]))};
+  float inv = rsqrtf(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);
+  z[0] *= inv; z[1] *= inv; z[2] *= inv;
+  const float zn = z[0] * nrm[0] + z[1] * nrm[1] + z[2] * nrm[2];
+  z[0] -= zn * nrm[0]; z[1] -= zn * nrm[1]; z[2] -= zn * nrm[2];
+  inv = rsqrtf(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);
+  z[0] *= inv; z[1] *= inv; z[2] *= inv;
+  // cosine to the normal: Wood (1994), d = 3 (Beta(1, 1) = U(0, 1)); streams 2.. until accepted
+  const float dm1 = 2.0f;
+  const float b = dm1 / (2.0f * kappa + sqrtf(4.0f * kappa * kappa + dm1 * dm1));
+  const float x0 = (1.0f - b) / (1.0f + b);
+  const float c = kappa * x0 + dm1 * logf(1.0f - x0 * x0);
+  float t = x0;
+  bool done = false;
+  for (uint32_t s = 2; s < 10 && !done; ++s) {
+    rng.draw((uint32_t)i, s, call, w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (done) break;
+      const float u = u01(w[k]);
+      const float tt = (1.0f - (1.0f + b) * u) / (1.0f - (1.0f - b) * u);
+      if (kappa * tt + dm1 * logf(1.0f - x0 * tt) - c >= -2.718281828459045f) { t = tt; done = true; }
+    }
+  }
+  const float st = sqrtf(fmaxf(0.0f, 1.0f - t * t));
+  float x[3] = {z[0] * st + t * nrm[0], z[1] * st + t * nrm[1], z[2] * st + t * nrm[2]};
+  inv = rsqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  if (x[0] * nrm[0] + x[1] * nrm[1] + x[2] * nrm[2] < 0.0f) inv = -inv;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    origins[(long)i * 3 + a] = p[a] * radius;
+    directions[(long)i * 3 + a] = x[a] * inv;
+  }
+}
+
+// ---- query rows of the DDF-fit losses ------------------------------------------------------------------------------------
+// DDFModel.get_outputs (neusky/models/ddf_model.py:193-219, :279-321, :324-360) evaluates the DDF on three sets of rays: the fit
+// rays themselves, one multi-view ray per fit ray (from a random point of the upper hemisphere towards the fit ray's ground-truth
+// termination point) and the sky rays traced backwards from where they leave the sphere.  This kernel writes, one thread per
+// evaluation, the sphere position and the encoded local direction row [d_loc | NeRF2(d_loc) | 0] (get_localised_transforms
+// :158-181, directional_distance_field.py:188-191,270-271) of all of them, plus the by-products the losses use.
+__device__ __forceinline__ void local_frame(const float pos[3], float x[3], float y[3], float z[3]) {
+  y[0] = -pos[0]; y[1] = -pos[1]; y[2] = -pos[2];
+  x[0] = -y[1]; x[1] = y[0]; x[2] = 0.0f;  // cross(up = (0, 0, 1), y)
+  const float xn = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  x[0] /= xn; x[1] /= xn; x[2] /= xn;
+  z[0] = y[1] * x[2] - y[2] * x[1]; z[1] = y[2] * x[0] - y[0] * x[2]; z[2] = y[0] * x[1] - y[1] * x[0];  // cross(y, x)
+  const float zn = sqrtf(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);
+  z[0] /= zn; z[1] /= zn; z[2] /= zn;
+}
+
+struct FitRowsArgs {
+  const float* positions; const float* directions; const float* term_dist;  // fit rays [N,3] [N,3] [N]
+  const float* mv_in;     // [N,3] or null: drawn here
+  const float* sky_o; const float* sky_d;  // [Ns,3]
+  const uint64_t* counter;
+  uint64_t seed;
+  float* q_pos; float* xrow; float* mv_out; float* sky_gt; float* dist_weight;
+  int N, Ns, ldx, want_mv, include_z;
+  float radius, weight_exp;
+};
+
+__device__ __forceinline__ void mv_point(const FitRowsArgs& a, int j, float pts[3]) {
+  if (a.mv_in) {
+    pts[0] = a.mv_in[j * 3]; pts[1] = a.mv_in[j * 3 + 1]; pts[2] = a.mv_in[j * 3 + 2];
+  } else {  // random_points_on_unit_sphere (:290)
+    Philox rng{(uint32_t)a.seed, (uint32_t)(a.seed >> 32)};
+    uint32_t w[4];
+    rng.draw((uint32_t)j, 0x6d76u, *a.counter, w);
+    const float theta = TWO_PI * u01(w[0]);
+    const float cphi = 2.0f * u01(w[1]) - 1.0f;
+    const float sphi = sqrtf(fmaxf(0.0f, 1.0f - cphi * cphi));
+    pts[0] = sphi * cosf(theta); pts[1] = sphi * sinf(theta); pts[2] = cphi;
+  }
+  pts[2] = fabsf(pts[2]);  // :295
+}
+
+__global__ __launch_bounds__(256) void ddf_fit_rows_fwd_kernel(FitRowsArgs a) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int n_mv = a.want_mv ? a.N : 0;
+  if (e >= a.N + n_mv + a.Ns) return;
+  float pos[3], wd[3];
+  if (e < a.N) {
+    for (int c = 0; c < 3; ++c) { pos[c] = a.positions[e * 3 + c]; wd[c] = a.directions[e * 3 + c]; }
+    if (a.dist_weight) {  // :224-238
+      const float d2 = pos[0] * pos[0] + pos[1] * pos[1] + (a.include_z ? pos[2] * pos[2] : 0.0f);
+      a.dist_weight[e] = 1.0f - powf(sqrtf(d2) / a.radius, a.weight_exp);
+    }
+  } else if (e < a.N + n_mv) {
+    const int j = e - a.N;
+    float pts[3];
+    mv_point(a, j, pts);
+    const float t = a.term_dist[j];
+    float dv[3];
+    for (int c = 0; c < 3; ++c) dv[c] = a.positions[j * 3 + c] + a.directions[j * 3 + c] * t - pts[c];  // :287, :298
+    const float len = sqrtf(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+    for (int c = 0; c < 3; ++c) { pos[c] = pts[c]; wd[c] = dv[c] / len; a.mv_out[j * 3 + c] = pts[c]; }
+  } else {
+    const int j = e - a.N - n_mv;
+    float o[3], d[3];
+    for (int c = 0; c < 3; ++c) { o[c] = a.sky_o[j * 3 + c]; d[c] = a.sky_d[j * 3 + c]; }
+    // ray_sphere_intersection (neusky/utils/utils.py:68-93): unit directions, far root, no clamping
+    const float b = 2.0f * (d[0] * o[0] + d[1] * o[1] + d[2] * o[2]);
+    const float cc = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] - a.radius * a.radius;
+    const float sq = sqrtf(b * b - 4.0f * cc);
+    const float t = fmaxf((-b - sq) * 0.5f, (-b + sq) * 0.5f);
+    float g2 = 0.0f;
+    for (int c = 0; c < 3; ++c) { pos[c] = o[c] + t * d[c]; wd[c] = -d[c]; g2 += (o[c] - pos[c]) * (o[c] - pos[c]); }
+    a.sky_gt[j] = sqrtf(g2);  // :343
+  }
+  float x[3], y[3], z[3];
+  local_frame(pos, x, y, z);
+  const float dl[3] = {x[0] * wd[0] + x[1] * wd[1] + x[2] * wd[2], y[0] * wd[0] + y[1] * wd[1] + y[2] * wd[2],
+                       z[0] * wd[0] + z[1] * wd[1] + z[2] * wd[2]};
+  float* row = a.xrow + (long)e * a.ldx;
+  for (int c = 0; c < 3; ++c) { a.q_pos[(long)e * 3 + c] = pos[c]; row[c] = dl[c]; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const float arg = TWO_PI * dl[i] * (f == 0 ? 1.0f : 4.0f);
+      row[3 + i * 2 + f] = sinf(arg);
+      row[9 + i * 2 + f] = sinf(arg + 1.5707963267948966f);
+    }
+  for (int c = 15; c < a.ldx; ++c) row[c] = 0.0f;
+}
+
+// gradient of the multi-view rows w.r.t. the fit rays' termination distance (the only differentiable input: the ground truth is
+// rendered from the SDF field and, with stop_sdf_gradients = False (neusky_config.py:45), trains it)
+__global__ __launch_bounds__(256) void ddf_fit_rows_bwd_kernel(const float* __restrict__ positions, const float* __restrict__ directions,
+                                                               const float* __restrict__ term_dist, const float* __restrict__ mv_points,
+                                                               const float* __restrict__ d_xrow, int ldx, int N,
+                                                               float* __restrict__ d_term_dist) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  const float pts[3] = {mv_points[j * 3], mv_points[j * 3 + 1], mv_points[j * 3 + 2]};
+  const float t = term_dist[j];
+  float dir[3], dv[3];
+  for (int c = 0; c < 3; ++c) { dir[c] = directions[j * 3 + c]; dv[c] = positions[j * 3 + c] + dir[c] * t - pts[c]; }
+  const float len = sqrtf(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+  const float u[3] = {dv[0] / len, dv[1] / len, dv[2] / len};
+  float x[3], y[3], z[3];
+  local_frame(pts, x, y, z);
+  const float dl[3] = {x[0] * u[0] + x[1] * u[1] + x[2] * u[2], y[0] * u[0] + y[1] * u[1] + y[2] * u[2], z[0] * u[0] + z[1] * u[1] + z[2] * u[2]};
+  const float* g = d_xrow + (long)j * ldx;
+  float gl[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float acc = g[i];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const float w = TWO_PI * (f == 0 ? 1.0f : 4.0f);
+      const float arg = w * dl[i];
+      acc += w * (g[3 + i * 2 + f] * cosf(arg) + g[9 + i * 2 + f] * cosf(arg + 1.5707963267948966f));
+    }
+    gl[i] = acc;
+  }
+  float gu[3];
+  for (int c = 0; c < 3; ++c) gu[c] = x[c] * gl[0] + y[c] * gl[1] + z[c] * gl[2];
+  const float ug = u[0] * gu[0] + u[1] * gu[1] + u[2] * gu[2];
+  float gt = 0.0f;
+  for (int c = 0; c < 3; ++c) gt += (gu[c] - u[c] * ug) / len * dir[c];
+  d_term_dist[j] = gt;
+}
+
+}  // namespace
+
+extern "C" int nsky_ddf_vmf_samples(int32_t n_positions, int32_t n_directions, float kappa, float radius, int32_t upper_hemisphere,
+                                    uint64_t seed, uint64_t* counter, float* origins, float* directions, nsky_stream_t stream) {
+  NSKY_CHECK_ARG(n_positions >= 0 && n_directions >= 0 && counter && kappa > 0.0f, "nsky_ddf_vmf_samples: bad argument");
+  const long n = (long)n_positions * n_directions;
+  if (n == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(origins && directions, "nsky_ddf_vmf_samples: null output");
+  hipLaunchKernelGGL(ddf_vmf_samples_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, n_positions, n_directions, kappa,
+                     radius, upper_hemisphere, seed, counter, origins, directions);
+  hipLaunchKernelGGL(advance_counter_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter);
+  NSKY_CHECK_LAUNCH("nsky_ddf_vmf_samples");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_ddf_fit_rows_fwd(const float* positions, const float* directions, const float* term_dist, int32_t N,
+                                     const float* mv_points_in, uint64_t seed, uint64_t* counter, const float* sky_o, const float* sky_d,
+                                     int32_t Ns, float radius, int32_t want_mv, float weight_exp, int32_t weight_include_z, float* q_pos,
+                                     float* xrow, int32_t ldx, float* mv_points_out, float* sky_gt, float* distance_weight,
+                                     nsky_stream_t stream) {
+  NSKY_CHECK_ARG(N >= 0 && Ns >= 0 && ldx >= 15 && radius > 0.0f, "nsky_ddf_fit_rows_fwd: bad sizes");
+  const int n_mv = want_mv ? N : 0;
+  const int E = N + n_mv + Ns;
+  if (E == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(q_pos && xrow && (N == 0 || (positions && directions)) && (n_mv == 0 || (term_dist && mv_points_out)) &&
+                     (Ns == 0 || (sky_o && sky_d && sky_gt)), "nsky_ddf_fit_rows_fwd: null argument");
+  NSKY_CHECK_ARG(n_mv == 0 || mv_points_in || counter, "nsky_ddf_fit_rows_fwd: multi-view points are neither given nor can they be drawn (no counter)");
+  FitRowsArgs a;
+  a.positions = positions; a.directions = directions; a.term_dist = term_dist; a.mv_in = mv_points_in; a.sky_o = sky_o; a.sky_d = sky_d;
+  a.counter = counter; a.seed = seed; a.q_pos = q_pos; a.xrow = xrow; a.mv_out = mv_points_out; a.sky_gt = sky_gt;
+  a.dist_weight = distance_weight; a.N = N; a.Ns = Ns; a.ldx = ldx; a.want_mv = want_mv; a.include_z = weight_include_z;
+  a.radius = radius; a.weight_exp = weight_exp;
+  hipLaunchKernelGGL(ddf_fit_rows_fwd_kernel, dim3(ceil_div(E, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  if (n_mv > 0 && !mv_points_in) hipLaunchKernelGGL(advance_counter_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter);
+  NSKY_CHECK_LAUNCH("nsky_ddf_fit_rows_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_ddf_fit_rows_bwd(const float* positions, const float* directions, const float* term_dist, const float* mv_points,
+                                     int32_t N, const float* d_xrow_mv, int32_t ldx, float* d_term_dist, nsky_stream_t stream) {
+  if (N == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(positions && directions && term_dist && mv_points && d_xrow_mv && d_term_dist && N > 0 && ldx >= 15,
+                 "nsky_ddf_fit_rows_bwd: bad argument");
+  hipLaunchKernelGGL(ddf_fit_rows_bwd_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, positions, directions, term_dist,
+                     mv_points, d_xrow_mv, ldx, N, d_term_dist);
+  NSKY_CHECK_LAUNCH("nsky_ddf_fit_rows_bwd");
+  return NSKY_OK;
+}

@@ -217,6 +217,47 @@ def hash_indices(geom, table, x, mode):
     return out
 
 
+# ------------------------------------------------------------------------------------------ sample generators
+_ddf_vmf_samples = _sig("nsky_ddf_vmf_samples", C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p,
+                        C.c_void_p, C.c_void_p)
+
+
+def ddf_vmf_samples(n_positions, n_directions, kappa, radius, upper_hemisphere, seed, counter, origins, directions):
+    """counter: int64 device tensor [1] (advanced by one); origins / directions: [n_positions * n_directions, 3] float32"""
+    n = n_positions * n_directions
+    assert counter.dtype == torch.int64 and counter.numel() == 1 and counter.is_cuda
+    assert origins.shape == (n, 3) and directions.shape == (n, 3) and origins.is_contiguous() and directions.is_contiguous()
+    check(_ddf_vmf_samples(n_positions, n_directions, float(kappa), float(radius), int(upper_hemisphere), int(seed) & (2**64 - 1),
+                           ptr(counter), ptr(origins), ptr(directions), stream_ptr()), "nsky_ddf_vmf_samples")
+
+
+_fit_rows_fwd = _sig("nsky_ddf_fit_rows_fwd", C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                     C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                     C.c_void_p, C.c_void_p, C.c_void_p)
+_fit_rows_bwd = _sig("nsky_ddf_fit_rows_bwd", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                     C.c_void_p)
+
+
+def ddf_fit_rows_fwd(positions, directions, term_dist, mv_points_in, seed, counter, sky_o, sky_d, radius, want_mv, weight_exp,
+                     weight_include_z, q_pos, xrow, mv_points_out, sky_gt, distance_weight):
+    """rows of the DDF-fit evaluations (fit rays | multi-view | sky) into q_pos [E,3] / xrow [E,ld]; see include/neusky_hip.h"""
+    N, Ns = positions.shape[0], (0 if sky_o is None else sky_o.shape[0])
+    E = N + (N if want_mv else 0) + Ns
+    assert q_pos.shape[0] == E and xrow.shape[0] == E and q_pos.stride() == (3, 1)
+    for t in (positions, directions, term_dist, mv_points_in, sky_o, sky_d, mv_points_out, sky_gt, distance_weight):
+        assert t is None or (t.is_contiguous() and t.dtype == torch.float32)
+    check(_fit_rows_fwd(ptr(positions), ptr(directions), ptr(term_dist), N, ptr(mv_points_in), int(seed) & (2**64 - 1), ptr(counter),
+                        ptr(sky_o), ptr(sky_d), Ns, float(radius), int(want_mv), float(weight_exp), int(weight_include_z), ptr(q_pos),
+                        ptr(xrow), ld(xrow), ptr(mv_points_out), ptr(sky_gt), ptr(distance_weight), stream_ptr()), "nsky_ddf_fit_rows_fwd")
+
+
+def ddf_fit_rows_bwd(positions, directions, term_dist, mv_points, d_xrow_mv, d_term_dist):
+    N = positions.shape[0]
+    assert d_xrow_mv.shape[0] == N and d_term_dist.numel() == N
+    check(_fit_rows_bwd(ptr(positions), ptr(directions), ptr(term_dist), ptr(mv_points), N, ptr(d_xrow_mv), ld(d_xrow_mv), ptr(d_term_dist),
+                        stream_ptr()), "nsky_ddf_fit_rows_bwd")
+
+
 # ------------------------------------------------------------------------------------------ render stages
 _P = C.c_void_p
 _I = C.c_int32

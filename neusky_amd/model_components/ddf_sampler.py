@@ -82,39 +82,22 @@ class VMFDDFSampler:
                          metadata={"directions_norm": torch.ones(n, 1, device=self.device)})
 
     def generate_ddf_samples_device(self, num_positions: int, num_directions: int) -> RayBundle:
-        """Same distribution as generate_ddf_samples, drawn entirely on the device with static shapes (no host RNG,
-        no upload, hipGraph-capturable): the rejection loop of :215-223 becomes one 2x-oversampled draw whose accepted
-        candidates are compacted with a stable sort (the acceptance test `>= -e` passes for almost every candidate)."""
-        dev = self.device
-        d, kappa = 3, self.concentration
-        theta = 2 * torch.pi * torch.rand(num_positions, device=dev)
-        phi = torch.acos(2 * torch.rand(num_positions, device=dev) - 1)
-        positions = torch.stack([torch.sin(phi) * torch.cos(theta), torch.sin(phi) * torch.sin(theta), torch.cos(phi)], 1)
-        if self.config.only_sample_upper_hemisphere:
-            positions = torch.where(positions[:, 2:3] < 0, -positions, positions)
-        normals = -positions
-        z = torch.randn(num_positions, num_directions, d, device=dev)
-        z = z / torch.norm(z, dim=-1, keepdim=True)
-        z = z - torch.einsum("nij,nj->ni", z, normals)[..., None] * normals[:, None, :]
-        z = z / torch.norm(z, dim=-1, keepdim=True)
+        """Same distribution as generate_ddf_samples, drawn by ONE HIP kernel (csrc/samplers.hip: counter-based RNG, the
+        rejection loop of :215-223 per sample, no host RNG, no upload, hipGraph-capturable: the call counter lives on the device)."""
+        from .. import hip
+        dev = torch.device(self.device)
         n = num_positions * num_directions
-        b = (d - 1) / (2 * kappa + (4 * kappa**2 + (d - 1) ** 2) ** 0.5)
-        x0 = (1 - b) / (1 + b)
-        c = kappa * x0 + (d - 1) * math.log(1 - x0**2)
-        u = torch.rand(2 * n, device=dev)
-        t = (1 - (1 + b) * u) / (1 - (1 - b) * u)
-        accept = (kappa * t + (d - 1) * torch.log(1 - x0 * t) - c) >= -math.e
-        order = torch.argsort((~accept).to(torch.int8), stable=True)
-        cos = t[order][:n].reshape(num_positions, num_directions)
-        sin = torch.sqrt(1 - cos**2)
-        x = z * sin[..., None] + cos[..., None] * normals[:, None, :]
-        x = x / torch.norm(x, dim=-1, keepdim=True)
-        flip = torch.einsum("nij,nj->ni", x, normals) < 0
-        x = torch.where(flip[..., None], -x, x)
-        P = (positions * self.ddf_sphere_radius)[:, None, :].expand(-1, num_directions, -1).reshape(-1, 3).contiguous()
-        return RayBundle(origins=P, directions=x.reshape(-1, 3).contiguous(), pixel_area=torch.ones(n, 1, device=dev),
-                         camera_indices=torch.zeros(n, 1, device=dev, dtype=torch.int64),
-                         metadata={"directions_norm": torch.ones(n, 1, device=dev)})
+        st = getattr(self, "_dev_state", None)
+        if st is None or st["n"] != n or st["ones"].device != dev:
+            st = self._dev_state = {"n": n, "counter": torch.zeros(1, dtype=torch.int64, device=dev), "seed": torch.initial_seed(),
+                                    "ones": torch.ones(n, 1, device=dev), "norm": torch.ones(n, 1, device=dev),
+                                    "cam": torch.zeros(n, 1, device=dev, dtype=torch.int64)}
+        origins = torch.empty(n, 3, device=dev)
+        directions = torch.empty(n, 3, device=dev)
+        hip.ddf_vmf_samples(num_positions, num_directions, self.concentration, self.ddf_sphere_radius,
+                            self.config.only_sample_upper_hemisphere, st["seed"], st["counter"], origins, directions)
+        return RayBundle(origins=origins, directions=directions, pixel_area=st["ones"], camera_indices=st["cam"],
+                         metadata={"directions_norm": st["norm"]})
 
     def __call__(self, generator=None) -> RayBundle:
         if generator is None and str(self.device) != "cpu":

@@ -81,23 +81,54 @@ class DDFModel(ModelBase):
                                           ends=torch.zeros_like(positions), pixel_area=torch.ones_like(positions[..., 0])))
         return self.field.forward(rs)[NeuSkyFieldHeadNames.TERMINATION_DISTANCE]
 
-    def prepare_queries(self, ray_bundle: RayBundle, batch, mv_points: Optional[torch.Tensor] = None):
-        """(positions [E,3], world directions [E,3]) of EVERY DDF evaluation get_outputs will need, in its order
-        (rays | multi-view | sky).  The pipeline hands them to NeuSkyFactoModel.compute_visibility so that they ride
-        in the same GEMM launches as the 262 144 visibility rows instead of a second chain of small launches."""
-        return self.get_outputs(ray_bundle, batch, None, prepare_only=True, mv_points=mv_points)
+    def prepare_queries(self, ray_bundle: RayBundle, batch, mv_points: Optional[torch.Tensor] = None) -> Dict[str, Any]:
+        """The inputs of EVERY DDF evaluation get_outputs will need (rays | multi-view | sky), for ops.DDFQueryRowsFn: the
+        pipeline hands them to NeuSkyFactoModel.compute_visibility so that they ride in the same chain launches as the 262 144
+        visibility rows instead of a second chain of small launches (and are encoded by one kernel instead of ~100 torch ops)."""
+        c = self.config
+        positions = ray_bundle.origins.reshape(-1, 3).contiguous()
+        directions = ray_bundle.directions.reshape(-1, 3).contiguous()
+        want_mv = bool(c.loss_inclusions["multi_view_loss"] and self.training and batch is not None)
+        want_sky = bool(c.loss_inclusions["sky_ray_loss"] and self.training and batch is not None)
+        rng = getattr(self, "_query_rng", None)
+        if rng is None or rng["counter"].device != positions.device:
+            rng = self._query_rng = {"counter": torch.zeros(1, dtype=torch.int64, device=positions.device), "seed": torch.initial_seed() + 1}
+        sky = batch["sky_ray_bundle"] if want_sky else None
+        return {"positions": positions, "directions": directions, "term_dist": batch["termination_dist"] if batch is not None else None,
+                "want_mv": want_mv, "mv_points_in": None if mv_points is None else mv_points.to(positions).contiguous(),
+                "seed": rng["seed"], "counter": rng["counter"],
+                "sky_o": None if sky is None else sky.origins.reshape(-1, 3).contiguous(),
+                "sky_d": None if sky is None else sky.directions.reshape(-1, 3).contiguous(),
+                "want_weight": bool(c.include_depth_loss_scene_center_weight and self.training and batch is not None),
+                "weight_exp": float(c.scene_center_weight_exp), "weight_include_z": bool(c.scene_center_weight_include_z)}
 
     def get_outputs(self, ray_bundle: RayBundle, batch, neusky, stop_gradients: bool = True,
-                    mv_points: Optional[torch.Tensor] = None, prepare_only: bool = False,
+                    mv_points: Optional[torch.Tensor] = None,
                     precomputed: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
-        """precomputed = {"mv_points": the points prepare_queries drew, "t_all": DDF output for its rows,
-        "sdf_main": sdf at the termination points of the first span} (see prepare_queries)."""
-        if precomputed is not None:
-            mv_points = precomputed["mv_points"]
+        """precomputed = what NeuSkyFactoModel.compute_visibility_compact left of the fit rows it evaluated (prepare_queries):
+        {"t_main", "t_mv", "t_sky": DDF outputs of the three spans, "sky_gt", "distance_weight", "mv_points", "sdf_main"}."""
         positions = ray_bundle.origins.reshape(-1, 3)
         directions = ray_bundle.directions.reshape(-1, 3)
         outputs: Dict[str, Any] = {}
         c = self.config
+        if precomputed is not None:  # every evaluation already ran with the visibility rows (prepare_queries): assemble
+            outputs["expected_termination_dist"] = precomputed["t_main"]
+            if c.include_depth_loss_scene_center_weight and self.training and batch is not None:
+                outputs["distance_weight"] = precomputed["distance_weight"]
+            if (c.loss_inclusions["sdf_l1_loss"] or c.loss_inclusions["sdf_l2_loss"]) and self.training:
+                if precomputed.get("sdf_main") is not None:
+                    outputs["sdf_at_termination"] = precomputed["sdf_main"]
+                elif neusky is not None:
+                    term = positions + directions * precomputed["t_main"].unsqueeze(-1)
+                    with torch.no_grad():
+                        outputs["sdf_at_termination"] = neusky.field.get_sdf_at_pos(term).detach()
+            if c.loss_inclusions["multi_view_loss"] and self.training and batch is not None:
+                outputs["multi_view_termintation_dist"] = batch["termination_dist"]  # (sic) :321
+                outputs["multi_view_expected_termination_dist"] = precomputed["t_mv"]
+            if c.loss_inclusions["sky_ray_loss"] and self.training and batch is not None:
+                outputs["sky_ray_termination_dist"] = precomputed["sky_gt"]  # :343
+                outputs["sky_ray_expected_termination_dist"] = precomputed["t_sky"]
+            return outputs
         # The reference issues up to three separate DDF evaluations here (the rays themselves :217, the multi-view
         # rays :319, the sky rays :360).  Their inputs do not depend on each other's outputs, so they are gathered
         # first and evaluated as ONE batch (one chain of GEMM launches instead of three).
@@ -122,19 +153,14 @@ class DDFModel(ModelBase):
             sp = ray_sphere_intersection(o, d, self.ddf_radius)
             n0 = sum(t.shape[0] for t in q_pos)
             q_pos.append(sp); q_dir.append(-d); spans["sky"] = (n0, n0 + sp.shape[0])
-        if prepare_only:
-            return {"positions": torch.cat(q_pos, 0), "directions": torch.cat(q_dir, 0), "n_main": positions.shape[0],
-                    "main_directions": directions, "mv_points": mv_points}
-        t_all = precomputed["t_all"] if precomputed is not None else self.query(torch.cat(q_pos, 0), torch.cat(q_dir, 0))
+        t_all = self.query(torch.cat(q_pos, 0), torch.cat(q_dir, 0))
         expected = t_all[spans["main"][0]:spans["main"][1]]
         outputs["expected_termination_dist"] = expected
         if c.include_depth_loss_scene_center_weight and self.training and batch is not None:  # :224-238
             dist = positions.norm(dim=-1) if c.scene_center_weight_include_z else positions[..., :2].norm(dim=-1)
             outputs["distance_weight"] = 1.0 - (dist / self.ddf_radius) ** c.scene_center_weight_exp
         if (c.loss_inclusions["sdf_l1_loss"] or c.loss_inclusions["sdf_l2_loss"]) and self.training:  # :241-254
-            if precomputed is not None and precomputed.get("sdf_main") is not None:
-                outputs["sdf_at_termination"] = precomputed["sdf_main"]
-            elif neusky is not None:
+            if neusky is not None:
                 term = positions + directions * expected.unsqueeze(-1)
                 if stop_gradients:
                     with torch.no_grad():

@@ -190,7 +190,7 @@ class NeuSkyFactoModel(ModelBase):
 
     def begin_step(self) -> None:
         """start of an optimisation step: drop the per-step caches of prepared (weight-normed / padded) matrices"""
-        ops.begin_step()
+        ops.begin_step(self.device)
         self.field.invalidate_weight_cache()
         for net in self.proposal_networks:
             net.invalidate_weight_cache()
@@ -357,24 +357,18 @@ class NeuSkyFactoModel(ModelBase):
         M = R * Dv
         ddf = self.visibility_field
         extra = getattr(self, "_extra_ddf", None) if self.training else None
-        E = extra["positions"].shape[0] if extra is not None else 0
         # the DDF-fit rows (rays | multi-view | sky, ddf_model.py:217,319,360) ride behind the visibility rows in the same
-        # buffers: the ray kernel writes the first M rows in place, the few fit rows are copied in (no 17 MB torch.cat)
-        pts_all = torch.empty(M + E, 3, device=dev)
-        xrow_all = torch.empty(M + E, 16, device=dev)
-        sphere_pts, xrow = pts_all[:M], xrow_all[:M]
-        surf_dist = torch.empty(M, device=dev)
-        term_dist = torch.empty(M, device=dev)
-        hip.visibility_rays(origins.detach().contiguous(), ray_directions.detach().contiguous(),
-                            depth.detach().reshape(-1).contiguous(), sel_dirs, self.ddf_radius, sphere_pts, xrow, surf_dist, term_dist)
+        # buffers and the same chain launches; two kernels write all of them (ops.DDFQueryRowsFn)
+        pts_all, xrow_all, surf_dist, term_dist, mv_points, sky_gt, dist_w = ops.DDFQueryRowsFn.apply(
+            None if extra is None else extra["term_dist"], origins.detach().contiguous(), ray_directions.detach().contiguous(),
+            depth.detach().reshape(-1).contiguous(), sel_dirs, self.ddf_radius, extra)
+        t_all = ddf.field.forward_rows(pts_all, xrow_all)  # :1716 -> ddf_model.py:217
         if extra is not None:
-            local = torch.einsum("ijl,ij->il", ddf.get_localised_transforms(extra["positions"]), extra["directions"])
-            pts_all[M:] = extra["positions"]
-            xrow_all[M:] = ddf.field.direction_rows(local)
-            t_all = ddf.field.forward_rows(pts_all, xrow_all)
-            t_hat, t_extra = t_all[:M], t_all[M:]
+            N, Ns = extra["positions"].shape[0], (extra["sky_o"].shape[0] if extra["sky_o"] is not None else 0)
+            t_hat, t_main, t_mv, t_sky = torch.split(t_all, [M, N, mv_points.shape[0], Ns])
         else:
-            t_hat = ddf.field.forward_rows(sphere_pts, xrow)  # :1716 -> ddf_model.py:217
+            t_hat = t_all
+        sphere_pts = pts_all[:M]
         out: Dict[str, Any] = {"expected_termination_dist": t_hat}
         stop_gradients = self.config.sdf_to_visibility_stop_gradients in ["sdf", "both"]  # :1712-1714
         vcfg = ddf.config
@@ -384,8 +378,8 @@ class NeuSkyFactoModel(ModelBase):
             term_pts = sphere_pts + world_dirs * t_hat[:, None]  # ddf_model.py:243
             n_main = 0
             if extra is not None and not stop_gradients and not extra["stop_gradients"]:
-                n_main = extra["n_main"]  # the fit rays' own termination points (ddf_model.py:243) join the same probe
-                term_pts = torch.cat([term_pts, extra["positions"][:n_main] + extra["main_directions"] * t_extra[:n_main, None]], 0)
+                n_main = extra["positions"].shape[0]  # the fit rays' own termination points (ddf_model.py:243) join the same probe
+                term_pts = torch.cat([term_pts, extra["positions"] + extra["directions"] * t_main[:, None]], 0)
             if stop_gradients:
                 with torch.no_grad():
                     sdf_all = self.field.get_sdf_at_pos(term_pts).detach()
@@ -395,7 +389,8 @@ class NeuSkyFactoModel(ModelBase):
             if n_main:
                 sdf_extra = sdf_all[M:]
         if extra is not None:
-            self._extra_ddf_out = {"mv_points": extra["mv_points"], "t_all": t_extra, "sdf_main": sdf_extra}
+            self._extra_ddf_out = {"mv_points": mv_points, "t_main": t_main, "t_mv": t_mv, "t_sky": t_sky, "sdf_main": sdf_extra,
+                                   "sky_gt": sky_gt, "distance_weight": dist_w}
         lower = 1.0 if self.config.lower_hermisphere_visibility else 0.0
         vis = ops.VisibilityFinishFn.apply(t_hat, surf_dist, threshold_distance, float(sigmoid_scale),
                                            sel.contiguous(), R, Dv, D, lower)

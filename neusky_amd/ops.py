@@ -90,10 +90,10 @@ def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None, acc
     else:
         if bias_like is not None:  # one zero-filled slab for both accumulators (16-byte aligned views)
             nw = (like.numel() + 3) // 4 * 4
-            flat = torch.zeros(nw + bias_like.numel(), device=like.device, dtype=like.dtype)
+            flat = zeros(nw + bias_like.numel(), device=like.device)
             dW, db = flat[:like.numel()].view_as(like), flat[nw:].view_as(bias_like)
         else:
-            dW, db = torch.zeros_like(like), None
+            dW, db = zeros_like(like), None
     splits = _splits(M, n_out, k_in)
     kw = dict(a_kcontig=False, b_kcontig=False, k_splits=splits, precision=BWD_PRECISION, a_native_nt=a_native_nt, b_native_nt=b_native_nt)
     if a_scale_max is not None and k_in > 64:  # fp32-grade products: fp16 hi + scaled residual, the gradient pre-scaled by its maximum
@@ -131,7 +131,7 @@ def shared_grad(like, bias_like):
     if not _SHARED_GRADS:  # first shared accumulator of this backward pass: forget them all when the pass ends
         torch.autograd.Variable._execution_engine.queue_callback(_SHARED_GRADS.clear)
     nw = (like.numel() + 3) // 4 * 4
-    flat = torch.zeros(nw + (bias_like.numel() if bias_like is not None else 0), device=like.device, dtype=like.dtype)
+    flat = zeros(nw + (bias_like.numel() if bias_like is not None else 0), device=like.device)
     dW = flat[:like.numel()].view_as(like)
     db = flat[nw:].view_as(bias_like) if bias_like is not None else None
     _SHARED_GRADS[key] = (like, dW, db)
@@ -139,7 +139,7 @@ def shared_grad(like, bias_like):
 
 
 def grad_bias(dZ, M, n_out, like):
-    db = torch.zeros_like(like)
+    db = zeros_like(like)
     hip.colsum(dZ, M, n_out, db)
     return db
 
@@ -152,9 +152,51 @@ _PLANES_K_STEP = 4   # the LDS-DMA kernel takes any K % 4 == 0 (a partial last k
 _PLANES_MIN_K = 36   # below: the layer is all epilogue, the 32-deep k-tile mostly padding
 
 
-def begin_step() -> None:
+# ---- zero arena ---------------------------------------------------------------------------------------------------------
+# A train step needs ~10^2 zero-initialised tensors (split-k / atomic accumulators, padded outputs, gradient slabs of weights
+# that are not optimizer-slab parameters).  Each torch.zeros is a fill launch; here they are carved out of ONE buffer that
+# begin_step allocates and zero-fills once, sized by what the previous step asked for.  Every region is handed out once, so
+# it is zero when it is handed out; the buffer lives as long as any view of it (autograd keeps them through the backward).
+_ARENA = {"buf": None, "off": 0, "need": 0, "cap": 0}
+_ARENA_ALIGN = 64  # floats: 256-byte aligned regions
+_ARENA_MAX_REGION = 1 << 22  # floats; larger requests get their own allocation
+
+
+def zeros(*shape, device) -> torch.Tensor:
+    """float32 zeros of `shape`, from the step's arena when it has room (otherwise a torch.zeros of its own)"""
+    if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+        shape = tuple(shape[0])
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if n > _ARENA_MAX_REGION:  # (a whole hash table's gradient, when it is not an optimizer-slab parameter)
+        return torch.zeros(shape, device=device)
+    a = _ARENA
+    n_al = (n + _ARENA_ALIGN - 1) // _ARENA_ALIGN * _ARENA_ALIGN
+    a["need"] += n_al
+    buf = a["buf"]
+    if buf is not None and n > 0 and buf.device == torch.device(device) and a["off"] + n_al <= a["cap"]:
+        # .data: same storage, but its own version counter and no view relation to the arena -- to autograd each region is an
+        # independent tensor (in-place writes to one region must not invalidate tensors saved from another)
+        out = buf[a["off"]:a["off"] + n].view(shape).data
+        a["off"] += n_al
+        return out
+    return torch.zeros(shape, device=device)
+
+
+def zeros_like(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        return torch.zeros_like(t)
+    return zeros(tuple(t.shape), device=t.device)
+
+
+def begin_step(device=None) -> None:
     _PLANES.clear()
     _FILM_STREAMS.clear()
+    a = _ARENA
+    a["cap"] = max(a["cap"], a["need"])
+    a["need"], a["off"] = 0, 0
+    a["buf"] = torch.zeros(a["cap"], device=device) if (device is not None and a["cap"] > 0 and torch.device(device).type == "cuda") else None
 
 
 def _planes(W, n_rows, n_k, transpose, precision):
@@ -246,7 +288,7 @@ class HashEncodeFn(torch.autograd.Function):
         d_out = d_out.contiguous()
         sink = ctx.sink
         accumulate = sink is not None and sink.grad is not None and sink.grad.is_contiguous() and sink.grad.shape == table.shape
-        dtable = sink.grad if accumulate else torch.zeros_like(table)
+        dtable = sink.grad if accumulate else zeros_like(table)
         dx = torch.empty(P, 3, device=x.device) if need_dx else None
         dT = d_out[P:].view(3, P, ldy) if tangents else None
         hip.encode_bwd(geom, table, x, mode, include_x, pe_freqs, pe_max_exp, d_out[:P], dT, dtable, dx)
@@ -265,7 +307,7 @@ class DenseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, Wp, bp, n_out, act, need_dx):
         M, K = X.shape[0], Wp.shape[1]
-        Y = torch.zeros(M, Wp.shape[0], device=X.device)
+        Y = zeros(M, Wp.shape[0], device=X.device)
         fgemm(X, Wp, Y, M, n_out, K, bias=bp, epi=_ACT[act])
         ctx.save_for_backward(X, Wp, bp, Y)
         ctx.cfg = (n_out, act, need_dx)
@@ -374,7 +416,7 @@ class FilmSirenFn(torch.autograd.Function):
             ys = [pp[(n_map + i) & 1][:, :H] for i in range(n_film)]
             zs = [None] * n_film
         FP = torch.empty(M, 2 * n_film * H, device=dev)
-        res = torch.zeros(M, n_out_p, device=dev)
+        res = zeros(M, n_out_p, device=dev)
         for r0, r1 in [(0, M)]:
             m = r1 - r0
             # mapping network: (Linear, LeakyReLU(0.2)) * n  -> Linear to 2*n_film*H  (siren.py:114-119)
@@ -414,7 +456,7 @@ class FilmSirenFn(torch.autograd.Function):
         dzs = [torch.empty(Mp, H, device=dev) for _ in range(n_film)]
         dfp = torch.empty(Mp, 2 * n_film * H, device=dev)
         rowmax = torch.empty(Mp, device=dev)
-        gmax = torch.zeros(n_film + 1 + n_map, device=dev)
+        gmax = zeros(n_film + 1 + n_map, device=dev)
         d_x = torch.empty(M, ld(x), device=dev) if ctx.need_dx else None  # the DDF's multi-view rays (ddf_model.py:297-322)
         hip.film_chain_bwd_film(net1, s1, t1, M, d_res, hs[-1], zs, dzs, dfp, rowmax, gmax[:n_film + 1], d_x)
         d_cond = torch.empty(M, ld(cond), device=dev) if need_dcond else None
@@ -430,7 +472,7 @@ class FilmSirenFn(torch.autograd.Function):
                 if sk is not None and sk.grad is not None and sk.grad.shape == t.shape and sk.grad.is_contiguous():
                     grads[idx], sunk[idx] = sk.grad, True
             sizes = [0 if sunk[idx] else (t.numel() + 3) // 4 * 4 for idx, t in enumerate(wb)]
-            flat = torch.zeros(max(sum(sizes), 4), device=dev)
+            flat = zeros(max(sum(sizes), 4), device=dev)
             off = 0
             for idx, t in enumerate(wb):
                 if not sunk[idx]:
@@ -486,7 +528,7 @@ class FilmSirenFn(torch.autograd.Function):
                 if sk is not None and sk.grad is not None and sk.grad.shape == t.shape and sk.grad.is_contiguous():
                     grads[idx], sunk[idx] = sk.grad, True
             sizes = [0 if sunk[idx] else (t.numel() + 3) // 4 * 4 for idx, t in enumerate(wb)]
-            flat = torch.zeros(max(sum(sizes), 4), device=dev)
+            flat = zeros(max(sum(sizes), 4), device=dev)
             off = 0
             for idx, t in enumerate(wb):
                 if not sunk[idx]:
@@ -573,11 +615,11 @@ class SDFAlbedoFn(torch.autograd.Function):
         fgemm(A0[N:], W1, A1[N:], 3 * N, Hd, Hd, epi=hip.EPI_MUL_AUX, aux0=S1, row_mod=N)
         GF = W2.shape[0] - 4  # geo feature dim (256)
         ldc = Wc0.shape[1]
-        CIN = torch.zeros(N, ldc, device=dev)
+        CIN = zeros(N, ldc, device=dev)
         fgemm(A1[:N], W2, CIN, N, GF + 1, Hd, bias=b2)  # [feat | sdf] straight into the colour-net input
         npe = 39  # x (3) + PE6 (36) columns of the encode row
         CIN[:, GF + 4:GF + 4 + npe] = ET[:N, :npe]
-        G = torch.zeros(3 * N, 4, device=dev)
+        G = zeros(3 * N, 4, device=dev)
         fgemm(A1[N:], W2[GF:GF + 1], G, 3 * N, 1, Hd)  # d sdf / d x_k = tangent . w_sdf
         Hc = Wc0.shape[0]
         if want_albedo:
@@ -585,7 +627,7 @@ class SDFAlbedoFn(torch.autograd.Function):
             fgemm(CIN, Wc0, C0, N, Hc, ldc, bias=bc0, epi=hip.EPI_RELU)
             C1 = torch.empty(N, Hc, device=dev)
             fgemm(C0, Wc1, C1, N, Hc, Hc, bias=bc1, epi=hip.EPI_RELU)
-            ALB = torch.zeros(N, 4, device=dev)
+            ALB = zeros(N, 4, device=dev)
             fgemm(C1, Wc2, ALB, N, 3, Hc, bias=bc2, epi=hip.EPI_SIGMOID, p0=1.0)
         else:  # geometry-only pass (DDF-fit ground truth, hash-grid density probe): the colour net's output is never read
             C0 = C1 = ALB = CIN.new_empty(0)
@@ -596,7 +638,7 @@ class SDFAlbedoFn(torch.autograd.Function):
         sdf = CIN[:, GF].clone()
         grad = G.view(3, N, 4)[:, :, 0].t().contiguous()
         if not want_albedo:
-            alb = sdf.new_zeros(N, 3)
+            alb = zeros(N, 3, device=sdf.device)
             ctx.mark_non_differentiable(alb)
             return sdf, grad, alb
         return sdf, grad, ALB[:, :3].clone()
@@ -612,7 +654,7 @@ class SDFAlbedoFn(torch.autograd.Function):
             # geo net's [feat | sdf | 0 0 0] output carries one
             return SDFAlbedoFn._backward_geo(ctx, g_sdf, g_grad, None)
         # ---- colour net
-        dpc2 = torch.zeros(N, 4, device=dev)
+        dpc2 = zeros(N, 4, device=dev)
         if g_alb is not None:
             alb = ALB[:, :3]
             dpc2[:, :3] = g_alb * alb * (1.0 - alb)
@@ -645,7 +687,7 @@ class SDFAlbedoFn(torch.autograd.Function):
             dH = dCIN[:, :GF + 4]
         else:
             dCIN = None
-            dH = torch.zeros(N, GF + 4, device=dev)
+            dH = zeros(N, GF + 4, device=dev)
             if g_sdf is not None:
                 dH[:, GF] = g_sdf
         # ---- geo net, last layer (value rows)
@@ -655,7 +697,7 @@ class SDFAlbedoFn(torch.autograd.Function):
         grad_input(dH, W2, N, Hd, GF + 4, dA1v)
         # tangent rows of the last layer: grad_k = ta1_k . w_sdf
         if g_grad is None:
-            g_grad = torch.zeros(N, 3, device=dev)
+            g_grad = zeros(N, 3, device=dev)
         g_grad = g_grad.contiguous()
         # d w_sdf += sum_{k,n} g_grad[n,k] ta1_k[n,:] : accumulated straight into the sdf row of dW2
         hip.weighted_colsum(A1[N:], 3 * N, Hd, g_grad.t().contiguous(), 1, dW2[GF])
@@ -697,7 +739,7 @@ class SDFValueFn(torch.autograd.Function):
         fgemm(E, W0, A0, M, Hd, Kin, bias=b0, epi=hip.EPI_SOFTPLUS, p0=beta, out1=S0)
         A1 = torch.empty(M, Hd, device=dev); S1 = torch.empty(M, Hd, device=dev)
         fgemm(A0, W1, A1, M, Hd, Hd, bias=b1, epi=hip.EPI_SOFTPLUS, p0=beta, out1=S1)
-        out = torch.zeros(M, 4, device=dev)
+        out = zeros(M, 4, device=dev)
         fgemm(A1, W2[GF:GF + 1], out, M, 1, Hd, bias=b2[GF:GF + 1])
         ctx.save_for_backward(E, A0, S0, A1, S1, W0, b0, W1, b1, W2, b2)
         ctx.cfg = (M, Hd, Kin, GF, beta, train_weights)
@@ -708,9 +750,9 @@ class SDFValueFn(torch.autograd.Function):
         E, A0, S0, A1, S1, W0, b0, W1, b1, W2, b2 = ctx.saved_tensors
         M, Hd, Kin, GF, beta, train_w = ctx.cfg
         dev = E.device
-        g = torch.zeros(M, 4, device=dev)
+        g = zeros(M, 4, device=dev)
         g[:, 0] = g_sdf
-        w2s = torch.zeros(4, Hd, device=dev)
+        w2s = zeros(4, Hd, device=dev)
         w2s[0] = W2[GF]
         dZ1 = torch.empty(M, Hd, device=dev)
         grad_input(g, w2s, M, Hd, 4, dZ1, epi=hip.EPI_MUL_AUX, aux0=S1)  # da1 * softplus'(z1)
@@ -761,7 +803,7 @@ class HemiCompositeFn(torch.autograd.Function):
         dev = a.device
         da, dn = torch.empty_like(a), torch.empty_like(n)
         dw = torch.empty_like(w)
-        dcol = torch.zeros_like(cam_colours)
+        dcol = zeros_like(cam_colours)
         dvis = torch.empty_like(vis) if vis is not None else None
         dbg = torch.empty_like(bg)
         hip.hemi_composite_bwd(a, n, w, dirs, cam_colours, cam_of_ray, vis, bg, lin, d_rgb.contiguous(), da, dn, dw, dcol, dvis, dbg)
@@ -790,11 +832,58 @@ class NeusWeightsFn(torch.autograd.Function):
     def backward(ctx, dw, dtb, _dacc, _ddep):
         sdf, grad, ray_dirs, starts, ends, variance, w = ctx.saved_tensors
         dsdf, dgrad = torch.empty_like(sdf), torch.empty_like(grad)
-        dvar = torch.zeros_like(variance)
-        dw = torch.zeros_like(w) if dw is None else dw.contiguous()
+        dvar = zeros_like(variance)
+        dw = zeros_like(w) if dw is None else dw.contiguous()
         hip.neus_weights_bwd(sdf, grad, ray_dirs, starts, ends, variance, ctx.anneal, dw,
                              None if dtb is None else dtb.contiguous(), dsdf, dgrad, dvar)
         return dsdf, dgrad, None, None, None, dvar, None
+
+
+class DDFQueryRowsFn(torch.autograd.Function):
+    """Every row the DDF network is evaluated on in a train step, in ONE pair of buffers: the R x Dv visibility rows
+    (hip.visibility_rays; not differentiable) followed by the DDF-fit rows (fit rays | multi-view | sky; hip.ddf_fit_rows_fwd,
+    ddf_model.py:193-360).  Differentiable input: the fit rays' ground-truth termination distance, through the multi-view
+    rows' directions.  fit = None: visibility rows only.
+    -> pts_all [M+E,3], xrow_all [M+E,16], surf_dist [M], term_dist [M], mv_points [N,3], sky_gt [Ns], distance_weight [N]"""
+
+    @staticmethod
+    def forward(ctx, term_dist_fit, origins, ray_dirs, depth, sel_dirs, radius, fit):
+        dev = origins.device
+        R, Dv = origins.shape[0], sel_dirs.shape[0]
+        M = R * Dv
+        N = fit["positions"].shape[0] if fit is not None else 0
+        n_mv = N if (fit is not None and fit["want_mv"]) else 0
+        sky_o = fit["sky_o"] if fit is not None else None
+        Ns = sky_o.shape[0] if sky_o is not None else 0
+        E = N + n_mv + Ns
+        pts_all = torch.empty(M + E, 3, device=dev)
+        xrow_all = torch.empty(M + E, 16, device=dev)
+        surf_dist = torch.empty(M, device=dev)
+        term_dist = torch.empty(M, device=dev)
+        hip.visibility_rays(origins, ray_dirs, depth, sel_dirs, radius, pts_all[:M], xrow_all[:M], surf_dist, term_dist)
+        mv_points = torch.empty(n_mv, 3, device=dev)
+        sky_gt = torch.empty(Ns, device=dev)
+        dist_w = torch.empty(N, device=dev) if (fit is not None and fit["want_weight"]) else None
+        if E > 0:
+            t = term_dist_fit.detach().reshape(-1).contiguous()
+            hip.ddf_fit_rows_fwd(fit["positions"], fit["directions"], t, fit["mv_points_in"], fit["seed"], fit["counter"], sky_o, fit["sky_d"],
+                                 radius, bool(n_mv), fit["weight_exp"], fit["weight_include_z"], pts_all[M:], xrow_all[M:],
+                                 mv_points if n_mv else None, sky_gt if Ns else None, dist_w)
+            ctx.save_for_backward(fit["positions"], fit["directions"], t, mv_points)
+        ctx.cfg = (M, N, n_mv, tuple(term_dist_fit.shape) if term_dist_fit is not None else None)
+        outs = (pts_all, xrow_all, surf_dist, term_dist, mv_points, sky_gt, dist_w if dist_w is not None else torch.empty(0, device=dev))
+        ctx.mark_non_differentiable(outs[0], *outs[2:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, _dp, d_xrow, *_):
+        M, N, n_mv, tshape = ctx.cfg
+        if n_mv == 0 or d_xrow is None or not ctx.needs_input_grad[0]:
+            return (None,) * 7
+        positions, directions, t, mv_points = ctx.saved_tensors
+        d_t = torch.empty(N, device=positions.device)
+        hip.ddf_fit_rows_bwd(positions, directions, t, mv_points, d_xrow[M + N:M + 2 * N], d_t)
+        return (d_t.view(tshape),) + (None,) * 6
 
 
 class VisibilityFinishFn(torch.autograd.Function):
@@ -814,7 +903,7 @@ class VisibilityFinishFn(torch.autograd.Function):
         t_hat, surf_dist, threshold, sel_index = ctx.saved_tensors
         scale, R, Dv, D = ctx.cfg
         d_t = torch.empty_like(t_hat)
-        d_thr = torch.zeros_like(threshold)
+        d_thr = zeros_like(threshold)
         hip.visibility_finish_bwd(t_hat, surf_dist, threshold, scale, sel_index, R, Dv, D, d_vis.contiguous(), d_t, d_thr)
         return d_t, None, d_thr, None, None, None, None, None, None
 

@@ -1,0 +1,68 @@
+"""The fused sample generators (csrc/samplers.hip) against the distributions of the reference's host samplers (their RNG
+streams are not portable; the oracle's restatement of the same algorithm gives the numbers to compare with)."""
+import math
+
+import pytest
+import torch
+
+from oracle import neusky_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _sampler(n_pos, n_dir, kappa=20.0):
+    from neusky_amd.model_components.ddf_sampler import VMFDDFSampler, VMFDDFSamplerConfig
+    return VMFDDFSampler(VMFDDFSamplerConfig(num_samples_on_sphere=n_pos, num_rays_per_sample=n_dir, concentration=kappa), device=DEV)
+
+
+def test_vmf_ddf_samples_distribution():
+    """ddf_sampler.py:205-286: unit positions on the upper hemisphere, unit directions into the inward half space, and the lobe's
+    concentration = that of the reference algorithm (the oracle's restatement, G10)"""
+    s = _sampler(64, 2000)
+    rb = s()
+    o, d = rb.origins.view(64, 2000, 3).cpu(), rb.directions.view(64, 2000, 3).cpu()
+    assert torch.allclose(o.norm(dim=-1), torch.ones(64, 2000), atol=1e-5) and bool((o[..., 2] >= 0).all())
+    assert bool((o[:, :1] == o).all()), "a position's directions share its origin"
+    assert torch.allclose(d.norm(dim=-1), torch.ones(64, 2000), atol=1e-5)
+    cos = (d * -o).sum(-1)
+    assert bool((cos >= 0).all())
+    P, D = O.vmf_ddf_rays(16, 4000, 20.0, 1.0, torch.Generator().manual_seed(1))
+    ref = (D.view(16, 4000, 3) * -P.view(16, 4000, 3)).sum(-1)
+    assert abs(float(cos.mean()) - float(ref.mean())) < 0.003, (float(cos.mean()), float(ref.mean()))
+    assert abs(float(cos.std()) - float(ref.std())) < 0.004
+    # positions: uniform on the (folded) sphere -> z uniform on [0, 1], azimuth uniform
+    z = o[:, 0, 2]
+    big = _sampler(20000, 1)().origins.cpu()
+    assert abs(float(big[:, 2].mean()) - 0.5) < 0.01 and abs(float(big[:, 2].var()) - 1 / 12) < 0.005
+    az = torch.atan2(big[:, 1], big[:, 0])
+    assert abs(float(az.mean())) < 0.05 and abs(float(az.var()) - math.pi**2 / 3) < 0.1
+    # the tangential part of a direction is uniform around the normal: no preferred azimuth in a fixed world frame
+    t = d - cos[..., None] * -o
+    assert float(t.mean(dim=(0, 1)).abs().max()) < 0.01
+    assert z.numel() == 64
+
+
+def test_vmf_ddf_samples_advance_and_reproduce():
+    s = _sampler(8, 16)
+    a = s()
+    b = s()
+    assert not torch.equal(a.directions, b.directions) and not torch.equal(a.origins, b.origins)
+    assert int(s._dev_state["counter"]) == 2
+    s._dev_state["counter"].zero_()
+    c = s()
+    assert torch.equal(a.directions, c.directions) and torch.equal(a.origins, c.origins)
+
+
+def test_vmf_ddf_samples_replay_in_a_hip_graph_draw_fresh_numbers():
+    s = _sampler(8, 16)
+    s()  # state tensors exist before capture
+    g = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(g):
+            rb = s()
+        g.replay(); first = rb.directions.clone()
+        g.replay(); second = rb.directions.clone()
+    torch.cuda.synchronize()
+    assert not torch.equal(first, second)
