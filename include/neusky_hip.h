@@ -191,6 +191,22 @@ typedef struct {
 } nsky_wgrad_problem;
 int nsky_wgrad_native_batch(const nsky_wgrad_problem* problems, int32_t n_problems, int32_t rows, nsky_stream_t stream);
 
+/* Per-ray reductions of the renderers, one pass each way: expected depth clipped to the global [min, max] of the sample mid
+ * points and, if max_clamp > 0, to max_clamp (nerfstudio DepthRenderer('expected'); neusky_model.py:591, :1342-1353),
+ * accumulation (:595), weighted normal (:812, :1357) and albedo on white (:813).  weights / starts / ends [R,S]; normals / albedo
+ * [R,S,3] (optional, with their outputs); sums [R,8] and bounds [2] are scratch kept for the backward: the caller sets bounds to
+ * (+inf, -inf) before the forward call. */
+int nsky_ray_reduce_fwd(const float* weights, const float* starts, const float* ends, const float* normals, const float* albedo,
+                        int32_t R, int32_t S, float max_clamp, float* sums, float* bounds, float* p2p, float* accumulation,
+                        float* normal, float* albedo_acc, nsky_stream_t stream);
+int nsky_ray_reduce_bwd(const float* weights, const float* starts, const float* ends, const float* normals, const float* albedo,
+                        const float* sums, const float* bounds, int32_t R, int32_t S, float max_clamp, const float* d_p2p,
+                        const float* d_accumulation, const float* d_normal, const float* d_albedo_acc, float* d_weights,
+                        float* d_normals, float* d_albedo, nsky_stream_t stream);
+/* unit rows of g [P,3] (torch.nn.functional.normalize(p=2, eps=1e-12), sdf_albedo_field.py:256) and its backward */
+int nsky_normalize3_fwd(const float* g, int64_t P, float* n, nsky_stream_t stream);
+int nsky_normalize3_bwd(const float* g, const float* d_n, int64_t P, float* d_g, nsky_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Sample generators (replace host-side torch RNG + upload in the reference).  Counter-based RNG (Philox4x32-10) keyed by
  * (seed, *counter); every call advances *counter (a device uint64 the caller owns) by one, so a replayed HIP graph draws

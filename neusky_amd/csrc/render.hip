@@ -627,6 +627,151 @@ __global__ __launch_bounds__(256) void interlevel_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Per-ray reductions of the renderers: expected depth (nerfstudio DepthRenderer('expected'), neusky_model.py:591,1342: clipped
+// to the global [min, max] of the sample mid points), accumulation (:595), weighted normal (:812) and albedo on a white
+// background (:813).  One wave per ray; the clip bounds are two float atomics into a [2] buffer the caller initialises to
+// (+inf, -inf); a finishing kernel applies them.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_min_float(float* addr, float v) {
+  int* ia = reinterpret_cast<int*>(addr);
+  int old = *ia;
+  while (__int_as_float(old) > v) {
+    const int prev = atomicCAS(ia, old, __float_as_int(v));
+    if (prev == old) break;
+    old = prev;
+  }
+}
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+  int* ia = reinterpret_cast<int*>(addr);
+  int old = *ia;
+  while (__int_as_float(old) < v) {
+    const int prev = atomicCAS(ia, old, __float_as_int(v));
+    if (prev == old) break;
+    old = prev;
+  }
+}
+
+__global__ __launch_bounds__(256) void ray_reduce_fwd_kernel(const float* __restrict__ w, const float* __restrict__ starts,
+                                                             const float* __restrict__ ends, const float* __restrict__ normals,
+                                                             const float* __restrict__ albedo, int R, int S, float* __restrict__ sums,
+                                                             float* __restrict__ bounds) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float mn = 3.0e38f, mx = -3.0e38f;
+  for (int k = lane; k < S; k += 64) {
+    const long i = (long)r * S + k;
+    const float wk = w[i], mid = (starts[i] + ends[i]) * 0.5f;
+    mn = fminf(mn, mid); mx = fmaxf(mx, mid);
+    acc[0] = fmaf(wk, mid, acc[0]);
+    acc[1] += wk;
+    if (normals)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[2 + c] = fmaf(wk, normals[i * 3 + c], acc[2 + c]);
+    if (albedo)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[5 + c] = fmaf(wk, albedo[i * 3 + c], acc[5 + c]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = wave_sum(acc[j]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off, 64)); mx = fmaxf(mx, __shfl_xor(mx, off, 64)); }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sums[(long)r * 8 + j] = acc[j];
+    atomic_min_float(bounds, mn);
+    atomic_max_float(bounds + 1, mx);
+  }
+}
+
+__global__ void ray_reduce_finish_kernel(const float* __restrict__ sums, const float* __restrict__ bounds, int R, float max_clamp,
+                                         float* __restrict__ p2p, float* __restrict__ accum, float* __restrict__ normal,
+                                         float* __restrict__ albedo_acc) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float* s = sums + (long)r * 8;
+  float d = s[0] / (s[1] + 1e-10f);
+  d = fminf(fmaxf(d, bounds[0]), bounds[1]);
+  if (max_clamp > 0.0f) d = fminf(d, max_clamp);
+  p2p[r] = d;
+  accum[r] = s[1];
+  if (normal)
+    for (int c = 0; c < 3; ++c) normal[r * 3 + c] = s[2 + c];
+  if (albedo_acc)
+    for (int c = 0; c < 3; ++c) albedo_acc[r * 3 + c] = s[5 + c] + (1.0f - s[1]);
+}
+
+__global__ __launch_bounds__(256) void ray_reduce_bwd_kernel(const float* __restrict__ w, const float* __restrict__ starts,
+                                                             const float* __restrict__ ends, const float* __restrict__ normals,
+                                                             const float* __restrict__ albedo, const float* __restrict__ sums,
+                                                             const float* __restrict__ bounds, int R, int S, float max_clamp,
+                                                             const float* __restrict__ d_p2p, const float* __restrict__ d_accum,
+                                                             const float* __restrict__ d_normal, const float* __restrict__ d_albedo_acc,
+                                                             float* __restrict__ d_w, float* __restrict__ d_normals,
+                                                             float* __restrict__ d_albedo) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float A = sums[(long)r * 8], B = sums[(long)r * 8 + 1];
+  const float depth = A / (B + 1e-10f);
+  // torch.clamp's backward passes the gradient where min <= x <= max
+  float gd = d_p2p ? d_p2p[r] : 0.0f;
+  if (!(depth >= bounds[0] && depth <= bounds[1])) gd = 0.0f;
+  if (max_clamp > 0.0f && !(fminf(fmaxf(depth, bounds[0]), bounds[1]) <= max_clamp)) gd = 0.0f;
+  const float ga = d_accum ? d_accum[r] : 0.0f;
+  float gn[3] = {0.f, 0.f, 0.f}, gb[3] = {0.f, 0.f, 0.f};
+  if (d_normal) for (int c = 0; c < 3; ++c) gn[c] = d_normal[r * 3 + c];
+  if (d_albedo_acc) for (int c = 0; c < 3; ++c) gb[c] = d_albedo_acc[r * 3 + c];
+  const float gbs = gb[0] + gb[1] + gb[2];
+  const float inv = 1.0f / (B + 1e-10f);
+  for (int k = lane; k < S; k += 64) {
+    const long i = (long)r * S + k;
+    const float wk = w[i], mid = (starts[i] + ends[i]) * 0.5f;
+    float g = gd * (mid - depth) * inv + ga - gbs;
+    if (normals) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        g = fmaf(normals[i * 3 + c], gn[c], g);
+        if (d_normals) d_normals[i * 3 + c] = wk * gn[c];
+      }
+    }
+    if (albedo) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        g = fmaf(albedo[i * 3 + c], gb[c], g);
+        if (d_albedo) d_albedo[i * 3 + c] = wk * gb[c];
+      }
+    }
+    d_w[i] = g;
+  }
+}
+
+// rows of g [P,3] -> unit rows (torch.nn.functional.normalize, eps = 1e-12; sdf_albedo_field.py:256) and the backward
+__global__ void normalize3_fwd_kernel(const float* __restrict__ g, long P, float* __restrict__ n) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const float x = g[p * 3], y = g[p * 3 + 1], z = g[p * 3 + 2];
+  const float inv = 1.0f / fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);
+  n[p * 3] = x * inv; n[p * 3 + 1] = y * inv; n[p * 3 + 2] = z * inv;
+}
+__global__ void normalize3_bwd_kernel(const float* __restrict__ g, const float* __restrict__ d_n, long P, float* __restrict__ d_g) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const float x = g[p * 3], y = g[p * 3 + 1], z = g[p * 3 + 2];
+  const float len = sqrtf(x * x + y * y + z * z);
+  const float a = d_n[p * 3], b = d_n[p * 3 + 1], c = d_n[p * 3 + 2];
+  if (len > 1e-12f) {
+    const float inv = 1.0f / len;
+    const float nx = x * inv, ny = y * inv, nz = z * inv;
+    const float dot = nx * a + ny * b + nz * c;
+    d_g[p * 3] = (a - nx * dot) * inv; d_g[p * 3 + 1] = (b - ny * dot) * inv; d_g[p * 3 + 2] = (c - nz * dot) * inv;
+  } else {  // the clamped branch: n = g / eps
+    d_g[p * 3] = a * 1e12f; d_g[p * 3 + 1] = b * 1e12f; d_g[p * 3 + 2] = c * 1e12f;
+  }
+}
+
 }  // namespace
 
 extern "C" int nsky_hemi_composite_fwd(const float* albedo, const float* normals, const float* weights, const float* dirs,
@@ -761,5 +906,48 @@ extern "C" int nsky_interlevel_bwd(const float* c, const float* w, const float* 
   hipLaunchKernelGGL((interlevel_kernel<true>), dim3(ceil_div(R, 4)), dim3(256), smem, (hipStream_t)stream, c, w, sb, wp, d_per_ray, R,
                      S, n, nullptr, d_wp);
   NSKY_CHECK_LAUNCH("nsky_interlevel_bwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_ray_reduce_fwd(const float* weights, const float* starts, const float* ends, const float* normals, const float* albedo,
+                                   int32_t R, int32_t S, float max_clamp, float* sums, float* bounds, float* p2p, float* accumulation,
+                                   float* normal, float* albedo_acc, nsky_stream_t stream) {
+  if (R == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(weights && starts && ends && sums && bounds && p2p && accumulation && R > 0 && S > 0, "nsky_ray_reduce_fwd: bad argument");
+  NSKY_CHECK_ARG((normals != nullptr) == (normal != nullptr) && (albedo != nullptr) == (albedo_acc != nullptr),
+                 "nsky_ray_reduce_fwd: normals / albedo inputs and outputs go together");
+  hipLaunchKernelGGL(ray_reduce_fwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, (hipStream_t)stream, weights, starts, ends, normals, albedo,
+                     R, S, sums, bounds);
+  hipLaunchKernelGGL(ray_reduce_finish_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, (hipStream_t)stream, sums, bounds, R, max_clamp, p2p,
+                     accumulation, normal, albedo_acc);
+  NSKY_CHECK_LAUNCH("nsky_ray_reduce_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_ray_reduce_bwd(const float* weights, const float* starts, const float* ends, const float* normals, const float* albedo,
+                                   const float* sums, const float* bounds, int32_t R, int32_t S, float max_clamp, const float* d_p2p,
+                                   const float* d_accumulation, const float* d_normal, const float* d_albedo_acc, float* d_weights,
+                                   float* d_normals, float* d_albedo, nsky_stream_t stream) {
+  if (R == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(weights && starts && ends && sums && bounds && d_weights && R > 0 && S > 0, "nsky_ray_reduce_bwd: bad argument");
+  hipLaunchKernelGGL(ray_reduce_bwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, (hipStream_t)stream, weights, starts, ends, normals, albedo,
+                     sums, bounds, R, S, max_clamp, d_p2p, d_accumulation, d_normal, d_albedo_acc, d_weights, d_normals, d_albedo);
+  NSKY_CHECK_LAUNCH("nsky_ray_reduce_bwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_normalize3_fwd(const float* g, int64_t P, float* n, nsky_stream_t stream) {
+  if (P == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(g && n && P > 0, "nsky_normalize3_fwd: bad argument");
+  hipLaunchKernelGGL(normalize3_fwd_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, (hipStream_t)stream, g, (long)P, n);
+  NSKY_CHECK_LAUNCH("nsky_normalize3_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_normalize3_bwd(const float* g, const float* d_n, int64_t P, float* d_g, nsky_stream_t stream) {
+  if (P == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(g && d_n && d_g && P > 0, "nsky_normalize3_bwd: bad argument");
+  hipLaunchKernelGGL(normalize3_bwd_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, (hipStream_t)stream, g, d_n, (long)P, d_g);
+  NSKY_CHECK_LAUNCH("nsky_normalize3_bwd");
   return NSKY_OK;
 }

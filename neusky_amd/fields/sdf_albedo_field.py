@@ -282,7 +282,7 @@ class SDFAlbedoField(FieldBase):
         outputs = {
             NeuSkyFieldHeadNames.ALBEDO: albedo.view(R, S, 3),
             FieldHeadNames.SDF: sdf.view(R, S, 1),
-            FieldHeadNames.NORMALS: F.normalize(grad.view(R, S, 3), p=2, dim=-1),
+            FieldHeadNames.NORMALS: (ops.NormalizeFn.apply(grad) if grad.is_cuda else F.normalize(grad, p=2, dim=-1)).view(R, S, 3),
             FieldHeadNames.GRADIENT: grad.view(R, S, 3),
         }
         if return_alphas:

@@ -305,6 +305,34 @@ def neus_weights_bwd(sdf, grad, ray_dirs, starts, ends, variance, anneal, d_weig
                     _c(d_trans_bg), _c(d_sdf), _c(d_grad), _c(d_variance), stream_ptr()), "nsky_neus_weights_bwd")
 
 
+_ray_reduce_fwd = _sig("nsky_ray_reduce_fwd", _P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P)
+_ray_reduce_bwd = _sig("nsky_ray_reduce_bwd", _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P)
+_normalize3_fwd = _sig("nsky_normalize3_fwd", _P, C.c_int64, _P, _P)
+_normalize3_bwd = _sig("nsky_normalize3_bwd", _P, _P, C.c_int64, _P, _P)
+
+
+def ray_reduce_fwd(weights, starts, ends, normals, albedo, max_clamp, sums, bounds, p2p, accumulation, normal, albedo_acc):
+    R, S = weights.shape
+    check(_ray_reduce_fwd(_c(weights), _c(starts), _c(ends), _c(normals), _c(albedo), R, S, float(max_clamp), _c(sums), _c(bounds), _c(p2p),
+                          _c(accumulation), _c(normal), _c(albedo_acc), stream_ptr()), "nsky_ray_reduce_fwd")
+
+
+def ray_reduce_bwd(weights, starts, ends, normals, albedo, sums, bounds, max_clamp, d_p2p, d_accumulation, d_normal, d_albedo_acc,
+                   d_weights, d_normals, d_albedo):
+    R, S = weights.shape
+    check(_ray_reduce_bwd(_c(weights), _c(starts), _c(ends), _c(normals), _c(albedo), _c(sums), _c(bounds), R, S, float(max_clamp),
+                          _c(d_p2p), _c(d_accumulation), _c(d_normal), _c(d_albedo_acc), _c(d_weights), _c(d_normals), _c(d_albedo),
+                          stream_ptr()), "nsky_ray_reduce_bwd")
+
+
+def normalize3_fwd(g, n):
+    check(_normalize3_fwd(_c(g), g.numel() // 3, _c(n), stream_ptr()), "nsky_normalize3_fwd")
+
+
+def normalize3_bwd(g, d_n, d_g):
+    check(_normalize3_bwd(_c(g), _c(d_n), g.numel() // 3, _c(d_g), stream_ptr()), "nsky_normalize3_bwd")
+
+
 def visibility_rays(origins, ray_dirs, depth, sel_dirs, radius, sphere_pts, xrow, surf_dist, term_dist=None):
     R, Dv = origins.shape[0], sel_dirs.shape[0]
     check(_vis_rays(_c(origins), _c(ray_dirs), _c(depth), _c(sel_dirs), R, Dv, radius, _c(sphere_pts), _c(xrow), ld(xrow),

@@ -320,9 +320,19 @@ class NeuSkyFactoModel(ModelBase):
 
     def render_depth(self, weights: torch.Tensor, ray_samples: RaySamples) -> torch.Tensor:
         """nerfstudio DepthRenderer('expected') (neusky_model.py:591): weights [R,S,1] -> [R,1]"""
+        if weights.is_cuda:
+            return self.ray_reductions(weights, ray_samples)[0]
         steps = (ray_samples.frustums.starts + ray_samples.frustums.ends) / 2
         depth = torch.sum(weights * steps, dim=-2) / (torch.sum(weights, -2) + 1e-10)
         return torch.clip(depth, steps.min(), steps.max())
+
+    @staticmethod
+    def ray_reductions(weights: torch.Tensor, ray_samples: RaySamples, normals: Optional[torch.Tensor] = None,
+                       albedo: Optional[torch.Tensor] = None, max_clamp: float = 0.0):
+        """(p2p_dist [R,1], accumulation [R,1], normal [R,3], albedo-on-white [R,3]) of :591-595 / :812-813 / :1342-1357 from one
+        fused pass (ops.RayReduceFn)"""
+        fr = ray_samples.frustums
+        return ops.RayReduceFn.apply(weights, fr.starts, fr.ends, normals, albedo, float(max_clamp))
 
     def compute_visibility(self, ray_samples: RaySamples, depth: torch.Tensor, illumination_directions: torch.Tensor,
                            threshold_distance: torch.Tensor, sigmoid_scale: float, compute_shadow_map: bool = False) -> Dict[str, Any]:
@@ -438,9 +448,13 @@ class NeuSkyFactoModel(ModelBase):
             "cam_of_ray": cam_of_ray, "hdr_background_colours": hdr_bg,
         }
         if self.config.use_visibility:
-            p2p_dist = self.render_depth(weights, ray_samples)  # :591
+            if weights.is_cuda:  # :591, :595 and get_outputs' :812-813 in one pass
+                p2p_dist, accumulation, out["normal"], out["albedo_on_white"] = self.ray_reductions(
+                    weights, ray_samples, field_outputs[FieldHeadNames.NORMALS], field_outputs[NeuSkyFieldHeadNames.ALBEDO])
+            else:
+                p2p_dist = self.render_depth(weights, ray_samples)  # :591
+                accumulation = weights.sum(dim=-2)  # :595
             depth = p2p_dist / ray_bundle.metadata["directions_norm"]  # :593
-            accumulation = weights.sum(dim=-2)  # :595
             p2p_vis = p2p_dist.detach() if self.config.sdf_to_visibility_stop_gradients in ["depth", "both"] else p2p_dist
             if p2p_vis.requires_grad:
                 raise NotImplementedError("visibility geometry is differentiated only in 'depth'/'both' mode (neusky_config.py:156)")
@@ -507,8 +521,11 @@ class NeuSkyFactoModel(ModelBase):
         if p2p_dist is None:
             p2p_dist = self.render_depth(weights, ray_samples)
         depth = p2p_dist / ray_bundle.metadata["directions_norm"]
-        normal = torch.sum(weights * fo[FieldHeadNames.NORMALS], dim=-2)  # :812 (SemanticRenderer-style)
-        albedo = torch.sum(weights * fo[NeuSkyFieldHeadNames.ALBEDO], dim=-2) + (1.0 - weights.sum(dim=-2))  # :813, white bg
+        if "normal" in so and "albedo_on_white" in so:
+            normal, albedo = so["normal"], so["albedo_on_white"]
+        else:
+            normal = torch.sum(weights * fo[FieldHeadNames.NORMALS], dim=-2)  # :812 (SemanticRenderer-style)
+            albedo = torch.sum(weights * fo[NeuSkyFieldHeadNames.ALBEDO], dim=-2) + (1.0 - weights.sum(dim=-2))  # :813, white bg
         outputs: Dict[str, Any] = {
             "rgb": rgb, "albedo": albedo, "accumulation": accumulation, "depth": depth, "p2p_dist": p2p_dist, "normal": normal,
             "weights": weights, "hdr_background_colours": so["hdr_background_colours"],
@@ -650,14 +667,19 @@ class NeuSkyFactoModel(ModelBase):
         ray_samples, _, _, _, _ = self._sample(ray_bundle, sub)
         fo = self.field(ray_samples, return_alphas=True, want_albedo=False)  # depth / mask / normals only (:1337-1367)
         weights = fo["weights"]
-        accumulations = weights.sum(dim=-2).reshape(-1, 1)
+        if weights.is_cuda:
+            p2p, accumulations, normals, _ = self.ray_reductions(
+                weights, ray_samples, fo[FieldHeadNames.NORMALS], None,
+                max_clamp=2 * self.visibility_field.ddf_radius if self.visibility_field is not None else 0.0)
+        else:
+            accumulations = weights.sum(dim=-2).reshape(-1, 1)
+            p2p = self.render_depth(weights, ray_samples).reshape(-1, 1)
+            if self.visibility_field is not None:
+                p2p = torch.clamp(p2p, max=2 * self.visibility_field.ddf_radius)
+            normals = torch.sum(weights * fo[FieldHeadNames.NORMALS], dim=-2).reshape(-1, 3)
         mask = (accumulations > mask_threshold).float()
-        p2p = self.render_depth(weights, ray_samples).reshape(-1, 1)
-        if self.visibility_field is not None:
-            p2p = torch.clamp(p2p, max=2 * self.visibility_field.ddf_radius)
         if log_depth:  # :1354-1355
             p2p = torch.log(p2p + 1e-6)
-        normals = torch.sum(weights * fo[FieldHeadNames.NORMALS], dim=-2).reshape(-1, 3)
         return {"ray_bundle": ray_bundle, "accumulations": accumulations, "mask": mask, "termination_dist": p2p, "normals": normals}
 
     def _eval_fit_bundle(self, datamanager):

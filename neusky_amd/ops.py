@@ -55,18 +55,38 @@ def pad4(n: int) -> int:
     return (n + 3) // 4 * 4
 
 
+class _PadFn(torch.autograd.Function):
+    """zero padding of a small weight / bias to multiples of 4: one copy into a zero-filled (arena) buffer forward, a VIEW of the
+    incoming gradient backward (torch's F.pad costs a pad kernel each way)"""
+
+    @staticmethod
+    def forward(ctx, w, shape):
+        out = zeros(shape, device=w.device)
+        if w.dim() == 2:
+            out[:w.shape[0], :w.shape[1]].copy_(w)
+        else:
+            out[:w.shape[0]].copy_(w)
+        ctx.orig = tuple(w.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        o = ctx.orig
+        return (g[:o[0], :o[1]] if len(o) == 2 else g[:o[0]]), None
+
+
 def pad_weight(w: torch.Tensor) -> torch.Tensor:
     """[out, in] -> zero padded [pad4(out), pad4(in)] (autograd-tracked)."""
     o, i = w.shape
     if o % 4 == 0 and i % 4 == 0:
         return w if w.is_contiguous() else w.contiguous()
-    return F.pad(w, (0, pad4(i) - i, 0, pad4(o) - o)).contiguous()
+    return _PadFn.apply(w, (pad4(o), pad4(i)))
 
 
 def pad_bias(b: torch.Tensor) -> torch.Tensor:
     if b.shape[0] % 4 == 0:
         return b if b.is_contiguous() else b.contiguous()
-    return F.pad(b, (0, pad4(b.shape[0]) - b.shape[0])).contiguous()
+    return _PadFn.apply(b, (pad4(b.shape[0]),))
 
 
 def _splits(M: int, n_out: int = 256, k_in: int = 256) -> int:
@@ -839,6 +859,77 @@ class NeusWeightsFn(torch.autograd.Function):
         return dsdf, dgrad, None, None, None, dvar, None
 
 
+class RayReduceFn(torch.autograd.Function):
+    """per-ray renderer reductions in one pass each way (hip.ray_reduce_*): weights [R,S], starts / ends [R,S], normals / albedo
+    [R,S,3] or None -> p2p [R,1] (expected depth, clipped as nerfstudio's DepthRenderer does, then to max_clamp if > 0),
+    accumulation [R,1], normal [R,3], albedo on white [R,3] (empty tensors for absent inputs)"""
+
+    @staticmethod
+    def forward(ctx, weights, starts, ends, normals, albedo, max_clamp):
+        R, S = weights.shape[0], weights.shape[1]
+        dev = weights.device
+        w = weights.detach().reshape(R, S).contiguous()
+        st, en = starts.detach().reshape(R, S).contiguous(), ends.detach().reshape(R, S).contiguous()
+        nr = None if normals is None else normals.detach().reshape(R, S, 3).contiguous()
+        al = None if albedo is None else albedo.detach().reshape(R, S, 3).contiguous()
+        sums = torch.empty(R, 8, device=dev)
+        bounds = _bounds_init(dev).clone()
+        p2p, acc = torch.empty(R, 1, device=dev), torch.empty(R, 1, device=dev)
+        normal = torch.empty(R, 3, device=dev) if nr is not None else None
+        alb = torch.empty(R, 3, device=dev) if al is not None else None
+        hip.ray_reduce_fwd(w, st, en, nr, al, max_clamp, sums, bounds, p2p, acc, normal, alb)
+        ctx.save_for_backward(w, st, en, nr, al, sums, bounds)
+        ctx.cfg = (R, S, max_clamp, tuple(weights.shape), None if normals is None else tuple(normals.shape),
+                   None if albedo is None else tuple(albedo.shape))
+        ctx.set_materialize_grads(False)
+        empty = torch.empty(0, device=dev)
+        return p2p, acc, (normal if normal is not None else empty), (alb if alb is not None else empty)
+
+    @staticmethod
+    def backward(ctx, d_p2p, d_acc, d_normal, d_alb):
+        w, st, en, nr, al, sums, bounds = ctx.saved_tensors
+        R, S, max_clamp, wshape, nshape, ashape = ctx.cfg
+        dev = w.device
+        c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        d_w = torch.empty(R, S, device=dev)
+        want_n = nr is not None and ctx.needs_input_grad[3] and d_normal is not None
+        want_a = al is not None and ctx.needs_input_grad[4] and d_alb is not None
+        d_nr = torch.empty(R, S, 3, device=dev) if want_n else None
+        d_al = torch.empty(R, S, 3, device=dev) if want_a else None
+        hip.ray_reduce_bwd(w, st, en, nr, al, sums, bounds, max_clamp, c(d_p2p), c(d_acc), c(d_normal) if nr is not None else None,
+                           c(d_alb) if al is not None else None, d_w, d_nr, d_al)
+        return (d_w.view(wshape), None, None, None if d_nr is None else d_nr.view(nshape), None if d_al is None else d_al.view(ashape), None)
+
+
+_BOUNDS_INIT: dict = {}
+
+
+def _bounds_init(device) -> torch.Tensor:
+    t = _BOUNDS_INIT.get(str(device))
+    if t is None:
+        t = _BOUNDS_INIT[str(device)] = torch.tensor([float("inf"), float("-inf")], device=device)
+    return t
+
+
+class NormalizeFn(torch.autograd.Function):
+    """F.normalize(g, p=2, dim=-1) for [..., 3] (sdf_albedo_field.py:256), one kernel each way"""
+
+    @staticmethod
+    def forward(ctx, g):
+        gc = g.detach().contiguous()
+        n = torch.empty_like(gc)
+        hip.normalize3_fwd(gc, n)
+        ctx.save_for_backward(gc)
+        return n
+
+    @staticmethod
+    def backward(ctx, d_n):
+        (gc,) = ctx.saved_tensors
+        d_g = torch.empty_like(gc)
+        hip.normalize3_bwd(gc, d_n.contiguous(), d_g)
+        return d_g
+
+
 class DDFQueryRowsFn(torch.autograd.Function):
     """Every row the DDF network is evaluated on in a train step, in ONE pair of buffers: the R x Dv visibility rows
     (hip.visibility_rays; not differentiable) followed by the DDF-fit rows (fit rays | multi-view | sky; hip.ddf_fit_rows_fwd,
@@ -871,6 +962,7 @@ class DDFQueryRowsFn(torch.autograd.Function):
                                  mv_points if n_mv else None, sky_gt if Ns else None, dist_w)
             ctx.save_for_backward(fit["positions"], fit["directions"], t, mv_points)
         ctx.cfg = (M, N, n_mv, tuple(term_dist_fit.shape) if term_dist_fit is not None else None)
+        ctx.set_materialize_grads(False)
         outs = (pts_all, xrow_all, surf_dist, term_dist, mv_points, sky_gt, dist_w if dist_w is not None else torch.empty(0, device=dev))
         ctx.mark_non_differentiable(outs[0], *outs[2:])
         return outs
