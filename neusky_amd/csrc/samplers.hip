@@ -224,6 +224,63 @@ __global__ __launch_bounds__(256) void ddf_fit_rows_bwd_kernel(const float* __re
   d_term_dist[j] = gt;
 }
 
+// ---- RENI++ decoder inputs for every (latent set, direction) pair -------------------------------------------------------
+// RENIField's rotation-invariant conditioning (reni_field.py invariant representation, used at neusky_model.py:1207-1252): for
+// latent codes Z [U,L,3] and directions d [D,3], row u D + d of the mapping network's input is [|Z_xy|, Z_z, Z_xy . d_xy] per
+// latent (3 L columns) and the FiLM input row is [|d_xy|, d_z | NeRF2 of those] (10 columns).  One thread per (row, latent);
+// the backward sums a row gradient back onto the latent codes (the decoder is frozen, the codes are trained).
+__global__ __launch_bounds__(256) void reni_grid_inputs_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ dirs, int U, int L,
+                                                                   int D, float* __restrict__ cond, int ldc, float* __restrict__ xrow,
+                                                                   int ldx) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)U * D * L) return;
+  const int l = (int)(t % L);
+  const long row = t / L;
+  const int d = (int)(row % D), u = (int)(row / D);
+  const float zx = Z[((long)u * L + l) * 3], zy = Z[((long)u * L + l) * 3 + 1], zz = Z[((long)u * L + l) * 3 + 2];
+  const float dx = dirs[d * 3], dy = dirs[d * 3 + 1];
+  float* c = cond + row * ldc + 3 * l;
+  c[0] = sqrtf(zx * zx + zy * zy);
+  c[1] = zz;
+  c[2] = zx * dx + zy * dy;
+  if (l == 0) {
+    for (int k = 3 * L; k < ldc; ++k) cond[row * ldc + k] = 0.0f;
+    float* x = xrow + row * ldx;
+    const float v[2] = {sqrtf(dx * dx + dy * dy), dirs[d * 3 + 2]};
+    x[0] = v[0]; x[1] = v[1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const float arg = TWO_PI * v[i] * (f == 0 ? 1.0f : 4.0f);
+        x[2 + i * 2 + f] = sinf(arg);
+        x[6 + i * 2 + f] = sinf(arg + 1.5707963267948966f);
+      }
+    for (int k = 10; k < ldx; ++k) x[k] = 0.0f;
+  }
+}
+
+__global__ __launch_bounds__(256) void reni_grid_inputs_bwd_kernel(const float* __restrict__ Z, const float* __restrict__ dirs, int U, int L,
+                                                                   int D, const float* __restrict__ d_cond, int ldc,
+                                                                   float* __restrict__ d_Z) {
+  // one wave per (u, 64 latents... ) -> simpler: thread per (u, l), walking the D rows (adjacent threads read adjacent 12-byte groups)
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= U * L) return;
+  const int l = t % L, u = t / L;
+  const float zx = Z[(long)t * 3], zy = Z[(long)t * 3 + 1];
+  float gn = 0.f, gz = 0.f, gx = 0.f, gy = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float* g = d_cond + ((long)u * D + d) * ldc + 3 * l;
+    gn += g[0];
+    gz += g[1];
+    gx = fmaf(g[2], dirs[d * 3], gx);
+    gy = fmaf(g[2], dirs[d * 3 + 1], gy);
+  }
+  const float n = sqrtf(zx * zx + zy * zy);
+  if (n > 0.0f) { gx += gn * zx / n; gy += gn * zy / n; }
+  d_Z[(long)t * 3] = gx; d_Z[(long)t * 3 + 1] = gy; d_Z[(long)t * 3 + 2] = gz;
+}
+
 }  // namespace
 
 extern "C" int nsky_ddf_vmf_samples(int32_t n_positions, int32_t n_directions, float kappa, float radius, int32_t upper_hemisphere,
@@ -270,5 +327,26 @@ extern "C" int nsky_ddf_fit_rows_bwd(const float* positions, const float* direct
   hipLaunchKernelGGL(ddf_fit_rows_bwd_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, positions, directions, term_dist,
                      mv_points, d_xrow_mv, ldx, N, d_term_dist);
   NSKY_CHECK_LAUNCH("nsky_ddf_fit_rows_bwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_reni_grid_inputs_fwd(const float* latents, const float* directions, int32_t U, int32_t L, int32_t D, float* cond,
+                                         int32_t ldcond, float* xrow, int32_t ldx, nsky_stream_t stream) {
+  const long n = (long)U * D * L;
+  if (n == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(latents && directions && cond && xrow && ldcond >= 3 * L && ldx >= 10, "nsky_reni_grid_inputs_fwd: bad argument");
+  hipLaunchKernelGGL(reni_grid_inputs_fwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, latents, directions, U, L, D,
+                     cond, ldcond, xrow, ldx);
+  NSKY_CHECK_LAUNCH("nsky_reni_grid_inputs_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_reni_grid_inputs_bwd(const float* latents, const float* directions, int32_t U, int32_t L, int32_t D, const float* d_cond,
+                                         int32_t ldcond, float* d_latents, nsky_stream_t stream) {
+  if ((long)U * L == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(latents && directions && d_cond && d_latents && ldcond >= 3 * L && D > 0, "nsky_reni_grid_inputs_bwd: bad argument");
+  hipLaunchKernelGGL(reni_grid_inputs_bwd_kernel, dim3(ceil_div((long)U * L, 256)), dim3(256), 0, (hipStream_t)stream, latents, directions,
+                     U, L, D, d_cond, ldcond, d_latents);
+  NSKY_CHECK_LAUNCH("nsky_reni_grid_inputs_bwd");
   return NSKY_OK;
 }

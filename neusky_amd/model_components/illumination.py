@@ -21,6 +21,7 @@ from torch import nn
 
 from ..fields.directional_distance_field import nerf_encoding
 from ..utils.siren import FiLMSiren
+from .. import ops
 
 
 def fibonacci_sphere(n: int) -> torch.Tensor:
@@ -244,6 +245,10 @@ class RENIField(nn.Module):
         Same arithmetic as forward() on the U*D pairs, built by broadcasting instead of gathering latents per pair."""
         U, L, _ = latent_codes.shape
         D = directions.shape[0]
+        if latent_codes.is_cuda:  # both input matrices from one kernel (no [U D, 3 L] stack / pad copies)
+            cond, x = ops.RENIGridInputsFn.apply(latent_codes, directions)
+            out = torch.exp(self.network(x, cond, train_weights=not self.config.fixed_decoder)).reshape(U, D, 3)
+            return out * scale[:, None, None] if scale is not None else out
         zxy, zz = latent_codes[..., :2], latent_codes[..., 2]
         dxy, dz = directions[:, :2], directions[:, 2]
         dot = torch.einsum("uln,dn->udl", zxy, dxy)

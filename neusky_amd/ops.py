@@ -930,6 +930,33 @@ class NormalizeFn(torch.autograd.Function):
         return d_g
 
 
+class RENIGridInputsFn(torch.autograd.Function):
+    """latents [U,L,3] x directions [D,3] -> (cond [U D, pad4(3 L)], xrow [U D, 12]): the RENI++ decoder's rotation-invariant
+    inputs for every pair (hip.reni_grid_inputs_*); differentiable w.r.t. the latent codes"""
+
+    @staticmethod
+    def forward(ctx, latents, directions):
+        U, L, _ = latents.shape
+        D = directions.shape[0]
+        Z, d = latents.detach().contiguous(), directions.detach().contiguous()
+        cond = torch.empty(U * D, pad4(3 * L), device=Z.device)
+        xrow = torch.empty(U * D, 12, device=Z.device)
+        hip.reni_grid_inputs_fwd(Z, d, cond, xrow)
+        ctx.save_for_backward(Z, d)
+        ctx.mark_non_differentiable(xrow)
+        ctx.set_materialize_grads(False)
+        return cond, xrow
+
+    @staticmethod
+    def backward(ctx, d_cond, _dx):
+        Z, d = ctx.saved_tensors
+        if d_cond is None:
+            return None, None
+        d_Z = torch.empty_like(Z)
+        hip.reni_grid_inputs_bwd(Z, d, d_cond if d_cond.stride(1) == 1 else d_cond.contiguous(), d_Z)
+        return d_Z, None
+
+
 class DDFQueryRowsFn(torch.autograd.Function):
     """Every row the DDF network is evaluated on in a train step, in ONE pair of buffers: the R x Dv visibility rows
     (hip.visibility_rays; not differentiable) followed by the DDF-fit rows (fit rays | multi-view | sky; hip.ddf_fit_rows_fwd,

@@ -66,3 +66,31 @@ def test_vmf_ddf_samples_replay_in_a_hip_graph_draw_fresh_numbers():
         g.replay(); second = rb.directions.clone()
     torch.cuda.synchronize()
     assert not torch.equal(first, second)
+
+
+def test_reni_grid_inputs_match_the_torch_construction():
+    """ops.RENIGridInputsFn against RENIField.forward_grid's torch construction of the same two matrices (values and d latents)"""
+    from neusky_amd import ops
+    from neusky_amd.fields.directional_distance_field import nerf_encoding
+    g = torch.Generator().manual_seed(2)
+    U, L, D = 7, 100, 512
+    Z = torch.randn(U, L, 3, generator=g)
+    dirs = torch.nn.functional.normalize(torch.randn(D, 3, generator=g), dim=-1)
+    Zd = Z.to(DEV).requires_grad_(True)
+    cond, x = ops.RENIGridInputsFn.apply(Zd, dirs.to(DEV))
+    Z64 = Z.double().requires_grad_(True)
+    d64 = dirs.double()
+    zxy, zz = Z64[..., :2], Z64[..., 2]
+    dxy, dz = d64[:, :2], d64[:, 2]
+    dot = torch.einsum("uln,dn->udl", zxy, dxy)
+    rc = torch.stack([zxy.norm(dim=-1)[:, None, :].expand(U, D, L), zz[:, None, :].expand(U, D, L), dot], -1).reshape(U * D, 3 * L)
+    rx = torch.stack([dxy.norm(dim=-1), dz], -1)[None].expand(U, D, 2).reshape(U * D, 2)
+    rx = torch.cat([rx, nerf_encoding(rx, 2, 2.0)], -1)
+    assert cond.shape == (U * D, 300) and x.shape == (U * D, 12)
+    assert torch.allclose(cond.cpu().double(), rc, atol=2e-6, rtol=1e-6), float((cond.cpu().double() - rc).abs().max())
+    assert torch.allclose(x.cpu().double()[:, :10], rx, atol=1e-5), float((x.cpu().double()[:, :10] - rx).abs().max())
+    assert bool((x[:, 10:] == 0).all())
+    gc = torch.randn(U * D, 300, generator=g)
+    (cond * gc.to(DEV)).sum().backward()
+    (rc * gc.double()).sum().backward()
+    assert torch.allclose(Zd.grad.cpu().double(), Z64.grad, atol=1e-4, rtol=1e-5)
