@@ -234,14 +234,17 @@ int nsky_ddf_fit_rows_fwd(const float* positions, const float* directions, const
 int nsky_ddf_fit_rows_bwd(const float* positions, const float* directions, const float* term_dist, const float* mv_points,
                           int32_t N, const float* d_xrow_mv, int32_t ldx, float* d_term_dist, nsky_stream_t stream);
 
-/* RENI++ decoder inputs for every (latent set u, direction d) pair (the rotation-invariant representation of RENIField, as fed at
- * neusky_model.py:1207-1252): row u D + d of cond [U D, ldcond] = [|Z_xy|, Z_z, Z_xy . d_xy] per latent (3 L columns, pad columns
- * zeroed), of xrow [U D, ldx] = [|d_xy|, d_z | NeRF2(2 freqs, 0..2) of those | 0].  latents [U,L,3], directions [D,3].
+/* RENI++ decoder inputs (the rotation-invariant representation of RENIField, as fed at neusky_model.py:1207-1252): for latent
+ * codes Z [U,L,3], a direction set [D,3] and R further (direction, latent index) pairs -- the batch's own rays (:535-549) --
+ * rows u D + d (every latent set against every direction), then U D + r, of cond [U D + R, ldcond] = [|Z_xy|, Z_z, Z_xy . d_xy] per
+ * latent (3 L columns, pad columns zeroed) and of xrow [.., ldx] = [|d_xy|, d_z | NeRF2(2 freqs, 0..2) of those | 0].
  * _bwd: d_latents [U,L,3] (overwritten) from d_cond. */
-int nsky_reni_grid_inputs_fwd(const float* latents, const float* directions, int32_t U, int32_t L, int32_t D, float* cond,
-                              int32_t ldcond, float* xrow, int32_t ldx, nsky_stream_t stream);
-int nsky_reni_grid_inputs_bwd(const float* latents, const float* directions, int32_t U, int32_t L, int32_t D, const float* d_cond,
-                              int32_t ldcond, float* d_latents, nsky_stream_t stream);
+int nsky_reni_grid_inputs_fwd(const float* latents, const float* directions, int32_t U, int32_t L, int32_t D, const float* ray_dirs,
+                              const int64_t* ray_latent, int32_t R, float* cond, int32_t ldcond, float* xrow, int32_t ldx,
+                              nsky_stream_t stream);
+int nsky_reni_grid_inputs_bwd(const float* latents, const float* directions, int32_t U, int32_t L, int32_t D, const float* ray_dirs,
+                              const int64_t* ray_latent, int32_t R, const float* d_cond, int32_t ldcond, float* d_latents,
+                              nsky_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multiresolution hash-grid encode (tiny-cuda-nn HashGrid semantics, fp32) fused with the rest of

@@ -230,15 +230,19 @@ __global__ __launch_bounds__(256) void ddf_fit_rows_bwd_kernel(const float* __re
 // latent (3 L columns) and the FiLM input row is [|d_xy|, d_z | NeRF2 of those] (10 columns).  One thread per (row, latent);
 // the backward sums a row gradient back onto the latent codes (the decoder is frozen, the codes are trained).
 __global__ __launch_bounds__(256) void reni_grid_inputs_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ dirs, int U, int L,
-                                                                   int D, float* __restrict__ cond, int ldc, float* __restrict__ xrow,
-                                                                   int ldx) {
+                                                                   int D, const float* __restrict__ ray_dirs,
+                                                                   const long* __restrict__ ray_latent, int R, float* __restrict__ cond,
+                                                                   int ldc, float* __restrict__ xrow, int ldx) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long)U * D * L) return;
+  if (t >= ((long)U * D + R) * L) return;
   const int l = (int)(t % L);
   const long row = t / L;
-  const int d = (int)(row % D), u = (int)(row / D);
+  int u;
+  const float* dp;
+  if (row < (long)U * D) { u = (int)(row / D); dp = dirs + (row % D) * 3; }
+  else { const long r = row - (long)U * D; u = (int)ray_latent[r]; dp = ray_dirs + r * 3; }  // the rays' own rows (:535-549)
   const float zx = Z[((long)u * L + l) * 3], zy = Z[((long)u * L + l) * 3 + 1], zz = Z[((long)u * L + l) * 3 + 2];
-  const float dx = dirs[d * 3], dy = dirs[d * 3 + 1];
+  const float dx = dp[0], dy = dp[1];
   float* c = cond + row * ldc + 3 * l;
   c[0] = sqrtf(zx * zx + zy * zy);
   c[1] = zz;
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(256) void reni_grid_inputs_fwd_kernel(const float* 
   if (l == 0) {
     for (int k = 3 * L; k < ldc; ++k) cond[row * ldc + k] = 0.0f;
     float* x = xrow + row * ldx;
-    const float v[2] = {sqrtf(dx * dx + dy * dy), dirs[d * 3 + 2]};
+    const float v[2] = {sqrtf(dx * dx + dy * dy), dp[2]};
     x[0] = v[0]; x[1] = v[1];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256) void reni_grid_inputs_fwd_kernel(const float* 
 __global__ __launch_bounds__(256) void reni_grid_inputs_bwd_kernel(const float* __restrict__ Z, const float* __restrict__ dirs, int U, int L,
                                                                    int D, const float* __restrict__ d_cond, int ldc,
                                                                    float* __restrict__ d_Z) {
-  // one wave per (u, 64 latents... ) -> simpler: thread per (u, l), walking the D rows (adjacent threads read adjacent 12-byte groups)
+  // thread per (u, l), walking the D rows (adjacent threads read adjacent 12-byte groups)
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= U * L) return;
   const int l = t % L, u = t / L;
@@ -279,6 +283,23 @@ __global__ __launch_bounds__(256) void reni_grid_inputs_bwd_kernel(const float* 
   const float n = sqrtf(zx * zx + zy * zy);
   if (n > 0.0f) { gx += gn * zx / n; gy += gn * zy / n; }
   d_Z[(long)t * 3] = gx; d_Z[(long)t * 3 + 1] = gy; d_Z[(long)t * 3 + 2] = gz;
+}
+
+// the rays' rows add onto their camera's latent gradient (after the kernel above has written it)
+__global__ __launch_bounds__(256) void reni_ray_inputs_bwd_kernel(const float* __restrict__ Z, const float* __restrict__ ray_dirs,
+                                                                  const long* __restrict__ ray_latent, int R, int L,
+                                                                  const float* __restrict__ d_cond_rays, int ldc, float* __restrict__ d_Z) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= R * L) return;
+  const int l = t % L, r = t / L;
+  const long u = ray_latent[r];
+  const float zx = Z[(u * L + l) * 3], zy = Z[(u * L + l) * 3 + 1];
+  const float* g = d_cond_rays + (long)r * ldc + 3 * l;
+  float gx = g[2] * ray_dirs[r * 3], gy = g[2] * ray_dirs[r * 3 + 1];
+  const float n = sqrtf(zx * zx + zy * zy);
+  if (n > 0.0f) { gx += g[0] * zx / n; gy += g[0] * zy / n; }
+  float* o = d_Z + (u * L + l) * 3;
+  atomicAdd(o, gx); atomicAdd(o + 1, gy); atomicAdd(o + 2, g[1]);
 }
 
 }  // namespace
@@ -330,23 +351,30 @@ extern "C" int nsky_ddf_fit_rows_bwd(const float* positions, const float* direct
   return NSKY_OK;
 }
 
-extern "C" int nsky_reni_grid_inputs_fwd(const float* latents, const float* directions, int32_t U, int32_t L, int32_t D, float* cond,
-                                         int32_t ldcond, float* xrow, int32_t ldx, nsky_stream_t stream) {
-  const long n = (long)U * D * L;
+extern "C" int nsky_reni_grid_inputs_fwd(const float* latents, const float* directions, int32_t U, int32_t L, int32_t D,
+                                         const float* ray_dirs, const int64_t* ray_latent, int32_t R, float* cond, int32_t ldcond,
+                                         float* xrow, int32_t ldx, nsky_stream_t stream) {
+  const long n = ((long)U * D + R) * L;
   if (n == 0) return NSKY_OK;
-  NSKY_CHECK_ARG(latents && directions && cond && xrow && ldcond >= 3 * L && ldx >= 10, "nsky_reni_grid_inputs_fwd: bad argument");
+  NSKY_CHECK_ARG(latents && cond && xrow && ldcond >= 3 * L && ldx >= 10 && (D == 0 || directions) && (R == 0 || (ray_dirs && ray_latent)),
+                 "nsky_reni_grid_inputs_fwd: bad argument");
   hipLaunchKernelGGL(reni_grid_inputs_fwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, latents, directions, U, L, D,
-                     cond, ldcond, xrow, ldx);
+                     ray_dirs, reinterpret_cast<const long*>(ray_latent), R, cond, ldcond, xrow, ldx);
   NSKY_CHECK_LAUNCH("nsky_reni_grid_inputs_fwd");
   return NSKY_OK;
 }
 
-extern "C" int nsky_reni_grid_inputs_bwd(const float* latents, const float* directions, int32_t U, int32_t L, int32_t D, const float* d_cond,
-                                         int32_t ldcond, float* d_latents, nsky_stream_t stream) {
+extern "C" int nsky_reni_grid_inputs_bwd(const float* latents, const float* directions, int32_t U, int32_t L, int32_t D,
+                                         const float* ray_dirs, const int64_t* ray_latent, int32_t R, const float* d_cond, int32_t ldcond,
+                                         float* d_latents, nsky_stream_t stream) {
   if ((long)U * L == 0) return NSKY_OK;
-  NSKY_CHECK_ARG(latents && directions && d_cond && d_latents && ldcond >= 3 * L && D > 0, "nsky_reni_grid_inputs_bwd: bad argument");
+  NSKY_CHECK_ARG(latents && d_cond && d_latents && ldcond >= 3 * L && (D == 0 || directions) && (R == 0 || (ray_dirs && ray_latent)),
+                 "nsky_reni_grid_inputs_bwd: bad argument");
   hipLaunchKernelGGL(reni_grid_inputs_bwd_kernel, dim3(ceil_div((long)U * L, 256)), dim3(256), 0, (hipStream_t)stream, latents, directions,
                      U, L, D, d_cond, ldcond, d_latents);
+  if (R > 0)
+    hipLaunchKernelGGL(reni_ray_inputs_bwd_kernel, dim3(ceil_div((long)R * L, 256)), dim3(256), 0, (hipStream_t)stream, latents, ray_dirs,
+                       reinterpret_cast<const long*>(ray_latent), R, L, d_cond + (long)U * D * ldcond, ldcond, d_latents);
   NSKY_CHECK_LAUNCH("nsky_reni_grid_inputs_bwd");
   return NSKY_OK;
 }

@@ -258,24 +258,29 @@ def ddf_fit_rows_bwd(positions, directions, term_dist, mv_points, d_xrow_mv, d_t
                         stream_ptr()), "nsky_ddf_fit_rows_bwd")
 
 
-_reni_in_fwd = _sig("nsky_reni_grid_inputs_fwd", C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
-                    C.c_int32, C.c_void_p)
-_reni_in_bwd = _sig("nsky_reni_grid_inputs_bwd", C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
-                    C.c_void_p)
+_reni_in_fwd = _sig("nsky_reni_grid_inputs_fwd", C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                    C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p)
+_reni_in_bwd = _sig("nsky_reni_grid_inputs_bwd", C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                    C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p)
 
 
-def reni_grid_inputs_fwd(latents, directions, cond, xrow):
+def reni_grid_inputs_fwd(latents, directions, ray_dirs, ray_latent, cond, xrow):
     U, L, _ = latents.shape
     D = directions.shape[0]
-    assert latents.is_contiguous() and directions.is_contiguous() and cond.shape[0] == U * D and xrow.shape[0] == U * D
-    check(_reni_in_fwd(ptr(latents), ptr(directions), U, L, D, ptr(cond), ld(cond), ptr(xrow), ld(xrow), stream_ptr()), "nsky_reni_grid_inputs_fwd")
+    R = 0 if ray_dirs is None else ray_dirs.shape[0]
+    assert latents.is_contiguous() and directions.is_contiguous() and cond.shape[0] == U * D + R and xrow.shape[0] == U * D + R
+    assert ray_dirs is None or (ray_dirs.is_contiguous() and ray_latent.dtype == torch.int64 and ray_latent.is_contiguous())
+    check(_reni_in_fwd(ptr(latents), ptr(directions), U, L, D, ptr(ray_dirs), ptr(ray_latent), R, ptr(cond), ld(cond), ptr(xrow), ld(xrow),
+                       stream_ptr()), "nsky_reni_grid_inputs_fwd")
 
 
-def reni_grid_inputs_bwd(latents, directions, d_cond, d_latents):
+def reni_grid_inputs_bwd(latents, directions, ray_dirs, ray_latent, d_cond, d_latents):
     U, L, _ = latents.shape
     D = directions.shape[0]
-    assert d_cond.shape[0] == U * D and d_latents.is_contiguous() and d_latents.shape == latents.shape
-    check(_reni_in_bwd(ptr(latents), ptr(directions), U, L, D, ptr(d_cond), ld(d_cond), ptr(d_latents), stream_ptr()), "nsky_reni_grid_inputs_bwd")
+    R = 0 if ray_dirs is None else ray_dirs.shape[0]
+    assert d_cond.shape[0] == U * D + R and d_latents.is_contiguous() and d_latents.shape == latents.shape
+    check(_reni_in_bwd(ptr(latents), ptr(directions), U, L, D, ptr(ray_dirs), ptr(ray_latent), R, ptr(d_cond), ld(d_cond), ptr(d_latents),
+                       stream_ptr()), "nsky_reni_grid_inputs_bwd")
 
 
 # ------------------------------------------------------------------------------------------ render stages

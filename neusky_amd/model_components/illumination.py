@@ -257,6 +257,16 @@ class RENIField(nn.Module):
         out = self._decode(cond, x).reshape(U, D, 3)
         return out * scale[:, None, None] if scale is not None else out
 
+    def forward_grid_and_rays(self, directions: torch.Tensor, latent_codes: torch.Tensor, scale: torch.Tensor,
+                              ray_directions: torch.Tensor, ray_latent: torch.Tensor):
+        """forward_grid(directions, latent_codes, scale) and forward(ray_directions, latent_codes[ray_latent], scale[ray_latent]) from
+        ONE pass of the decoder: the rays' rows ride behind the U D grid rows (-> [U,D,3], [R,3])"""
+        U, D = latent_codes.shape[0], directions.shape[0]
+        cond, x = ops.RENIGridInputsFn.apply(latent_codes, directions, ray_directions, ray_latent)
+        out = torch.exp(self.network(x, cond, train_weights=not self.config.fixed_decoder))
+        grid, rays = out[:U * D].reshape(U, D, 3), out[U * D:]
+        return grid * scale[:, None, None], rays * scale[ray_latent][:, None]
+
     def forward(self, directions: torch.Tensor, latent_codes: torch.Tensor, scale: Optional[torch.Tensor] = None,
                 rotation: Optional[torch.Tensor] = None) -> torch.Tensor:
         """directions [B,3], latent_codes [B,L,3], scale [B] -> HDR radiance [B,3] (already unnormalised)."""

@@ -275,6 +275,9 @@ class NeuSkyFactoModel(ModelBase):
             # are being fitted: static shape, no torch.unique host sync, hipGraph-safe); rows of cameras absent from the
             # batch are never read by the renderer and receive zero gradient
             inverse = camera_indices
+            if rotation is None and dirs.is_cuda:  # the rays' own background rows (:535-549) ride in the same decoder pass
+                cols, bg = self.illumination_field.forward_grid_and_rays(dirs, latents, scales, ray_directions, camera_indices)
+                return dirs, cols, inverse.to(torch.int32), bg
             cols = self.illumination_field.forward_grid(dirs, latents, scales) if rotation is None else None
             unique = torch.arange(latents.shape[0], device=dirs.device)
         else:

@@ -931,30 +931,34 @@ class NormalizeFn(torch.autograd.Function):
 
 
 class RENIGridInputsFn(torch.autograd.Function):
-    """latents [U,L,3] x directions [D,3] -> (cond [U D, pad4(3 L)], xrow [U D, 12]): the RENI++ decoder's rotation-invariant
-    inputs for every pair (hip.reni_grid_inputs_*); differentiable w.r.t. the latent codes"""
+    """latents [U,L,3] x directions [D,3] (+ R ray rows: ray_dirs [R,3] with the latent set ray_latent [R] of each) ->
+    (cond [U D + R, pad4(3 L)], xrow [U D + R, 12]): the RENI++ decoder's rotation-invariant inputs of every pair and of the batch's
+    own rays (hip.reni_grid_inputs_*); differentiable w.r.t. the latent codes"""
 
     @staticmethod
-    def forward(ctx, latents, directions):
+    def forward(ctx, latents, directions, ray_dirs=None, ray_latent=None):
         U, L, _ = latents.shape
         D = directions.shape[0]
+        R = 0 if ray_dirs is None else ray_dirs.shape[0]
         Z, d = latents.detach().contiguous(), directions.detach().contiguous()
-        cond = torch.empty(U * D, pad4(3 * L), device=Z.device)
-        xrow = torch.empty(U * D, 12, device=Z.device)
-        hip.reni_grid_inputs_fwd(Z, d, cond, xrow)
-        ctx.save_for_backward(Z, d)
+        rd = None if ray_dirs is None else ray_dirs.detach().contiguous()
+        rl = None if ray_latent is None else ray_latent.to(torch.int64).contiguous()
+        cond = torch.empty(U * D + R, pad4(3 * L), device=Z.device)
+        xrow = torch.empty(U * D + R, 12, device=Z.device)
+        hip.reni_grid_inputs_fwd(Z, d, rd, rl, cond, xrow)
+        ctx.save_for_backward(Z, d, rd, rl)
         ctx.mark_non_differentiable(xrow)
         ctx.set_materialize_grads(False)
         return cond, xrow
 
     @staticmethod
     def backward(ctx, d_cond, _dx):
-        Z, d = ctx.saved_tensors
+        Z, d, rd, rl = ctx.saved_tensors
         if d_cond is None:
-            return None, None
+            return None, None, None, None
         d_Z = torch.empty_like(Z)
-        hip.reni_grid_inputs_bwd(Z, d, d_cond if d_cond.stride(1) == 1 else d_cond.contiguous(), d_Z)
-        return d_Z, None
+        hip.reni_grid_inputs_bwd(Z, d, rd, rl, d_cond if d_cond.stride(1) == 1 else d_cond.contiguous(), d_Z)
+        return d_Z, None, None, None
 
 
 class DDFQueryRowsFn(torch.autograd.Function):

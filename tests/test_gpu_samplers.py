@@ -78,6 +78,20 @@ def test_reni_grid_inputs_match_the_torch_construction():
     dirs = torch.nn.functional.normalize(torch.randn(D, 3, generator=g), dim=-1)
     Zd = Z.to(DEV).requires_grad_(True)
     cond, x = ops.RENIGridInputsFn.apply(Zd, dirs.to(DEV))
+    # ... and with ray rows behind the grid rows: the same rows as a one-direction-per-latent gather
+    R = 333
+    rd = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    rl = torch.randint(0, U, (R,), generator=g)
+    Zr = Z.to(DEV).requires_grad_(True)
+    cond2, x2 = ops.RENIGridInputsFn.apply(Zr, dirs.to(DEV), rd.to(DEV), rl.to(DEV))
+    assert torch.equal(cond2[:U * D], cond) and torch.equal(x2[:U * D], x)
+    from neusky_amd.model_components.illumination import RENIField
+    Zq = Z.double().requires_grad_(True)
+    rc2, rx2 = RENIField.invariant_inputs(Zq[rl], rd.double())
+    assert torch.allclose(cond2[U * D:].cpu().double(), rc2, atol=2e-6, rtol=1e-6) and torch.allclose(x2[U * D:, :2].cpu().double(), rx2, atol=1e-6)
+    gr = torch.randn(R, 300, generator=g)
+    (cond2[U * D:] * gr.to(DEV)).sum().backward(); (rc2 * gr.double()).sum().backward()
+    assert torch.allclose(Zr.grad.cpu().double(), Zq.grad, atol=1e-4, rtol=1e-5)
     Z64 = Z.double().requires_grad_(True)
     d64 = dirs.double()
     zxy, zz = Z64[..., :2], Z64[..., 2]
