@@ -264,25 +264,37 @@ __global__ __launch_bounds__(256) void reni_grid_inputs_fwd_kernel(const float* 
   }
 }
 
-__global__ __launch_bounds__(256) void reni_grid_inputs_bwd_kernel(const float* __restrict__ Z, const float* __restrict__ dirs, int U, int L,
+// d_Z (zero-filled by the launcher) += the grid rows' gradient.  Workgroup = (latent set u, 32 consecutive directions), thread =
+// one of the 3 L columns of the row gradient: 32 independent 4-byte loads per thread (whole 1200-byte rows per wave group), then
+// one or two float atomics per thread.
+constexpr int RENI_BWD_ROWS = 32;
+__global__ __launch_bounds__(320) void reni_grid_inputs_bwd_kernel(const float* __restrict__ Z, const float* __restrict__ dirs, int U, int L,
                                                                    int D, const float* __restrict__ d_cond, int ldc,
                                                                    float* __restrict__ d_Z) {
-  // thread per (u, l), walking the D rows (adjacent threads read adjacent 12-byte groups)
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= U * L) return;
-  const int l = t % L, u = t / L;
-  const float zx = Z[(long)t * 3], zy = Z[(long)t * 3 + 1];
-  float gn = 0.f, gz = 0.f, gx = 0.f, gy = 0.f;
-  for (int d = 0; d < D; ++d) {
-    const float* g = d_cond + ((long)u * D + d) * ldc + 3 * l;
-    gn += g[0];
-    gz += g[1];
-    gx = fmaf(g[2], dirs[d * 3], gx);
-    gy = fmaf(g[2], dirs[d * 3 + 1], gy);
+  const int u = blockIdx.y, d0 = blockIdx.x * RENI_BWD_ROWS;
+  for (int col = threadIdx.x; col < 3 * L; col += blockDim.x) {
+    const int l = col / 3, k = col % 3;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < RENI_BWD_ROWS; ++j) {
+      const int d = d0 + j;
+      if (d < D) {
+        const float g = d_cond[((long)u * D + d) * ldc + col];
+        if (k == 2) { s0 = fmaf(g, dirs[d * 3], s0); s1 = fmaf(g, dirs[d * 3 + 1], s1); }
+        else s0 += g;
+      }
+    }
+    float* o = d_Z + ((long)u * L + l) * 3;
+    if (k == 0) {
+      const float zx = Z[((long)u * L + l) * 3], zy = Z[((long)u * L + l) * 3 + 1];
+      const float n = sqrtf(zx * zx + zy * zy);
+      if (n > 0.0f) { atomicAdd(o, s0 * zx / n); atomicAdd(o + 1, s0 * zy / n); }
+    } else if (k == 1) {
+      atomicAdd(o + 2, s0);
+    } else {
+      atomicAdd(o, s0); atomicAdd(o + 1, s1);
+    }
   }
-  const float n = sqrtf(zx * zx + zy * zy);
-  if (n > 0.0f) { gx += gn * zx / n; gy += gn * zy / n; }
-  d_Z[(long)t * 3] = gx; d_Z[(long)t * 3 + 1] = gy; d_Z[(long)t * 3 + 2] = gz;
 }
 
 // the rays' rows add onto their camera's latent gradient (after the kernel above has written it)
@@ -370,8 +382,13 @@ extern "C" int nsky_reni_grid_inputs_bwd(const float* latents, const float* dire
   if ((long)U * L == 0) return NSKY_OK;
   NSKY_CHECK_ARG(latents && d_cond && d_latents && ldcond >= 3 * L && (D == 0 || directions) && (R == 0 || (ray_dirs && ray_latent)),
                  "nsky_reni_grid_inputs_bwd: bad argument");
-  hipLaunchKernelGGL(reni_grid_inputs_bwd_kernel, dim3(ceil_div((long)U * L, 256)), dim3(256), 0, (hipStream_t)stream, latents, directions,
-                     U, L, D, d_cond, ldcond, d_latents);
+  if (hipMemsetAsync(d_latents, 0, sizeof(float) * 3 * (size_t)U * L, (hipStream_t)stream) != hipSuccess) {
+    nsky_set_error("nsky_reni_grid_inputs_bwd: memset failed");
+    return NSKY_ERR_LAUNCH;
+  }
+  if (D > 0)
+    hipLaunchKernelGGL(reni_grid_inputs_bwd_kernel, dim3(ceil_div(D, RENI_BWD_ROWS), U), dim3(320), 0, (hipStream_t)stream, latents,
+                       directions, U, L, D, d_cond, ldcond, d_latents);
   if (R > 0)
     hipLaunchKernelGGL(reni_ray_inputs_bwd_kernel, dim3(ceil_div((long)R * L, 256)), dim3(256), 0, (hipStream_t)stream, latents, ray_dirs,
                        reinterpret_cast<const long*>(ray_latent), R, L, d_cond + (long)U * D * ldcond, ldcond, d_latents);

@@ -223,7 +223,7 @@ class NeuSkyFactoModel(ModelBase):
             if randoms is not None and "jitters" in randoms:
                 jitters = [j.to(dev) for j in randoms["jitters"]]
             else:
-                jitters = [torch.rand(R, 1, device=dev) for _ in range(n_lvls)]
+                jitters = list(torch.rand(n_lvls, R, 1, device=dev).unbind(0))  # one draw for all levels
         else:
             jitters = None
         sbins, ebins, weights_list, sbins_list, inds_list = self.proposal_sampler(
