@@ -99,16 +99,18 @@ class KernelTimer:
             return t._timed(f"film_bwd_map_kernel<{H}>", o["film_chain_bwd_map"], fl, fl, net, stream, table, M, *a, **kw)
 
         def wgrad(problems, rows):
-            fl = sum(2.0 * rows * 32 * q.nnt_a * 32 * q.nnt_b for q in problems)
+            wa = lambda q: q.width_a if q.lda > 0 else 32 * q.nnt_a  # noqa: E731
+            wb = lambda q: q.width_b if q.ldb > 0 else 32 * q.nnt_b  # noqa: E731
+            fl = sum(2.0 * rows * wa(q) * wb(q) for q in problems)
             # algorithmic bytes: every operand matrix once (the layer input shared by the blocks of a wide layer counts once)
             seen, by = set(), 0.0
             for q in problems:
-                for p_, nt in ((q.dZ, q.nnt_a), (q.X, q.nnt_b)):
+                for p_, w in ((q.dZ, wa(q)), (q.X, wb(q))):
                     if p_ not in seen:
                         seen.add(p_)
-                        by += 4.0 * rows * 32 * nt
-            widths = sorted({32 * q.nnt_b for q in problems})
-            return t._timed(f"wgrad_native_kernel<{widths[-1]}>", o["wgrad_native_batch"], fl, fl, problems, rows, nbytes=by)
+                        by += 4.0 * rows * w
+            kind = "row-major, bf16 x2" if problems[0].lda > 0 else "tile-native, fp16 split"
+            return t._timed(f"wgrad_native_kernel ({kind})", o["wgrad_native_batch"], fl, fl, problems, rows, nbytes=by)
 
         hip.gemm, hip.gemm_planes, hip.film_chain_fwd, hip.film_chain_bwd_film, hip.film_chain_bwd_map = gemm, gemm_planes, fwd, bwd_film, bwd_map
         hip.wgrad_native_batch = wgrad

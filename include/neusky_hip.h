@@ -27,7 +27,7 @@ extern "C" {
 typedef void* nsky_stream_t; /* hipStream_t */
 
 const char* nsky_last_error(void);
-int nsky_abi_version(void); /* 5 (bumped when a struct layout or an entry point's signature changes) */
+int nsky_abi_version(void); /* 6 (bumped when a struct layout or an entry point's signature changes) */
 
 /* ------------------------------------------------------------------------------------------
  * Dense layer on the matrix cores: C[M,N] = epilogue( sum_k A(m,k) * B(n,k) + bias[n] )
@@ -188,6 +188,12 @@ typedef struct {
   float* db;                 /* may be null */
   const float* a_scale_max;  /* may be null */
   float b_scale;
+  /* ROW-MAJOR operands instead of tile-native ones (the SDF / colour field's weight gradients, autograd's MmBackward of
+   * sdf_albedo_field.py:147-161,199-207): lda, ldb > 0 = leading dimensions of dZ [rows, width_a] and X [rows, width_b] (widths and
+   * leading dimensions multiples of 4; nnt_*, a_scale_max, b_scale unused); the products are then the 2-term bf16 split (2^-16 per
+   * product, no pre-scaling).  All problems of one launch are of the same kind.  bias_rows > 0: db sums only the first bias_rows rows
+   * (stacked value + tangent rows: only the value rows carry a bias). */
+  int32_t lda, ldb, width_a, width_b, bias_rows;
 } nsky_wgrad_problem;
 int nsky_wgrad_native_batch(const nsky_wgrad_problem* problems, int32_t n_problems, int32_t rows, nsky_stream_t stream);
 

@@ -40,8 +40,11 @@ struct WgradProblem {
   float* db;        // [32 nnt_a] or null
   const float* a_scale_max;  // device scalar: largest |dZ| (null: dZ is taken as it is)
   float b_scale;    // power of two applied to X
-  int nnt_a, nnt_b, ldw;
+  int nnt_a, nnt_b, ldw;   // tiles of 32 features each operand is walked in (row-major: ceil(width / 32) rounded up to the block)
   int tile0;        // first output block of this problem in the launch's block list
+  int lda, ldb;     // row-major operands: leading dimensions (floats)
+  int wa, wb;       // features that exist (dW is [wa, wb]); native: 32 nnt
+  int bias_rows;    // db sums the first bias_rows rows only
 };
 struct WgradArgs {
   WgradProblem p[NSKY_WGRAD_MAX_PROBLEMS];
@@ -65,7 +68,17 @@ __device__ __forceinline__ int xcd_contiguous(int id, int total) {
   return xcd * per + min(xcd, rem) + idx;
 }
 
-template <int WM, int WN, int TM, int TN>
+template <bool BF>
+__device__ __forceinline__ f32x16 mma(f16x8 x, f16x8 y, f32x16 acc) {
+  typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+  if (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b16x8, x), __builtin_bit_cast(b16x8, y), acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, acc, 0, 0, 0);
+}
+
+// RM: both operands are ROW-MAJOR [rows, ld] matrices (the SDF / colour field's stacked value + tangent rows) and the products are
+// the 2-term bf16 split (hi hi + hi lo + lo hi, no pre-scaling: gradients keep bf16's exponent range; 2^-16 per product) instead of
+// the pre-scaled fp16 one; a load instruction then covers 8 rows x 128 B, lane = (row 8 u + lane / 8, features 4 (lane % 8) ..).
+template <int WM, int WN, int TM, int TN, bool RM>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void wgrad_native_kernel(WgradArgs a) {
   constexpr int NW = WM * WN;       // waves; also the 32-feature tiles per operand and workgroup (wave w stages tile w of each)
   constexpr int NT = NW;
@@ -92,17 +105,29 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void wgrad_nati
   const float a_scale = P.a_scale_max ? pow2_scale(*P.a_scale_max, a_inv) : 1.0f;
   const float b_scale = P.b_scale;
 
-  // ---- staging: this wave's block of each operand, lane = (row c, half hh), unit u = features 8 u + 4 hh .. + 3 of row c
+  // ---- staging: this wave's block of each operand.  Native: lane = (row c, half hh), unit u = features 8 u + 4 hh .. + 3 of row c.
+  // Row-major: lane = (row 8 u + lane / 8 of the block, features 4 (lane % 8) .. + 3 of the tile)
   const int c = lane & 31, hh = lane >> 5;
-  const float* pa = P.A + ((long)r_beg * P.nnt_a + nb * NT + wave) * 1024 + lane * 4;
-  const float* pb = P.B + ((long)r_beg * P.nnt_b + kb * NT + wave) * 1024 + lane * 4;
-  const long a_step = (long)P.nnt_a * 1024, b_step = (long)P.nnt_b * 1024;
+  const int rq = lane >> 3, fq = lane & 7;
+  const int fa = (nb * NT + wave) * 32 + 4 * fq, fb = (kb * NT + wave) * 32 + 4 * fq;  // RM: first feature of this lane's quad
+  const bool fa_ok = fa < P.wa, fb_ok = fb < P.wb;
+  const float* pa = RM ? P.A + (long)r_beg * 32 * P.lda + min(fa, max(P.wa - 4, 0))
+                       : P.A + ((long)r_beg * P.nnt_a + nb * NT + wave) * 1024 + lane * 4;
+  const float* pb = RM ? P.B + (long)r_beg * 32 * P.ldb + min(fb, max(P.wb - 4, 0))
+                       : P.B + ((long)r_beg * P.nnt_b + kb * NT + wave) * 1024 + lane * 4;
+  const long a_step = RM ? 32l * P.lda : (long)P.nnt_a * 1024, b_step = RM ? 32l * P.ldb : (long)P.nnt_b * 1024;
+  int rm_row0 = 0;  // RM: first row of the block pa2 / pb2 point at (a unit's row is clamped to the last existing row; dropped when staged)
   // eight staging units per row block and wave: unit 2 u = 16 bytes of dZ (features 8 u + 4 hh .. + 3 of row c), 2 u + 1 = of X
   f32x4 raw[8];
   const float* pa2 = pa;  // block the next reload of a unit reads
   const float* pb2 = pb;
   auto reload = [&](int uu) {
-    raw[uu] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(((uu & 1) ? pb2 : pa2) + (uu >> 1) * 256));
+    if (RM) {
+      const int row = min(rm_row0 + 8 * (uu >> 1) + rq, a.rows - 1) - rm_row0;
+      raw[uu] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(((uu & 1) ? pb2 + (long)row * P.ldb : pa2 + (long)row * P.lda)));
+    } else {
+      raw[uu] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(((uu & 1) ? pb2 : pa2) + (uu >> 1) * 256));
+    }
   };
   float bias[4][4];
 #pragma unroll
@@ -111,23 +136,41 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void wgrad_nati
     for (int i = 0; i < 4; ++i) bias[u][i] = 0.0f;
   const bool want_bias = P.db != nullptr && kb == 0;
   // image byte offset of this lane's 8-byte slot of unit u: row c, chunk u ^ ((c >> 1) & 3), half hh
+  // (RM: row 8 u + rq, chunk (fq >> 1) ^ ((row >> 1) & 3), half fq & 1)
   const int w_base = wave * 4096 + c * 64 + 8 * hh;
   const int w_swz = (c >> 1) & 3;
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-  auto stage_unit = [&](int uu, bool live, unsigned char* stage) {  // split unit uu and write it to the images of `stage`
+  typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
+  // live_row: the unit's row exists; bias_on: it also counts for the bias sum (native: one flag per block and lane)
+  auto stage_unit = [&](int uu, int row0, bool row_block_live, unsigned char* stage) {  // split unit uu, write it to the images of `stage`
     const int op = uu & 1, u = uu >> 1;
     const float s = op == 0 ? a_scale : b_scale;
-    f16x4 h4, l4;
+    const int row = row0 + (RM ? 8 * u + rq : c);
+    const bool live = row_block_live && row < a.rows && (!RM || (op == 0 ? fa_ok : fb_ok));
+    const bool bias_on = op == 0 && row < P.bias_rows;
+    float v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float v = live ? raw[uu][i] * s : 0.0f;
-      if (op == 0) bias[u][i] += v;
-      h4[i] = (_Float16)v;
-      l4[i] = (_Float16)(v - (float)h4[i]);
+      v[i] = live ? raw[uu][i] * s : 0.0f;
+      if (op == 0) bias[u][i] += bias_on ? v[i] : 0.0f;
     }
-    unsigned char* img = stage + op * OPB + w_base + 16 * (u ^ w_swz);
-    *reinterpret_cast<f16x4*>(img) = h4;
-    *reinterpret_cast<f16x4*>(img + 2048) = l4;
+    unsigned char* img;
+    if (RM) {
+      const int r = 8 * u + rq;
+      img = stage + op * OPB + wave * 4096 + r * 64 + 16 * ((fq >> 1) ^ ((r >> 1) & 3)) + 8 * (fq & 1);
+      b16x4 h4, l4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { h4[i] = (__bf16)v[i]; l4[i] = (__bf16)(v[i] - (float)h4[i]); }
+      *reinterpret_cast<b16x4*>(img) = h4;
+      *reinterpret_cast<b16x4*>(img + 2048) = l4;
+    } else {
+      img = stage + op * OPB + w_base + 16 * (u ^ w_swz);
+      f16x4 h4, l4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { h4[i] = (_Float16)v[i]; l4[i] = (_Float16)(v[i] - (float)h4[i]); }
+      *reinterpret_cast<f16x4*>(img) = h4;
+      *reinterpret_cast<f16x4*>(img + 2048) = l4;
+    }
   };
 
   // ---- fragments: lane (r = lane & 31, h = lane >> 5) of a 16-row k-step gets rows 8 h + 0..7 of feature r from two transposed
@@ -159,17 +202,17 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void wgrad_nati
   // staging units (its loads were issued one block earlier) and moves into the other stage ONE UNIT PER (k-step, X tile) POINT of
   // the MFMA stream; the unit's registers are refilled at once with block r + 2, so eight 1 KB loads per wave stay in flight
   // the whole time and the split's VALU work rides between the MFMAs instead of after them.
+  rm_row0 = r_beg * 32;
 #pragma unroll
   for (int uu = 0; uu < 8; ++uu) reload(uu);
   {
-    const bool live = r_beg * 32 + c < a.rows;
-    if (r_beg + 1 < r_end) { pa2 += a_step; pb2 += b_step; }
+    if (r_beg + 1 < r_end) { pa2 += a_step; pb2 += b_step; rm_row0 += 32; }
 #pragma unroll
     for (int uu = 0; uu < 8; ++uu) {
-      stage_unit(uu, live, smem);
+      stage_unit(uu, r_beg * 32, true, smem);
       reload(uu);
     }
-    if (r_beg + 2 < r_end) { pa2 += a_step; pb2 += b_step; }
+    if (r_beg + 2 < r_end) { pa2 += a_step; pb2 += b_step; rm_row0 += 32; }
   }
   static_assert(TN == 4 || TN == 2, "one staging unit per (k-step, X tile) point, or two");
   constexpr int UPP = 8 / (2 * TN);  // staging units per point
@@ -178,7 +221,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void wgrad_nati
     __syncthreads();  // stage cur is complete; nobody still reads the other one
     // past the end of the split the units are staged all the same (as zeros, into the stage nobody reads): no branch in the
     // block, so the loads are waited for by count and not all at once
-    const bool live = r + 1 < r_end && (r + 1) * 32 + c < a.rows;
+    const bool live = r + 1 < r_end;
     const unsigned char* st = smem + cur * STAGE;
     unsigned char* nxt = smem + (cur ^ 1) * STAGE;
 #pragma unroll
@@ -201,21 +244,21 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void wgrad_nati
           bl[(j + 1) & 1] = frag(st + OPB + (wn * TN + j + 1) * 4096 + 2048, ks);
         }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j & 1], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i) acc[i][j] = mma<RM>(al[i], bh[j & 1], acc[i][j]);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j & 1], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i) acc[i][j] = mma<RM>(ah[i], bl[j & 1], acc[i][j]);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j & 1], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i) acc[i][j] = mma<RM>(ah[i], bh[j & 1], acc[i][j]);
 #pragma unroll
         for (int k = 0; k < UPP; ++k) {
           const int uu = (ks * TN + j) * UPP + k;
-          stage_unit(uu, live, nxt);
+          stage_unit(uu, (r + 1) * 32, live, nxt);
           reload(uu);  // block r + 2 (or, past the end of the split, a block that is never staged)
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (r + 3 < r_end) { pa2 += a_step; pb2 += b_step; }
+    if (r + 3 < r_end) { pa2 += a_step; pb2 += b_step; rm_row0 += 32; }
     cur ^= 1;
   }
 
@@ -227,11 +270,22 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void wgrad_nati
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       float* out = P.dW + (long)(n0 + 32 * i + 4 * h) * P.ldw + k0 + 32 * j + (lane & 31);
+      const bool col_ok = k0 + 32 * j + (lane & 31) < P.wb;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) atomicAdd(out + (long)(8 * (g >> 2) + (g & 3)) * P.ldw, acc[i][j][g] * out_scale);
+      for (int g = 0; g < 16; ++g)
+        if (col_ok && n0 + 32 * i + 4 * h + 8 * (g >> 2) + (g & 3) < P.wa)
+          atomicAdd(out + (long)(8 * (g >> 2) + (g & 3)) * P.ldw, acc[i][j][g] * out_scale);
       __builtin_amdgcn_sched_barrier(0);
     }
-  if (want_bias) {
+  if (want_bias && RM) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = (bias[0][i] + bias[1][i]) + (bias[2][i] + bias[3][i]);  // the four units hold different rows of the same features
+#pragma unroll
+      for (int off = 8; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);  // over the 8 row groups
+      if (rq == 0 && fa + i < P.wa) atomicAdd(P.db + fa + i, v * a_inv);
+    }
+  } else if (want_bias) {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -251,27 +305,43 @@ extern "C" int nsky_wgrad_native_batch(const nsky_wgrad_problem* problems, int32
                  "nsky_wgrad_native_batch: 1..%d problems expected, got %d", NSKY_WGRAD_MAX_PROBLEMS, n_problems);
   if (rows == 0) return NSKY_OK;
   WgradArgs a;
+  const bool rm = problems[0].lda > 0;  // row-major operands (all problems of a launch alike)
   bool wide = true;
   for (int i = 0; i < n_problems; ++i) {
     const nsky_wgrad_problem& q = problems[i];
     NSKY_CHECK_ARG(q.dZ && q.X && q.dW, "nsky_wgrad_native_batch: problem %d: null argument", i);
-    NSKY_CHECK_ARG(q.nnt_a > 0 && q.nnt_b > 0 && q.nnt_a % 4 == 0 && q.nnt_b % 4 == 0,
-                   "nsky_wgrad_native_batch: problem %d: both operands need a multiple of 128 features (got %d and %d tiles of 32)", i,
-                   q.nnt_a, q.nnt_b);
-    NSKY_CHECK_ARG(q.ldw >= 32 * q.nnt_b, "nsky_wgrad_native_batch: problem %d: ldw %d < %d", i, q.ldw, 32 * q.nnt_b);
-    int e = 0;
-    NSKY_CHECK_ARG(q.b_scale > 0.0f && frexpf(q.b_scale, &e) == 0.5f, "nsky_wgrad_native_batch: problem %d: b_scale must be a power of two", i);
-    wide = wide && q.nnt_a % 8 == 0 && q.nnt_b % 8 == 0;
+    NSKY_CHECK_ARG((q.lda > 0) == rm && (q.ldb > 0) == rm, "nsky_wgrad_native_batch: problem %d: row-major and tile-native operands in one launch", i);
+    if (rm) {
+      NSKY_CHECK_ARG(q.width_a >= 4 && q.width_b >= 4 && q.width_a % 4 == 0 && q.width_b % 4 == 0 && q.lda >= q.width_a && q.ldb >= q.width_b &&
+                         q.lda % 4 == 0 && q.ldb % 4 == 0, "nsky_wgrad_native_batch: problem %d: row-major widths / leading dimensions must be multiples of 4", i);
+      NSKY_CHECK_ARG(q.ldw >= q.width_b && q.a_scale_max == nullptr, "nsky_wgrad_native_batch: problem %d: ldw %d < %d, or a scale with row-major operands", i,
+                     q.ldw, q.width_b);
+      wide = wide && q.width_a > 128 && q.width_b > 128;
+    } else {
+      NSKY_CHECK_ARG(q.nnt_a > 0 && q.nnt_b > 0 && q.nnt_a % 4 == 0 && q.nnt_b % 4 == 0,
+                     "nsky_wgrad_native_batch: problem %d: both operands need a multiple of 128 features (got %d and %d tiles of 32)", i,
+                     q.nnt_a, q.nnt_b);
+      NSKY_CHECK_ARG(q.ldw >= 32 * q.nnt_b, "nsky_wgrad_native_batch: problem %d: ldw %d < %d", i, q.ldw, 32 * q.nnt_b);
+      int e = 0;
+      NSKY_CHECK_ARG(q.b_scale > 0.0f && frexpf(q.b_scale, &e) == 0.5f, "nsky_wgrad_native_batch: problem %d: b_scale must be a power of two", i);
+      wide = wide && q.nnt_a % 8 == 0 && q.nnt_b % 8 == 0;
+    }
   }
-  // 256 x 256 output blocks, 8 waves, one workgroup per CU -- or, if any problem is not a multiple of 256 wide, 128 x 128, 4 waves, two per CU
+  // 256 x 256 output blocks, 8 waves, one workgroup per CU -- or, if any problem is narrower, 128 x 128, 4 waves, two per CU
   const int NT = wide ? 8 : 4;
   int tiles = 0;
   for (int i = 0; i < n_problems; ++i) {
     const nsky_wgrad_problem& q = problems[i];
     WgradProblem& P = a.p[i];
-    P.A = q.dZ; P.B = q.X; P.dW = q.dW; P.db = q.db; P.a_scale_max = q.a_scale_max; P.b_scale = q.b_scale;
-    P.nnt_a = q.nnt_a; P.nnt_b = q.nnt_b; P.ldw = q.ldw; P.tile0 = tiles;
-    tiles += (q.nnt_a / NT) * (q.nnt_b / NT);
+    P.A = q.dZ; P.B = q.X; P.dW = q.dW; P.db = q.db; P.a_scale_max = q.a_scale_max; P.b_scale = rm ? 1.0f : q.b_scale;
+    P.nnt_a = rm ? ceil_div(q.width_a, 32 * NT) * NT : q.nnt_a;
+    P.nnt_b = rm ? ceil_div(q.width_b, 32 * NT) * NT : q.nnt_b;
+    P.ldw = q.ldw; P.tile0 = tiles;
+    P.lda = q.lda; P.ldb = q.ldb;
+    P.wa = rm ? q.width_a : 32 * q.nnt_a;
+    P.wb = rm ? q.width_b : 32 * q.nnt_b;
+    P.bias_rows = q.bias_rows > 0 ? q.bias_rows : rows;
+    tiles += (P.nnt_a / NT) * (P.nnt_b / NT);
   }
   a.n_problems = n_problems; a.rows = rows; a.n_tiles = tiles;
   a.row_blocks = ceil_div(rows, 32);
@@ -284,22 +354,25 @@ extern "C" int nsky_wgrad_native_batch(const nsky_wgrad_problem* problems, int32
   const dim3 grid(a.n_tiles * splits);
   const size_t smem = 2 * 2 * NT * 4096;
   static bool attr_set = [] {  // not a stream operation: once per process, outside any capture
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_native_kernel<4, 2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_native_kernel<2, 2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_native_kernel<4, 2, 2, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_native_kernel<2, 2, 2, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_native_kernel<4, 2, 2, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_native_kernel<2, 2, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)attr_set;
-  if (wide)
-    hipLaunchKernelGGL((wgrad_native_kernel<4, 2, 2, 4>), grid, dim3(512), smem, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL((wgrad_native_kernel<2, 2, 2, 2>), grid, dim3(256), smem, (hipStream_t)stream, a);
+  const hipStream_t st = (hipStream_t)stream;
+  if (wide && rm) hipLaunchKernelGGL((wgrad_native_kernel<4, 2, 2, 4, true>), grid, dim3(512), smem, st, a);
+  else if (wide) hipLaunchKernelGGL((wgrad_native_kernel<4, 2, 2, 4, false>), grid, dim3(512), smem, st, a);
+  else if (rm) hipLaunchKernelGGL((wgrad_native_kernel<2, 2, 2, 2, true>), grid, dim3(256), smem, st, a);
+  else hipLaunchKernelGGL((wgrad_native_kernel<2, 2, 2, 2, false>), grid, dim3(256), smem, st, a);
   NSKY_CHECK_LAUNCH("nsky_wgrad_native_batch");
   return NSKY_OK;
 }
 
 extern "C" int nsky_wgrad_native(const float* dZ, int32_t nnt_a, const float* X, int32_t nnt_b, int32_t rows, float* dW, int32_t ldw,
                                  float* db, const float* a_scale_max, float b_scale, nsky_stream_t stream) {
-  nsky_wgrad_problem q;
+  nsky_wgrad_problem q = {};
   q.dZ = dZ; q.nnt_a = nnt_a; q.X = X; q.nnt_b = nnt_b; q.dW = dW; q.ldw = ldw; q.db = db; q.a_scale_max = a_scale_max; q.b_scale = b_scale;
   return nsky_wgrad_native_batch(&q, 1, rows, stream);
 }

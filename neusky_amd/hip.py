@@ -52,7 +52,7 @@ class GemmDesc(C.Structure):
 
 _lib.nsky_last_error.restype = C.c_char_p
 _lib.nsky_abi_version.restype = C.c_int
-ABI_VERSION = 5  # the ctypes structures below mirror this version of include/neusky_hip.h
+ABI_VERSION = 6  # the ctypes structures below mirror this version of include/neusky_hip.h
 if _lib.nsky_abi_version() != ABI_VERSION:
     raise NeuSkyHipError(f"libneusky_hip.so has ABI version {_lib.nsky_abi_version()}, this package binds version {ABI_VERSION}: rebuild (build.sh)")
 
@@ -555,7 +555,8 @@ _wgrad_native = _sig("nsky_wgrad_native", C.c_void_p, C.c_int32, C.c_void_p, C.c
 
 class WgradProblem(C.Structure):
     _fields_ = [("dZ", C.c_void_p), ("nnt_a", C.c_int32), ("X", C.c_void_p), ("nnt_b", C.c_int32), ("dW", C.c_void_p), ("ldw", C.c_int32),
-                ("db", C.c_void_p), ("a_scale_max", C.c_void_p), ("b_scale", C.c_float)]
+                ("db", C.c_void_p), ("a_scale_max", C.c_void_p), ("b_scale", C.c_float),
+                ("lda", C.c_int32), ("ldb", C.c_int32), ("width_a", C.c_int32), ("width_b", C.c_int32), ("bias_rows", C.c_int32)]
 
 
 WGRAD_MAX_PROBLEMS = 16
@@ -566,6 +567,13 @@ def wgrad_problem(dZ, nnt_a, X, nnt_b, rows, dW, db=None, a_scale_max=None, b_sc
     assert dW.stride(1) == 1 and dW.shape[0] >= 32 * nnt_a and dW.shape[1] >= 32 * nnt_b
     assert dZ.numel() >= film_rows(rows) * 32 * nnt_a and X.numel() >= film_rows(rows) * 32 * nnt_b
     return WgradProblem(ptr(dZ), nnt_a, ptr(X), nnt_b, ptr(dW), ld(dW), ptr(db), ptr(a_scale_max), float(b_scale))
+
+
+def wgrad_problem_rowmajor(dZ, n_out, X, k_in, rows, dW, db=None, bias_rows=0) -> WgradProblem:
+    """dW[n_out, k_in] += dZ[:rows, :n_out]^T X[:rows, :k_in] over ROW-MAJOR operands (2-term bf16 products); see include/neusky_hip.h"""
+    assert dW.stride(1) == 1 and dW.shape[0] >= n_out and dW.shape[1] >= k_in and n_out % 4 == 0 and k_in % 4 == 0
+    assert dZ.shape[0] >= rows and X.shape[0] >= rows and ld(dZ) >= n_out and ld(X) >= k_in
+    return WgradProblem(ptr(dZ), 0, ptr(X), 0, ptr(dW), ld(dW), ptr(db), None, 1.0, ld(dZ), ld(X), n_out, k_in, int(bias_rows))
 
 
 def wgrad_native_batch(problems, rows):

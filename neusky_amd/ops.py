@@ -89,6 +89,16 @@ def pad_bias(b: torch.Tensor) -> torch.Tensor:
     return _PadFn.apply(b, (pad4(b.shape[0]),))
 
 
+WGRAD_STREAM_MIN_ROWS = 32768
+
+
+def flush_wgrad(batch: dict) -> None:
+    """run the weight-gradient problems grad_weight queued in `batch`: one launch per row count"""
+    for M, items in batch.items():
+        hip.wgrad_native_batch([it[0] for it in items], M)
+    batch.clear()
+
+
 def _splits(M: int, n_out: int = 256, k_in: int = 256) -> int:
     """split-K factor of a weight-gradient GEMM (reduction over M rows).  The split kernel keeps 2 workgroups per CU
     resident (512 on the chip), so the launch is sized to a whole number of such waves: tiles x splits = 512 w with
@@ -100,11 +110,13 @@ def _splits(M: int, n_out: int = 256, k_in: int = 256) -> int:
     return max(1, min((512 * waves) // tiles, M // 128))
 
 
-def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None, acc=None, a_native_nt=0, b_native_nt=0, a_scale_max=None):
+def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None, acc=None, a_native_nt=0, b_native_nt=0, a_scale_max=None,
+                batch=None):
     """dW[n_out, k_in] = dZ[:M, :n_out]^T @ X[:M, :k_in] (split-K over M, atomically reduced).
     With bias_like, also returns db[n_out] = column sums of dZ (over the first `bias_rows` rows when the tail rows are
     tangent rows that carry no bias) from the same pass over dZ.  acc=(dW, db): accumulate into existing buffers
-    (row-chunked callers)."""
+    (row-chunked callers).  batch: a dict the caller flushes with flush_wgrad at the end of its backward -- long row-major
+    reductions are then only queued here and run as ONE launch per row count."""
     if acc is not None:
         dW, db = acc
     else:
@@ -114,6 +126,15 @@ def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None, acc
             dW, db = flat[:like.numel()].view_as(like), flat[nw:].view_as(bias_like)
         else:
             dW, db = zeros_like(like), None
+    if (BWD_PRECISION == hip.PREC_BF16X2 and a_native_nt == 0 and b_native_nt == 0 and a_scale_max is None and M >= WGRAD_STREAM_MIN_ROWS
+            and n_out >= 64 and k_in >= 64 and n_out % 4 == 0 and k_in % 4 == 0 and dZ.is_cuda and ld(dZ) % 4 == 0 and ld(X) % 4 == 0):
+        # long reductions over row-major operands (the field's layers): the streaming kernel, dW and db in one pass
+        prob = hip.wgrad_problem_rowmajor(dZ, n_out, X, k_in, M, dW, db, 0 if bias_rows is None else bias_rows)
+        if batch is not None:
+            batch.setdefault(M, []).append((prob, dZ, X))  # (the operands are kept alive until the flush)
+        else:
+            hip.wgrad_native_batch([prob], M)
+        return dW if db is None else (dW, db)
     splits = _splits(M, n_out, k_in)
     kw = dict(a_kcontig=False, b_kcontig=False, k_splits=splits, precision=BWD_PRECISION, a_native_nt=a_native_nt, b_native_nt=b_native_nt)
     if a_scale_max is not None and k_in > 64:  # fp32-grade products: fp16 hi + scaled residual, the gradient pre-scaled by its maximum
@@ -672,33 +693,35 @@ class SDFAlbedoFn(torch.autograd.Function):
         if not colour:
             # no gradient reaches the colour net (geometry-only pass, or albedo unused downstream): only the sdf slot of the
             # geo net's [feat | sdf | 0 0 0] output carries one
-            return SDFAlbedoFn._backward_geo(ctx, g_sdf, g_grad, None)
+            return SDFAlbedoFn._backward_geo(ctx, g_sdf, g_grad, None, {})
         # ---- colour net
         dpc2 = zeros(N, 4, device=dev)
         if g_alb is not None:
             alb = ALB[:, :3]
             dpc2[:, :3] = g_alb * alb * (1.0 - alb)
         dWc2, dbc2, f_c2 = shared_grad(Wc2, bc2)
-        grad_weight(dpc2, C1, N, 4, Hc, Wc2, bc2, acc=(dWc2, dbc2))
+        wq: dict = {}  # the layers' weight gradients are queued and run as one launch per row count at the end
+        grad_weight(dpc2, C1, N, 4, Hc, Wc2, bc2, acc=(dWc2, dbc2), batch=wq)
         dpc1 = torch.empty(N, Hc, device=dev)
         grad_input(dpc2, Wc2, N, Hc, 4, dpc1, epi=hip.EPI_BWD_RELU, aux0=C1)
         dWc1, dbc1, f_c1 = shared_grad(Wc1, bc1)
-        grad_weight(dpc1, C0, N, Hc, Hc, Wc1, bc1, acc=(dWc1, dbc1))
+        grad_weight(dpc1, C0, N, Hc, Hc, Wc1, bc1, acc=(dWc1, dbc1), batch=wq)
         dpc0 = torch.empty(N, Hc, device=dev)
         grad_input(dpc1, Wc1, N, Hc, Hc, dpc0, epi=hip.EPI_BWD_RELU, aux0=C0)
         dWc0, dbc0, f_c0 = shared_grad(Wc0, bc0)
-        grad_weight(dpc0, CIN, N, Hc, ldc, Wc0, bc0, acc=(dWc0, dbc0))
+        grad_weight(dpc0, CIN, N, Hc, ldc, Wc0, bc0, acc=(dWc0, dbc0), batch=wq)
         dCIN = torch.empty(N, ldc, device=dev)
         grad_input(dpc0, Wc0, N, ldc, Hc, dCIN)
         # the sdf slot / pad columns of Wc0 are structural zeros: overwrite them with the upstream sdf gradient
         dCIN[:, GF:GF + 4] = 0.0
         if g_sdf is not None:
             dCIN[:, GF] = g_sdf
-        return SDFAlbedoFn._backward_geo(ctx, g_sdf, g_grad, (dCIN, dWc0, dbc0, f_c0, dWc1, dbc1, f_c1, dWc2, dbc2, f_c2))
+        return SDFAlbedoFn._backward_geo(ctx, g_sdf, g_grad, (dCIN, dWc0, dbc0, f_c0, dWc1, dbc1, f_c1, dWc2, dbc2, f_c2), wq)
 
     @staticmethod
-    def _backward_geo(ctx, g_sdf, g_grad, colour):
-        """geo-net part of the backward; colour = (dCIN, colour-net weight gradients ...) or None when the colour net took none"""
+    def _backward_geo(ctx, g_sdf, g_grad, colour, wq):
+        """geo-net part of the backward; colour = (dCIN, colour-net weight gradients ...) or None when the colour net took none;
+        wq: the weight-gradient problems queued so far (flushed here, at the end)"""
         ET, A0, S0, A1, S1, CIN, C0, C1, ALB, W0, b0, W1, b1, W2, b2, Wc0, bc0, Wc1, bc1, Wc2, bc2 = ctx.saved_tensors
         N, Hd, Kin, GF, ldc, Hc, beta = ctx.cfg
         dev = ET.device
@@ -712,7 +735,7 @@ class SDFAlbedoFn(torch.autograd.Function):
                 dH[:, GF] = g_sdf
         # ---- geo net, last layer (value rows)
         dW2, db2, f_2 = shared_grad(W2, b2)
-        grad_weight(dH, A1[:N], N, GF + 4, Hd, W2, b2, acc=(dW2, db2))
+        grad_weight(dH, A1[:N], N, GF + 4, Hd, W2, b2, acc=(dW2, db2), batch=wq)
         dA1v = torch.empty(N, Hd, device=dev)
         grad_input(dH, W2, N, Hd, GF + 4, dA1v)
         # tangent rows of the last layer: grad_k = ta1_k . w_sdf
@@ -726,18 +749,19 @@ class SDFAlbedoFn(torch.autograd.Function):
         D1 = torch.empty(4 * N, Hd, device=dev)
         hip.softplus_tangent_bwd(dA1v, S1, A1[N:], None, g_grad, w2s, beta, N, Hd, D1[:N], D1[N:])
         dW1, db1, f_1 = shared_grad(W1, b1)
-        grad_weight(D1, A0, 4 * N, Hd, Hd, W1, b1, bias_rows=N, acc=(dW1, db1))
+        grad_weight(D1, A0, 4 * N, Hd, Hd, W1, b1, bias_rows=N, acc=(dW1, db1), batch=wq)
         dA0 = torch.empty(4 * N, Hd, device=dev)
         grad_input(D1, W1, 4 * N, Hd, Hd, dA0)
         # ---- layer 0
         D0 = torch.empty(4 * N, Hd, device=dev)
         hip.softplus_tangent_bwd(dA0[:N], S0, A0[N:], dA0[N:], None, None, beta, N, Hd, D0[:N], D0[N:])
         dW0, db0, f_0 = shared_grad(W0, b0)
-        grad_weight(D0, ET, 4 * N, Hd, Kin, W0, b0, bias_rows=N, acc=(dW0, db0))
+        grad_weight(D0, ET, 4 * N, Hd, Kin, W0, b0, bias_rows=N, acc=(dW0, db0), batch=wq)
         dET = torch.empty(4 * N, Kin, device=dev)
         grad_input(D0, W0, 4 * N, Kin, Hd, dET)
         if dCIN is not None:  # x / PE columns of the colour-net input came straight from the encode row
             dET[:N, :39] += dCIN[:, GF + 4:GF + 4 + 39]
+        flush_wgrad(wq)
         k = lambda first, t: t if first else None  # noqa: E731  later nodes of the pass added in place
         if colour is None:
             return (dET, k(f_0, dW0), k(f_0, db0), k(f_1, dW1), k(f_1, db1), k(f_2, dW2), k(f_2, db2), None, None, None, None, None, None,
@@ -786,9 +810,11 @@ class SDFValueFn(torch.autograd.Function):
             hip.weighted_colsum(A1, M, Hd, g, 4, dW2[GF])
             db2[GF] += g_sdf.sum()
             dW1, db1, f1 = shared_grad(W1, b1)
-            grad_weight(dZ1, A0, M, Hd, Hd, W1, b1, acc=(dW1, db1))
+            wq: dict = {}
+            grad_weight(dZ1, A0, M, Hd, Hd, W1, b1, acc=(dW1, db1), batch=wq)
             dW0, db0, f0 = shared_grad(W0, b0)
-            grad_weight(dZ0, E, M, Hd, Kin, W0, b0, acc=(dW0, db0))
+            grad_weight(dZ0, E, M, Hd, Kin, W0, b0, acc=(dW0, db0), batch=wq)
+            flush_wgrad(wq)
             if not f2: dW2 = db2 = None
             if not f1: dW1 = db1 = None
             if not f0: dW0 = db0 = None

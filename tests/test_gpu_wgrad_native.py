@@ -92,6 +92,46 @@ def test_wgrad_native_batch_is_the_sum_of_its_problems(shapes):
             assert bool(((db.double() - dzd.double().sum(0)).abs() <= 1e-6 * dzd.double().abs().sum(0)).all())
 
 
+@pytest.mark.parametrize("M,n_out,k_in,bias_rows", [(4096, 256, 256, 0), (393216, 256, 256, 98304), (98304, 260, 256, 0), (50001, 256, 72, 12500),
+                                                     (33333, 256, 300, 0), (40000, 128, 64, 0)])
+def test_wgrad_rowmajor_matches_float64(M, n_out, k_in, bias_rows):
+    """row-major operands (the field's stacked value + tangent rows), 2-term bf16 products: 2^-16 per product relative to |dZ|^T |X|"""
+    from neusky_amd import hip
+    dz, x = _case(M, n_out, k_in, 7, True)
+    lda, ldb = n_out + 4, k_in + 8  # leading dimensions wider than the matrices; the pad columns hold garbage
+    A = torch.full((M, lda), float("nan")); A[:, :n_out] = dz
+    B = torch.full((M, ldb), float("nan")); B[:, :k_in] = x
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    dW0 = torch.randn(n_out, k_in + 4, device=DEV) * 1e-3
+    db0 = torch.randn(n_out, device=DEV) * 1e-3
+    dW, db = dW0.clone(), db0.clone()
+    hip.wgrad_native_batch([hip.wgrad_problem_rowmajor(Ad[:, :n_out], n_out, Bd[:, :k_in], k_in, M, dW[:, :k_in], db, bias_rows)], M)
+    torch.cuda.synchronize()
+    dzd, xd = dz.to(DEV).double(), x.to(DEV).double()
+    ref = dzd.T @ xd
+    bar = dzd.abs().T @ xd.abs()
+    err = ((dW - dW0)[:, :k_in].double() - ref).abs()
+    assert bool((err <= 6e-5 * bar + 2e-5 * dW0[:, :k_in].double().abs() + 1e-30).all()), float((err / (bar + 1e-30)).max())
+    assert torch.equal(dW[:, k_in:], dW0[:, k_in:]), "columns past k_in untouched"
+    br = bias_rows if bias_rows else M
+    refb = dzd[:br].sum(0)
+    errb = ((db - db0).double() - refb).abs()
+    assert bool((errb <= 2e-6 * dzd[:br].abs().sum(0) + 2e-5 * db0.double().abs()).all())
+
+
+def test_grad_weight_routes_long_rowmajor_reductions_to_the_streaming_kernel():
+    from neusky_amd import ops
+    M, n_out, k_in = 40000, 256, 72
+    dz, x = _case(M, n_out, k_in, 3, False)
+    dzd, xd = dz.to(DEV), x.to(DEV)
+    like, blike = torch.zeros(n_out, k_in, device=DEV), torch.zeros(n_out, device=DEV)
+    dW, db = ops.grad_weight(dzd, xd, M, n_out, k_in, like, blike)
+    ref = dzd.double().T @ xd.double()
+    bar = dzd.double().abs().T @ xd.double().abs()
+    assert bool(((dW.double() - ref).abs() <= 6e-5 * bar).all())
+    assert torch.allclose(db.double(), dzd.double().sum(0), atol=1e-4, rtol=1e-4)
+
+
 def test_wgrad_native_rejects_unsupported_widths():
     from neusky_amd import hip
     z = torch.zeros(32, 96, device=DEV)
