@@ -406,20 +406,23 @@ __global__ __launch_bounds__(256) void encode_bwd_coarse_kernel(Grid g, const fl
 // per second chip-wide, and a hashed level sends every corner of every point to a different line.  Here a workgroup OWNS a
 // 16384-entry chunk of one level's slab (128 KB of float2 accumulators in LDS) and adds every corner that lands in it with
 // ds_add_f32; the chunk is written back once, as whole lines.  Three things keep the owners cheap:
-//   * a pre-pass writes ONE 32-bit key per (level, point): for a hashed level the chunk numbers of its four (y, z) corner pairs
-//     (x and x + 1 differ below bit 14, the chunk bits start there: the two x-corners of a pair share a chunk), for a dense level
-//     the index of corner 0.  An owner's walk over all points is then a coalesced key load and a few compares per point;
-//   * the points that pass (1/8 of them on a hashed level) are queued in LDS and worked through by full waves -- positions,
-//     weights and the exact corner indices are recomputed only for those;
+//   * a pre-pass writes, per (level, chunk), a BITMAP over the points: bit p is set when point p can have a corner in that chunk
+//     (hashed level: the chunk numbers of its four (y, z) corner pairs -- x and x + 1 differ below bit 14, the chunk bits start
+//     there, so the two x-corners of a pair share a chunk; dense level: the chunks its corner-index range touches).  A workgroup
+//     of the pre-pass assembles the 32 x 1024-point bitmap tile of its level in LDS and writes whole words: no global atomics.
+//     An owner then reads 1/32 of a bit per point instead of walking all points;
+//   * the set bits (1/8 of the points on a hashed level) are queued in LDS and worked through by full waves -- positions,
+//     weights and the exact corner indices are computed only for those;
 //   * ds_add_f32 retires about one lane per clock and CU, so a level's adds must be spread over ~32 workgroups: levels with
 //     few chunks (the dense ones) split their POINTS over several workgroups per chunk, whose write-backs are then atomic.
 constexpr int OWN_CH = 16384;            // entries per chunk (a power of two: chunk number = index >> 14)
 constexpr int OWN_SHIFT = 14;
 constexpr int OWN_THREADS = 1024;
-constexpr int OWN_U = 12;                // keys per thread and trip (the queue of a trip: 12288 x 2 B beside the 128 KB chunk)
-constexpr int OWN_TRIP = OWN_THREADS * OWN_U;
+constexpr int OWN_TRIP = 8192;           // points per trip = capacity of the queue (8192 x 2 B beside the 128 KB chunk)
+constexpr int OWN_TRIP_WORDS = OWN_TRIP / 32;
 constexpr int OWN_WG_PER_LEVEL = 32;
-constexpr uint32_t KEY_ALWAYS = 0xFFFFFFFFu;  // dense level, point outside the grid: every owner looks at it
+constexpr int OWN_MAX_CHUNKS = 32;       // per level: slabs of at most 2^19 entries
+constexpr int BM_POINTS = 1024;          // points per workgroup of the bitmap pre-pass
 
 struct OwnerArgs {
   Grid g;
@@ -427,7 +430,8 @@ struct OwnerArgs {
   const float* dY;
   const float* dT;
   float* dtable;
-  uint32_t* keys;          // [n_levels_owned][P]
+  uint32_t* bitmaps;       // [n_levels_owned][32 chunks][words], words = 32 * ceil(P / 1024): bit p % 32 of word p / 32
+  int words;
   int P, mode, feat0, lddy;
   int n_levels_owned;      // scatter levels
   int level[16];           // their level numbers
@@ -442,38 +446,55 @@ __host__ __device__ __forceinline__ bool level_is_dense(uint32_t size, uint32_t 
 struct F3 { float v[3]; };
 constexpr uint32_t HASH_P1 = 2654435761u, HASH_P2 = 805459861u;
 
-__global__ __launch_bounds__(256) void owner_keys_kernel(OwnerArgs a) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= a.P) return;
-  const F3 xv = reinterpret_cast<const F3*>(a.x)[p];
-  float pos[3], J[3][3];
-  grid_position(xv.v, a.mode, pos, J);
-  for (int li = 0; li < a.n_levels_owned; ++li) {
-    const int level = a.level[li];
+__global__ __launch_bounds__(BM_POINTS) void owner_bitmaps_kernel(OwnerArgs a) {
+  __shared__ uint32_t bm[OWN_MAX_CHUNKS][BM_POINTS / 32];
+  const int tid = threadIdx.x, li = blockIdx.y;
+  const int p = blockIdx.x * BM_POINTS + tid;
+  reinterpret_cast<uint32_t*>(bm)[tid] = 0u;  // 32 x 32 words = 1024
+  __syncthreads();
+  const int level = a.level[li];
+  const uint32_t res = (uint32_t)a.g.resolution[level];
+  const uint32_t size = a.g.offset[level + 1] - a.g.offset[level];
+  const int nch = (int)((size + OWN_CH - 1) / OWN_CH);
+  if (p < a.P) {
+    const F3 xv = reinterpret_cast<const F3*>(a.x)[p];
+    float pos[3], J[3][3];
+    grid_position(xv.v, a.mode, pos, J);
     const float scale = a.g.scale[level];
-    const uint32_t res = (uint32_t)a.g.resolution[level];
-    const uint32_t size = a.g.offset[level + 1] - a.g.offset[level];
     uint32_t pg[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) pg[d] = (uint32_t)(int)floorf(fmaf(scale, pos[d], 0.5f));
-    uint32_t key;
+    uint32_t chunks = 0;  // bit c: chunk c may receive a corner of this point
     if (level_is_dense(size, res)) {
-      // corner 0's index; a point whose cell is not inside the grid (index arithmetic wraps, grid_index's modulo bites) is rare
-      const bool inside = pg[0] < res - 1u && pg[1] < res - 1u && pg[2] < res - 1u;  // (a negative cell is a huge unsigned number)
-      key = inside ? pg[0] + pg[1] * res + pg[2] * res * res : KEY_ALWAYS;
+      // inside the grid the eight corner indices lie in [corner 0, corner 0 + 1 + res + res^2]; a point whose cell is not inside
+      // (index arithmetic wraps, grid_index's modulo bites; a negative cell is a huge unsigned number) is looked at by every owner
+      const bool inside = pg[0] < res - 1u && pg[1] < res - 1u && pg[2] < res - 1u;
+      if (inside) {
+        const uint32_t i0 = pg[0] + pg[1] * res + pg[2] * res * res, i1 = i0 + 1u + res + res * res;
+        for (uint32_t c = i0 >> OWN_SHIFT; c <= min(i1 >> OWN_SHIFT, (uint32_t)nch - 1u); ++c) chunks |= 1u << c;
+      } else {
+        chunks = nch >= 32 ? 0xFFFFFFFFu : (1u << nch) - 1u;
+      }
     } else {
       const uint32_t smask = size - 1, Y0 = pg[1] * HASH_P1, Z0 = pg[2] * HASH_P2;
-      const uint32_t yz[4] = {Y0 ^ Z0, (Y0 + HASH_P1) ^ Z0, Y0 ^ (Z0 + HASH_P2), (Y0 + HASH_P1) ^ (Z0 + HASH_P2)};
-      // x and x + 1 agree above bit 13 unless x ends in fourteen ones (cell -1 is the common case): their shared high bits are
-      // folded into the pair's chunk number; the rare carry case is flagged and looked at by every owner of the level
-      const uint32_t xhi = pg[0] & ~(uint32_t)(OWN_CH - 1);
-      key = 0;
+      if ((pg[0] & (uint32_t)(OWN_CH - 1)) == (uint32_t)(OWN_CH - 1)) {
+        chunks = nch >= 32 ? 0xFFFFFFFFu : (1u << nch) - 1u;  // x + 1 carries into the chunk bits (cell -1 is the common case): rare
+      } else {
+        const uint32_t xhi = pg[0] & ~(uint32_t)(OWN_CH - 1);
+        const uint32_t yz[4] = {Y0 ^ Z0, (Y0 + HASH_P1) ^ Z0, Y0 ^ (Z0 + HASH_P2), (Y0 + HASH_P1) ^ (Z0 + HASH_P2)};
 #pragma unroll
-      for (int bc = 0; bc < 4; ++bc) key |= (((yz[bc] ^ xhi) & smask) >> OWN_SHIFT) << (5 * bc);
-      if ((pg[0] & (uint32_t)(OWN_CH - 1)) == (uint32_t)(OWN_CH - 1)) key |= 0x80000000u;
+        for (int bc = 0; bc < 4; ++bc) chunks |= 1u << (((yz[bc] ^ xhi) & smask) >> OWN_SHIFT);
+      }
     }
-    a.keys[(long)li * a.P + p] = key;
+    while (chunks) {
+      const int c = __ffs(chunks) - 1;
+      chunks &= chunks - 1;
+      atomicOr(&bm[c][tid >> 5], 1u << (tid & 31));
+    }
   }
+  __syncthreads();
+  const int c = tid >> 5, w = tid & 31;
+  if (c < nch) a.bitmaps[((long)li * OWN_MAX_CHUNKS + c) * a.words + blockIdx.x * (BM_POINTS / 32) + w] = bm[c][w];
 }
 
 template <bool TANGENTS>
@@ -496,48 +517,40 @@ __global__ __launch_bounds__(OWN_THREADS) void encode_bwd_owner_kernel(OwnerArgs
   const uint32_t smask = size - 1;  // hashed: size is a power of two (checked on the host), grid_index's modulo is this mask
   const uint32_t c_beg = chunk * OWN_CH;
   const int n_own = (int)min((uint32_t)OWN_CH, size - c_beg);
-  const uint32_t span = 1u + res + res * res;  // dense: corner 7's index minus corner 0's
   for (int i = tid; i < 2 * OWN_CH; i += OWN_THREADS) acc[i] = 0.0f;
   if (tid == 0) *qn = 0;
   __syncthreads();
 
-  const int per = (a.P + splits - 1) / splits;
-  const int p_beg = ps * per, p_end = min(a.P, p_beg + per);
+  // this workgroup's share of the points: whole bitmap words
+  const int words_per = (a.words + splits - 1) / splits;
+  const int w_beg = ps * words_per, w_end = min(a.words, w_beg + words_per);
   const int col = a.feat0 + 2 * level;
   const bool smooth = g.smoothstep != 0;
-  const uint32_t* keys = a.keys + (long)li * a.P;
+  const uint32_t* bits = a.bitmaps + ((long)li * OWN_MAX_CHUNKS + chunk) * a.words;
   const F3* xs = reinterpret_cast<const F3*>(a.x);
-  // The walk is latency bound (keys from L2, then per queued point a 12-byte position gather and its dY row): the next trip's
-  // keys are requested before this trip's queue is worked through, and a queued point's two loads are issued together.
-  uint32_t key[OWN_U];
-  auto fetch_keys = [&](int p0) {
+  for (int w0 = w_beg; w0 < w_end; w0 += OWN_TRIP_WORDS) {
+    const int p0 = w0 * 32;
+    // ---- the trip's set bits go to the queue (a word per lane of the first four waves; one reservation per wave)
+    if (tid < OWN_TRIP_WORDS) {
+      uint32_t word = w0 + tid < w_end ? bits[w0 + tid] : 0u;
+      const int cnt = __popc(word);
+      int incl = cnt;  // inclusive scan over the wave
 #pragma unroll
-    for (int u = 0; u < OWN_U; ++u) key[u] = keys[min(p0 + u * OWN_THREADS + tid, p_end - 1)];
-  };
-  if (p_beg < p_end) fetch_keys(p_beg);
-  for (int p0 = p_beg; p0 < p_end; p0 += OWN_TRIP) {
-    // ---- walk: one key per point; candidates go to the queue (wave-aggregated reservation)
-#pragma unroll
-    for (int u = 0; u < OWN_U; ++u) {
-      const int p = p0 + u * OWN_THREADS + tid;
-      bool cand;
-      if (dense) {
-        cand = key[u] == KEY_ALWAYS || (key[u] + span >= c_beg && key[u] < c_beg + (uint32_t)OWN_CH);
-      } else {
-        cand = (key[u] >> 31) != 0u;
-#pragma unroll
-        for (int bc = 0; bc < 4; ++bc) cand = cand || (((key[u] >> (5 * bc)) & 31u) == chunk);
+      for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
       }
-      cand = cand && p < p_end;
-      const unsigned long long bal = __ballot(cand);
-      if (bal) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(qn, (uint32_t)__popcll(bal));
-        base = __shfl(base, 0, 64);
-        if (cand) queue[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)(p - p0);
+      const int total = __shfl(incl, 63, 64);
+      uint32_t base = 0;
+      if (lane == 0 && total) base = atomicAdd(qn, (uint32_t)total);
+      base = __shfl(base, 0, 64);
+      uint32_t at = base + (uint32_t)(incl - cnt);
+      while (word) {
+        const int b = __ffs(word) - 1;
+        word &= word - 1;
+        queue[at++] = (uint16_t)(tid * 32 + b);
       }
     }
-    if (p0 + OWN_TRIP < p_end) fetch_keys(p0 + OWN_TRIP);
     __syncthreads();
     // ---- the queued points, by full waves: exact corner indices, weights, adds
     const int nq = (int)*qn;
@@ -660,16 +673,19 @@ extern "C" int nsky_encode_fwd(const nsky_hashgrid_desc* d, const float* x, int3
   return NSKY_OK;
 }
 
-static int fine_levels(const Grid& g) {  // levels that do not fit the LDS-privatised coarse pass
-  int n_coarse = 0;
-  while (n_coarse < g.n_levels && (size_t)g.offset[n_coarse + 1] * 2 * sizeof(float) <= 144 * 1024) ++n_coarse;
-  return g.n_levels - n_coarse;
+static bool owner_geometry_ok(const Grid& g) {  // every level: at most 32 chunks; hashed slabs of 2^T entries (tcnn's geometry)
+  for (int l = 0; l < g.n_levels; ++l) {
+    const uint32_t sz = g.offset[l + 1] - g.offset[l];
+    if (sz > (uint32_t)OWN_MAX_CHUNKS * OWN_CH) return false;
+    if (!level_is_dense(sz, (uint32_t)g.resolution[l]) && (sz & (sz - 1)) != 0) return false;
+  }
+  return true;
 }
 
 extern "C" int64_t nsky_encode_bwd_workspace_bytes(const nsky_hashgrid_desc* d, int32_t P) {
   Grid g;
-  if (make_grid(d, g, "nsky_encode_bwd_workspace_bytes") != NSKY_OK || P < NSKY_ENCODE_BWD_OWNER_MIN_POINTS) return 0;
-  return (int64_t)fine_levels(g) * P * (int64_t)sizeof(uint32_t);
+  if (make_grid(d, g, "nsky_encode_bwd_workspace_bytes") != NSKY_OK || P < NSKY_ENCODE_BWD_OWNER_MIN_POINTS || !owner_geometry_ok(g)) return 0;
+  return (int64_t)g.n_levels * OWN_MAX_CHUNKS * ((int64_t)ceil_div(P, BM_POINTS) * (BM_POINTS / 32)) * (int64_t)sizeof(uint32_t);
 }
 
 extern "C" int nsky_encode_bwd(const nsky_hashgrid_desc* d, const float* x, int32_t P, int32_t mode, int32_t include_x,
@@ -682,69 +698,65 @@ extern "C" int nsky_encode_bwd(const nsky_hashgrid_desc* d, const float* x, int3
   NSKY_CHECK_ARG(mode >= 0 && mode <= 2 && pe_freqs >= 0 && pe_freqs <= 6, "nsky_encode_bwd: bad mode/pe_freqs");
   hipStream_t s = (hipStream_t)stream;
   const int feat0 = (include_x ? 3 : 0) + 6 * pe_freqs;
-  // coarse levels whose slabs fit together in LDS (<= 144 KiB) are privatised per workgroup
-  int n_coarse = 0;
-  while (n_coarse < g.n_levels && (size_t)g.offset[n_coarse + 1] * 2 * sizeof(float) <= 144 * 1024) ++n_coarse;
-  if (n_coarse > 0) {
-    const int blocks = 256;
-    const int ppb = ((P + blocks - 1) / blocks + 15) / 16 * 16;
-    const size_t smem = (size_t)g.offset[n_coarse] * 2 * sizeof(float);
-    dim3 grid(ceil_div(P, ppb));
-    // raise the dynamic-LDS ceiling once per process (not a stream operation; kept out of captured regions)
-    static bool attr_set = [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_coarse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_coarse_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (workspace != nullptr && P >= NSKY_ENCODE_BWD_OWNER_MIN_POINTS && owner_geometry_ok(g)) {
+    // Many points: chunk owners for EVERY level (LDS accumulation, above).
+    OwnerArgs oa;
+    oa.g = g; oa.x = x; oa.dY = dY; oa.dT = dT; oa.dtable = dtable; oa.P = P; oa.mode = mode; oa.feat0 = feat0; oa.lddy = lddy;
+    oa.bitmaps = reinterpret_cast<uint32_t*>(workspace);
+    oa.words = ceil_div(P, BM_POINTS) * (BM_POINTS / 32);
+    oa.n_levels_owned = 0;
+    int wgs = 0;
+    for (int l = 0; l < g.n_levels; ++l) {
+      const int nch = ceil_div((long)(g.offset[l + 1] - g.offset[l]), OWN_CH);
+      // hashed: the hash spreads a level's adds evenly over its 32 chunks; dense: the points' spatial distribution decides,
+      // and a scene's points crowd a few slabs -- twice the workgroups per level, split over the points
+      const bool dense_l = level_is_dense(g.offset[l + 1] - g.offset[l], (uint32_t)g.resolution[l]);
+      int sp = (dense_l ? 2 * OWN_WG_PER_LEVEL : OWN_WG_PER_LEVEL) / nch;
+      if (sp < 1) sp = 1;
+      oa.level[oa.n_levels_owned] = l;
+      oa.splits[oa.n_levels_owned] = sp;
+      oa.wg0[oa.n_levels_owned++] = wgs;
+      wgs += nch * sp;
+    }
+    oa.wg0[oa.n_levels_owned] = wgs;
+    static bool own_attr = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_owner_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_owner_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       return true;
     }();
-    (void)attr_set;
-    if (dT) {
-      hipLaunchKernelGGL(encode_bwd_coarse_kernel<true>, grid, dim3(256), smem, s, g, x, P, mode, feat0, dY, lddy, dT, dtable, n_coarse, ppb);
-    } else {
-      hipLaunchKernelGGL(encode_bwd_coarse_kernel<false>, grid, dim3(256), smem, s, g, x, P, mode, feat0, dY, lddy, dT, dtable, n_coarse, ppb);
-    }
-    NSKY_CHECK_LAUNCH("nsky_encode_bwd(coarse)");
-  }
-  if (n_coarse < g.n_levels) {
-    // fine / hashed levels.  Many points: chunk owners (LDS accumulation, above); few points: the direct scatter (an owner walks
-    // every point for each of its ~10^2..10^3 chunks, which only pays once the atomics it replaces outnumber that walk)
-    bool own_ok = workspace != nullptr;  // hashed slabs of 2^T <= 2^19 entries (what tcnn's geometry produces): 5-bit chunk numbers
-    for (int l = n_coarse; l < g.n_levels; ++l) {
-      const uint32_t sz = g.offset[l + 1] - g.offset[l];
-      if (!level_is_dense(sz, (uint32_t)g.resolution[l]) && ((sz & (sz - 1)) != 0 || sz > 32u * OWN_CH)) own_ok = false;
-    }
-    if (P >= NSKY_ENCODE_BWD_OWNER_MIN_POINTS && own_ok) {
-      OwnerArgs oa;
-      oa.g = g; oa.x = x; oa.dY = dY; oa.dT = dT; oa.dtable = dtable; oa.P = P; oa.mode = mode; oa.feat0 = feat0; oa.lddy = lddy;
-      oa.keys = reinterpret_cast<uint32_t*>(workspace);
-      oa.n_levels_owned = 0;
-      int wgs = 0;
-      for (int l = n_coarse; l < g.n_levels; ++l) {
-        const int nch = ceil_div((long)(g.offset[l + 1] - g.offset[l]), OWN_CH);
-        // hashed: the hash spreads a level's adds evenly over its 32 chunks; dense: the points' spatial distribution decides,
-        // and a scene's points crowd a few slabs -- twice the workgroups per level, split over the points
-        const bool dense_l = level_is_dense(g.offset[l + 1] - g.offset[l], (uint32_t)g.resolution[l]);
-        int sp = (dense_l ? 2 * OWN_WG_PER_LEVEL : OWN_WG_PER_LEVEL) / nch;
-        if (sp < 1) sp = 1;
-        oa.level[oa.n_levels_owned] = l;
-        oa.splits[oa.n_levels_owned] = sp;
-        oa.wg0[oa.n_levels_owned++] = wgs;
-        wgs += nch * sp;
-      }
-      oa.wg0[oa.n_levels_owned] = wgs;
-      static bool own_attr = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_owner_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_owner_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)own_attr;
+    hipLaunchKernelGGL(owner_bitmaps_kernel, dim3(ceil_div(P, BM_POINTS), oa.n_levels_owned), dim3(BM_POINTS), 0, s, oa);
+    const size_t smem = 2 * OWN_CH * sizeof(float) + OWN_TRIP * sizeof(uint16_t) + 16;
+    if (dT)
+      hipLaunchKernelGGL(encode_bwd_owner_kernel<true>, dim3(wgs), dim3(OWN_THREADS), smem, s, oa);
+    else
+      hipLaunchKernelGGL(encode_bwd_owner_kernel<false>, dim3(wgs), dim3(OWN_THREADS), smem, s, oa);
+    NSKY_CHECK_LAUNCH("nsky_encode_bwd(owner)");
+  } else {
+    // Few points (an owner's fixed costs -- zero and write back 128 KB per chunk -- only pay once the atomics they replace outnumber
+    // them): coarse levels whose slabs fit together in LDS (<= 144 KiB) are privatised per workgroup, the rest scatter directly
+    int n_coarse = 0;
+    while (n_coarse < g.n_levels && (size_t)g.offset[n_coarse + 1] * 2 * sizeof(float) <= 144 * 1024) ++n_coarse;
+    if (n_coarse > 0) {
+      const int blocks = 256;
+      const int ppb = ((P + blocks - 1) / blocks + 15) / 16 * 16;
+      const size_t smem = (size_t)g.offset[n_coarse] * 2 * sizeof(float);
+      dim3 grid(ceil_div(P, ppb));
+      // raise the dynamic-LDS ceiling once per process (not a stream operation; kept out of captured regions)
+      static bool attr_set = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_coarse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_bwd_coarse_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
       }();
-      (void)own_attr;
-      hipLaunchKernelGGL(owner_keys_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, s, oa);
-      const size_t smem = 2 * OWN_CH * sizeof(float) + OWN_TRIP * sizeof(uint16_t) + 16;
-      if (dT)
-        hipLaunchKernelGGL(encode_bwd_owner_kernel<true>, dim3(wgs), dim3(OWN_THREADS), smem, s, oa);
-      else
-        hipLaunchKernelGGL(encode_bwd_owner_kernel<false>, dim3(wgs), dim3(OWN_THREADS), smem, s, oa);
-      NSKY_CHECK_LAUNCH("nsky_encode_bwd(owner)");
-    } else {
+      (void)attr_set;
+      if (dT) {
+        hipLaunchKernelGGL(encode_bwd_coarse_kernel<true>, grid, dim3(256), smem, s, g, x, P, mode, feat0, dY, lddy, dT, dtable, n_coarse, ppb);
+      } else {
+        hipLaunchKernelGGL(encode_bwd_coarse_kernel<false>, grid, dim3(256), smem, s, g, x, P, mode, feat0, dY, lddy, dT, dtable, n_coarse, ppb);
+      }
+      NSKY_CHECK_LAUNCH("nsky_encode_bwd(coarse)");
+    }
+    if (n_coarse < g.n_levels) {
       dim3 grid(ceil_div(P, 16), g.n_levels - n_coarse);
       if (dT)
         hipLaunchKernelGGL(encode_bwd_scatter_kernel<true>, grid, dim3(256), 0, s, g, x, P, mode, feat0, dY, lddy, dT, dtable, n_coarse);
