@@ -155,8 +155,9 @@ __device__ inline TileDesc bwd_map_tile(const nsky_film_net& n, int idx) {
   const int NT = n.hidden / 32, H = n.hidden, Gh = groups_of(H);
   const int nkg = 2 * n.n_film * H / 128;
   d.nrows = 32; d.transposed = 1; d.k0 = 0;
-  if (idx < nkg * NT) {
-    const int kg = idx / NT, u = idx % NT;
+  if (idx < nkg * NT) {  // two passes over the k-groups, each for half of the output tiles (the kernel keeps NT / 2 accumulators)
+    const int NH = NT / 2;
+    const int pass = idx / (nkg * NH), kg = (idx % (nkg * NH)) / NH, u = pass * NH + idx % NH;
     d.W = n.mo_w; d.ld = n.mo_ld; d.row0 = 32 * u; d.K = 128; d.k0 = 128 * kg; d.group = idx;
     return d;
   }
@@ -958,16 +959,20 @@ struct BwdMapArgs {
 };
 
 template <int H>
-__global__ __launch_bounds__(256, 1) void film_bwd_map_kernel(const BwdMapArgs a) {
-  constexpr int NT = H / 32, KS = H / 16;
+__global__ __launch_bounds__(512, 2) void film_bwd_map_kernel(const BwdMapArgs a) {
+  // Eight waves (two per SIMD, 256 registers each) share one weight stream over 256 batch rows.  The register budget is met as in
+  // the FiLM backward: the head product runs as two passes over the 2 n_film H head rows with NT / 2 accumulator tiles each, and no
+  // layer's matrix stays in registers -- a finished tile of dpre is stored (tile-native, also the weight gradient's operand) and the
+  // layer below reads the tiles back (the lane that stored a piece loads it).
+  constexpr int NT = H / 32, KS = H / 16, NH = NT / 2, PW = 2;
   __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + SCALE_FLOATS * 4];
   float* sl = reinterpret_cast<float*>(smem + RING_BYTES);
   const nsky_film_net& net = a.net;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5;
-  for (int i = tid; i < SCALE_FLOATS; i += 256) sl[i] = a.table[BIAS_FLOATS + i];
-  const long rt = (long)blockIdx.x * 4 + wave;
+  for (int i = tid; i < SCALE_FLOATS; i += 512) sl[i] = a.table[BIAS_FLOATS + i];
+  const long rt = (long)blockIdx.x * 8 + wave;
   const long row = rt * 32 + c;
   const bool live = row < a.M;
   const bool wave_live = rt * 32 < a.M;
@@ -978,100 +983,118 @@ __global__ __launch_bounds__(256, 1) void film_bwd_map_kernel(const BwdMapArgs a
   __syncthreads();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   WStream ws;
-  ws.src = a.stream + wave * 4096 + lane * 16;
-  ws.dst = (uint32_t)(uintptr_t)smem + wave * 4096;
+  ws.src = a.stream + wave * (PW * 1024) + lane * 16;
+  ws.dst = (uint32_t)(uintptr_t)smem + wave * (PW * 1024);
   ws.lds_lane = (uint32_t)(uintptr_t)smem + lane * 16;
-  ws_begin(ws);
+  ws_begin<PW>(ws);
 
-  float dh[NT][16];
-#pragma unroll
-  for (int u = 0; u < NT; ++u)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dh[u][r] = 0.0f;
   int tile = 0;
   const float* fblk = a.dfp + rts * ntot * 1024;
-  f32x4 fq[16];  // 128 head rows = 4 native tiles x 4 pieces, one k-group ahead
-#pragma unroll
-  for (int j = 0; j < 16; ++j) fq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int top = net.n_map - 1;
+  float m = 0.0f;  // largest |dpre_top| of this lane's row half
+  f32x4 fq[16];    // 128 head rows = 4 native tiles x 4 pieces, one k-group ahead
 #define NSKY_FQ_WAIT(N)                                                                                                         \
   asm volatile("s_waitcnt vmcnt(%16)"                                                                                           \
                : "+v"(fq[0]), "+v"(fq[1]), "+v"(fq[2]), "+v"(fq[3]), "+v"(fq[4]), "+v"(fq[5]), "+v"(fq[6]), "+v"(fq[7]), "+v"(fq[8]), \
                  "+v"(fq[9]), "+v"(fq[10]), "+v"(fq[11]), "+v"(fq[12]), "+v"(fq[13]), "+v"(fq[14]), "+v"(fq[15])                \
                : "n"(N)                                                                                                         \
                : "memory")
+  for (int pass = 0; pass < 2; ++pass) {
+    float dh[NH][16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) hidden_load4(fq[j], fblk + (j >> 2) * 1024 + (j & 3) * 256 + lane * 4);
-  NSKY_FQ_WAIT(0);  // first group (the ring's first pieces are older and land with it)
-  for (int kg = 0; kg < nkg; ++kg) {
-    f16x8 ph[8], pl[8];
+    for (int u = 0; u < NH; ++u)
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      float x8[8];
+      for (int r = 0; r < 16; ++r) dh[u][r] = 0.0f;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const f32x4 q = fq[(ks >> 1) * 4 + 2 * (ks & 1) + u];
-        x8[4 * u] = q[0] * f_scale; x8[4 * u + 1] = q[1] * f_scale; x8[4 * u + 2] = q[2] * f_scale; x8[4 * u + 3] = q[3] * f_scale;
+    for (int j = 0; j < 16; ++j) fq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) hidden_load4(fq[j], fblk + (j >> 2) * 1024 + (j & 3) * 256 + lane * 4);
+    NSKY_FQ_WAIT(0);  // first group of the pass (everything older lands with it)
+    for (int kg = 0; kg < nkg; ++kg) {
+      f16x8 ph[8], pl[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        float x8[8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const f32x4 q = fq[(ks >> 1) * 4 + 2 * (ks & 1) + u];
+          x8[4 * u] = q[0] * f_scale; x8[4 * u + 1] = q[1] * f_scale; x8[4 * u + 2] = q[2] * f_scale; x8[4 * u + 3] = q[3] * f_scale;
+        }
+        split8(x8, ph[ks], pl[ks]);
       }
-      split8(x8, ph[ks], pl[ks]);
+      {
+        const int kn = kg + 1 < nkg ? kg + 1 : kg;  // the last group re-requests itself (same count of operations in flight)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) hidden_load4(fq[j], fblk + (long)(4 * kn + (j >> 2)) * 1024 + (j & 3) * 256 + lane * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < NH; ++u) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        product<8, PW>(ws, ph, pl, acc);
+        const float inv = f_inv * sl[tile++];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[u][r] = fmaf(acc[r], inv, dh[u][r]);
+      }
+      // the next group's 16 pieces were requested before this group's NH products (NH transitions x PW DMA pieces)
+      NSKY_FQ_WAIT(PW * NH);
     }
-    {
-      const int kn = kg + 1 < nkg ? kg + 1 : kg;  // the last group re-requests itself (same count of operations in flight)
+    // dpre of the top mapping layer for this half of the features: dh * leaky'(h_top) (the activation keeps the sign of the
+    // pre-activation), stored tile by tile
 #pragma unroll
-      for (int j = 0; j < 16; ++j) hidden_load4(fq[j], fblk + (long)(4 * kn + (j >> 2)) * 1024 + (j & 3) * 256 + lane * 4);
-    }
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-      product<8>(ws, ph, pl, acc);
-      const float inv = f_inv * sl[tile++];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dh[u][r] = fmaf(acc[r], inv, dh[u][r]);
-    }
-    // the next group's 16 pieces were requested before this group's NT products (NT transitions x 4 DMA pieces)
-    NSKY_FQ_WAIT(4 * NT);
-  }
-#undef NSKY_FQ_WAIT
-
-  for (int l = net.n_map - 1; l >= 0; --l) {
-    // dpre = dh * leaky'(h_l): the activation keeps the sign of the pre-activation
-    float m = 0.0f;
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
+    for (int u = 0; u < NH; ++u) {
+      const int t = pass * NH + u;
       float hv[16];
-      load_tile(a.h_save[l] + (rts * NT + u) * 1024, lane, hv);
+      load_tile(a.h_save[top] + (rts * NT + t) * 1024, lane, hv);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         dh[u][r] = hv[r] > 0.0f ? dh[u][r] : 0.2f * dh[u][r];
         m = fmaxf(m, fabsf(dh[u][r]));
       }
-      if (wave_live) store_tile(a.dpre_save[l] + (rt * NT + u) * 1024, lane, dh[u]);
+      if (wave_live) store_tile(a.dpre_save[top] + (rt * NT + t) * 1024, lane, dh[u]);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+#undef NSKY_FQ_WAIT
+
+  for (int l = top; l >= 0; --l) {
     publish_max(a.gmax + l, m, live, wave_live, lane);
     float d_inv;
     const float s = row_scale(m, d_inv);
+    // B planes of dpre_l: its NT tiles come back from where this wave stored them
     f16x8 ph[KS], pl[KS];
 #pragma unroll
-    for (int u = 0; u < NT; ++u)
+    for (int u = 0; u < NT; ++u) {
+      float dv[16];
+      load_tile(a.dpre_save[l] + (rts * NT + u) * 1024, lane, dv);
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         float x8[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x8[j] = dh[u][8 * v + j] * s;
+        for (int j = 0; j < 8; ++j) x8[j] = dv[8 * v + j] * s;
         split8(x8, ph[2 * u + v], pl[2 * u + v]);
       }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the h_l loads: compiler-visible, none may be pending across the products
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // compiler-visible loads: none may be pending across the products
+    m = 0.0f;
     if (l > 0) {
-#pragma unroll
       for (int u = 0; u < NT; ++u) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        product<KS>(ws, ph, pl, acc);
+        product<KS, PW>(ws, ph, pl, acc);
         const float inv = d_inv * sl[tile++];
+        float hv[16], dv[16];
+        load_tile(a.h_save[l - 1] + (rts * NT + u) * 1024, lane, hv);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dh[u][r] = acc[r] * inv;
+        for (int r = 0; r < 16; ++r) {
+          const float g = acc[r] * inv;
+          dv[r] = hv[r] > 0.0f ? g : 0.2f * g;
+          m = fmaxf(m, fabsf(dv[r]));
+        }
+        if (wave_live) store_tile(a.dpre_save[l - 1] + (rt * NT + u) * 1024, lane, dv);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     } else {
       const int ct = (net.cond_dim + 31) / 32;
@@ -1079,7 +1102,7 @@ __global__ __launch_bounds__(256, 1) void film_bwd_map_kernel(const BwdMapArgs a
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        product<KS>(ws, ph, pl, acc);
+        product<KS, PW>(ws, ph, pl, acc);
         const float inv = d_inv * sl[tile++];
         if (a.d_cond && live) {
 #pragma unroll
@@ -1207,9 +1230,9 @@ extern "C" int nsky_film_chain_bwd_map(const nsky_film_net* net, const void* str
     a.dpre_save[l] = l < net->n_map ? dpre_save[l] : nullptr;
     if (l < net->n_map) NSKY_CHECK_ARG(a.h_save[l] && a.dpre_save[l] && ((uintptr_t)a.h_save[l] % 16) == 0 && ((uintptr_t)a.dpre_save[l] % 16) == 0, "nsky_film_chain_bwd_map: h_save / dpre_save[%d]", l);
   }
-  const dim3 grid(ceil_div(M, 128));
-  if (net->hidden == 256) hipLaunchKernelGGL((film_bwd_map_kernel<256>), grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((film_bwd_map_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid(ceil_div(M, 256));
+  if (net->hidden == 256) hipLaunchKernelGGL((film_bwd_map_kernel<256>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((film_bwd_map_kernel<128>), grid, dim3(512), 0, (hipStream_t)stream, a);
   NSKY_CHECK_LAUNCH("nsky_film_chain_bwd_map");
   return NSKY_OK;
 }
