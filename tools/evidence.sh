@@ -7,6 +7,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/ev_$TAG
 mkdir -p $O
 cd $R
+python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 python bench.py > $O/bench_line.json 2> $O/bench.err
 tail -1 $O/bench_line.json
 python tools/bench_forward_only.py > $O/forward_only.json 2> $O/forward_only.err; tail -1 $O/forward_only.json
