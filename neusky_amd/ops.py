@@ -525,9 +525,11 @@ class FilmSirenFn(torch.autograd.Function):
             # streaming weight-gradient kernel for all of them; the rest (row-major d_res / x / cond operands) per layer
             native = []
 
-            def wgrad(dZ, X, n_out, k_in, like, bias_like, iw, a_nt, b_nt, smax):
+            def wgrad(dZ, X, n_out, k_in, like, bias_like, iw, a_nt, b_nt, smax, x_scale=64.0):
+                # x_scale: power of two applied to X before its fp16 split: 2^6 for sine outputs (|y| <= 1), 2^3 for the mapping
+                # network's LeakyReLU activations (unbounded in principle: |h| up to 8000 stays inside fp16's range)
                 if a_nt > 0 and b_nt > 0 and a_nt % 4 == 0 and b_nt % 4 == 0 and smax is not None:
-                    native.append(hip.wgrad_problem(dZ, a_nt, X, b_nt, M, grads[iw], grads[iw + 1], smax))
+                    native.append(hip.wgrad_problem(dZ, a_nt, X, b_nt, M, grads[iw], grads[iw + 1], smax, x_scale))
                 else:
                     grad_weight(dZ, X, M, n_out, k_in, like, bias_like, acc=acc(iw), a_native_nt=a_nt, b_native_nt=b_nt, a_scale_max=smax)
 
@@ -535,9 +537,9 @@ class FilmSirenFn(torch.autograd.Function):
             for i in range(n_film - 1, 0, -1):
                 wgrad(dzs[i], ys[i - 1], H, H, fw[i], fb[i], o + 2 * i, nt, nt, gmax[i:i + 1])
             wgrad(dzs[0], x, H, fw[0].shape[1], fw[0], fb[0], o, nt, 0, None)
-            wgrad(dfp, hs[-1], 2 * n_film * H, Hm, mwo, mbo, 2 * n_map, 2 * n_film * nt, ntm, gmax[n_film:n_film + 1])
+            wgrad(dfp, hs[-1], 2 * n_film * H, Hm, mwo, mbo, 2 * n_map, 2 * n_film * nt, ntm, gmax[n_film:n_film + 1], 8.0)
             for l in range(n_map - 1, 0, -1):
-                wgrad(dpres[l], hs[l - 1], Hm, Hm, mw[l], mb[l], 2 * l, ntm, ntm, gmax[n_film + 1 + l:n_film + 2 + l])
+                wgrad(dpres[l], hs[l - 1], Hm, Hm, mw[l], mb[l], 2 * l, ntm, ntm, gmax[n_film + 1 + l:n_film + 2 + l], 8.0)
             k0 = mw[0].shape[1]
             wgrad(dpres[0], cond, Hm, k0, mw[0], mb[0], 0, ntm, 0, gmax[n_film + 1:n_film + 2] if k0 > 64 else None)
             if native:
