@@ -491,6 +491,12 @@ __device__ __forceinline__ void store_tile(float* blk, int lane, const float (&v
 #pragma unroll
   for (int g = 0; g < 4; ++g) stg4(blk + g * 256 + lane * 4, make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]));
 }
+// a tile nothing reads again before the backward (saved h / z): non-temporal, it need not displace the weight stream in L2
+__device__ __forceinline__ void store_tile_nt(float* blk, int lane, const float (&v)[16]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    __builtin_nontemporal_store(f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]}, reinterpret_cast<f32x4*>(blk + g * 256 + lane * 4));
+}
 __device__ __forceinline__ void load_tile(const float* blk, int lane, float (&v)[16]) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -562,7 +568,7 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
           m = fmaxf(m, fabsf(o));
         }
       }
-      if (a.h_save[0] && wave_live) store_tile(a.h_save[0] + (rt * NT + t) * 1024, lane, hn[t]);
+      if (a.h_save[0] && wave_live) store_tile_nt(a.h_save[0] + (rt * NT + t) * 1024, lane, hn[t]);
     }
     const float s = row_scale(m, h_inv);
 #pragma unroll
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
           m = fmaxf(m, fabsf(o));
         }
       }
-      if (a.h_save[l] && wave_live) store_tile(a.h_save[l] + (rt * NT + t) * 1024, lane, hn[t]);
+      if (a.h_save[l] && wave_live) store_tile_nt(a.h_save[l] + (rt * NT + t) * 1024, lane, hn[t]);
     }
     const float s = row_scale(m, h_inv);
 #pragma unroll
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
         }
       }
       if (wave_live) {
-        if (zblk) store_tile(zblk + t * 1024, lane, zz);
+        if (zblk) store_tile_nt(zblk + t * 1024, lane, zz);
         store_tile(yblk + t * 1024, lane, yy);
       }
     }

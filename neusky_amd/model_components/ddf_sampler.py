@@ -9,7 +9,7 @@ from typing import Optional, Type
 import torch
 
 from ..cameras.rays import RayBundle
-from ..utils.utils import to_device_async
+from ..utils.utils import device_rng_seed, to_device_async
 
 
 @dataclass
@@ -89,7 +89,7 @@ class VMFDDFSampler:
         n = num_positions * num_directions
         st = getattr(self, "_dev_state", None)
         if st is None or st["n"] != n or st["ones"].device != dev:
-            st = self._dev_state = {"n": n, "counter": torch.zeros(1, dtype=torch.int64, device=dev), "seed": torch.initial_seed(),
+            st = self._dev_state = {"n": n, "counter": torch.zeros(1, dtype=torch.int64, device=dev), "seed": device_rng_seed(0),
                                     "ones": torch.ones(n, 1, device=dev), "norm": torch.ones(n, 1, device=dev),
                                     "cam": torch.zeros(n, 1, device=dev, dtype=torch.int64)}
         origins = torch.empty(n, 3, device=dev)

@@ -39,3 +39,11 @@ def to_device_async(t: torch.Tensor, device) -> torch.Tensor:
     if t.device.type != "cpu" or str(device) == "cpu":
         return t.to(device)
     return t.contiguous().pin_memory().to(device, non_blocking=True)
+
+
+def device_rng_seed(stream_id: int = 0) -> int:
+    """seed of an in-kernel counter-based generator (csrc/samplers.hip): torch's seed, the rank (ranks that were seeded alike must not
+    draw the same rays) and a per-generator stream id"""
+    import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    return (torch.initial_seed() + 7919 * rank + 104729 * stream_id) & (2**63 - 1)
