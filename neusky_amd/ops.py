@@ -233,7 +233,8 @@ def zeros_like(t: torch.Tensor) -> torch.Tensor:
 
 def begin_step(device=None) -> None:
     _PLANES.clear()
-    _FILM_STREAMS.clear()
+    for key in [k for k, hit in _FILM_STREAMS.items() if any(t.requires_grad for t in hit[0])]:
+        del _FILM_STREAMS[key]  # (streams packed from frozen weights -- keyed by storage and version -- stay)
     a = _ARENA
     a["cap"] = max(a["cap"], a["need"])
     a["need"], a["off"] = 0, 0
@@ -385,7 +386,7 @@ def _film_fused_ok(M, H, Hm, n_map, n_film, mw, fw, ow, x, cond) -> bool:
 
 def _film_stream(wb, n_map, n_film, mw, mb, mwo, mbo, fw, fb, ow, ob, direction=0):
     """per-step cache of one packed weight stream of a network (direction 0 forward, 1 FiLM backward, 2 mapping backward;
-    dropped by begin_step: the optimiser changed the weights) -> (descriptor, stream bytes, bias / scale table)"""
+    dropped by begin_step when any of its weights is trainable: the optimiser changed them) -> (descriptor, stream bytes, bias / scale table)"""
     key = (wb[0].data_ptr(), wb[0]._version, wb[-2].data_ptr(), n_map, n_film, direction)
     hit = _FILM_STREAMS.get(key)
     cur = torch.cuda.current_stream()

@@ -61,15 +61,20 @@ class FiLMSiren(nn.Module):
             self.final_layer.weight.uniform_(-math.sqrt(6.0 / hidden_features) / 25.0, math.sqrt(6.0 / hidden_features) / 25.0)
 
     def invalidate_weight_cache(self) -> None:
+        """once per optimisation step -- unless every weight is frozen (the RENI++ decoder): its padded copies and, through them,
+        its packed weight streams (ops._film_stream) then stay valid from step to step"""
+        if getattr(self, "_wcache", None) and not any(p.requires_grad for p in self.parameters()):
+            return
         self._wcache = {}
 
     def padded_weights(self):
         c = getattr(self, "_wcache", None)
-        if c is not None and "wb" in c and c["grad"] == torch.is_grad_enabled():
+        ver = tuple(p._version for p in self.parameters())  # (a frozen net keeps its cache over steps: a checkpoint load must drop it)
+        if c is not None and "wb" in c and c["grad"] == torch.is_grad_enabled() and c["ver"] == ver:
             return c["wb"]
         wb = self._padded_weights_uncached()
         if c is not None:
-            c["wb"], c["grad"] = wb, torch.is_grad_enabled()
+            c["wb"], c["grad"], c["ver"] = wb, torch.is_grad_enabled(), ver
         return wb
 
     def _padded_weights_uncached(self):
