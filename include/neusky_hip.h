@@ -27,7 +27,7 @@ extern "C" {
 typedef void* nsky_stream_t; /* hipStream_t */
 
 const char* nsky_last_error(void);
-int nsky_abi_version(void); /* 6 (bumped when a struct layout or an entry point's signature changes) */
+int nsky_abi_version(void); /* 7 (bumped when a struct layout or an entry point's signature changes) */
 
 /* ------------------------------------------------------------------------------------------
  * Dense layer on the matrix cores: C[M,N] = epilogue( sum_k A(m,k) * B(n,k) + bias[n] )
@@ -168,6 +168,28 @@ int nsky_film_chain_bwd_film(const nsky_film_net* net, const void* stream_buf, c
 int nsky_film_chain_bwd_map(const nsky_film_net* net, const void* stream_buf, const float* table, int32_t M, const float* dfp,
                             const float* dfp_rowmax, const float* const* h_save, float* const* dpre_save, float* d_cond,
                             int32_t ldcond, float* gmax, nsky_stream_t stream);
+/* SDF value chain: SDFAlbedoField.get_sdf_at_pos (neusky/fields/sdf_albedo_field.py:169-174; nerfstudio SDFField geometry network:
+ * Linear + Softplus(beta) twice, then the sdf row of the last Linear) for M encode rows, forward and backward as one kernel each
+ * (same weight-stream machinery as the FiLM-SIREN chain: nsky_sdf_stream_layout / nsky_sdf_pack once per optimizer step and
+ * direction, 0 = forward, 1 = backward).  a0_save / a1_save: the two softplus outputs, tile-native [ceil32(M), hidden] (scratch in
+ * inference).  _bwd: g_sdf [M] -> dz1 / dz0 (tile-native pre-activation gradients: the operands of the weight gradients,
+ * nsky_wgrad_native), dE [M, ldE] (optional), dw2 [hidden] += sum_rows g a1 and db2 [1] += sum_rows g (optional), gmax [2] = max |dz1|, max |dz0| (caller
+ * zero-fills).  hidden = 256, in_dim <= 80 (multiple of 4). */
+typedef struct {
+  int32_t in_dim, hidden;
+  const float* w0; int32_t ld0; const float* b0;   /* [hidden, in_dim] */
+  const float* w1; int32_t ld1; const float* b1;   /* [hidden, hidden] */
+  const float* w2; const float* b2;                /* the sdf row [hidden] of the last layer and its bias (1 value; may be null) */
+  float beta;
+} nsky_sdf_net;
+int nsky_sdf_stream_layout(const nsky_sdf_net* net, int32_t direction, int64_t* stream_bytes, int32_t* n_tiles);
+int nsky_sdf_pack(const nsky_sdf_net* net, int32_t direction, void* stream_buf, float* table, nsky_stream_t stream);
+int nsky_sdf_chain_fwd(const nsky_sdf_net* net, const void* stream_buf, const float* table, const float* E, int32_t ldE, int32_t M,
+                       float* a0_save, float* a1_save, float* sdf, nsky_stream_t stream);
+int nsky_sdf_chain_bwd(const nsky_sdf_net* net, const void* stream_buf, const float* table, int32_t M, const float* g_sdf,
+                       const float* a0_save, const float* a1_save, float* dz1, float* dz0, float* dE, int32_t ldE, float* dw2,
+                       float* db2, float* gmax, nsky_stream_t stream);
+
 /* Weight and bias gradient of one dense layer of the chain straight over two tile-native matrices (what autograd's
  * AddmmBackward / the MmBackward pair of nn.Linear computes for siren.py:59-66, :167-172 and the mapping network's layers):
  *     dW[n, k] += sum_rows dZ[row, n] X[row, k]   (n < 32 nnt_a, k < 32 nnt_b; dW row-major, leading dimension ldw)

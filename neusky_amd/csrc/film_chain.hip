@@ -193,22 +193,10 @@ __device__ inline void write_bias_table(const nsky_film_net& n, float* bl, int t
   for (int i = tid; i < 32; i += 256) bl[off + i] = (n.out_b && i < n.out_dim) ? n.out_b[i] : 0.0f;
 }
 
-// one block per tile: absmax -> power-of-two scale -> fp16 hi / residual planes in fragment order
-__global__ __launch_bounds__(256) void film_pack_kernel(nsky_film_net net, int direction, unsigned char* __restrict__ stream,
-                                                        float* __restrict__ table) {
-  __shared__ float w[32][PACK_KMAX + 1];
-  __shared__ float red[256];
+// one block per tile: absmax -> power-of-two scale -> fp16 hi / residual planes in fragment order (tile = blockIdx.x)
+__device__ __forceinline__ void pack_tile(const TileDesc& d, unsigned char* __restrict__ stream, float* __restrict__ scales,
+                                          float (*w)[PACK_KMAX + 1], float* red) {
   const int tid = threadIdx.x;
-  long total_groups;
-  int n_tiles;
-  dir_layout(net, direction, total_groups, n_tiles);
-  if ((int)blockIdx.x == n_tiles) {  // the extra block: every bias of the network, in the order the chain kernels index them
-    write_bias_table(net, table, tid);
-    return;
-  }
-  float* scales = table + BIAS_FLOATS;
-  const TileDesc d = direction == 0 ? fwd_tile(net, fwd_layout(net), blockIdx.x)
-                                    : (direction == 1 ? bwd_film_tile(net, blockIdx.x) : bwd_map_tile(net, blockIdx.x));
   const int Kp = ksteps_of(d.K) * 16;
   float m = 0.0f;
   for (int idx = tid; idx < 32 * Kp; idx += 256) {
@@ -249,6 +237,23 @@ __global__ __launch_bounds__(256) void film_pack_kernel(nsky_film_net net, int d
     *reinterpret_cast<f16x8*>(base + (long)ks * SLAB + lane * 16) = hi;
     *reinterpret_cast<f16x8*>(base + (long)ks * SLAB + 1024 + lane * 16) = lo;
   }
+}
+
+__global__ __launch_bounds__(256) void film_pack_kernel(nsky_film_net net, int direction, unsigned char* __restrict__ stream,
+                                                        float* __restrict__ table) {
+  __shared__ float w[32][PACK_KMAX + 1];
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  long total_groups;
+  int n_tiles;
+  dir_layout(net, direction, total_groups, n_tiles);
+  if ((int)blockIdx.x == n_tiles) {  // the extra block: every bias of the network, in the order the chain kernels index them
+    write_bias_table(net, table, tid);
+    return;
+  }
+  const TileDesc d = direction == 0 ? fwd_tile(net, fwd_layout(net), blockIdx.x)
+                                    : (direction == 1 ? bwd_film_tile(net, blockIdx.x) : bwd_map_tile(net, blockIdx.x));
+  pack_tile(d, stream, table + BIAS_FLOATS, w, red);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1124,6 +1129,318 @@ __global__ __launch_bounds__(512, 2) void film_bwd_map_kernel(const BwdMapArgs a
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
+// =====================================================================================================================
+// SDF value chain: the geometry network evaluated for its signed distance only (SDFAlbedoField.get_sdf_at_pos,
+// sdf_albedo_field.py:169-174: encode row -> Linear + Softplus(beta) -> Linear + Softplus(beta) -> the sdf row of the last Linear),
+// forward and backward as one kernel each on the machinery above.  Used at the DDF termination points (2.6e5 rows per step).
+// Eight waves per workgroup share the (small: 0.4 MB) weight stream; the hidden activations are written once, tile-native, for the
+// backward and for the weight gradients, and read back by the wave that wrote them to form the next layer's operand planes once
+// their row maximum is known.  sigmoid(beta z) is recovered from the saved softplus output: 1 - exp(-beta a).
+struct SdfLayout { int NT, G0, Gh, KS0; };
+__host__ __device__ inline SdfLayout sdf_layout(const nsky_sdf_net& n) {
+  SdfLayout L;
+  L.NT = n.hidden / 32; L.KS0 = ksteps_of(n.in_dim); L.G0 = groups_of(n.in_dim); L.Gh = groups_of(n.hidden);
+  return L;
+}
+__host__ __device__ inline void sdf_dir_layout(const nsky_sdf_net& n, int direction, long& total_groups, int& n_tiles) {
+  const SdfLayout L = sdf_layout(n);
+  if (direction == 0) { n_tiles = 2 * L.NT; total_groups = (long)L.NT * (L.G0 + L.Gh); }
+  else { const int ct = (n.in_dim + 31) / 32; n_tiles = L.NT + ct; total_groups = (long)(L.NT + ct) * L.Gh; }
+}
+__device__ inline TileDesc sdf_tile(const nsky_sdf_net& n, int direction, int idx) {
+  const SdfLayout L = sdf_layout(n);
+  TileDesc d;
+  d.k0 = 0; d.nrows = 32;
+  if (direction == 0) {
+    d.transposed = 0;
+    if (idx < L.NT) { d.W = n.w0; d.ld = n.ld0; d.row0 = 32 * idx; d.K = n.in_dim; d.group = (long)idx * L.G0; }
+    else { d.W = n.w1; d.ld = n.ld1; d.row0 = 32 * (idx - L.NT); d.K = n.hidden; d.group = (long)L.NT * L.G0 + (long)(idx - L.NT) * L.Gh; }
+  } else {
+    d.transposed = 1; d.K = n.hidden; d.group = (long)idx * L.Gh;
+    if (idx < L.NT) { d.W = n.w1; d.ld = n.ld1; d.row0 = 32 * idx; }
+    else { d.W = n.w0; d.ld = n.ld0; d.row0 = 32 * (idx - L.NT); d.nrows = min(32, n.in_dim - 32 * (idx - L.NT)); }
+  }
+  return d;
+}
+// table: [b0: H][b1: H][w2 (the sdf row): H][b2: 1] at 0, reciprocal tile scales at BIAS_FLOATS
+__global__ __launch_bounds__(256) void sdf_pack_kernel(nsky_sdf_net net, int direction, unsigned char* __restrict__ stream,
+                                                       float* __restrict__ table) {
+  __shared__ float w[32][PACK_KMAX + 1];
+  __shared__ float red[256];
+  long total_groups;
+  int n_tiles;
+  sdf_dir_layout(net, direction, total_groups, n_tiles);
+  if ((int)blockIdx.x == n_tiles) {
+    const int H = net.hidden;
+    for (int i = threadIdx.x; i < H; i += 256) {
+      table[i] = net.b0 ? net.b0[i] : 0.0f;
+      table[H + i] = net.b1 ? net.b1[i] : 0.0f;
+      table[2 * H + i] = net.w2[i];
+    }
+    if (threadIdx.x == 0) table[3 * H] = net.b2 ? net.b2[0] : 0.0f;
+    return;
+  }
+  pack_tile(sdf_tile(net, direction, blockIdx.x), stream, table + BIAS_FLOATS, w, red);
+}
+
+struct SdfFwdArgs {
+  nsky_sdf_net net;
+  const unsigned char* stream;
+  const float* table;
+  const float* E; int ldE;   // [M, ldE] encode rows
+  int M;
+  float* a0; float* a1;      // native [ceil32(M), H] softplus outputs of the two hidden layers
+  float* sdf;                // [M]
+};
+
+// planes of KS k-steps from NT tiles this wave stored (scaled by the row maximum m): the lane that stored a piece loads it
+template <int NT>
+__device__ __forceinline__ float planes_from_tiles(const float* blk, int lane, float m, f16x8 (&ph)[2 * NT], f16x8 (&pl)[2 * NT]) {
+  float inv;
+  const float s = row_scale(m, inv);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    float v[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 q = ldg4_nt(blk + t * 1024 + g * 256 + lane * 4);
+      v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float x8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x8[j] = v[8 * u + j] * s;
+      split8(x8, ph[2 * t + u], pl[2 * t + u]);
+    }
+  }
+  return inv;
+}
+
+__device__ __forceinline__ float softplus_b(float v, float beta, float inv_beta) {  // torch.nn.functional.softplus(beta, threshold 20)
+  const float bv = beta * v;
+  const float t = __expf(-fabsf(bv));
+  const float u = 1.0f + t, um1 = u - 1.0f;
+  const float l = um1 == 0.0f ? t : __logf(u) * (t * __builtin_amdgcn_rcpf(um1));
+  return bv > 20.0f ? v : (fmaxf(bv, 0.0f) + l) * inv_beta;
+}
+
+template <int H, int KS0>
+__global__ __launch_bounds__(512, 2) void sdf_fwd_kernel(const SdfFwdArgs a) {
+  constexpr int NT = H / 32, KS = H / 16, PW = 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + (3 * H + 4 + 64) * 4];
+  float* bl = reinterpret_cast<float*>(smem + RING_BYTES);  // b0 | b1 | w2 | b2
+  float* sl = bl + 3 * H + 4;                               // tile scales (2 NT <= 64)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  for (int i = tid; i < 3 * H + 1; i += 512) bl[i] = a.table[i];
+  for (int i = tid; i < 2 * NT; i += 512) sl[i] = a.table[BIAS_FLOATS + i];
+  const long rt = (long)blockIdx.x * 8 + wave;
+  const long row = rt * 32 + c;
+  const bool live = row < a.M;
+  const long rowc = live ? row : a.M - 1;
+  const bool wave_live = rt * 32 < a.M;
+  const long rts = wave_live ? rt : 0;  // a wave wholly beyond M works on tile 0's rows and stores nothing
+  const float beta = a.net.beta, inv_beta = 1.0f / beta;
+  f16x8 eh[KS0], el[KS0];
+  const float e_inv = load_planes<KS0>(a.E + rowc * a.ldE, a.net.in_dim, KS0, h, eh, el);
+  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WStream ws;
+  ws.src = a.stream + wave * (PW * 1024) + lane * 16;
+  ws.dst = (uint32_t)(uintptr_t)smem + wave * (PW * 1024);
+  ws.lds_lane = (uint32_t)(uintptr_t)smem + lane * 16;
+  ws_begin<PW>(ws);
+  int tile = 0;
+  float* a0blk = a.a0 + rts * NT * 1024;
+  float* a1blk = a.a1 + rts * NT * 1024;
+  float m = 0.0f;
+  for (int t = 0; t < NT; ++t) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    product<KS0, PW>(ws, eh, el, acc);
+    const float inv = e_inv * sl[tile++];
+    float v[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 b4 = *reinterpret_cast<const float4*>(bl + 32 * t + 8 * g + 4 * h);
+      const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[4 * g + q] = softplus_b(fmaf(acc[4 * g + q], inv, bb[q]), beta, inv_beta);
+        m = fmaxf(m, v[4 * g + q]);
+      }
+    }
+    if (wave_live) store_tile(a0blk + t * 1024, lane, v);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's a0 stores have left before it reads them back
+  f16x8 ah[KS], al[KS];
+  const float a_inv = planes_from_tiles<NT>(a0blk, lane, m, ah, al);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float part = 0.0f;
+  for (int t = 0; t < NT; ++t) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    product<KS, PW>(ws, ah, al, acc);
+    const float inv = a_inv * sl[tile++];
+    float v[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 b4 = *reinterpret_cast<const float4*>(bl + H + 32 * t + 8 * g + 4 * h);
+      const float4 w4 = *reinterpret_cast<const float4*>(bl + 2 * H + 32 * t + 8 * g + 4 * h);
+      const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[4 * g + q] = softplus_b(fmaf(acc[4 * g + q], inv, bb[q]), beta, inv_beta);
+        part = fmaf(v[4 * g + q], ww[q], part);
+      }
+    }
+    if (wave_live) store_tile_nt(a1blk + t * 1024, lane, v);
+  }
+  part += __shfl_xor(part, 32, 64);  // the two lane halves hold different features of the same row
+  if (live && h == 0) a.sdf[row] = part + bl[3 * H];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+struct SdfBwdArgs {
+  nsky_sdf_net net;
+  const unsigned char* stream;
+  const float* table;
+  int M;
+  const float* g;            // [M] gradient of the sdf
+  const float* a0; const float* a1;
+  float* dz1; float* dz0;    // native [ceil32(M), H]: pre-activation gradients (also the weight gradients' operands)
+  float* dE; int ldE;        // [M, ldE] or NULL
+  float* dw2;                // [H] += sum_rows g a1 (or NULL)
+  float* db2;                // [1] += sum_rows g (with dw2)
+  float* gmax;               // [2]: max |dz1|, max |dz0| (zero-initialised by the caller)
+};
+
+template <int H>
+__global__ __launch_bounds__(512, 2) void sdf_bwd_kernel(const SdfBwdArgs a) {
+  constexpr int NT = H / 32, KS = H / 16, PW = 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + (2 * H + 4 + 64) * 4];
+  float* w2 = reinterpret_cast<float*>(smem + RING_BYTES);  // the sdf row
+  float* dw2s = w2 + H;                                      // this workgroup's sum_rows g a1, then sum_rows g
+  float* sl = dw2s + H + 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int ct = (a.net.in_dim + 31) / 32;
+  for (int i = tid; i < H; i += 512) { w2[i] = a.table[2 * H + i]; dw2s[i] = 0.0f; }
+  if (tid < 4) dw2s[H + tid] = 0.0f;
+  for (int i = tid; i < NT + ct; i += 512) sl[i] = a.table[BIAS_FLOATS + i];
+  const long rt = (long)blockIdx.x * 8 + wave;
+  const long row = rt * 32 + c;
+  const bool live = row < a.M;
+  const bool wave_live = rt * 32 < a.M;
+  const long rts = wave_live ? rt : 0;
+  const float beta = a.net.beta;
+  const float g = live ? a.g[row] : 0.0f;
+  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WStream ws;
+  ws.src = a.stream + wave * (PW * 1024) + lane * 16;
+  ws.dst = (uint32_t)(uintptr_t)smem + wave * (PW * 1024);
+  ws.lds_lane = (uint32_t)(uintptr_t)smem + lane * 16;
+  ws_begin<PW>(ws);
+  if (a.dw2) {
+    float p = h == 0 ? g : 0.0f;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+    if (lane == 0) atomicAdd(dw2s + H, p);
+  }
+  int tile = 0;
+  float* dz1blk = a.dz1 + rts * NT * 1024;
+  float* dz0blk = a.dz0 + rts * NT * 1024;
+  // ---- dz1 = g w2 sigmoid(beta z1); dw2 += g a1
+  float m = 0.0f;
+  for (int t = 0; t < NT; ++t) {
+    float av[16], dv[16];
+    load_tile(a.a1 + (rts * NT + t) * 1024, lane, av);
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const float4 w4 = *reinterpret_cast<const float4*>(w2 + 32 * t + 8 * gq + 4 * h);
+      const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 4 * gq + q;
+        dv[r] = g * ww[q] * -expm1f(-beta * av[r]);
+        m = fmaxf(m, fabsf(dv[r]));
+        if (a.dw2) {
+          float p = g * av[r];
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);  // over the 32 rows of this lane half
+          if (c == 0) atomicAdd(dw2s + 32 * t + 8 * gq + 4 * h + q, p);
+        }
+      }
+    }
+    if (wave_live) store_tile(dz1blk + t * 1024, lane, dv);
+  }
+  publish_max(a.gmax, m, live, wave_live, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  f16x8 ph[KS], pl[KS];
+  float p_inv = planes_from_tiles<NT>(dz1blk, lane, m, ph, pl);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- dz0 = (W1^T dz1) sigmoid(beta z0)
+  m = 0.0f;
+  for (int u = 0; u < NT; ++u) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    product<KS, PW>(ws, ph, pl, acc);
+    const float inv = p_inv * sl[tile++];
+    float av[16], dv[16];
+    load_tile(a.a0 + (rts * NT + u) * 1024, lane, av);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dv[r] = acc[r] * inv * -expm1f(-beta * av[r]);
+      m = fmaxf(m, fabsf(dv[r]));
+    }
+    if (wave_live) store_tile(dz0blk + u * 1024, lane, dv);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // compiler-visible loads: none pending across the next product
+  }
+  publish_max(a.gmax + 1, m, live, wave_live, lane);
+  // ---- dE = W0^T dz0
+  if (a.dE) {
+    p_inv = planes_from_tiles<NT>(dz0blk, lane, m, ph, pl);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int u = 0; u < ct; ++u) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      product<KS, PW>(ws, ph, pl, acc);
+      const float inv = p_inv * sl[tile++];
+      if (live) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int fo = 32 * u + 8 * gq + 4 * h;
+          if (fo < a.ldE)
+            stg4(a.dE + row * a.ldE + fo, make_float4(acc[4 * gq] * inv, acc[4 * gq + 1] * inv, acc[4 * gq + 2] * inv, acc[4 * gq + 3] * inv));
+        }
+      }
+    }
+  }
+  if (a.dw2) {
+    __syncthreads();
+    for (int i = tid; i < H; i += 512)
+      if (dw2s[i] != 0.0f) atomicAdd(a.dw2 + i, dw2s[i]);
+    if (tid == 0 && a.db2 && dw2s[H] != 0.0f) atomicAdd(a.db2, dw2s[H]);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+int check_sdf_net(const nsky_sdf_net* n, const char* who) {
+  NSKY_CHECK_ARG(n, "%s: null network", who);
+  NSKY_CHECK_ARG(n->hidden == 256 && n->in_dim >= 4 && n->in_dim <= 80 && n->in_dim % 4 == 0, "%s: hidden %d (256) / in_dim %d (4..80, multiple of 4)", who,
+                 n->hidden, n->in_dim);
+  NSKY_CHECK_ARG(n->w0 && n->w1 && n->w2 && n->ld0 >= n->in_dim && n->ld1 >= n->hidden && n->beta > 0.0f, "%s: weights", who);
+  return NSKY_OK;
+}
+
 int check_net(const nsky_film_net* n, const char* who) {
   NSKY_CHECK_ARG(n, "%s: null network", who);
   NSKY_CHECK_ARG(n->hidden == 128 || n->hidden == 256, "%s: hidden width %d (128 or 256)", who, n->hidden);
@@ -1240,5 +1557,63 @@ extern "C" int nsky_film_chain_bwd_map(const nsky_film_net* net, const void* str
   if (net->hidden == 256) hipLaunchKernelGGL((film_bwd_map_kernel<256>), grid, dim3(512), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((film_bwd_map_kernel<128>), grid, dim3(512), 0, (hipStream_t)stream, a);
   NSKY_CHECK_LAUNCH("nsky_film_chain_bwd_map");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_sdf_stream_layout(const nsky_sdf_net* net, int32_t direction, int64_t* stream_bytes, int32_t* n_tiles) {
+  if (int rc = check_sdf_net(net, "nsky_sdf_stream_layout")) return rc;
+  NSKY_CHECK_ARG(direction == 0 || direction == 1, "nsky_sdf_stream_layout: direction %d", direction);
+  long groups; int tiles;
+  sdf_dir_layout(*net, direction, groups, tiles);
+  if (stream_bytes) *stream_bytes = (groups + RING_GROUPS + 2) * (int64_t)GROUP;
+  if (n_tiles) *n_tiles = tiles;
+  return NSKY_OK;
+}
+
+extern "C" int nsky_sdf_pack(const nsky_sdf_net* net, int32_t direction, void* stream_buf, float* table, nsky_stream_t stream) {
+  if (int rc = check_sdf_net(net, "nsky_sdf_pack")) return rc;
+  NSKY_CHECK_ARG((direction == 0 || direction == 1) && stream_buf && table, "nsky_sdf_pack: bad argument");
+  long groups; int tiles;
+  sdf_dir_layout(*net, direction, groups, tiles);
+  hipLaunchKernelGGL(sdf_pack_kernel, dim3(tiles + 1), dim3(256), 0, (hipStream_t)stream, *net, direction, (unsigned char*)stream_buf, table);
+  NSKY_CHECK_LAUNCH("nsky_sdf_pack");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_sdf_chain_fwd(const nsky_sdf_net* net, const void* stream_buf, const float* table, const float* E, int32_t ldE,
+                                  int32_t M, float* a0_save, float* a1_save, float* sdf, nsky_stream_t stream) {
+  if (int rc = check_sdf_net(net, "nsky_sdf_chain_fwd")) return rc;
+  NSKY_CHECK_ARG(stream_buf && table && E && a0_save && a1_save && sdf && M > 0 && ldE >= net->in_dim && ldE % 4 == 0, "nsky_sdf_chain_fwd: bad argument");
+  NSKY_CHECK_ARG(((uintptr_t)E % 16) == 0 && ((uintptr_t)a0_save % 16) == 0 && ((uintptr_t)a1_save % 16) == 0 && ((uintptr_t)stream_buf % 16) == 0,
+                 "nsky_sdf_chain_fwd: alignment");
+  SdfFwdArgs a;
+  a.net = *net; a.stream = (const unsigned char*)stream_buf; a.table = table; a.E = E; a.ldE = ldE; a.M = M; a.a0 = a0_save; a.a1 = a1_save;
+  a.sdf = sdf;
+  const dim3 grid(ceil_div(M, 256));
+  const int ks0 = ksteps_of(net->in_dim);
+#define NSKY_SDF_FWD(KK) hipLaunchKernelGGL((sdf_fwd_kernel<256, KK>), grid, dim3(512), 0, (hipStream_t)stream, a)
+  switch (ks0) {
+    case 1: NSKY_SDF_FWD(1); break;
+    case 2: NSKY_SDF_FWD(2); break;
+    case 3: NSKY_SDF_FWD(3); break;
+    case 4: NSKY_SDF_FWD(4); break;
+    default: NSKY_SDF_FWD(5); break;
+  }
+#undef NSKY_SDF_FWD
+  NSKY_CHECK_LAUNCH("nsky_sdf_chain_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_sdf_chain_bwd(const nsky_sdf_net* net, const void* stream_buf, const float* table, int32_t M, const float* g_sdf,
+                                  const float* a0_save, const float* a1_save, float* dz1, float* dz0, float* dE, int32_t ldE, float* dw2,
+                                  float* db2, float* gmax, nsky_stream_t stream) {
+  if (int rc = check_sdf_net(net, "nsky_sdf_chain_bwd")) return rc;
+  NSKY_CHECK_ARG(stream_buf && table && g_sdf && a0_save && a1_save && dz1 && dz0 && gmax && M > 0, "nsky_sdf_chain_bwd: bad argument");
+  if (dE) NSKY_CHECK_ARG(ldE % 4 == 0 && ldE >= net->in_dim && ((uintptr_t)dE % 16) == 0, "nsky_sdf_chain_bwd: dE layout");
+  SdfBwdArgs a;
+  a.net = *net; a.stream = (const unsigned char*)stream_buf; a.table = table; a.M = M; a.g = g_sdf; a.a0 = a0_save; a.a1 = a1_save;
+  a.dz1 = dz1; a.dz0 = dz0; a.dE = dE; a.ldE = ldE; a.dw2 = dw2; a.db2 = db2; a.gmax = gmax;
+  hipLaunchKernelGGL((sdf_bwd_kernel<256>), dim3(ceil_div(M, 256)), dim3(512), 0, (hipStream_t)stream, a);
+  NSKY_CHECK_LAUNCH("nsky_sdf_chain_bwd");
   return NSKY_OK;
 }

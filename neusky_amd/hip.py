@@ -52,7 +52,7 @@ class GemmDesc(C.Structure):
 
 _lib.nsky_last_error.restype = C.c_char_p
 _lib.nsky_abi_version.restype = C.c_int
-ABI_VERSION = 6  # the ctypes structures below mirror this version of include/neusky_hip.h
+ABI_VERSION = 7  # the ctypes structures below mirror this version of include/neusky_hip.h
 if _lib.nsky_abi_version() != ABI_VERSION:
     raise NeuSkyHipError(f"libneusky_hip.so has ABI version {_lib.nsky_abi_version()}, this package binds version {ABI_VERSION}: rebuild (build.sh)")
 
@@ -622,6 +622,53 @@ def film_stream_layout(net: FilmNet, direction: int = 0):
 
 def film_pack(net: FilmNet, stream_buf, scales, direction: int = 0):
     check(_film_pack(C.byref(net), direction, ptr(stream_buf), ptr(scales), stream_ptr()), "nsky_film_pack")
+
+
+class SdfNet(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("hidden", C.c_int32),
+                ("w0", C.c_void_p), ("ld0", C.c_int32), ("b0", C.c_void_p),
+                ("w1", C.c_void_p), ("ld1", C.c_int32), ("b1", C.c_void_p),
+                ("w2", C.c_void_p), ("b2", C.c_void_p), ("beta", C.c_float)]
+
+
+_sdf_layout = _sig("nsky_sdf_stream_layout", C.POINTER(SdfNet), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32))
+_sdf_pack = _sig("nsky_sdf_pack", C.POINTER(SdfNet), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p)
+_sdf_fwd = _sig("nsky_sdf_chain_fwd", C.POINTER(SdfNet), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                C.c_void_p, C.c_void_p)
+_sdf_bwd = _sig("nsky_sdf_chain_bwd", C.POINTER(SdfNet), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+
+
+def sdf_supported(in_dim: int, hidden: int) -> bool:
+    return hidden == 256 and 4 <= in_dim <= 80 and in_dim % 4 == 0
+
+
+def sdf_net(W0, b0, W1, b1, w2_row, b2_elem, beta) -> SdfNet:
+    """the geometry network evaluated for its sdf only: W0 [hidden, in_dim], W1 [hidden, hidden], w2_row [hidden] (a contiguous
+    row view), b2_elem a 1-element view; the caller keeps the tensors alive while the descriptor is in use"""
+    return SdfNet(in_dim=W0.shape[1], hidden=W0.shape[0], w0=ptr(W0), ld0=ld(W0), b0=ptr(b0), w1=ptr(W1), ld1=ld(W1), b1=ptr(b1),
+                  w2=ptr(w2_row), b2=ptr(b2_elem), beta=float(beta))
+
+
+def sdf_stream_layout(net: SdfNet, direction: int = 0):
+    nbytes, ntiles = C.c_int64(0), C.c_int32(0)
+    check(_sdf_layout(C.byref(net), direction, C.byref(nbytes), C.byref(ntiles)), "nsky_sdf_stream_layout")
+    return nbytes.value, ntiles.value
+
+
+def sdf_pack(net: SdfNet, stream_buf, table, direction: int = 0):
+    check(_sdf_pack(C.byref(net), direction, ptr(stream_buf), ptr(table), stream_ptr()), "nsky_sdf_pack")
+
+
+def sdf_chain_fwd(net: SdfNet, stream_buf, table, E, M, a0_save, a1_save, sdf):
+    check(_sdf_fwd(C.byref(net), ptr(stream_buf), ptr(table), ptr(E), ld(E), M, ptr(a0_save), ptr(a1_save), ptr(sdf), stream_ptr()),
+          "nsky_sdf_chain_fwd")
+    return sdf
+
+
+def sdf_chain_bwd(net: SdfNet, stream_buf, table, M, g_sdf, a0_save, a1_save, dz1, dz0, dE, dw2, db2, gmax):
+    check(_sdf_bwd(C.byref(net), ptr(stream_buf), ptr(table), M, ptr(g_sdf), ptr(a0_save), ptr(a1_save), ptr(dz1), ptr(dz0),
+                   ptr(dE), 0 if dE is None else ld(dE), ptr(dw2), ptr(db2), ptr(gmax), stream_ptr()), "nsky_sdf_chain_bwd")
 
 
 def _ptr_array(ts, n):

@@ -233,6 +233,7 @@ def zeros_like(t: torch.Tensor) -> torch.Tensor:
 
 def begin_step(device=None) -> None:
     _PLANES.clear()
+    _SDF_STREAMS.clear()
     for key in [k for k, hit in _FILM_STREAMS.items() if any(t.requires_grad for t in hit[0])]:
         del _FILM_STREAMS[key]  # (streams packed from frozen weights -- keyed by storage and version -- stay)
     a = _ARENA
@@ -773,8 +774,31 @@ class SDFAlbedoFn(torch.autograd.Function):
                 k(f_c1, dWc1), k(f_c1, dbc1), k(f_c2, dWc2), k(f_c2, dbc2), None, None)
 
 
+FUSED_SDF_MIN_ROWS = 4096
+_SDF_STREAMS: dict = {}
+
+
+def _sdf_stream(W0, b0, W1, b1, W2, b2, GF, beta, direction):
+    """per-step cache of the packed weight stream of the sdf value chain (direction 0 forward, 1 backward; dropped by begin_step)"""
+    key = (W0.data_ptr(), W0._version, W1.data_ptr(), W2.data_ptr(), GF, direction)
+    hit = _SDF_STREAMS.get(key)
+    cur = torch.cuda.current_stream()
+    if hit is None:
+        keep = (W0, b0, W1, b1, W2, b2, W2[GF], b2[GF:GF + 1])
+        net = hip.sdf_net(W0, b0, W1, b1, keep[6], keep[7], beta)
+        nbytes, _ = hip.sdf_stream_layout(net, direction)
+        stream = torch.zeros(nbytes, dtype=torch.uint8, device=W0.device)
+        table = torch.empty(hip.FILM_TABLE_FLOATS, device=W0.device)
+        hip.sdf_pack(net, stream, table, direction)
+        hit = _SDF_STREAMS[key] = (keep, net, stream, table, cur)
+    elif hit[4] != cur:
+        cur.wait_stream(hit[4])
+    return hit[1], hit[2], hit[3]
+
+
 class SDFValueFn(torch.autograd.Function):
-    """get_sdf_at_pos (sdf_albedo_field.py:169-174): value-only geo net on encode rows E [M,72] -> sdf [M]."""
+    """get_sdf_at_pos (sdf_albedo_field.py:169-174): value-only geo net on encode rows E [M,72] -> sdf [M].
+    Long batches (the DDF termination points) run the fused value chain: one kernel each way plus the weight gradients."""
 
     @staticmethod
     def forward(ctx, E, W0, b0, W1, b1, W2, b2, beta, train_weights):
@@ -782,6 +806,17 @@ class SDFValueFn(torch.autograd.Function):
         dev = E.device
         Hd, Kin = W0.shape
         GF = W2.shape[0] - 4
+        ctx.fused = (FWD_PRECISION == hip.PREC_F16X2 and M >= FUSED_SDF_MIN_ROWS and E.is_cuda and hip.sdf_supported(Kin, Hd)
+                     and ld(E) >= Kin and ld(E) % 4 == 0)
+        ctx.cfg = (M, Hd, Kin, GF, beta, train_weights)
+        if ctx.fused:
+            net, stream, table = _sdf_stream(W0, b0, W1, b1, W2, b2, GF, beta, 0)
+            Mp = hip.film_rows(M)
+            A0 = torch.empty(Mp, Hd, device=dev); A1 = torch.empty(Mp, Hd, device=dev)
+            sdf = torch.empty(M, device=dev)
+            hip.sdf_chain_fwd(net, stream, table, E, M, A0, A1, sdf)
+            ctx.save_for_backward(E, A0, A1, W0, b0, W1, b1, W2, b2)
+            return sdf
         A0 = torch.empty(M, Hd, device=dev); S0 = torch.empty(M, Hd, device=dev)
         fgemm(E, W0, A0, M, Hd, Kin, bias=b0, epi=hip.EPI_SOFTPLUS, p0=beta, out1=S0)
         A1 = torch.empty(M, Hd, device=dev); S1 = torch.empty(M, Hd, device=dev)
@@ -789,11 +824,40 @@ class SDFValueFn(torch.autograd.Function):
         out = zeros(M, 4, device=dev)
         fgemm(A1, W2[GF:GF + 1], out, M, 1, Hd, bias=b2[GF:GF + 1])
         ctx.save_for_backward(E, A0, S0, A1, S1, W0, b0, W1, b1, W2, b2)
-        ctx.cfg = (M, Hd, Kin, GF, beta, train_weights)
         return out[:, 0]
 
     @staticmethod
+    def _backward_fused(ctx, g_sdf):
+        E, A0, A1, W0, b0, W1, b1, W2, b2 = ctx.saved_tensors
+        M, Hd, Kin, GF, beta, train_w = ctx.cfg
+        dev = E.device
+        net, stream, table = _sdf_stream(W0, b0, W1, b1, W2, b2, GF, beta, 1)
+        Mp = hip.film_rows(M)
+        dZ1 = torch.empty(Mp, Hd, device=dev); dZ0 = torch.empty(Mp, Hd, device=dev)
+        dE = torch.empty(M, ld(E), device=dev) if ctx.needs_input_grad[0] else None
+        gmax = zeros(4, device=dev)
+        dW0 = db0 = dW1 = db1 = dW2 = db2 = None
+        f0 = f1 = f2 = False
+        if train_w:
+            dW2, db2, f2 = shared_grad(W2, b2)
+            dW1, db1, f1 = shared_grad(W1, b1)
+            dW0, db0, f0 = shared_grad(W0, b0)
+        hip.sdf_chain_bwd(net, stream, table, M, g_sdf.contiguous(), A0, A1, dZ1, dZ0, dE,
+                          dW2[GF] if train_w else None, db2[GF:GF + 1] if train_w else None, gmax)
+        if train_w:
+            nt = Hd // 32
+            # softplus outputs are unbounded in principle: 2^3 keeps |a| up to 8000 inside fp16's range (as for the mapping network)
+            hip.wgrad_native_batch([hip.wgrad_problem(dZ1, nt, A0, nt, M, dW1, db1, gmax[0:1], 8.0)], M)
+            grad_weight(dZ0, E, M, Hd, Kin, W0, b0, acc=(dW0, db0), a_native_nt=nt, b_native_nt=0, a_scale_max=gmax[1:2])
+            if not f2: dW2 = db2 = None
+            if not f1: dW1 = db1 = None
+            if not f0: dW0 = db0 = None
+        return dE, dW0, db0, dW1, db1, dW2, db2, None, None
+
+    @staticmethod
     def backward(ctx, g_sdf):
+        if ctx.fused:
+            return SDFValueFn._backward_fused(ctx, g_sdf)
         E, A0, S0, A1, S1, W0, b0, W1, b1, W2, b2 = ctx.saved_tensors
         M, Hd, Kin, GF, beta, train_w = ctx.cfg
         dev = E.device
