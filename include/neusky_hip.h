@@ -262,6 +262,23 @@ int nsky_ddf_fit_rows_fwd(const float* positions, const float* directions, const
 int nsky_ddf_fit_rows_bwd(const float* positions, const float* directions, const float* term_dist, const float* mv_points,
                           int32_t N, const float* d_xrow_mv, int32_t ldx, float* d_term_dist, nsky_stream_t stream);
 
+
+/* HDR output of the RENI++ decoder for the direction grid and the batch's own rays (neusky_model.py:488-549: exp output activation,
+ * unnormalised by the per-image scale): raw [U D + R, ldr] (the chain's head output, 3 used columns) ->
+ * grid [U D, 3] = exp(raw) scale[u], rays [R, 3] = exp(raw) scale[ray_latent[r]].  _bwd: d_raw [U D + R, ldr] (pad columns zeroed;
+ * d_grid / d_rays may be NULL = zero), d_scale [U] += (caller zero-fills; NULL = not wanted). */
+int nsky_reni_output_fwd(const float* raw, int32_t ldr, const float* scale, const int64_t* ray_latent, int32_t U, int32_t D, int32_t R,
+                         float* grid, float* rays, nsky_stream_t stream);
+int nsky_reni_output_bwd(const float* raw, int32_t ldr, const float* scale, const int64_t* ray_latent, int32_t U, int32_t D, int32_t R,
+                         const float* d_grid, const float* d_rays, float* d_raw, float* d_scale, nsky_stream_t stream);
+
+/* Illumination directions of one step: IcosahedronSampler with a random rotation (neusky/model_components/illumination_samplers.py:75-110,
+ * drawn per step at neusky_model.py:456-458) and the upper-hemisphere subset of the rotated set (neusky_model.py:1650-1657).
+ * base [D,3]; rotation_in: a 3x3 row-major matrix, or NULL = drawn from (seed, *counter) (Philox; the counter is advanced by one);
+ * dirs [D,3] = base R^T; sel [D/2] = indices of the D/2 largest z, ascending (= the z > 0 subset of a centrally symmetric set);
+ * rot_out [9] optional.  D even, <= 1024. */
+int nsky_illumination_directions(const float* base, int32_t D, const float* rotation_in, uint64_t seed, uint64_t* counter, float* dirs,
+                                 int32_t* sel, float* rot_out, nsky_stream_t stream);
 /* RENI++ decoder inputs (the rotation-invariant representation of RENIField, as fed at neusky_model.py:1207-1252): for latent
  * codes Z [U,L,3], a direction set [D,3] and R further (direction, latent index) pairs -- the batch's own rays (:535-549) --
  * rows u D + d (every latent set against every direction), then U D + r, of cond [U D + R, ldcond] = [|Z_xy|, Z_z, Z_xy . d_xy] per

@@ -314,6 +314,119 @@ __global__ __launch_bounds__(256) void reni_ray_inputs_bwd_kernel(const float* _
   atomicAdd(o, gx); atomicAdd(o + 1, gy); atomicAdd(o + 2, g[1]);
 }
 
+// The decoder's HDR output for the direction grid and the batch's own rays (neusky_model.py:488-549: exp output activation of the
+// RENI++ head, unnormalised by the per-image scale): grid[u, d] = exp(raw[u D + d]) scale[u], rays[r] = exp(raw[U D + r]) scale[ray_latent[r]].
+__global__ __launch_bounds__(256) void reni_output_fwd_kernel(const float* __restrict__ raw, int ldr, const float* __restrict__ scale,
+                                                              const long* __restrict__ ray_latent, int U, int D, int R,
+                                                              float* __restrict__ grid, float* __restrict__ rays) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= U * D + R) return;
+  const float s = scale[i < U * D ? i / D : ray_latent[i - U * D]];
+  float* o = i < U * D ? grid + 3l * i : rays + 3l * (i - U * D);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) o[c] = expf(raw[(long)i * ldr + c]) * s;
+}
+
+// d_raw = d_out exp(raw) scale (pad columns zero), d_scale[u] += sum d_out exp(raw): one atomic per wave and image for the grid rows
+// (consecutive rows share their image), one per row for the rays
+__global__ __launch_bounds__(256) void reni_output_bwd_kernel(const float* __restrict__ raw, int ldr, const float* __restrict__ scale,
+                                                              const long* __restrict__ ray_latent, int U, int D, int R,
+                                                              const float* __restrict__ d_grid, const float* __restrict__ d_rays,
+                                                              float* __restrict__ d_raw, float* __restrict__ d_scale) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = U * D + R;
+  const bool live = i < n;
+  const int ic = live ? i : n - 1;
+  const bool is_grid = ic < U * D;
+  const int u = is_grid ? ic / D : (int)ray_latent[ic - U * D];
+  const float* g = is_grid ? (d_grid ? d_grid + 3l * ic : nullptr) : (d_rays ? d_rays + 3l * (ic - U * D) : nullptr);
+  const float s = scale[u];
+  float acc = 0.0f;
+  float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (live && g) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float e = expf(raw[(long)ic * ldr + c]);
+      out[c] = g[c] * e * s;
+      acc += g[c] * e;
+    }
+  }
+  if (live) {
+    for (int c = 0; c < ldr; ++c) d_raw[(long)ic * ldr + c] = c < 3 ? out[c] : 0.0f;
+  }
+  if (!d_scale) return;
+  acc = live ? acc : 0.0f;
+  // segmented wave reduction over runs of equal u (sorted for the grid rows; arbitrary for the rays: those fall back to per-lane atomics)
+  const int lane = threadIdx.x & 63;
+  const int u0 = __shfl(u, 0, 64);
+  const bool uniform = __all(!live || (is_grid && u == u0));
+  if (uniform) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0 && acc != 0.0f) atomicAdd(d_scale + u0, acc);
+  } else if (live && acc != 0.0f) {
+    atomicAdd(d_scale + u, acc);
+  }
+}
+
+// IcosahedronSampler with apply_random_rotation (neusky/model_components/illumination_samplers.py:75-110 -> neusky_model.py:456-458)
+// and the upper-hemisphere subset of the rotated set (neusky_model.py:1650-1657) in ONE workgroup: a uniform random rotation from a
+// unit quaternion of four normals (or the caller's matrix), dirs = base R^T, and sel = the indices of the D / 2 directions with the
+// largest z in ascending order (for a centrally symmetric set this IS the z > 0 subset, with a size a replayed graph can rely on).
+// The call counter is advanced by the kernel itself (one workgroup: every reader is behind the barrier).
+__global__ __launch_bounds__(1024) void illumination_directions_kernel(const float* __restrict__ base, int D, const float* __restrict__ rotation_in,
+                                                                       uint64_t seed, uint64_t* __restrict__ counter, float* __restrict__ dirs,
+                                                                       int32_t* __restrict__ sel, float* __restrict__ rot_out) {
+  __shared__ float R[9];
+  __shared__ float zs[1024];
+  __shared__ int wave_total[16];
+  const int t = threadIdx.x;
+  if (t == 0) {
+    if (rotation_in) {
+      for (int i = 0; i < 9; ++i) R[i] = rotation_in[i];
+    } else {
+      const Philox g{(uint32_t)seed, (uint32_t)(seed >> 32)};
+      uint32_t w[4];
+      g.draw(0x4c494748u, 0u, *counter, w);
+      const float r0 = sqrtf(-2.0f * logf(u01(w[0]))), r1 = sqrtf(-2.0f * logf(u01(w[2])));
+      float q[4] = {r0 * cosf(TWO_PI * u01(w[1])), r0 * sinf(TWO_PI * u01(w[1])), r1 * cosf(TWO_PI * u01(w[3])), r1 * sinf(TWO_PI * u01(w[3]))};
+      const float inv = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+      const float qw = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
+      const float c = 2.0f * qw * qw - 1.0f;  // R = (2 w^2 - 1) I + 2 (v v^T + w [v]x)
+      R[0] = c + 2.0f * x * x;        R[1] = 2.0f * (x * y - qw * z); R[2] = 2.0f * (x * z + qw * y);
+      R[3] = 2.0f * (y * x + qw * z); R[4] = c + 2.0f * y * y;        R[5] = 2.0f * (y * z - qw * x);
+      R[6] = 2.0f * (z * x - qw * y); R[7] = 2.0f * (z * y + qw * x); R[8] = c + 2.0f * z * z;
+    }
+    if (rot_out)
+      for (int i = 0; i < 9; ++i) rot_out[i] = R[i];
+  }
+  __syncthreads();
+  if (t == 0 && !rotation_in) *counter += 1;
+  float z = -INFINITY;
+  if (t < D) {
+    const float bx = base[3 * t], by = base[3 * t + 1], bz = base[3 * t + 2];
+    dirs[3 * t] = R[0] * bx + R[1] * by + R[2] * bz;
+    dirs[3 * t + 1] = R[3] * bx + R[4] * by + R[5] * bz;
+    z = R[6] * bx + R[7] * by + R[8] * bz;
+    dirs[3 * t + 2] = z;
+  }
+  zs[t] = z;
+  __syncthreads();
+  int rank = 0;
+  for (int j = 0; j < D; ++j) {
+    const float zj = zs[j];
+    rank += (zj > z || (zj == z && j < t)) ? 1 : 0;
+  }
+  const bool chosen = t < D && rank < D / 2;
+  const unsigned long long mask = __ballot(chosen);
+  const int lane = t & 63, wave = t >> 6;
+  if (lane == 0) wave_total[wave] = __popcll(mask);
+  __syncthreads();
+  int before = 0;
+  for (int w = 0; w < wave; ++w) before += wave_total[w];
+  if (chosen) sel[before + __popcll(mask & ((1ull << lane) - 1ull))] = t;
+}
+
 }  // namespace
 
 extern "C" int nsky_ddf_vmf_samples(int32_t n_positions, int32_t n_directions, float kappa, float radius, int32_t upper_hemisphere,
@@ -393,5 +506,38 @@ extern "C" int nsky_reni_grid_inputs_bwd(const float* latents, const float* dire
     hipLaunchKernelGGL(reni_ray_inputs_bwd_kernel, dim3(ceil_div((long)R * L, 256)), dim3(256), 0, (hipStream_t)stream, latents, ray_dirs,
                        reinterpret_cast<const long*>(ray_latent), R, L, d_cond + (long)U * D * ldcond, ldcond, d_latents);
   NSKY_CHECK_LAUNCH("nsky_reni_grid_inputs_bwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_illumination_directions(const float* base, int32_t D, const float* rotation_in, uint64_t seed, uint64_t* counter, float* dirs,
+                                            int32_t* sel, float* rot_out, nsky_stream_t stream) {
+  NSKY_CHECK_ARG(base && dirs && sel && D >= 2 && D <= 1024 && D % 2 == 0 && (rotation_in || counter),
+                 "nsky_illumination_directions: bad argument (D %d: even, <= 1024)", D);
+  hipLaunchKernelGGL(illumination_directions_kernel, dim3(1), dim3((D + 63) / 64 * 64), 0, (hipStream_t)stream, base, D, rotation_in, seed, counter,
+                     dirs, sel, rot_out);
+  NSKY_CHECK_LAUNCH("nsky_illumination_directions");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_reni_output_fwd(const float* raw, int32_t ldr, const float* scale, const int64_t* ray_latent, int32_t U, int32_t D, int32_t R,
+                                    float* grid, float* rays, nsky_stream_t stream) {
+  NSKY_CHECK_ARG(raw && scale && ldr >= 3 && U >= 0 && D >= 0 && R >= 0 && (U * D == 0 || grid) && (R == 0 || (rays && ray_latent)),
+                 "nsky_reni_output_fwd: bad argument");
+  const int n = U * D + R;
+  if (n == 0) return NSKY_OK;
+  hipLaunchKernelGGL(reni_output_fwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, raw, ldr, scale, (const long*)ray_latent, U, D,
+                     R, grid, rays);
+  NSKY_CHECK_LAUNCH("nsky_reni_output_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_reni_output_bwd(const float* raw, int32_t ldr, const float* scale, const int64_t* ray_latent, int32_t U, int32_t D, int32_t R,
+                                    const float* d_grid, const float* d_rays, float* d_raw, float* d_scale, nsky_stream_t stream) {
+  NSKY_CHECK_ARG(raw && scale && d_raw && ldr >= 3 && ldr <= 4 && U >= 0 && D >= 0 && R >= 0 && (R == 0 || ray_latent), "nsky_reni_output_bwd: bad argument");
+  const int n = U * D + R;
+  if (n == 0) return NSKY_OK;
+  hipLaunchKernelGGL(reni_output_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, raw, ldr, scale, (const long*)ray_latent, U, D,
+                     R, d_grid, d_rays, d_raw, d_scale);
+  NSKY_CHECK_LAUNCH("nsky_reni_output_bwd");
   return NSKY_OK;
 }

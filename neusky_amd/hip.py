@@ -231,6 +231,21 @@ def ddf_vmf_samples(n_positions, n_directions, kappa, radius, upper_hemisphere, 
                            ptr(counter), ptr(origins), ptr(directions), stream_ptr()), "nsky_ddf_vmf_samples")
 
 
+_illum_dirs = _sig("nsky_illumination_directions", C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_void_p)
+
+
+def illumination_directions(base, rotation, seed, counter, dirs, sel, rot_out=None):
+    """base [D,3] -> dirs [D,3] = base R^T, sel [D/2] int32 (ascending indices of the upper half); R = rotation [3,3] or drawn from
+    (seed, counter) when rotation is None (counter: int64 device tensor [1], advanced by one)"""
+    D = base.shape[0]
+    assert base.is_contiguous() and dirs.is_contiguous() and dirs.shape == (D, 3) and sel.dtype == torch.int32 and sel.numel() == D // 2
+    assert rotation is None or (rotation.is_contiguous() and rotation.shape == (3, 3) and rotation.dtype == torch.float32)
+    assert rotation is not None or (counter.dtype == torch.int64 and counter.numel() == 1)
+    check(_illum_dirs(ptr(base), D, ptr(rotation), int(seed) & (2**64 - 1), ptr(counter), ptr(dirs), ptr(sel), ptr(rot_out), stream_ptr()),
+          "nsky_illumination_directions")
+
+
 _fit_rows_fwd = _sig("nsky_ddf_fit_rows_fwd", C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                      C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                      C.c_void_p, C.c_void_p, C.c_void_p)
@@ -281,6 +296,26 @@ def reni_grid_inputs_bwd(latents, directions, ray_dirs, ray_latent, d_cond, d_la
     assert d_cond.shape[0] == U * D + R and d_latents.is_contiguous() and d_latents.shape == latents.shape
     check(_reni_in_bwd(ptr(latents), ptr(directions), U, L, D, ptr(ray_dirs), ptr(ray_latent), R, ptr(d_cond), ld(d_cond), ptr(d_latents),
                        stream_ptr()), "nsky_reni_grid_inputs_bwd")
+
+
+_reni_out_fwd = _sig("nsky_reni_output_fwd", C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                     C.c_void_p)
+_reni_out_bwd = _sig("nsky_reni_output_bwd", C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                     C.c_void_p, C.c_void_p, C.c_void_p)
+
+
+def reni_output_fwd(raw, scale, ray_latent, U, D, grid, rays):
+    R = 0 if rays is None else rays.shape[0]
+    assert raw.shape[0] == U * D + R and raw.stride(1) == 1 and scale.is_contiguous() and scale.numel() >= U
+    assert grid.is_contiguous() and (rays is None or (rays.is_contiguous() and ray_latent.dtype == torch.int64 and ray_latent.is_contiguous()))
+    check(_reni_out_fwd(ptr(raw), ld(raw), ptr(scale), ptr(ray_latent), U, D, R, ptr(grid), ptr(rays), stream_ptr()), "nsky_reni_output_fwd")
+
+
+def reni_output_bwd(raw, scale, ray_latent, U, D, R, d_grid, d_rays, d_raw, d_scale):
+    assert d_raw.shape == raw.shape and d_raw.is_contiguous() and raw.is_contiguous()
+    assert (d_grid is None or d_grid.is_contiguous()) and (d_rays is None or d_rays.is_contiguous())
+    check(_reni_out_bwd(ptr(raw), ld(raw), ptr(scale), ptr(ray_latent), U, D, R, ptr(d_grid), ptr(d_rays), ptr(d_raw), ptr(d_scale), stream_ptr()),
+          "nsky_reni_output_bwd")
 
 
 # ------------------------------------------------------------------------------------------ render stages

@@ -152,9 +152,25 @@ class IcosahedronSampler:
         this IS the z > 0 subset).  Rotation drawn on the device; everything has static shapes (hipGraph-safe)."""
         key = str(device)
         if key not in self._dev_cache:
-            self._dev_cache[key] = self.directions.to(device)
+            self._dev_cache[key] = self.directions.to(device, torch.float32).contiguous()
         base = self._dev_cache[key]
         rot = self.config.apply_random_rotation if apply_random_rotation is None else apply_random_rotation
+        D = base.shape[0]
+        if base.is_cuda and (rotation is not None or rot) and not self.config.remove_lower_hemisphere and D % 2 == 0 and D <= 1024 \
+                and (rotation is None or rotation.dim() == 2):
+            # one kernel: rotation (drawn in the kernel, or the caller's), rotated set and its upper half (csrc/samplers.hip)
+            from .. import hip
+            from ..utils.utils import device_rng_seed
+            ckey = key + ":rng"
+            if ckey not in self._dev_cache:
+                self._dev_cache[ckey] = (device_rng_seed(2), torch.zeros(1, dtype=torch.int64, device=base.device))
+            seed, counter = self._dev_cache[ckey]
+            dirs = torch.empty(D, 3, device=base.device)
+            sel = torch.empty(D // 2, dtype=torch.int32, device=base.device)
+            self.last_rotation = torch.empty(3, 3, device=base.device)
+            hip.illumination_directions(base, None if rotation is None else rotation.to(base.device, torch.float32).contiguous(),
+                                        seed, counter, dirs, sel, self.last_rotation)
+            return dirs, sel
         if rotation is not None:
             rotation = rotation.to(device)
         elif rot:
@@ -263,9 +279,8 @@ class RENIField(nn.Module):
         ONE pass of the decoder: the rays' rows ride behind the U D grid rows (-> [U,D,3], [R,3])"""
         U, D = latent_codes.shape[0], directions.shape[0]
         cond, x = ops.RENIGridInputsFn.apply(latent_codes, directions, ray_directions, ray_latent)
-        out = torch.exp(self.network(x, cond, train_weights=not self.config.fixed_decoder))
-        grid, rays = out[:U * D].reshape(U, D, 3), out[U * D:]
-        return grid * scale[:, None, None], rays * scale[ray_latent][:, None]
+        raw = self.network(x, cond, train_weights=not self.config.fixed_decoder, padded_output=True)
+        return ops.RENIOutputFn.apply(raw, scale, ray_latent, U, D)  # exp + the per-image scale of both row sets
 
     def forward(self, directions: torch.Tensor, latent_codes: torch.Tensor, scale: Optional[torch.Tensor] = None,
                 rotation: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -1054,6 +1054,34 @@ class RENIGridInputsFn(torch.autograd.Function):
         return d_Z, None, None, None
 
 
+class RENIOutputFn(torch.autograd.Function):
+    """raw head output [U D + R, 4] of the decoder -> (grid [U, D, 3], rays [R, 3]) = exp(raw) x the per-image scale
+    (hip.reni_output_*; neusky_model.py:488-549); differentiable w.r.t. raw and scale"""
+
+    @staticmethod
+    def forward(ctx, raw, scale, ray_latent, U, D):
+        raw, sc = raw.contiguous(), scale.detach().contiguous()
+        R = raw.shape[0] - U * D
+        rl = ray_latent.to(torch.int64).contiguous() if R else None
+        grid = torch.empty(U, D, 3, device=raw.device)
+        rays = torch.empty(R, 3, device=raw.device) if R else None
+        hip.reni_output_fwd(raw, sc, rl, U, D, grid, rays)
+        ctx.save_for_backward(raw, sc, rl)
+        ctx.cfg = (U, D, R)
+        ctx.set_materialize_grads(False)
+        return grid, rays
+
+    @staticmethod
+    def backward(ctx, d_grid, d_rays):
+        raw, sc, rl = ctx.saved_tensors
+        U, D, R = ctx.cfg
+        d_raw = torch.empty_like(raw)
+        d_scale = zeros_like(sc) if ctx.needs_input_grad[1] else None
+        hip.reni_output_bwd(raw, sc, rl, U, D, R, None if d_grid is None else d_grid.contiguous(), None if d_rays is None else d_rays.contiguous(),
+                            d_raw, d_scale)
+        return d_raw, d_scale, None, None, None
+
+
 class DDFQueryRowsFn(torch.autograd.Function):
     """Every row the DDF network is evaluated on in a train step, in ONE pair of buffers: the R x Dv visibility rows
     (hip.visibility_rays; not differentiable) followed by the DDF-fit rows (fit rays | multi-view | sky; hip.ddf_fit_rows_fwd,

@@ -86,9 +86,10 @@ class FiLMSiren(nn.Module):
         wb += [ops.pad_weight(self.final_layer.weight), ops.pad_bias(self.final_layer.bias)]
         return wb
 
-    def forward(self, x: torch.Tensor, conditioning_input: torch.Tensor, train_weights: bool = True) -> torch.Tensor:
-        """x [M, pad4(in_dim)], conditioning_input [M, pad4(cond_dim)] (zero padded columns) -> [M, out_dim]"""
+    def forward(self, x: torch.Tensor, conditioning_input: torch.Tensor, train_weights: bool = True, padded_output: bool = False) -> torch.Tensor:
+        """x [M, pad4(in_dim)], conditioning_input [M, pad4(cond_dim)] (zero padded columns) -> [M, out_dim]
+        (padded_output: the kernels' own [M, pad4(out_dim)] matrix, for a caller whose next kernel reads it as it is)"""
         need_dcond = conditioning_input.requires_grad
         out = ops.FilmSirenFn.apply(x, conditioning_input, self.n_map, self.n_film, train_weights, need_dcond,
                                     *self.padded_weights())
-        return out[:, :self.out_dim]
+        return out if padded_output else out[:, :self.out_dim]

@@ -108,3 +108,88 @@ def test_reni_grid_inputs_match_the_torch_construction():
     (cond * gc.to(DEV)).sum().backward()
     (rc * gc.double()).sum().backward()
     assert torch.allclose(Zd.grad.cpu().double(), Z64.grad, atol=1e-4, rtol=1e-5)
+
+
+def _illumination_sampler(num_directions=512, icosphere_order=None):
+    from neusky_amd.model_components.illumination import IcosahedronSampler, IcosahedronSamplerConfig
+    kw = dict(num_directions=num_directions) if icosphere_order is None else dict(icosphere_order=icosphere_order)
+    return IcosahedronSampler(IcosahedronSamplerConfig(apply_random_rotation=True, **kw))
+
+
+def test_illumination_directions_kernel_with_a_given_rotation_matches_host_path():
+    """illumination_samplers.py:75-110 + neusky_model.py:1650-1657: rotated set and its z > 0 subset (ascending indices)"""
+    from neusky_amd.model_components.illumination import random_rotation
+    s = _illumination_sampler(512)
+    for seed in range(4):
+        R = random_rotation(torch.Generator().manual_seed(seed)).float()
+        dirs, sel = s.on_device(DEV, rotation=R)
+        want = s.directions.double() @ R.double().T
+        assert torch.allclose(dirs.cpu().double(), want, atol=2e-7)
+        want_sel = torch.nonzero(want[:, 2] > 0)[:, 0]
+        assert sel.dtype == torch.int32 and torch.equal(sel.cpu().long(), want_sel)
+        assert torch.allclose(s.last_rotation.cpu(), R)
+        h_dirs, h_sel = s.on_device("cpu", rotation=R)  # the torch path (host logic)
+        assert torch.equal(h_sel.long(), want_sel) and torch.allclose(h_dirs.double(), want, atol=2e-6)
+
+
+def test_illumination_directions_kernel_draws_uniform_rotations():
+    torch.manual_seed(11)
+    s = _illumination_sampler(512)
+    base = s.directions.double()
+    rots = []
+    for _ in range(200):
+        dirs, sel = s.on_device(DEV)
+        R = s.last_rotation.cpu().double()
+        rots.append(R)
+        assert torch.allclose(R @ R.T, torch.eye(3, dtype=torch.float64), atol=1e-5) and abs(float(torch.det(R)) - 1.0) < 1e-5
+        assert torch.allclose(dirs.cpu().double(), base @ R.T, atol=2e-6)
+        z = dirs[:, 2].cpu()
+        assert sel.numel() == 256 and bool((z[sel.cpu().long()] > 0).all()) and int((z > 0).sum()) == 256
+        assert bool((sel[1:] > sel[:-1]).all())
+    R = torch.stack(rots)
+    assert (R[1:] - R[:-1]).abs().amax(dim=(1, 2)).min() > 1e-3, "successive calls draw different rotations"
+    # Haar measure: every matrix entry has mean 0 and variance 1/3; the image of e_z is uniform on the sphere
+    assert R.mean(0).abs().max() < 0.15 and (R.var(0) - 1.0 / 3.0).abs().max() < 0.1
+    # same seed, same call number -> same rotation (counter-based generator)
+    torch.manual_seed(11)
+    s2 = _illumination_sampler(512)
+    s2.on_device(DEV)
+    assert torch.equal(s2.last_rotation.cpu().double(), rots[0])
+
+
+def test_illumination_directions_kernel_icosphere_set():
+    """icosphere order 2 (162 vertices, centrally symmetric): not a multiple of the wave size"""
+    s = _illumination_sampler(icosphere_order=2)
+    D = s.directions.shape[0]
+    assert D % 2 == 0
+    dirs, sel = s.on_device(DEV)
+    z = dirs[:, 2].cpu()
+    assert sel.numel() == D // 2 and torch.equal(sel.cpu().long(), torch.nonzero(z > 0)[:, 0])
+
+
+def test_reni_output_matches_exp_times_scale():
+    """ops.RENIOutputFn against neusky_model.py:488-549's exp + per-image scale (float64 autograd): values, d raw, d scale"""
+    from neusky_amd import ops
+    g = torch.Generator().manual_seed(4)
+    U, D, R = 7, 100, 333  # 700 grid rows: a wave holds rows of two images
+    raw = torch.randn(U * D + R, 4, generator=g)
+    scale = torch.rand(U, generator=g) + 0.5
+    rl = torch.randint(0, U, (R,), generator=g)
+    rawd, sd = raw.to(DEV).requires_grad_(True), scale.to(DEV).requires_grad_(True)
+    grid, rays = ops.RENIOutputFn.apply(rawd, sd, rl.to(DEV), U, D)
+    r64, s64 = raw.double().requires_grad_(True), scale.double().requires_grad_(True)
+    e = torch.exp(r64[:, :3])
+    want_grid, want_rays = e[:U * D].reshape(U, D, 3) * s64[:, None, None], e[U * D:] * s64[rl][:, None]
+    assert torch.allclose(grid.cpu().double(), want_grid, rtol=2e-6) and torch.allclose(rays.cpu().double(), want_rays, rtol=2e-6)
+    gg, gr = torch.randn(U, D, 3, generator=g), torch.randn(R, 3, generator=g)
+    ((grid * gg.to(DEV)).sum() + (rays * gr.to(DEV)).sum()).backward()
+    ((want_grid * gg.double()).sum() + (want_rays * gr.double()).sum()).backward()
+    assert torch.allclose(rawd.grad.cpu().double()[:, :3], r64.grad[:, :3], rtol=1e-5, atol=1e-6) and bool((rawd.grad[:, 3] == 0).all())
+    assert torch.allclose(sd.grad.cpu().double(), s64.grad, rtol=1e-4, atol=1e-4)
+    # only the rays' output used (the grid's gradient is absent, not zero-filled)
+    rawd.grad = None; sd.grad = None
+    grid, rays = ops.RENIOutputFn.apply(rawd, sd, rl.to(DEV), U, D)
+    (rays * gr.to(DEV)).sum().backward()
+    want = torch.autograd.grad(((torch.exp(r64[U * D:, :3]) * s64[rl][:, None]) * gr.double()).sum(), [r64, s64])
+    assert torch.allclose(rawd.grad.cpu().double()[:, :3], want[0][:, :3], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(sd.grad.cpu().double(), want[1], rtol=1e-4, atol=1e-4)

@@ -38,4 +38,9 @@ for s, e, n in step:
         print(f"{(s-t0)/1e3:9.1f} us  {(e-s)/1e3:8.1f} us  {short}")
 if run: tot_small_wall += run[-1][1] - run[0][0]
 flush()
+if len(sys.argv) >= 4:  # every kernel whose start lies in [argv[2], argv[3]] us of the step
+    lo, hi = float(sys.argv[2]) * 1e3, float(sys.argv[3]) * 1e3
+    for s, e, n in step:
+        if lo <= s - t0 <= hi:
+            print(f"  {(s-t0)/1e3:9.1f} {(e-s)/1e3:7.1f}  " + n.replace("void at::native::", "").replace("(anonymous namespace)::", "")[:150])
 print("total wall inside small-kernel runs: %.1f us of %.1f" % (tot_small_wall / 1e3, (step[-1][1] - t0) / 1e3))
