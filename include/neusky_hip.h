@@ -473,6 +473,12 @@ int nsky_weight_norm_bwd(const float* d_out, int32_t ldo, const float* v, const 
                          int32_t n_rows_out, int32_t in_features, int32_t ldv, const int32_t* row_map,
                          const int32_t* inverse_col, float* dv, float* dg, nsky_stream_t stream);
 
+/* Copies n_segments float runs (src -> dst, n floats each) in one launch: the parameter gradients autograd keeps in tensors of its
+ * own (torch's AccumulateGrad with an undefined .grad) into their places in the optimizer's gradient slab, instead of one add
+ * kernel per parameter (nerfstudio Optimizers.zero_grad_all / optimizer_scheduler_step_all around neusky_config.py:216-237). */
+typedef struct { const float* src; float* dst; int64_t n; } nsky_segment;
+int nsky_gather_segments(const nsky_segment* segments, int32_t n_segments, nsky_stream_t stream);
+
 /* Adam update (torch.optim.Adam semantics, no weight decay / amsgrad) over a flat slab of n floats;
  * the five optimizer groups of neusky/configs/neusky_config.py:216-237.  grad_scale multiplies g first. */
 int nsky_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -229,6 +229,28 @@ __global__ void bins_to_samples_kernel(const float* __restrict__ sbins, const fl
   }
 }
 
+// gradients autograd left in tensors of its own -> their places in the optimizer slab, one launch for all of them
+constexpr int GATHER_MAX = 64;
+struct GatherArgs {
+  const float* src[GATHER_MAX];
+  float* dst[GATHER_MAX];
+  long n[GATHER_MAX];
+};
+__global__ __launch_bounds__(256) void gather_segments_kernel(const GatherArgs a) {
+  const int s = blockIdx.y;
+  const float* __restrict__ src = a.src[s];
+  float* __restrict__ dst = a.dst[s];
+  const long n = a.n[s];
+  const long stride = (long)gridDim.x * 256, t0 = (long)blockIdx.x * 256 + threadIdx.x;
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    const long n4 = n >> 2;
+    for (long i = t0; i < n4; i += stride) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    for (long i = 4 * n4 + t0; i < n; i += stride) dst[i] = src[i];
+  } else {
+    for (long i = t0; i < n; i += stride) dst[i] = src[i];
+  }
+}
+
 }  // namespace
 
 extern "C" int nsky_softplus_tangent_bwd(const float* da, const float* s, const float* ta, const float* dta, const float* ggrad,
@@ -318,5 +340,25 @@ extern "C" int nsky_bins_to_samples(const float* sbins, const float* nears, cons
   hipLaunchKernelGGL(bins_to_samples_kernel, dim3(ceil_div((long)R * (n + 1), 256)), dim3(256), 0, (hipStream_t)stream, sbins,
                      nears, fars, origins, directions, R, n, ebins, positions);
   NSKY_CHECK_LAUNCH("nsky_bins_to_samples");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_gather_segments(const nsky_segment* segments, int32_t n_segments, nsky_stream_t stream) {
+  NSKY_CHECK_ARG(n_segments >= 0 && (n_segments == 0 || segments), "nsky_gather_segments: bad argument");
+  for (int s0 = 0; s0 < n_segments; s0 += GATHER_MAX) {
+    const int cnt = n_segments - s0 < GATHER_MAX ? n_segments - s0 : GATHER_MAX;
+    GatherArgs a;
+    long longest = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const nsky_segment& g = segments[s0 + i];
+      NSKY_CHECK_ARG(g.n >= 0 && (g.n == 0 || (g.src && g.dst)), "nsky_gather_segments: segment %d", s0 + i);
+      a.src[i] = g.src; a.dst[i] = g.dst; a.n[i] = g.n;
+      longest = g.n > longest ? g.n : longest;
+    }
+    if (longest == 0) continue;
+    const long bx = (longest / 4 + 2047) / 2048;  // ~8 float4 per thread
+    hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)(bx < 1 ? 1 : (bx > 256 ? 256 : bx)), cnt), dim3(256), 0, (hipStream_t)stream, a);
+  }
+  NSKY_CHECK_LAUNCH("nsky_gather_segments");
   return NSKY_OK;
 }

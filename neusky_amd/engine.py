@@ -111,9 +111,31 @@ class Optimizers:
         for g in self.groups:
             g.bind(self.flat_g[off:off + g.numel])
             off += g.numel
+        self._views = [(p, p.grad) for g in self.groups for p in g.params]
+        self._backward_seen = False
 
     def zero_grad_all(self) -> None:
         self.flat_g.zero_()
+        # Parameters whose gradient no kernel writes into the slab itself (everything behind weight norm / padding / plain torch
+        # ops) start the backward with an undefined .grad: autograd's AccumulateGrad then keeps the incoming tensor instead of
+        # launching one add kernel per parameter, and collect_grads() moves all of them into the slab with one launch.
+        if self._backward_seen and self.flat_g.is_cuda:
+            for p, _ in self._views:
+                if not getattr(p, "_nsky_sunk", False):
+                    p.grad = None
+
+    def collect_grads(self) -> None:
+        """after backward (inside the captured region of a graphed step): every parameter's .grad is its slab view again and
+        holds the step's gradient"""
+        self._backward_seen = True
+        pairs = []
+        for p, view in self._views:
+            g = p.grad
+            if g is not None and g.data_ptr() != view.data_ptr():
+                pairs.append((g if g.is_contiguous() else g.contiguous(), view))
+            p.grad = view
+        if pairs:
+            hip.gather_segments(pairs)
 
     def state_dict(self) -> Dict[str, Dict]:
         """per group: Adam moments, bias-correction step count and the flat parameter slab (what nerfstudio's trainer keeps
@@ -134,6 +156,7 @@ class Optimizers:
 
     def all_reduce_gradients(self) -> None:
         """one all-reduce (mean) of the whole gradient slab over RCCL / xGMI"""
+        self.collect_grads()  # (a no-op after train_iteration / a graphed step: a caller that ran backward() itself lands here)
         if self.world_size <= 1:
             return
         if dist.get_backend() == "nccl":
@@ -143,6 +166,7 @@ class Optimizers:
             self.flat_g.div_(self.world_size)
 
     def optimizer_scheduler_step_all(self, step: int) -> None:
+        self.collect_grads()
         for g in self.groups:
             g.steps += 1
             lr = g.opt.lr * (g.sched.factor(step) if g.sched is not None else 1.0)
@@ -155,6 +179,7 @@ def train_iteration(pipeline, optimizers: Optimizers, step: int, **kw):
     _, loss_dict, metrics_dict = pipeline.get_train_loss_dict(step, **kw)
     loss = total_loss(loss_dict)
     loss.backward()
+    optimizers.collect_grads()
     optimizers.all_reduce_gradients()
     optimizers.optimizer_scheduler_step_all(step)
     return loss.detach(), loss_dict, metrics_dict
@@ -211,6 +236,7 @@ class GraphedTrainStep:
         _, loss_dict, metrics = self.pipeline.get_train_loss_dict(step, ray_bundle=self.rb, batch=self.batch, randoms=self.randoms)
         loss = total_loss(loss_dict)
         loss.backward()
+        self.opt.collect_grads()
         return loss.detach(), {k: v.detach() for k, v in loss_dict.items()}, metrics
 
     def load(self, ray_bundle, batch, sky=None) -> None:

@@ -659,6 +659,24 @@ def film_pack(net: FilmNet, stream_buf, scales, direction: int = 0):
     check(_film_pack(C.byref(net), direction, ptr(stream_buf), ptr(scales), stream_ptr()), "nsky_film_pack")
 
 
+class Segment(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int64)]
+
+
+_gather_segments = _sig("nsky_gather_segments", C.POINTER(Segment), C.c_int32, C.c_void_p)
+
+
+def gather_segments(pairs):
+    """pairs: [(src, dst)] contiguous float32 tensors of equal numel: dst <- src for all of them in ONE launch"""
+    if not pairs:
+        return
+    arr = (Segment * len(pairs))()
+    for i, (src, dst) in enumerate(pairs):
+        assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel() and src.dtype == dst.dtype == torch.float32
+        arr[i] = Segment(src.data_ptr(), dst.data_ptr(), src.numel())
+    check(_gather_segments(arr, len(pairs), stream_ptr()), "nsky_gather_segments")
+
+
 class SdfNet(C.Structure):
     _fields_ = [("in_dim", C.c_int32), ("hidden", C.c_int32),
                 ("w0", C.c_void_p), ("ld0", C.c_int32), ("b0", C.c_void_p),

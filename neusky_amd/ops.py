@@ -331,6 +331,8 @@ class HashEncodeFn(torch.autograd.Function):
         d_out = d_out.contiguous()
         sink = ctx.sink
         accumulate = sink is not None and sink.grad is not None and sink.grad.is_contiguous() and sink.grad.shape == table.shape
+        if accumulate:
+            sink._nsky_sunk = True  # (engine.Optimizers.zero_grad_all: this parameter's .grad stays its slab view)
         dtable = sink.grad if accumulate else zeros_like(table)
         dx = torch.empty(P, 3, device=x.device) if need_dx else None
         dT = d_out[P:].view(3, P, ldy) if tangents else None
@@ -514,6 +516,7 @@ class FilmSirenFn(torch.autograd.Function):
                 sk = ctx.sinks[idx]
                 if sk is not None and sk.grad is not None and sk.grad.shape == t.shape and sk.grad.is_contiguous():
                     grads[idx], sunk[idx] = sk.grad, True
+                    sk._nsky_sunk = True
             sizes = [0 if sunk[idx] else (t.numel() + 3) // 4 * 4 for idx, t in enumerate(wb)]
             flat = zeros(max(sum(sizes), 4), device=dev)
             off = 0
@@ -572,6 +575,7 @@ class FilmSirenFn(torch.autograd.Function):
                 sk = ctx.sinks[idx]
                 if sk is not None and sk.grad is not None and sk.grad.shape == t.shape and sk.grad.is_contiguous():
                     grads[idx], sunk[idx] = sk.grad, True
+                    sk._nsky_sunk = True
             sizes = [0 if sunk[idx] else (t.numel() + 3) // 4 * 4 for idx, t in enumerate(wb)]
             flat = zeros(max(sum(sizes), 4), device=dev)
             off = 0
