@@ -494,17 +494,17 @@ class NeuSkyFactoModel(ModelBase):
         return out
 
     def _grid_alpha(self, grid_samples: RaySamples) -> torch.Tensor:
+        """three alphas per probe point, one per axis gap (SDFField.get_alpha on isolated samples, :715-732): the 3 P (point, gap)
+        pairs are 3 P one-sample rays of ONE NeuS launch (with a single sample the weight is the alpha)"""
         x = grid_samples.frustums.origins
         d = grid_samples.frustums.directions
         sdf, grad, _ = self.field.field_values(x, want_albedo=False)
         P = x.shape[0]
-        cols = []
-        for a in range(3):
-            rs = RaySamples(frustums=Frustums(origins=x, directions=d, starts=torch.zeros(P, 1, device=x.device),
-                                              ends=torch.zeros(P, 1, device=x.device)),
-                            deltas=grid_samples.deltas[a].expand(P))
-            cols.append(self.field.get_alpha(rs, sdf, grad))
-        return torch.cat(cols, -1)
+        rep = lambda t, w: t.reshape(1, P, w).expand(3, P, w).reshape(3 * P, w)  # noqa: E731  (row a P + p = gap a, point p)
+        ends = grid_samples.deltas.reshape(3, 1, 1).expand(3, P, 1).reshape(3 * P, 1)
+        w, _, _, _ = ops.NeusWeightsFn.apply(rep(sdf, 1), rep(grad, 3).reshape(3 * P, 1, 3), rep(d, 3), ops.zeros(3 * P, 1, device=x.device), ends,
+                                             self.field.deviation_network.variance, self.field._cos_anneal_ratio)
+        return w.reshape(3, P).t()
 
     # ------------------------------------------------------------------ outputs
     def get_outputs(self, ray_bundle: RayBundle, batch=None, rotation=None, step=None, randoms=None) -> Dict[str, Any]:
