@@ -418,8 +418,7 @@ __global__ __launch_bounds__(256) void encode_bwd_coarse_kernel(Grid g, const fl
 constexpr int OWN_CH = 16384;            // entries per chunk (a power of two: chunk number = index >> 14)
 constexpr int OWN_SHIFT = 14;
 constexpr int OWN_THREADS = 1024;
-constexpr int OWN_TRIP = 8192;           // points per trip = capacity of the queue (8192 x 2 B beside the 128 KB chunk)
-constexpr int OWN_TRIP_WORDS = OWN_TRIP / 32;
+constexpr int OWN_QCAP = 16384 - 64;      // queue entries (2 B each; with the scan's 32 wave totals: 32 KB beside the 128 KB chunk = all 160 KB)
 constexpr int OWN_WG_PER_LEVEL = 32;
 constexpr int OWN_MAX_CHUNKS = 32;       // per level: slabs of at most 2^19 entries
 constexpr int BM_POINTS = 1024;          // points per workgroup of the bitmap pre-pass
@@ -497,12 +496,72 @@ __global__ __launch_bounds__(BM_POINTS) void owner_bitmaps_kernel(OwnerArgs a) {
   if (c < nch) a.bitmaps[((long)li * OWN_MAX_CHUNKS + c) * a.words + blockIdx.x * (BM_POINTS / 32) + w] = bm[c][w];
 }
 
+// one queued point of an owner: exact corner indices, interpolation weights, ds_add_f32 of the corners inside the chunk
+template <bool TANGENTS>
+__device__ __forceinline__ void owner_point(const OwnerArgs& a, float* acc, const float (&xv)[3], const float2 gy, const float2 (&gt)[3],
+                                            float scale, uint32_t res, uint32_t size, bool dense, bool smooth, uint32_t chunk, uint32_t c_beg) {
+  const uint32_t smask = size - 1;  // hashed: size is a power of two (checked on the host), grid_index's modulo is this mask
+  float pos[3], J[3][3];
+  grid_position(xv, a.mode, pos, J);
+  uint32_t pg[3];
+  float w[3], dw[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float q = fmaf(scale, pos[d], 0.5f);
+    const float fl = floorf(q);
+    pg[d] = (uint32_t)(int)fl;
+    const float td = q - fl;
+    w[d] = smooth ? td * td * (3.0f - 2.0f * td) : td;
+    dw[d] = smooth ? 6.0f * td * (1.0f - td) * scale : scale;
+  }
+  float2 gpa[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};  // gradient w.r.t. d feat / d pos_a, pulled back through J
+  if (TANGENTS)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { gpa[d].x = fmaf(gt[k].x, J[d][k], gpa[d].x); gpa[d].y = fmaf(gt[k].y, J[d][k], gpa[d].y); }
+  // y / z terms of the index in wrapping 32-bit arithmetic, as grid_index forms them: hashed y P1 ^ z P2, dense y res + z res^2
+  const uint32_t YM = dense ? res : HASH_P1, ZM = dense ? res * res : HASH_P2;
+  const uint32_t Y0 = pg[1] * YM, Z0 = pg[2] * ZM;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint32_t xk = pg[0] + (k & 1), yk = Y0 + ((k & 2) ? YM : 0u), zk = Z0 + ((k & 4) ? ZM : 0u);
+    uint32_t idx;
+    if (dense) {
+      idx = xk + yk + zk;
+      if (idx >= size) idx %= size;
+    } else {
+      idx = (xk ^ yk ^ zk) & smask;
+    }
+    if ((idx >> OWN_SHIFT) != chunk) continue;
+    const float wx = (k & 1) ? w[0] : 1.0f - w[0];
+    const float wy = (k & 2) ? w[1] : 1.0f - w[1];
+    const float wz = (k & 4) ? w[2] : 1.0f - w[2];
+    float a0 = wx * wy * wz * gy.x, a1 = wx * wy * wz * gy.y;
+    if (TANGENTS) {
+      const float cx = ((k & 1) ? dw[0] : -dw[0]) * wy * wz;
+      const float cy = ((k & 2) ? dw[1] : -dw[1]) * wx * wz;
+      const float cz = ((k & 4) ? dw[2] : -dw[2]) * wx * wy;
+      a0 += cx * gpa[0].x + cy * gpa[1].x + cz * gpa[2].x;
+      a1 += cx * gpa[0].y + cy * gpa[1].y + cz * gpa[2].y;
+    }
+    const int loc = (int)(idx - c_beg);
+    atomicAdd(acc + 2 * loc, a0);      // ds_add_f32
+    atomicAdd(acc + 2 * loc + 1, a1);
+  }
+}
+
+// An owner works through its share of the points in PHASES: up to OWN_PHASE_WORDS bitmap words (65 536 points: the span a 16-bit
+// queue entry can address) are read two per thread, a block-wide prefix sum of their popcounts places every set bit in the queue
+// without atomics, and the queue is then worked off with OWN_MLP points per thread in flight.  (With one 8 192-point trip per
+// barrier pair -- the first form -- a hashed level's owner had ONE point per thread per trip: 33 serial memory round trips.)
+// The phase shrinks to 1024 / 512 / 256 words when the queue could not hold its bits (dense levels: most bits are set).
 template <bool TANGENTS>
 __global__ __launch_bounds__(OWN_THREADS) void encode_bwd_owner_kernel(OwnerArgs a) {
-  extern __shared__ float acc[];  // 2 * OWN_CH accumulators, then the queue of one trip (point number - trip start) and its counter
+  extern __shared__ float acc[];  // 2 * OWN_CH accumulators, then the queue (point number - phase start) and the scan's wave totals
   uint16_t* queue = reinterpret_cast<uint16_t*>(acc + 2 * OWN_CH);
-  uint32_t* qn = reinterpret_cast<uint32_t*>(queue + OWN_TRIP);
-  const int tid = threadIdx.x, lane = tid & 63;
+  int* wtot = reinterpret_cast<int*>(queue + OWN_QCAP);  // [2][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int li = 0;
   while (li + 1 < a.n_levels_owned && (int)blockIdx.x >= a.wg0[li + 1]) ++li;
   const int level = a.level[li], splits = a.splits[li];
@@ -514,12 +573,9 @@ __global__ __launch_bounds__(OWN_THREADS) void encode_bwd_owner_kernel(OwnerArgs
   const uint32_t res = (uint32_t)g.resolution[level];
   const uint32_t size = g.offset[level + 1] - g.offset[level];
   const bool dense = level_is_dense(size, res);
-  const uint32_t smask = size - 1;  // hashed: size is a power of two (checked on the host), grid_index's modulo is this mask
   const uint32_t c_beg = chunk * OWN_CH;
   const int n_own = (int)min((uint32_t)OWN_CH, size - c_beg);
-  for (int i = tid; i < 2 * OWN_CH; i += OWN_THREADS) acc[i] = 0.0f;
-  if (tid == 0) *qn = 0;
-  __syncthreads();
+  for (int i = tid; i < OWN_CH / 2; i += OWN_THREADS) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // this workgroup's share of the points: whole bitmap words
   const int words_per = (a.words + splits - 1) / splits;
@@ -528,98 +584,97 @@ __global__ __launch_bounds__(OWN_THREADS) void encode_bwd_owner_kernel(OwnerArgs
   const bool smooth = g.smoothstep != 0;
   const uint32_t* bits = a.bitmaps + ((long)li * OWN_MAX_CHUNKS + chunk) * a.words;
   const F3* xs = reinterpret_cast<const F3*>(a.x);
-  for (int w0 = w_beg; w0 < w_end; w0 += OWN_TRIP_WORDS) {
-    const int p0 = w0 * 32;
-    // ---- the trip's set bits go to the queue (a word per lane of the first four waves; one reservation per wave)
-    if (tid < OWN_TRIP_WORDS) {
-      uint32_t word = w0 + tid < w_end ? bits[w0 + tid] : 0u;
-      const int cnt = __popc(word);
-      int incl = cnt;  // inclusive scan over the wave
+  constexpr int MLP = TANGENTS ? 2 : 4;
+  for (int wb = w_beg; wb < w_end;) {
+    uint32_t word0 = wb + tid < w_end ? bits[wb + tid] : 0u;
+    uint32_t word1 = wb + OWN_THREADS + tid < w_end ? bits[wb + OWN_THREADS + tid] : 0u;
+    const int c0 = __popc(word0), c1 = __popc(word1);
+    int i0 = c0, i1 = c1;  // inclusive scans over the wave
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-      }
-      const int total = __shfl(incl, 63, 64);
-      uint32_t base = 0;
-      if (lane == 0 && total) base = atomicAdd(qn, (uint32_t)total);
-      base = __shfl(base, 0, 64);
-      uint32_t at = base + (uint32_t)(incl - cnt);
-      while (word) {
-        const int b = __ffs(word) - 1;
-        word &= word - 1;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v0 = __shfl_up(i0, off, 64), v1 = __shfl_up(i1, off, 64);
+      if (lane >= off) { i0 += v0; i1 += v1; }
+    }
+    __syncthreads();  // (the previous phase's queue and totals are no longer read; the first pass: acc is zero)
+    if (lane == 63) { wtot[wave] = i0; wtot[16 + wave] = i1; }
+    __syncthreads();
+    int base0 = 0, base1 = 0, half0 = 0, quarter0 = 0, total1 = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int t0 = wtot[w], t1 = wtot[16 + w];
+      if (w < wave) { base0 += t0; base1 += t1; }
+      if (w < 8) quarter0 += t0;   // words [0, 512)
+      half0 += t0;                 // words [0, 1024)
+      total1 += t1;
+    }
+    int nw, nq;  // words taken by this phase, their set bits (uniform)
+    if (half0 + total1 <= OWN_QCAP) { nw = 2 * OWN_THREADS; nq = half0 + total1; }
+    else if (half0 <= OWN_QCAP) { nw = OWN_THREADS; nq = half0; }
+    else if (quarter0 <= OWN_QCAP) { nw = 512; nq = quarter0; }
+    else { nw = 256; nq = wtot[0] + wtot[1] + wtot[2] + wtot[3]; }  // <= 8192 bits
+    if (tid < nw) {
+      int at = base0 + i0 - c0;
+      while (word0) {
+        const int b = __ffs(word0) - 1;
+        word0 &= word0 - 1;
         queue[at++] = (uint16_t)(tid * 32 + b);
       }
     }
-    __syncthreads();
-    // ---- the queued points, by full waves: exact corner indices, weights, adds
-    const int nq = (int)*qn;
-    for (int e = tid; e < nq; e += OWN_THREADS) {
-      const int p = p0 + (int)queue[e];
-      const F3 xv = xs[p];
-      const float2 gy = *reinterpret_cast<const float2*>(a.dY + (long)p * a.lddy + col);
-      float2 gt[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-      if (TANGENTS)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) gt[k] = *reinterpret_cast<const float2*>(a.dT + ((long)k * a.P + p) * a.lddy + col);
-      float pos[3], J[3][3];
-      grid_position(xv.v, a.mode, pos, J);
-      uint32_t pg[3];
-      float w[3], dw[3];
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        const float q = fmaf(scale, pos[d], 0.5f);
-        const float fl = floorf(q);
-        pg[d] = (uint32_t)(int)fl;
-        const float td = q - fl;
-        w[d] = smooth ? td * td * (3.0f - 2.0f * td) : td;
-        dw[d] = smooth ? 6.0f * td * (1.0f - td) * scale : scale;
-      }
-      float2 gpa[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};  // gradient w.r.t. d feat / d pos_a, pulled back through J
-      if (TANGENTS)
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-          for (int d = 0; d < 3; ++d) { gpa[d].x = fmaf(gt[k].x, J[d][k], gpa[d].x); gpa[d].y = fmaf(gt[k].y, J[d][k], gpa[d].y); }
-      // y / z terms of the index in wrapping 32-bit arithmetic, as grid_index forms them: hashed y P1 ^ z P2, dense y res + z res^2
-      const uint32_t YM = dense ? res : HASH_P1, ZM = dense ? res * res : HASH_P2;
-      const uint32_t Y0 = pg[1] * YM, Z0 = pg[2] * ZM;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t xk = pg[0] + (k & 1), yk = Y0 + ((k & 2) ? YM : 0u), zk = Z0 + ((k & 4) ? ZM : 0u);
-        uint32_t idx;
-        if (dense) {
-          idx = xk + yk + zk;
-          if (idx >= size) idx %= size;
-        } else {
-          idx = (xk ^ yk ^ zk) & smask;
-        }
-        if ((idx >> OWN_SHIFT) != chunk) continue;
-        const float wx = (k & 1) ? w[0] : 1.0f - w[0];
-        const float wy = (k & 2) ? w[1] : 1.0f - w[1];
-        const float wz = (k & 4) ? w[2] : 1.0f - w[2];
-        float a0 = wx * wy * wz * gy.x, a1 = wx * wy * wz * gy.y;
-        if (TANGENTS) {
-          const float cx = ((k & 1) ? dw[0] : -dw[0]) * wy * wz;
-          const float cy = ((k & 2) ? dw[1] : -dw[1]) * wx * wz;
-          const float cz = ((k & 4) ? dw[2] : -dw[2]) * wx * wy;
-          a0 += cx * gpa[0].x + cy * gpa[1].x + cz * gpa[2].x;
-          a1 += cx * gpa[0].y + cy * gpa[1].y + cz * gpa[2].y;
-        }
-        const int loc = (int)(idx - c_beg);
-        atomicAdd(acc + 2 * loc, a0);      // ds_add_f32
-        atomicAdd(acc + 2 * loc + 1, a1);
+    if (OWN_THREADS + tid < nw) {
+      int at = half0 + base1 + i1 - c1;
+      while (word1) {
+        const int b = __ffs(word1) - 1;
+        word1 &= word1 - 1;
+        queue[at++] = (uint16_t)((OWN_THREADS + tid) * 32 + b);
       }
     }
     __syncthreads();
-    if (tid == 0) *qn = 0;
-    __syncthreads();
+    // ---- the queued points, by full waves, MLP of them per thread in flight
+    const int p0 = wb * 32;
+    for (int e0 = tid; e0 < nq; e0 += MLP * OWN_THREADS) {
+      F3 xv[MLP];
+      float2 gy[MLP], gt[MLP][3];
+#pragma unroll
+      for (int j = 0; j < MLP; ++j) {
+        const int e = e0 + j * OWN_THREADS;
+        const int p = p0 + (int)queue[e < nq ? e : e0];
+        xv[j] = xs[p];
+        gy[j] = *reinterpret_cast<const float2*>(a.dY + (long)p * a.lddy + col);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          gt[j][k] = TANGENTS ? *reinterpret_cast<const float2*>(a.dT + ((long)k * a.P + p) * a.lddy + col) : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < MLP; ++j)
+        if (e0 + j * OWN_THREADS < nq) owner_point<TANGENTS>(a, acc, xv[j].v, gy[j], gt[j], scale, res, size, dense, smooth, chunk, c_beg);
+    }
+    wb += nw;
   }
+  __syncthreads();
   float* out = a.dtable + 2l * (g.offset[level] + c_beg);
-  if (splits == 1) {
+  if (splits == 1 && (n_own & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    // this workgroup is the only writer of these entries in the launch: read-modify-write of whole lines, four 16-byte pieces per
+    // thread in flight (an `if (v != 0) out[i] += v` loop is one memory round trip per iteration)
+    const int n4 = n_own >> 1;
+    float4* o4 = reinterpret_cast<float4*>(out);
+    const float4* a4 = reinterpret_cast<const float4*>(acc);
+    for (int i0 = tid; i0 < n4; i0 += 4 * OWN_THREADS) {
+      float4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = i0 + j * OWN_THREADS < n4 ? o4[i0 + j * OWN_THREADS] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j * OWN_THREADS;
+        if (i < n4) {
+          const float4 d = a4[i];
+          o4[i] = make_float4(v[j].x + d.x, v[j].y + d.y, v[j].z + d.z, v[j].w + d.w);
+        }
+      }
+    }
+  } else if (splits == 1) {
     for (int i = tid; i < 2 * n_own; i += OWN_THREADS) {
       const float v = acc[i];
-      if (v != 0.0f) out[i] += v;  // this workgroup is the only writer of these entries in the launch
+      if (v != 0.0f) out[i] += v;
     }
   } else {
     for (int i = tid; i < 2 * n_own; i += OWN_THREADS) {
@@ -726,7 +781,7 @@ extern "C" int nsky_encode_bwd(const nsky_hashgrid_desc* d, const float* x, int3
     }();
     (void)own_attr;
     hipLaunchKernelGGL(owner_bitmaps_kernel, dim3(ceil_div(P, BM_POINTS), oa.n_levels_owned), dim3(BM_POINTS), 0, s, oa);
-    const size_t smem = 2 * OWN_CH * sizeof(float) + OWN_TRIP * sizeof(uint16_t) + 16;
+    const size_t smem = 2 * OWN_CH * sizeof(float) + 16384 * sizeof(uint16_t);
     if (dT)
       hipLaunchKernelGGL(encode_bwd_owner_kernel<true>, dim3(wgs), dim3(OWN_THREADS), smem, s, oa);
     else
