@@ -420,6 +420,7 @@ constexpr int OWN_SHIFT = 14;
 constexpr int OWN_THREADS = 1024;
 constexpr int OWN_QCAP = 16384 - 64;      // queue entries (2 B each; with the scan's 32 wave totals: 32 KB beside the 128 KB chunk = all 160 KB)
 constexpr int OWN_WG_PER_LEVEL = 32;
+constexpr int OWN_DENSE_SPLITS = 32;    // workgroups per chunk of a dense level
 constexpr int OWN_MAX_CHUNKS = 32;       // per level: slabs of at most 2^19 entries
 constexpr int BM_POINTS = 1024;          // points per workgroup of the bitmap pre-pass
 
@@ -575,14 +576,22 @@ __global__ __launch_bounds__(OWN_THREADS) void encode_bwd_owner_kernel(OwnerArgs
   const bool dense = level_is_dense(size, res);
   const uint32_t c_beg = chunk * OWN_CH;
   const int n_own = (int)min((uint32_t)OWN_CH, size - c_beg);
-  for (int i = tid; i < OWN_CH / 2; i += OWN_THREADS) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-
   // this workgroup's share of the points: whole bitmap words
   const int words_per = (a.words + splits - 1) / splits;
   const int w_beg = ps * words_per, w_end = min(a.words, w_beg + words_per);
+  const uint32_t* bits = a.bitmaps + ((long)li * OWN_MAX_CHUNKS + chunk) * a.words;
+  if (splits > 1) {  // (a dense level's chunk none of this share's points touches: nothing to add)
+    uint32_t any = 0;
+    for (int w = w_beg + tid; w < w_end; w += OWN_THREADS) any |= bits[w];
+    if (tid == 0) wtot[0] = 0;  // (no __syncthreads_or: its static LDS word would not fit beside 160 KB of dynamic LDS)
+    __syncthreads();
+    if (any) wtot[0] = 1;
+    __syncthreads();
+    if (!wtot[0]) return;
+  }
+  for (int i = tid; i < OWN_CH / 2; i += OWN_THREADS) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int col = a.feat0 + 2 * level;
   const bool smooth = g.smoothstep != 0;
-  const uint32_t* bits = a.bitmaps + ((long)li * OWN_MAX_CHUNKS + chunk) * a.words;
   const F3* xs = reinterpret_cast<const F3*>(a.x);
   constexpr int MLP = TANGENTS ? 2 : 4;
   for (int wb = w_beg; wb < w_end;) {
@@ -761,13 +770,17 @@ extern "C" int nsky_encode_bwd(const nsky_hashgrid_desc* d, const float* x, int3
     oa.words = ceil_div(P, BM_POINTS) * (BM_POINTS / 32);
     oa.n_levels_owned = 0;
     int wgs = 0;
-    for (int l = 0; l < g.n_levels; ++l) {
+    for (int l = g.n_levels - 1; l >= 0; --l) {  // finest first: the hashed levels' owners are the long tasks, the dense levels' short ones fill in behind
       const int nch = ceil_div((long)(g.offset[l + 1] - g.offset[l]), OWN_CH);
-      // hashed: the hash spreads a level's adds evenly over its 32 chunks; dense: the points' spatial distribution decides,
-      // and a scene's points crowd a few slabs -- twice the workgroups per level, split over the points
+      // hashed: the hash spreads a level's adds evenly over its 32 chunks; dense: the points' spatial distribution decides, and a
+      // scene's points crowd a few slabs (a chunk of a dense level is a few z-planes: measured on a train step's termination points,
+      // four workgroups of a 14-chunk level had all the work) -- every chunk's points are split over OWN_DENSE_SPLITS workgroups
+      // (64 for a one-chunk level); a workgroup whose share of the bitmap is empty leaves before it touches its accumulators
       const bool dense_l = level_is_dense(g.offset[l + 1] - g.offset[l], (uint32_t)g.resolution[l]);
-      int sp = (dense_l ? 2 * OWN_WG_PER_LEVEL : OWN_WG_PER_LEVEL) / nch;
+      int sp = dense_l ? (2 * OWN_WG_PER_LEVEL / nch > OWN_DENSE_SPLITS ? 2 * OWN_WG_PER_LEVEL / nch : OWN_DENSE_SPLITS) : OWN_WG_PER_LEVEL / nch;
       if (sp < 1) sp = 1;
+      const int max_sp = oa.words / 32 > 1 ? oa.words / 32 : 1;  // at least 32 bitmap words (1024 points) per workgroup
+      if (sp > max_sp) sp = max_sp;
       oa.level[oa.n_levels_owned] = l;
       oa.splits[oa.n_levels_owned] = sp;
       oa.wg0[oa.n_levels_owned++] = wgs;
