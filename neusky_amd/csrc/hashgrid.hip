@@ -524,16 +524,50 @@ __device__ __forceinline__ void owner_point(const OwnerArgs& a, float* acc, cons
   // y / z terms of the index in wrapping 32-bit arithmetic, as grid_index forms them: hashed y P1 ^ z P2, dense y res + z res^2
   const uint32_t YM = dense ? res : HASH_P1, ZM = dense ? res * res : HASH_P2;
   const uint32_t Y0 = pg[1] * YM, Z0 = pg[2] * ZM;
+  if (!dense) {
+    // Hashed level: a point's eight corners are four (y, z) pairs of two x-neighbours, and typically ONE pair lies in this chunk.
+    // An LDS atomic costs its ~64 clocks whatever its lane mask, so the wave does not walk all eight corners under masks: every lane
+    // lists its pairs that touch the chunk and the wave walks list positions (one or two, rarely more: the ballot decides).
+    uint32_t pairs = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t yz = (Y0 + ((q & 1) ? YM : 0u)) ^ (Z0 + ((q & 2) ? ZM : 0u));
+      const uint32_t i0 = (pg[0] ^ yz) & smask, i1 = ((pg[0] + 1u) ^ yz) & smask;
+      if ((i0 >> OWN_SHIFT) == chunk || (i1 >> OWN_SHIFT) == chunk) pairs |= 1u << q;
+    }
+    while (__ballot(pairs != 0)) {
+      if (pairs) {
+        const int q = __ffs(pairs) - 1;
+        pairs &= pairs - 1;
+        const uint32_t yz = (Y0 + ((q & 1) ? YM : 0u)) ^ (Z0 + ((q & 2) ? ZM : 0u));
+        const float wy = (q & 1) ? w[1] : 1.0f - w[1];
+        const float wz = (q & 2) ? w[2] : 1.0f - w[2];
+#pragma unroll
+        for (int xb = 0; xb < 2; ++xb) {
+          const uint32_t idx = ((pg[0] + (uint32_t)xb) ^ yz) & smask;
+          if ((idx >> OWN_SHIFT) != chunk) continue;
+          const float wx = xb ? w[0] : 1.0f - w[0];
+          float a0 = wx * wy * wz * gy.x, a1 = wx * wy * wz * gy.y;
+          if (TANGENTS) {
+            const float cx = (xb ? dw[0] : -dw[0]) * wy * wz;
+            const float cy = ((q & 1) ? dw[1] : -dw[1]) * wx * wz;
+            const float cz = ((q & 2) ? dw[2] : -dw[2]) * wx * wy;
+            a0 += cx * gpa[0].x + cy * gpa[1].x + cz * gpa[2].x;
+            a1 += cx * gpa[0].y + cy * gpa[1].y + cz * gpa[2].y;
+          }
+          const int loc = (int)(idx - c_beg);
+          atomicAdd(acc + 2 * loc, a0);      // ds_add_f32
+          atomicAdd(acc + 2 * loc + 1, a1);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const uint32_t xk = pg[0] + (k & 1), yk = Y0 + ((k & 2) ? YM : 0u), zk = Z0 + ((k & 4) ? ZM : 0u);
-    uint32_t idx;
-    if (dense) {
-      idx = xk + yk + zk;
-      if (idx >= size) idx %= size;
-    } else {
-      idx = (xk ^ yk ^ zk) & smask;
-    }
+    uint32_t idx = xk + yk + zk;
+    if (idx >= size) idx %= size;
     if ((idx >> OWN_SHIFT) != chunk) continue;
     const float wx = (k & 1) ? w[0] : 1.0f - w[0];
     const float wy = (k & 2) ? w[1] : 1.0f - w[1];
@@ -778,6 +812,12 @@ extern "C" int nsky_encode_bwd(const nsky_hashgrid_desc* d, const float* x, int3
       // (64 for a one-chunk level); a workgroup whose share of the bitmap is empty leaves before it touches its accumulators
       const bool dense_l = level_is_dense(g.offset[l + 1] - g.offset[l], (uint32_t)g.resolution[l]);
       int sp = dense_l ? (2 * OWN_WG_PER_LEVEL / nch > OWN_DENSE_SPLITS ? 2 * OWN_WG_PER_LEVEL / nch : OWN_DENSE_SPLITS) : OWN_WG_PER_LEVEL / nch;
+      // the coarsest hashed levels: a crowded cell sends all its points to the same four chunks (measured on a train step's termination
+      // points: the first hashed level's busiest owner alone took 0.15 ms) -- their chunks' points are shared by up to four workgroups
+      if (!dense_l) {
+        const int crowd = 512 / g.resolution[l];
+        sp *= crowd > 4 ? 4 : (crowd < 1 ? 1 : crowd);
+      }
       if (sp < 1) sp = 1;
       const int max_sp = oa.words / 32 > 1 ? oa.words / 32 : 1;  // at least 32 bitmap words (1024 points) per workgroup
       if (sp > max_sp) sp = max_sp;

@@ -65,10 +65,10 @@ for geom, table, x, mode, include_x, pe, pmax, dY, dT, want_dx in calls:
             q = ((x.clamp(-1, 1) * 0.5 + 0.5) * geom.scales[l] + 0.5).floor().long()
             cells.append((geom.resolutions[l], int(torch.unique(q[:, 0] * 4096 * 4096 + q[:, 1] * 4096 + q[:, 2]).numel())))
         per = []
-        for k in range(1, nd + 1):
+        for k in range(1, geom.n_levels + 1):
             sk = copy.copy(geom)
             sk.n_levels, sk.scales, sk.resolutions, sk.offsets = k, geom.scales[:k], geom.resolutions[:k], geom.offsets[:k + 1]
             tk, dk = table[:sk.n_params].contiguous(), torch.zeros(sk.n_params, 2, device=x.device)
             per.append(round(t(lambda: orig(sk, tk, x, mode, include_x, pe, pmax, dY, dT, dk, None)), 3))
-        print(f"    first k levels, k = 1..{nd}: {per} ms")
+        print(f"    first k levels, k = 1..{geom.n_levels}: {per} ms")
         print(f"    dense levels only ({nd}): as-is {d:.3f} ms, uniform-random {e:.3f} ms; distinct cells (res, n): {cells}")
