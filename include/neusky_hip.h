@@ -27,7 +27,7 @@ extern "C" {
 typedef void* nsky_stream_t; /* hipStream_t */
 
 const char* nsky_last_error(void);
-int nsky_abi_version(void); /* 7 (bumped when a struct layout or an entry point's signature changes) */
+int nsky_abi_version(void); /* 8 (bumped when a struct layout or an entry point's signature changes) */
 
 /* ------------------------------------------------------------------------------------------
  * Dense layer on the matrix cores: C[M,N] = epilogue( sum_k A(m,k) * B(n,k) + bias[n] )
@@ -439,11 +439,12 @@ int nsky_density_weights_bwd(const float* raw, int32_t ld_raw, const float* ebin
  * torch.autograd.grad(..., create_graph=True) at neusky/fields/sdf_albedo_field.py:235-238 feeding the eikonal
  * loss (neusky/models/neusky_model.py:958-960) and the shading normals (:251).
  *   s = sigmoid(beta z) [N,ld]; ta = tangent activations [3][N,ld]; da (optional) [N,ld];
- *   dta [3][N,ld]  OR  the outer product ggrad[N,3] x wvec[C];   out: dz [N,ld], du [3][N,ld].
+ *   dta [3][N,ld]  OR  the outer product ggrad[N,3] x wvec[C];   out: dz [N,ld], du [3][N,ld];
+ *   wsum (optional, outer-product form only) [C] += sum_{n,k} ggrad[n,k] ta_k[n,:] = the gradient of wvec, from the same pass.
  */
 int nsky_softplus_tangent_bwd(const float* da, const float* s, const float* ta, const float* dta, const float* ggrad,
                               const float* wvec, float beta, int32_t N, int32_t C, int32_t ld, float* dz, float* du,
-                              nsky_stream_t stream);
+                              float* wsum, nsky_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Proposal PDF re-sampling: nerfstudio PDFSampler.generate_ray_samples as driven by

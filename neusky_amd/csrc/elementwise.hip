@@ -229,6 +229,62 @@ __global__ void bins_to_samples_kernel(const float* __restrict__ sbins, const fl
   }
 }
 
+// float4 form (C % 4 == 0, ld % 4 == 0, 16-byte aligned matrices): a wave reads one 1 KB row segment per instruction, the four
+// waves of a block take every fourth row of the block's row range.  In the outer-product mode the same pass also forms
+// wsum[c] += sum_{n,k} ggrad[n,k] ta_k[n,c] (the gradient of wvec: the sdf row of the geometry network's last layer), which
+// otherwise costs a second read of the three tangent matrices.
+__global__ __launch_bounds__(256) void softplus_tangent_bwd4_kernel(const float* __restrict__ da, const float* __restrict__ s,
+                                                                    const float* __restrict__ ta, const float* __restrict__ dta,
+                                                                    const float* __restrict__ ggrad, const float* __restrict__ wvec, float beta,
+                                                                    int N, int Cc, int ld, float* __restrict__ dz, float* __restrict__ du,
+                                                                    float* __restrict__ wsum, int rows_per_block) {
+  const int c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
+  const int phase = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(N, r0 + rows_per_block);
+  float4 wacc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < Cc) {
+    const float4 wv = wvec ? *reinterpret_cast<const float4*>(wvec + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n = r0 + phase; n < r1; n += 4) {
+      const long o = (long)n * ld + c;
+      const float4 sv = *reinterpret_cast<const float4*>(s + o);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (da) {
+        const float4 d = *reinterpret_cast<const float4*>(da + o);
+        acc = make_float4(d.x * sv.x, d.y * sv.y, d.z * sv.z, d.w * sv.w);
+      }
+      const float4 k1 = make_float4(beta * (1.0f - sv.x), beta * (1.0f - sv.y), beta * (1.0f - sv.z), beta * (1.0f - sv.w));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const long ok = ((long)k * N + n) * ld + c;
+        const float4 t = *reinterpret_cast<const float4*>(ta + ok);
+        float4 g;
+        if (dta) {
+          g = *reinterpret_cast<const float4*>(dta + ok);
+        } else {
+          const float gg = ggrad[(long)n * 3 + k];
+          g = make_float4(gg * wv.x, gg * wv.y, gg * wv.z, gg * wv.w);
+          wacc.x = fmaf(gg, t.x, wacc.x); wacc.y = fmaf(gg, t.y, wacc.y); wacc.z = fmaf(gg, t.z, wacc.z); wacc.w = fmaf(gg, t.w, wacc.w);
+        }
+        acc.x = fmaf(g.x * t.x, k1.x, acc.x); acc.y = fmaf(g.y * t.y, k1.y, acc.y);
+        acc.z = fmaf(g.z * t.z, k1.z, acc.z); acc.w = fmaf(g.w * t.w, k1.w, acc.w);
+        *reinterpret_cast<float4*>(du + ok) = make_float4(g.x * sv.x, g.y * sv.y, g.z * sv.z, g.w * sv.w);
+      }
+      *reinterpret_cast<float4*>(dz + o) = acc;
+    }
+  }
+  if (!wsum) return;
+  __shared__ float4 red[256];
+  red[threadIdx.x] = wacc;
+  __syncthreads();
+  if (phase == 0 && c < Cc) {
+    const float4 a = red[threadIdx.x], b = red[threadIdx.x + 64], cc = red[threadIdx.x + 128], d = red[threadIdx.x + 192];
+    atomicAdd(wsum + c, (a.x + b.x) + (cc.x + d.x));
+    atomicAdd(wsum + c + 1, (a.y + b.y) + (cc.y + d.y));
+    atomicAdd(wsum + c + 2, (a.z + b.z) + (cc.z + d.z));
+    atomicAdd(wsum + c + 3, (a.w + b.w) + (cc.w + d.w));
+  }
+}
+
 // gradients autograd left in tensors of its own -> their places in the optimizer slab, one launch for all of them
 constexpr int GATHER_MAX = 64;
 struct GatherArgs {
@@ -255,12 +311,25 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const GatherArgs a
 
 extern "C" int nsky_softplus_tangent_bwd(const float* da, const float* s, const float* ta, const float* dta, const float* ggrad,
                                          const float* wvec, float beta, int32_t N, int32_t C, int32_t ld, float* dz, float* du,
-                                         nsky_stream_t stream) {
+                                         float* wsum, nsky_stream_t stream) {
   if ((long)N * C == 0) return NSKY_OK;
   NSKY_CHECK_ARG(s && ta && dz && du && (dta || (ggrad && wvec)) && ld >= C, "nsky_softplus_tangent_bwd: bad argument");
+  NSKY_CHECK_ARG(!wsum || (!dta && ggrad), "nsky_softplus_tangent_bwd: wsum goes with the outer-product form (ggrad x wvec)");
+  auto al = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (C % 4 == 0 && ld % 4 == 0 && al(da) && al(s) && al(ta) && al(dta) && al(wvec) && al(dz) && al(du)) {
+    const int rows_per_block = 192;  // 512 blocks at the step's 98 304 rows
+    hipLaunchKernelGGL(softplus_tangent_bwd4_kernel, dim3(ceil_div(C, 256), ceil_div(N, rows_per_block)), dim3(256), 0, (hipStream_t)stream, da, s,
+                       ta, dta, ggrad, wvec, beta, N, C, ld, dz, du, wsum, rows_per_block);
+    NSKY_CHECK_LAUNCH("nsky_softplus_tangent_bwd");
+    return NSKY_OK;
+  }
   const long n = (long)N * C;
   hipLaunchKernelGGL(softplus_tangent_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, da, s, ta, dta, ggrad,
                      wvec, beta, N, C, ld, dz, du);
+  if (wsum) {  // (unaligned operands: the weighted column sum as its own pass)
+    for (int k = 0; k < 3; ++k)
+      if (int rc = nsky_weighted_colsum_f32(ta + (long)k * N * ld, N, C, ld, ggrad + k, 3, wsum, stream)) return rc;
+  }
   NSKY_CHECK_LAUNCH("nsky_softplus_tangent_bwd");
   return NSKY_OK;
 }

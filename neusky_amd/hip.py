@@ -52,7 +52,7 @@ class GemmDesc(C.Structure):
 
 _lib.nsky_last_error.restype = C.c_char_p
 _lib.nsky_abi_version.restype = C.c_int
-ABI_VERSION = 7  # the ctypes structures below mirror this version of include/neusky_hip.h
+ABI_VERSION = 8  # the ctypes structures below mirror this version of include/neusky_hip.h
 if _lib.nsky_abi_version() != ABI_VERSION:
     raise NeuSkyHipError(f"libneusky_hip.so has ABI version {_lib.nsky_abi_version()}, this package binds version {ABI_VERSION}: rebuild (build.sh)")
 
@@ -411,15 +411,16 @@ def visibility_finish_bwd(t_hat, surf_dist, threshold, scale, sel_index, R, Dv, 
 
 
 # ------------------------------------------------------------------------------------------ elementwise helpers
-_sp_tan_bwd = _sig("nsky_softplus_tangent_bwd", _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P)
+_sp_tan_bwd = _sig("nsky_softplus_tangent_bwd", _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P)
 _pdf_sample = _sig("nsky_pdf_sample", _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P)
 _adam = _sig("nsky_adam_step", _P, _P, _P, _P, C.c_int64, _F, _F, _F, _F, _I, _F, _P)
 _wn_fwd = _sig("nsky_weight_norm_fwd", _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P)
 _wn_bwd = _sig("nsky_weight_norm_bwd", _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P)
 
 
-def softplus_tangent_bwd(da, s, ta, dta, ggrad, wvec, beta, N, Cc, dz, du):
-    check(_sp_tan_bwd(ptr(da), ptr(s), ptr(ta), ptr(dta), ptr(ggrad), ptr(wvec), beta, N, Cc, ld(s), ptr(dz), ptr(du),
+def softplus_tangent_bwd(da, s, ta, dta, ggrad, wvec, beta, N, Cc, dz, du, wsum=None):
+    """wsum [Cc] (outer-product form): += sum_{n,k} ggrad[n,k] ta_k[n,:], the gradient of wvec, from the same pass"""
+    check(_sp_tan_bwd(ptr(da), ptr(s), ptr(ta), ptr(dta), ptr(ggrad), ptr(wvec), beta, N, Cc, ld(s), ptr(dz), ptr(du), ptr(wsum),
                       stream_ptr()), "nsky_softplus_tangent_bwd")
 
 

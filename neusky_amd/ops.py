@@ -750,12 +750,11 @@ class SDFAlbedoFn(torch.autograd.Function):
         if g_grad is None:
             g_grad = zeros(N, 3, device=dev)
         g_grad = g_grad.contiguous()
-        # d w_sdf += sum_{k,n} g_grad[n,k] ta1_k[n,:] : accumulated straight into the sdf row of dW2
-        hip.weighted_colsum(A1[N:], 3 * N, Hd, g_grad.t().contiguous(), 1, dW2[GF])
         w2s = W2[GF].contiguous()
-        # ---- layer 1 (reverse over forward)
+        # ---- layer 1 (reverse over forward); the same pass over the tangent rows accumulates d w_sdf += sum_{k,n} g_grad[n,k] ta1_k[n,:]
+        # straight into the sdf row of dW2
         D1 = torch.empty(4 * N, Hd, device=dev)
-        hip.softplus_tangent_bwd(dA1v, S1, A1[N:], None, g_grad, w2s, beta, N, Hd, D1[:N], D1[N:])
+        hip.softplus_tangent_bwd(dA1v, S1, A1[N:], None, g_grad, w2s, beta, N, Hd, D1[:N], D1[N:], wsum=dW2[GF])
         dW1, db1, f_1 = shared_grad(W1, b1)
         grad_weight(D1, A0, 4 * N, Hd, Hd, W1, b1, bias_rows=N, acc=(dW1, db1), batch=wq)
         dA0 = torch.empty(4 * N, Hd, device=dev)
