@@ -27,7 +27,7 @@ extern "C" {
 typedef void* nsky_stream_t; /* hipStream_t */
 
 const char* nsky_last_error(void);
-int nsky_abi_version(void); /* 8 (bumped when a struct layout or an entry point's signature changes) */
+int nsky_abi_version(void); /* 9 (bumped when a struct layout or an entry point's signature changes) */
 
 /* ------------------------------------------------------------------------------------------
  * Dense layer on the matrix cores: C[M,N] = epilogue( sum_k A(m,k) * B(n,k) + bias[n] )
@@ -320,11 +320,11 @@ int nsky_encode_fwd(const nsky_hashgrid_desc* g, const float* x, int32_t P, int3
 /* Backward of nsky_encode_fwd.  dY [P,lddy] = gradient w.r.t. the rows; dT (optional) [3][P][lddy] =
  * gradient w.r.t. the tangent rows (second-order path: eikonal / normals).  Accumulates (float adds, order not
  * fixed) into dtable [offset[L]][2]; dx (optional, [P,3], overwritten) = dY . d(row)/dx.
- * workspace (optional): nsky_encode_bwd_workspace_bytes(g, P) bytes of scratch; with it, and at least
- * NSKY_ENCODE_BWD_OWNER_MIN_POINTS points, the fine levels' gradient is accumulated by chunk-owning workgroups in LDS
+ * workspace (optional): nsky_encode_bwd_workspace_bytes(g, P, dT != NULL) bytes of scratch, 256-byte aligned; with it, and at
+ * least NSKY_ENCODE_BWD_OWNER_MIN_POINTS points, the table gradient is accumulated by chunk-owning workgroups in LDS
  * instead of by global atomics (same result up to the order of the float adds). */
 #define NSKY_ENCODE_BWD_OWNER_MIN_POINTS 32768
-int64_t nsky_encode_bwd_workspace_bytes(const nsky_hashgrid_desc* g, int32_t P);
+int64_t nsky_encode_bwd_workspace_bytes(const nsky_hashgrid_desc* g, int32_t P, int32_t tangents);
 int nsky_encode_bwd(const nsky_hashgrid_desc* g, const float* x, int32_t P, int32_t mode, int32_t include_x,
                     int32_t pe_freqs, float pe_max_exp, const float* dY, int32_t lddy, const float* dT, float* dtable,
                     float* dx, void* workspace, nsky_stream_t stream);

@@ -52,7 +52,7 @@ class GemmDesc(C.Structure):
 
 _lib.nsky_last_error.restype = C.c_char_p
 _lib.nsky_abi_version.restype = C.c_int
-ABI_VERSION = 8  # the ctypes structures below mirror this version of include/neusky_hip.h
+ABI_VERSION = 9  # the ctypes structures below mirror this version of include/neusky_hip.h
 if _lib.nsky_abi_version() != ABI_VERSION:
     raise NeuSkyHipError(f"libneusky_hip.so has ABI version {_lib.nsky_abi_version()}, this package binds version {ABI_VERSION}: rebuild (build.sh)")
 
@@ -169,7 +169,7 @@ _encode_bwd = _sig("nsky_encode_bwd", C.POINTER(HashGridDesc), C.c_void_p, C.c_i
                    C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 _encode_bwd_ws = _lib.nsky_encode_bwd_workspace_bytes
 _encode_bwd_ws.restype = C.c_int64
-_encode_bwd_ws.argtypes = [C.POINTER(HashGridDesc), C.c_int32]
+_encode_bwd_ws.argtypes = [C.POINTER(HashGridDesc), C.c_int32, C.c_int32]
 _hash_indices = _sig("nsky_hash_indices", C.POINTER(HashGridDesc), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p)
 
 
@@ -204,7 +204,7 @@ def encode_bwd(geom, table, x, mode, include_x, pe_freqs, pe_max_exp, dY, dT, dt
     assert dtable.shape == table.shape and dtable.is_contiguous()
     desc = grid_desc(geom, table)
     if isinstance(workspace, str):
-        nbytes = _encode_bwd_ws(C.byref(desc), P)
+        nbytes = _encode_bwd_ws(C.byref(desc), P, int(dT is not None))
         workspace = torch.empty(nbytes // 4, dtype=torch.int32, device=x.device) if nbytes > 0 else None
     check(_encode_bwd(C.byref(desc), ptr(x), P, mode, int(include_x), pe_freqs, pe_max_exp, ptr(dY), ld(dY),
                       ptr(dT), ptr(dtable), ptr(dx), ptr(workspace), stream_ptr()), "nsky_encode_bwd")
