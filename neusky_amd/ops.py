@@ -664,10 +664,14 @@ class SDFAlbedoFn(torch.autograd.Function):
         fgemm(A0[N:], W1, A1[N:], 3 * N, Hd, Hd, epi=hip.EPI_MUL_AUX, aux0=S1, row_mod=N)
         GF = W2.shape[0] - 4  # geo feature dim (256)
         ldc = Wc0.shape[1]
-        CIN = zeros(N, ldc, device=dev)
+        # (not zero-filled as a whole -- 118 MB at the step's 98 304 samples: only its pad columns, which meet zero weight columns)
+        CIN = torch.empty(N, ldc, device=dev)
         fgemm(A1[:N], W2, CIN, N, GF + 1, Hd, bias=b2)  # [feat | sdf] straight into the colour-net input
         npe = 39  # x (3) + PE6 (36) columns of the encode row
+        CIN[:, GF + 1:GF + 4] = 0.0
         CIN[:, GF + 4:GF + 4 + npe] = ET[:N, :npe]
+        if GF + 4 + npe < ldc:
+            CIN[:, GF + 4 + npe:] = 0.0
         G = zeros(3 * N, 4, device=dev)
         fgemm(A1[N:], W2[GF:GF + 1], G, 3 * N, 1, Hd)  # d sdf / d x_k = tangent . w_sdf
         Hc = Wc0.shape[0]
