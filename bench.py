@@ -86,17 +86,25 @@ class KernelTimer:
         def fwd(net, stream, table, cond, x, M, *a, **kw):
             H, nm, nf, cd, xd, od = dims(net)
             fl = 2.0 * M * (cd * H + (nm - 1) * H * H + H * 2 * nf * H + xd * H + (nf - 1) * H * H + H * od)
-            return t._timed(f"film_fwd_kernel<{H}>", o["film_chain_fwd"], fl, fl, net, stream, table, cond, x, M, *a, **kw)
+            # algorithmic bytes: the input rows in, the saved activations (when kept) and the head output out, each once
+            saves = (nm + 2 * nf) if (len(a) > 0 and a[0] is not None) else 0
+            by = 4.0 * M * (cond.shape[1] + x.shape[1] + saves * H + 4)
+            return t._timed(f"film_fwd_kernel<{H}>", o["film_chain_fwd"], fl, fl, net, stream, table, cond, x, M, *a, nbytes=by, **kw)
 
         def bwd_film(net, stream, table, M, *a, **kw):
             H, nm, nf, cd, xd, od = dims(net)
             fl = 2.0 * M * ((nf - 1) * H * H + H * xd)
-            return t._timed(f"film_bwd_kernel<{H}>", o["film_chain_bwd_film"], fl, fl + 2.0 * M * 2 * nf * H * H, net, stream, table, M, *a, **kw)
+            # algorithmic bytes: d_res, h_last and the z saves in; dz and dF / dphase out (the parked dY and the read-back of dz are the
+            # kernel's own traffic, not counted)
+            by = 4.0 * M * (4 + H + nf * H + nf * H + 2 * nf * H + 16)
+            return t._timed(f"film_bwd_kernel<{H}>", o["film_chain_bwd_film"], fl, fl + 2.0 * M * 2 * nf * H * H, net, stream, table, M, *a,
+                            nbytes=by, **kw)
 
         def bwd_map(net, stream, table, M, *a, **kw):
             H, nm, nf, cd, xd, od = dims(net)
             fl = 2.0 * M * (2 * nf * H * H + (nm - 1) * H * H + H * cd)
-            return t._timed(f"film_bwd_map_kernel<{H}>", o["film_chain_bwd_map"], fl, fl, net, stream, table, M, *a, **kw)
+            by = 4.0 * M * (2 * nf * H + nm * H + nm * H + cd)  # dF / dphase and the h saves in, dpre and d_cond out
+            return t._timed(f"film_bwd_map_kernel<{H}>", o["film_chain_bwd_map"], fl, fl, net, stream, table, M, *a, nbytes=by, **kw)
 
         def wgrad(problems, rows):
             wa = lambda q: q.width_a if q.lda > 0 else 32 * q.nnt_a  # noqa: E731
@@ -340,7 +348,10 @@ def main():
             "roofline": {**roof, "traffic": traffic,
                          "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r02_pmc_traffic.json)",
                          "kernel": dom["kernel"] + " = the kernel family with the largest total time in the eager timing iteration",
-                         "peak_note": "fp16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-grade product = 833.3 TFLOP/s of algorithmic FLOPs",
+                         "peak_note": ("HBM3E ~8 TB/s; achieved = algorithmic bytes (inputs, saved activations and outputs once each) / launch time; "
+                                       "the kernel's byte floor exceeds its flop floor at 833.3 TFLOP/s") if roof["bound"] == "hbm" else
+                                      "fp16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-grade product = 833.3 TFLOP/s of algorithmic FLOPs",
+                         "algorithmic_bytes_per_launch": dom.get("algorithmic_bytes_per_launch"),
                          "precision_policy": ops._POLICY, "launches_timed": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
                          "algorithmic_flops_per_launch": dom["algorithmic_flops_per_launch"],
                          "executed_flops_per_launch": dom["executed_flops_per_launch"]},
