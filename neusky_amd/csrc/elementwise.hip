@@ -44,21 +44,32 @@ __global__ __launch_bounds__(256) void pdf_sample_kernel(const float* __restrict
   float* cdf = sm + wave * 2 * (n0 + 1);
   float* eb = cdf + (n0 + 1);
   for (int i = lane; i <= n0; i += 64) eb[i] = bins[(long)r * (n0 + 1) + i];
-  if (lane == 0) {
-    // sequential sums, accumulated in double and rounded to float at every step (exactly what a CPU
-    // float cumsum does): the CDF, and so every searchsorted index, is bit-reproducible
+  {
+    // The CDF a CPU float cumsum gives, bit for bit: sums accumulated in double and rounded to float at every step.  The terms are
+    // floats within a few binades of each other (every weight carries the histogram padding), so their double partial sums are EXACT
+    // and therefore independent of the order of the additions: the wave adds them in parallel (a strided sum for the total, an
+    // inclusive scan per block of 64 bins for the CDF) and gets what the sequential loop got.
     const float* w = weights + (long)r * n0;
-    double acc = 0.0;
-    for (int i = 0; i < n0; ++i) acc += (double)(w[i] + hist_pad);
-    float wsum = (float)acc;
+    double part = 0.0;
+    for (int i = lane; i < n0; i += 64) part += (double)(w[i] + hist_pad);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    float wsum = (float)part;
     const float padding = fmaxf(eps - wsum, 0.0f);
     const float padn = padding / (float)n0;
     wsum += padding;
-    acc = 0.0;
-    cdf[0] = 0.0f;
-    for (int i = 0; i < n0; ++i) {
-      acc += (double)(((w[i] + hist_pad) + padn) / wsum);
-      cdf[i + 1] = fminf(1.0f, (float)acc);
+    if (lane == 0) cdf[0] = 0.0f;
+    double carry = 0.0;
+    for (int base = 0; base < n0; base += 64) {
+      const int i = base + lane;
+      double incl = i < n0 ? (double)(((w[i] + hist_pad) + padn) / wsum) : 0.0;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const double v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+      }
+      if (i < n0) cdf[i + 1] = fminf(1.0f, (float)(carry + incl));
+      carry += __shfl(incl, 63, 64);
     }
   }
   __builtin_amdgcn_wave_barrier();

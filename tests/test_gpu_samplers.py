@@ -193,3 +193,21 @@ def test_reni_output_matches_exp_times_scale():
     want = torch.autograd.grad(((torch.exp(r64[U * D:, :3]) * s64[rl][:, None]) * gr.double()).sum(), [r64, s64])
     assert torch.allclose(rawd.grad.cpu().double()[:, :3], want[0][:, :3], rtol=1e-5, atol=1e-6)
     assert torch.allclose(sd.grad.cpu().double(), want[1], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n0,nb", [(256, 97), (96, 65), (100, 33), (7, 5)])
+def test_pdf_sample_indices_bit_exact_against_float32_torch(n0, nb):
+    """nsky_pdf_sample (nerfstudio PDFSampler via ProposalNetworkSampler, neusky_model.py:561): the searchsorted indices equal
+    those of the float32 torch formulation (oracle.pdf_sample_bins run in float32: CPU cumsum order) bit for bit, the new bins to rounding"""
+    from neusky_amd import hip
+    g = torch.Generator().manual_seed(n0 * 1000 + nb)
+    R = 300
+    weights = torch.rand(R, n0, generator=g) ** 3
+    weights[::7] *= 1e-4  # nearly empty rays
+    bins = torch.sort(torch.rand(R, n0 + 1, generator=g), -1).values
+    jitter = torch.rand(R, 1, generator=g)
+    want_bins, want_inds = O.pdf_sample_bins(bins, weights, nb - 1, jitter)
+    u = torch.linspace(0.0, 1.0 - (1.0 / nb), steps=nb)
+    got_bins, got_inds = hip.pdf_sample(weights.to(DEV), bins.to(DEV), u.to(DEV), jitter.reshape(-1).to(DEV), nb, want_inds=True)
+    assert torch.equal(got_inds.cpu().long(), want_inds)
+    assert torch.allclose(got_bins.cpu(), want_bins, atol=1e-6)
