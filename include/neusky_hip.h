@@ -231,6 +231,13 @@ int nsky_ray_reduce_bwd(const float* weights, const float* starts, const float* 
                         const float* sums, const float* bounds, int32_t R, int32_t S, float max_clamp, const float* d_p2p,
                         const float* d_accumulation, const float* d_normal, const float* d_albedo_acc, float* d_weights,
                         float* d_normals, float* d_albedo, nsky_stream_t stream);
+
+/* Points along rays: out[i] = origins[i] + sign t[i] dirs[i % n_dirs] (the DDF's predicted termination points: ddf_model.py:243,
+ * neusky_model.py:1716-1724 with the R x Dv visibility rows sharing their Dv directions), and its backward
+ * d_t[i] = sign <d_out[i], dirs[i % n_dirs]> (origins and directions carry no gradient on this path). */
+int nsky_ray_points_fwd(const float* origins, const float* dirs, int32_t n_dirs, float sign, const float* t, int64_t n, float* out,
+                        nsky_stream_t stream);
+int nsky_ray_points_bwd(const float* dirs, int32_t n_dirs, float sign, const float* d_out, int64_t n, float* d_t, nsky_stream_t stream);
 /* unit rows of g [P,3] (torch.nn.functional.normalize(p=2, eps=1e-12), sdf_albedo_field.py:256) and its backward */
 int nsky_normalize3_fwd(const float* g, int64_t P, float* n, nsky_stream_t stream);
 int nsky_normalize3_bwd(const float* g, const float* d_n, int64_t P, float* d_g, nsky_stream_t stream);

@@ -772,6 +772,24 @@ __global__ void normalize3_bwd_kernel(const float* __restrict__ g, const float* 
   }
 }
 
+// points along rays: out[i] = o[i] + sign t[i] d[i % n_dirs] (the DDF's predicted termination points, ddf_model.py:243 and
+// neusky_model.py:1716-1724: sphere point minus the direction to the sun-side sample times the predicted distance), and d t
+__global__ void ray_points_fwd_kernel(const float* __restrict__ o, const float* __restrict__ d, int n_dirs, float sign,
+                                      const float* __restrict__ t, long n, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* dd = d + 3 * (i % n_dirs);
+  const float tt = sign * t[i];
+  out[3 * i] = fmaf(dd[0], tt, o[3 * i]); out[3 * i + 1] = fmaf(dd[1], tt, o[3 * i + 1]); out[3 * i + 2] = fmaf(dd[2], tt, o[3 * i + 2]);
+}
+__global__ void ray_points_bwd_kernel(const float* __restrict__ d, int n_dirs, float sign, const float* __restrict__ d_out, long n,
+                                      float* __restrict__ d_t) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* dd = d + 3 * (i % n_dirs);
+  d_t[i] = sign * (d_out[3 * i] * dd[0] + d_out[3 * i + 1] * dd[1] + d_out[3 * i + 2] * dd[2]);
+}
+
 }  // namespace
 
 extern "C" int nsky_hemi_composite_fwd(const float* albedo, const float* normals, const float* weights, const float* dirs,
@@ -949,5 +967,22 @@ extern "C" int nsky_normalize3_bwd(const float* g, const float* d_n, int64_t P, 
   NSKY_CHECK_ARG(g && d_n && d_g && P > 0, "nsky_normalize3_bwd: bad argument");
   hipLaunchKernelGGL(normalize3_bwd_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, (hipStream_t)stream, g, d_n, (long)P, d_g);
   NSKY_CHECK_LAUNCH("nsky_normalize3_bwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_ray_points_fwd(const float* origins, const float* dirs, int32_t n_dirs, float sign, const float* t, int64_t n, float* out,
+                                   nsky_stream_t stream) {
+  if (n == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(origins && dirs && t && out && n > 0 && n_dirs > 0, "nsky_ray_points_fwd: bad argument");
+  hipLaunchKernelGGL(ray_points_fwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, origins, dirs, n_dirs, sign, t, (long)n, out);
+  NSKY_CHECK_LAUNCH("nsky_ray_points_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_ray_points_bwd(const float* dirs, int32_t n_dirs, float sign, const float* d_out, int64_t n, float* d_t, nsky_stream_t stream) {
+  if (n == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(dirs && d_out && d_t && n > 0 && n_dirs > 0, "nsky_ray_points_bwd: bad argument");
+  hipLaunchKernelGGL(ray_points_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, dirs, n_dirs, sign, d_out, (long)n, d_t);
+  NSKY_CHECK_LAUNCH("nsky_ray_points_bwd");
   return NSKY_OK;
 }

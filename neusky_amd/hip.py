@@ -660,6 +660,23 @@ def film_pack(net: FilmNet, stream_buf, scales, direction: int = 0):
     check(_film_pack(C.byref(net), direction, ptr(stream_buf), ptr(scales), stream_ptr()), "nsky_film_pack")
 
 
+_ray_points_fwd = _sig("nsky_ray_points_fwd", C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
+_ray_points_bwd = _sig("nsky_ray_points_bwd", C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
+
+
+def ray_points_fwd(origins, dirs, sign, t, out):
+    """out[i] = origins[i] + sign t[i] dirs[i % len(dirs)]; out may be a row slice of a larger [*, 3] buffer"""
+    n = origins.shape[0]
+    assert origins.is_contiguous() and dirs.is_contiguous() and t.is_contiguous() and out.is_contiguous() and out.shape == (n, 3) and t.numel() == n
+    check(_ray_points_fwd(ptr(origins), ptr(dirs), dirs.shape[0], float(sign), ptr(t), n, ptr(out), stream_ptr()), "nsky_ray_points_fwd")
+
+
+def ray_points_bwd(dirs, sign, d_out, d_t):
+    n = d_out.shape[0]
+    assert dirs.is_contiguous() and d_out.is_contiguous() and d_t.is_contiguous() and d_t.numel() == n
+    check(_ray_points_bwd(ptr(dirs), dirs.shape[0], float(sign), ptr(d_out), n, ptr(d_t), stream_ptr()), "nsky_ray_points_bwd")
+
+
 class Segment(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int64)]
 

@@ -387,12 +387,12 @@ class NeuSkyFactoModel(ModelBase):
         vcfg = ddf.config
         sdf_extra = None
         if (vcfg.loss_inclusions["sdf_l1_loss"] or vcfg.loss_inclusions["sdf_l2_loss"]) and ddf.training:
-            world_dirs = (-sel_dirs)[None].expand(R, Dv, 3).reshape(-1, 3)
-            term_pts = sphere_pts + world_dirs * t_hat[:, None]  # ddf_model.py:243
             n_main = 0
             if extra is not None and not stop_gradients and not extra["stop_gradients"]:
                 n_main = extra["positions"].shape[0]  # the fit rays' own termination points (ddf_model.py:243) join the same probe
-                term_pts = torch.cat([term_pts, extra["positions"] + extra["directions"] * t_main[:, None]], 0)
+            # sphere point - direction x predicted distance (ddf_model.py:243), one kernel per row set into one buffer
+            term_pts = ops.TermPointsFn.apply(sphere_pts, sel_dirs, t_hat, extra["positions"] if n_main else None,
+                                              extra["directions"] if n_main else None, t_main if n_main else None)
             if stop_gradients:
                 with torch.no_grad():
                     sdf_all = self.field.get_sdf_at_pos(term_pts).detach()

@@ -1089,6 +1089,40 @@ class RENIOutputFn(torch.autograd.Function):
         return d_raw, d_scale, None, None, None
 
 
+class TermPointsFn(torch.autograd.Function):
+    """The DDF's predicted termination points of the visibility rows and (optionally) of the fit rays, in ONE [M + N, 3] buffer:
+    sphere_pts[m] - sel_dirs[m % Dv] t_hat[m]  |  fit_pos[n] + fit_dirs[n] t_main[n]   (neusky_model.py:1716-1724, ddf_model.py:243);
+    differentiable w.r.t. the two distance vectors (hip.ray_points_*)"""
+
+    @staticmethod
+    def forward(ctx, sphere_pts, sel_dirs, t_hat, fit_pos, fit_dirs, t_main):
+        M = sphere_pts.shape[0]
+        N = 0 if fit_pos is None else fit_pos.shape[0]
+        sp, sd = sphere_pts.detach().contiguous(), sel_dirs.detach().contiguous()
+        out = torch.empty(M + N, 3, device=sp.device)
+        hip.ray_points_fwd(sp, sd, -1.0, t_hat.detach().contiguous(), out[:M])
+        fd = None
+        if N:
+            fd = fit_dirs.detach().contiguous()
+            hip.ray_points_fwd(fit_pos.detach().contiguous(), fd, 1.0, t_main.detach().contiguous(), out[M:])
+        ctx.save_for_backward(sd, fd)
+        ctx.cfg = (M, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        sd, fd = ctx.saved_tensors
+        M, N = ctx.cfg
+        d_out = d_out.contiguous()
+        d_hat = torch.empty(M, device=d_out.device)
+        hip.ray_points_bwd(sd, -1.0, d_out[:M], d_hat)
+        d_main = None
+        if N:
+            d_main = torch.empty(N, device=d_out.device)
+            hip.ray_points_bwd(fd, 1.0, d_out[M:], d_main)
+        return None, None, d_hat, None, None, d_main
+
+
 class DDFQueryRowsFn(torch.autograd.Function):
     """Every row the DDF network is evaluated on in a train step, in ONE pair of buffers: the R x Dv visibility rows
     (hip.visibility_rays; not differentiable) followed by the DDF-fit rows (fit rays | multi-view | sky; hip.ddf_fit_rows_fwd,

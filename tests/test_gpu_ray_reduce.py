@@ -73,3 +73,27 @@ def test_normalize_matches_torch():
     (n * gn.to(DEV)).sum().backward(); (r * gn.double()).sum().backward()
     scale = x64.grad.abs().max(dim=-1, keepdim=True).values + 1e-30
     assert float(((xd.grad.cpu().double() - x64.grad).abs() / scale).max()) < 1e-4
+
+
+def test_term_points_match_torch_autograd():
+    """ops.TermPointsFn (ddf_model.py:243 / neusky_model.py:1716-1724) against the torch expression it replaces, values and both gradients"""
+    from neusky_amd import ops
+    g = torch.Generator().manual_seed(8)
+    R, Dv, N = 37, 19, 55
+    M = R * Dv
+    sp = torch.randn(M, 3, generator=g)
+    sel = torch.nn.functional.normalize(torch.randn(Dv, 3, generator=g), dim=-1)
+    pos, dirs = torch.randn(N, 3, generator=g), torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    t_hat, t_main = torch.rand(M, generator=g), torch.rand(N, generator=g)
+    th, tm = t_hat.to(DEV).requires_grad_(True), t_main.to(DEV).requires_grad_(True)
+    out = ops.TermPointsFn.apply(sp.to(DEV), sel.to(DEV), th, pos.to(DEV), dirs.to(DEV), tm)
+    th64, tm64 = t_hat.double().requires_grad_(True), t_main.double().requires_grad_(True)
+    wd = (-sel.double())[None].expand(R, Dv, 3).reshape(-1, 3)
+    ref = torch.cat([sp.double() + wd * th64[:, None], pos.double() + dirs.double() * tm64[:, None]], 0)
+    assert torch.allclose(out.cpu().double(), ref, atol=1e-6)
+    probe = torch.randn(M + N, 3, generator=g)
+    (out * probe.to(DEV)).sum().backward(); (ref * probe.double()).sum().backward()
+    assert torch.allclose(th.grad.cpu().double(), th64.grad, atol=1e-5) and torch.allclose(tm.grad.cpu().double(), tm64.grad, atol=1e-5)
+    # visibility rows only
+    out2 = ops.TermPointsFn.apply(sp.to(DEV), sel.to(DEV), th.detach(), None, None, None)
+    assert torch.equal(out2, out[:M].detach())
