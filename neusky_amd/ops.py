@@ -321,7 +321,12 @@ class HashEncodeFn(torch.autograd.Function):
         ctx.cfg = (geom, mode, include_x, pe_freqs, pe_max_exp, tangents, need_dx, P, ldy)
         # Parameters re-homed into an optimizer slab (engine._Group) own a pre-zeroed gradient view: the backward scatters
         # straight into it instead of zero-filling a 49 MB table of its own and adding that to .grad afterwards
-        ctx.sink = table if getattr(table, "_nsky_grad_sink", False) else None
+        sink = table if getattr(table, "_nsky_grad_sink", False) else None
+        base = table._base
+        if sink is None and base is not None and getattr(base, "_nsky_grad_sink", False) and base.numel() == table.numel() \
+                and base.is_contiguous() and table.is_contiguous() and base.data_ptr() == table.data_ptr():
+            sink = base  # the [n, 2] view of a flat parameter (tcnn's `params` layout): its gradient view is the same memory
+        ctx.sink = sink
         return out
 
     @staticmethod
@@ -330,10 +335,10 @@ class HashEncodeFn(torch.autograd.Function):
         geom, mode, include_x, pe_freqs, pe_max_exp, tangents, need_dx, P, ldy = ctx.cfg
         d_out = d_out.contiguous()
         sink = ctx.sink
-        accumulate = sink is not None and sink.grad is not None and sink.grad.is_contiguous() and sink.grad.shape == table.shape
+        accumulate = sink is not None and sink.grad is not None and sink.grad.is_contiguous() and sink.grad.numel() == table.numel()
         if accumulate:
             sink._nsky_sunk = True  # (engine.Optimizers.zero_grad_all: this parameter's .grad stays its slab view)
-        dtable = sink.grad if accumulate else zeros_like(table)
+        dtable = sink.grad.view_as(table) if accumulate else zeros_like(table)
         dx = torch.empty(P, 3, device=x.device) if need_dx else None
         dT = d_out[P:].view(3, P, ldy) if tangents else None
         hip.encode_bwd(geom, table, x, mode, include_x, pe_freqs, pe_max_exp, d_out[:P], dT, dtable, dx)

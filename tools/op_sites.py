@@ -26,6 +26,7 @@ SKIP = {"aten.view.default", "aten._unsafe_view.default", "aten.reshape.default"
 sites = collections.Counter()
 views = collections.Counter()
 ops_at = collections.defaultdict(collections.Counter)
+large = []
 
 
 class Counter(TorchDispatchMode):
@@ -47,6 +48,9 @@ class Counter(TorchDispatchMode):
                 site = "backward:" + (node.name() if node is not None else "other")
             sites[site] += 1
             ops_at[site][name] += 1
+            big = [tuple(a.shape) for a in args if isinstance(a, torch.Tensor) and a.numel() >= (1 << 18)]
+            if big and not site.startswith("ops.py"):  # plain torch ops on large tensors: candidates for a kernel of their own
+                large.append((site, name, big))
         return func(*args, **(kwargs or {}))
 
 
@@ -64,3 +68,6 @@ for s, n in sites.most_common(400):
 print("---- slices / selects / index of tensors that require grad (each costs a zeros + copy pair in backward)")
 for s_, n in views.most_common(40):
     print(f"{n:5d}  {s_}")
+print("---- torch ops on tensors of >= 2^18 elements outside ops.py")
+for site, name, shapes in large:
+    print(f"  {site:58s} {name:34s} {shapes}")
