@@ -357,7 +357,8 @@ class DenseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, Wp, bp, n_out, act, need_dx):
         M, K = X.shape[0], Wp.shape[1]
-        Y = zeros(M, Wp.shape[0], device=X.device)
+        # (zero-filled only when it has pad columns the kernel does not write: a [262144, 64] proposal layer is 67 MB)
+        Y = torch.empty(M, n_out, device=X.device) if n_out == Wp.shape[0] else zeros(M, Wp.shape[0], device=X.device)
         fgemm(X, Wp, Y, M, n_out, K, bias=bp, epi=_ACT[act])
         ctx.save_for_backward(X, Wp, bp, Y)
         ctx.cfg = (n_out, act, need_dx)
@@ -370,7 +371,7 @@ class DenseFn(torch.autograd.Function):
         M, K = X.shape[0], Wp.shape[1]
         dZ = dY.contiguous()
         if act == "relu":
-            dZ = dZ * (Y > 0)
+            dZ = torch.ops.aten.threshold_backward(dZ, Y, 0.0)  # dY where Y > 0, one pass (no mask tensor)
         dW, db = grad_weight(dZ, X, M, n_out, K, Wp, bp)
         dX = None
         if need_dx:
