@@ -270,6 +270,12 @@ int nsky_ddf_fit_rows_bwd(const float* positions, const float* directions, const
                           int32_t N, const float* d_xrow_mv, int32_t ldx, float* d_term_dist, nsky_stream_t stream);
 
 
+/* Probe points of the hash-grid density loss (neusky_model.py:704-724): positions [P,3] = lattice + (u gap - gap / 2), u ~ U(0,1)^3,
+ * directions [P,3] uniform on the sphere; gap3_host: three floats in HOST memory (the cell size per axis); (seed, *counter): Philox,
+ * the counter is advanced by one. */
+int nsky_grid_probe_points(const float* lattice, const float* gap3_host, int32_t P, uint64_t seed, uint64_t* counter, float* positions,
+                           float* directions, nsky_stream_t stream);
+
 /* HDR output of the RENI++ decoder for the direction grid and the batch's own rays (neusky_model.py:488-549: exp output activation,
  * unnormalised by the per-image scale): raw [U D + R, ldr] (the chain's head output, 3 used columns) ->
  * grid [U D, 3] = exp(raw) scale[u], rays [R, 3] = exp(raw) scale[ray_latent[r]].  _bwd: d_raw [U D + R, ldr] (pad columns zeroed;

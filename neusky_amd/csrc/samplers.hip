@@ -314,6 +314,26 @@ __global__ __launch_bounds__(256) void reni_ray_inputs_bwd_kernel(const float* _
   atomicAdd(o, gx); atomicAdd(o + 1, gy); atomicAdd(o + 2, g[1]);
 }
 
+// Probe points of the hash-grid density loss (neusky_model.py:704-724): every lattice point jittered uniformly inside its cell
+// (lattice + (u gap - gap / 2), u ~ U(0,1)^3) with a uniformly random unit direction (a normalised normal 3-vector).
+__global__ __launch_bounds__(256) void grid_probe_points_kernel(const float* __restrict__ lattice, float gx, float gy, float gz, int P, uint64_t seed,
+                                                                const uint64_t* __restrict__ counter, float* __restrict__ pos,
+                                                                float* __restrict__ dirs) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const Philox g{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t a[4], b[4];
+  g.draw(0x47524944u, (uint32_t)p, *counter, a);
+  g.draw(0x47524945u, (uint32_t)p, *counter, b);
+  pos[3 * p] = lattice[3 * p] + (u01(a[0]) * gx - 0.5f * gx);
+  pos[3 * p + 1] = lattice[3 * p + 1] + (u01(a[1]) * gy - 0.5f * gy);
+  pos[3 * p + 2] = lattice[3 * p + 2] + (u01(a[2]) * gz - 0.5f * gz);
+  const float r0 = sqrtf(-2.0f * logf(u01(b[0]))), r1 = sqrtf(-2.0f * logf(u01(b[2])));
+  const float x = r0 * cosf(TWO_PI * u01(b[1])), y = r0 * sinf(TWO_PI * u01(b[1])), z = r1 * cosf(TWO_PI * u01(b[3]));
+  const float inv = 1.0f / sqrtf(x * x + y * y + z * z);
+  dirs[3 * p] = x * inv; dirs[3 * p + 1] = y * inv; dirs[3 * p + 2] = z * inv;
+}
+
 // The decoder's HDR output for the direction grid and the batch's own rays (neusky_model.py:488-549: exp output activation of the
 // RENI++ head, unnormalised by the per-image scale): grid[u, d] = exp(raw[u D + d]) scale[u], rays[r] = exp(raw[U D + r]) scale[ray_latent[r]].
 __global__ __launch_bounds__(256) void reni_output_fwd_kernel(const float* __restrict__ raw, int ldr, const float* __restrict__ scale,
@@ -539,5 +559,16 @@ extern "C" int nsky_reni_output_bwd(const float* raw, int32_t ldr, const float* 
   hipLaunchKernelGGL(reni_output_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, raw, ldr, scale, (const long*)ray_latent, U, D,
                      R, d_grid, d_rays, d_raw, d_scale);
   NSKY_CHECK_LAUNCH("nsky_reni_output_bwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_grid_probe_points(const float* lattice, const float* gap3_host, int32_t P, uint64_t seed, uint64_t* counter, float* positions,
+                                      float* directions, nsky_stream_t stream) {
+  if (P == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(lattice && gap3_host && counter && positions && directions && P > 0, "nsky_grid_probe_points: bad argument");
+  hipLaunchKernelGGL(grid_probe_points_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, (hipStream_t)stream, lattice, gap3_host[0], gap3_host[1],
+                     gap3_host[2], P, seed, counter, positions, directions);
+  hipLaunchKernelGGL(advance_counter_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter);
+  NSKY_CHECK_LAUNCH("nsky_grid_probe_points");
   return NSKY_OK;
 }

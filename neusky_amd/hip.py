@@ -298,6 +298,19 @@ def reni_grid_inputs_bwd(latents, directions, ray_dirs, ray_latent, d_cond, d_la
                        stream_ptr()), "nsky_reni_grid_inputs_bwd")
 
 
+_grid_probe = _sig("nsky_grid_probe_points", C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+
+
+def grid_probe_points(lattice, gap, seed, counter, positions, directions):
+    """lattice [P,3] (device), gap: three python floats; positions / directions [P,3] out; counter: int64 device tensor [1] (advanced)"""
+    P = lattice.shape[0]
+    assert lattice.is_contiguous() and positions.is_contiguous() and directions.is_contiguous() and positions.shape == (P, 3)
+    assert counter.dtype == torch.int64 and counter.numel() == 1 and counter.is_cuda
+    g3 = (C.c_float * 3)(*[float(v) for v in gap])
+    check(_grid_probe(ptr(lattice), g3, P, int(seed) & (2**64 - 1), ptr(counter), ptr(positions), ptr(directions), stream_ptr()),
+          "nsky_grid_probe_points")
+
+
 _reni_out_fwd = _sig("nsky_reni_output_fwd", C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                      C.c_void_p)
 _reni_out_bwd = _sig("nsky_reni_output_bwd", C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

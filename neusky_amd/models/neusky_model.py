@@ -33,7 +33,7 @@ from ..model_components.illumination import IcosahedronSamplerConfig, RENIFieldC
 from ..model_components.losses import LossDict, RENISkyPixelLoss, interlevel_loss, monosdf_normal_loss, scale_dict, total_loss
 from ..model_components.ray_samplers import HashMLPDensityField, ProposalNetworkSampler
 from ..model_components.renderers import RGBLambertianRendererWithVisibility
-from ..utils.utils import linear_to_sRGB, to_device_async
+from ..utils.utils import device_rng_seed, linear_to_sRGB, to_device_async
 from ..plugin import ModelBase
 
 
@@ -475,16 +475,18 @@ class NeuSkyFactoModel(ModelBase):
                 lin = [torch.linspace(float(mn[i]), float(mx[i]), res) for i in range(3)]
                 X, Y, Z = torch.meshgrid(*lin, indexing="ij")
                 self._grid_lattice = torch.stack((X, Y, Z), -1).reshape(-1, 3).to(dev)
-                self._grid_gap = torch.tensor([(float(mx[i]) - float(mn[i])) / res for i in range(3)]).to(dev)
+                self._grid_gap_host = [(float(mx[i]) - float(mn[i])) / res for i in range(3)]
+                self._grid_gap = torch.tensor(self._grid_gap_host).to(dev)
+                self._grid_rng = (device_rng_seed(3), torch.zeros(1, dtype=torch.int64, device=dev))
                 self._grid_cache_key = key
             gap = self._grid_gap
             if randoms is not None and "grid_perturb" in randoms:
                 perturb, gdir = randoms["grid_perturb"].to(dev), randoms["grid_dirs"].to(dev)
-            else:  # the reference draws these on the CPU every step (:704-712); drawn on the device here
-                perturb = torch.rand(self._grid_lattice.shape, device=dev)
-                gdir = torch.randn(self._grid_lattice.shape, device=dev)
-            positions = self._grid_lattice + (perturb * gap - gap / 2)
-            gdir = gdir / torch.norm(gdir, dim=-1, keepdim=True)
+                positions = self._grid_lattice + (perturb * gap - gap / 2)
+                gdir = gdir / torch.norm(gdir, dim=-1, keepdim=True)
+            else:  # the reference draws these on the CPU every step (:704-712); drawn in one kernel here (csrc/samplers.hip)
+                positions, gdir = torch.empty_like(self._grid_lattice), torch.empty_like(self._grid_lattice)
+                hip.grid_probe_points(self._grid_lattice, self._grid_gap_host, self._grid_rng[0], self._grid_rng[1], positions, gdir)
             P = positions.shape[0]
             grid_samples = RaySamples(frustums=Frustums(origins=positions, directions=gdir, starts=torch.zeros(P, 1, device=dev),
                                                         ends=torch.zeros(P, 1, device=dev), pixel_area=None), deltas=gap)

@@ -211,3 +211,33 @@ def test_pdf_sample_indices_bit_exact_against_float32_torch(n0, nb):
     got_bins, got_inds = hip.pdf_sample(weights.to(DEV), bins.to(DEV), u.to(DEV), jitter.reshape(-1).to(DEV), nb, want_inds=True)
     assert torch.equal(got_inds.cpu().long(), want_inds)
     assert torch.allclose(got_bins.cpu(), want_bins, atol=1e-6)
+
+
+def test_grid_probe_points_distribution():
+    """neusky_model.py:704-724: jitter uniform inside each lattice cell, directions uniform on the sphere, fresh draws per call"""
+    from neusky_amd import hip
+    res = 10
+    lin = torch.linspace(-1.0, 1.0, res)
+    lattice = torch.stack(torch.meshgrid(lin, lin, lin, indexing="ij"), -1).reshape(-1, 3).to(DEV)
+    gap = [0.2, 0.2, 0.25]
+    counter = torch.zeros(1, dtype=torch.int64, device=DEV)
+    pos, dirs = torch.empty_like(lattice), torch.empty_like(lattice)
+    draws = []
+    for _ in range(40):
+        hip.grid_probe_points(lattice, gap, 1234, counter, pos, dirs)
+        draws.append(((pos - lattice).cpu(), dirs.cpu().clone()))
+    assert int(counter) == 40
+    off = torch.stack([d[0] for d in draws])  # [40, 1000, 3]
+    g = torch.tensor(gap)
+    assert bool((off.abs() <= g / 2 + 1e-6).all())
+    u = off / g + 0.5  # ~ U(0, 1)
+    assert (u.mean((0, 1)) - 0.5).abs().max() < 0.01 and (u.var((0, 1)) - 1.0 / 12.0).abs().max() < 0.005
+    d = torch.stack([d[1] for d in draws])
+    assert torch.allclose(d.norm(dim=-1), torch.ones(40, 1000), atol=1e-5)
+    assert d.mean((0, 1)).abs().max() < 0.02 and (d.var((0, 1)) - 1.0 / 3.0).abs().max() < 0.01
+    assert (draws[0][0] - draws[1][0]).abs().max() > 1e-3
+    # same seed and call number -> the same draw
+    c2 = torch.zeros(1, dtype=torch.int64, device=DEV)
+    p2, d2 = torch.empty_like(lattice), torch.empty_like(lattice)
+    hip.grid_probe_points(lattice, gap, 1234, c2, p2, d2)
+    assert torch.equal((p2 - lattice).cpu(), draws[0][0]) and torch.equal(d2.cpu(), draws[0][1])
