@@ -527,6 +527,13 @@ int nsky_main_losses_bwd(const nsky_main_losses_desc* d, const float* wsum, cons
                          float* d_weights, float* d_normal, float* d_hdr_bg, float* d_grid, float* d_sdf_term, float* d_vis_thr,
                          nsky_stream_t stream);
 
+
+/* Scalar training metrics of a model in one launch: out[0] = 10 log10(peak_sq / mean(((pred - gt) mask)^2)) over n elements (mask
+ * optional: PSNR of neusky_model.py:1066-1068 with peak 1; depth PSNR of ddf_model.py:381-405 with peak = the DDF radius and the batch
+ * mask); with variance (the NeuS deviation parameter, 1 float): out[1] = clip(exp(10 v), 1e-6, 1e6), out[2] = 1 / out[1]
+ * (neusky_model.py:1071-1072).  None of it is differentiated. */
+int nsky_train_metrics(const float* pred, const float* gt, const float* mask, int64_t n, float peak_sq, const float* variance, float* out,
+                       nsky_stream_t stream);
 /* DDF model, get_loss_dict, neusky/models/ddf_model.py:407-493:
  *   terms[5] = { depth L1 x scene-centre weight (:427-433), sdf L2, sdf L1, multi-view hinge^2 with the reference's
  *                [M] - [M,1] -> [M,M] broadcast (:475-483), sky-ray L1 (:485-490) }, unscaled. */

@@ -327,6 +327,36 @@ int grid_for(long total) {
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
+// The scalar training metrics of one model in ONE launch (one workgroup): PSNR = 10 log10(peak^2 / mean(((pred - gt) mask)^2))
+// (neusky_model.py:1066-1068 with peak = 1, no mask; ddf_model.py:381-405 with peak = the DDF radius and the batch mask), and, when the
+// NeuS variance parameter is handed in, s_val = clip(exp(10 v), 1e-6, 1e6) and 1 / s_val (neusky_model.py:1071-1072).
+__global__ __launch_bounds__(1024) void train_metrics_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                             const float* __restrict__ mask, long n, float peak_sq,
+                                                             const float* __restrict__ variance, float* __restrict__ out) {
+  __shared__ double red[16];
+  double acc = 0.0;
+  for (long i = threadIdx.x; i < n; i += 1024) {
+    const float m = mask ? mask[i] : 1.0f;
+    const float d = pred[i] * m - gt[i] * m;
+    acc += (double)(d * d);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    const float mse = (float)(t / (double)n);
+    out[0] = 10.0f * log10f(peak_sq / mse);
+    if (variance) {
+      const float sv = fminf(fmaxf(expf(variance[0] * 10.0f), 1e-6f), 1e6f);
+      out[1] = sv;
+      out[2] = 1.0f / sv;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int nsky_main_losses_fwd(const nsky_main_losses_desc* d, float* terms, float* wsum, nsky_stream_t stream) {
@@ -379,5 +409,13 @@ extern "C" int nsky_ddf_losses_bwd(const nsky_ddf_losses_desc* d, const float* d
   hipLaunchKernelGGL(ddf_losses_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *d, d_terms, d_expected, d_sdf,
                      d_mv_expected, d_sky_expected, d_term, d_mv_term);
   NSKY_CHECK_LAUNCH("nsky_ddf_losses_bwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_train_metrics(const float* pred, const float* gt, const float* mask, int64_t n, float peak_sq, const float* variance, float* out,
+                                  nsky_stream_t stream) {
+  NSKY_CHECK_ARG(pred && gt && out && n > 0 && peak_sq > 0.0f, "nsky_train_metrics: bad argument");
+  hipLaunchKernelGGL(train_metrics_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, gt, mask, (long)n, peak_sq, variance, out);
+  NSKY_CHECK_LAUNCH("nsky_train_metrics");
   return NSKY_OK;
 }

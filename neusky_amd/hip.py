@@ -690,6 +690,20 @@ def ray_points_bwd(dirs, sign, d_out, d_t):
     check(_ray_points_bwd(ptr(dirs), dirs.shape[0], float(sign), ptr(d_out), n, ptr(d_t), stream_ptr()), "nsky_ray_points_bwd")
 
 
+_train_metrics = _sig("nsky_train_metrics", C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p)
+
+
+def train_metrics(pred, gt, mask, peak_sq, variance=None):
+    """-> out [3] float32: [PSNR-like 10 log10(peak_sq / mse of the (masked) difference), s_val, 1 / s_val] (the last two when
+    variance is given); pred / gt / mask contiguous with the same number of elements"""
+    n = pred.numel()
+    assert pred.is_contiguous() and gt.is_contiguous() and gt.numel() == n and (mask is None or (mask.is_contiguous() and mask.numel() == n))
+    assert pred.dtype == gt.dtype == torch.float32 and (mask is None or mask.dtype == torch.float32)
+    out = torch.empty(3, device=pred.device)
+    check(_train_metrics(ptr(pred), ptr(gt), ptr(mask), n, float(peak_sq), ptr(variance), ptr(out), stream_ptr()), "nsky_train_metrics")
+    return out
+
+
 class Segment(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int64)]
 

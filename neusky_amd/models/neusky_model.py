@@ -600,11 +600,21 @@ class NeuSkyFactoModel(ModelBase):
     def get_metrics_dict(self, outputs, batch) -> Dict[str, Any]:
         """neusky_model.py:1064-1077"""
         image = batch["image"].to(self.device)
-        mse = F.mse_loss(outputs["rgb"].detach(), image)
-        m: Dict[str, Any] = {"psnr": -10.0 * torch.log10(mse)}
+        rgb = outputs["rgb"].detach()
+        if rgb.is_cuda and rgb.dtype == torch.float32 and image.dtype == torch.float32 and rgb.shape == image.shape:
+            # psnr, s_val and 1 / s_val from one launch (hip.train_metrics) instead of nine
+            v = self.field.deviation_network.variance.detach() if self.training else None
+            mv = hip.train_metrics(rgb.contiguous(), image.contiguous(), None, 1.0, v)
+            m: Dict[str, Any] = {"psnr": mv[0]}
+            if self.training:
+                m["s_val"], m["inv_s"] = mv[1:2], mv[2:3]
+        else:
+            mse = F.mse_loss(rgb, image)
+            m = {"psnr": -10.0 * torch.log10(mse)}
+            if self.training:
+                m["s_val"] = self.field.deviation_network.get_variance().detach()
+                m["inv_s"] = 1.0 / m["s_val"]
         if self.training:
-            m["s_val"] = self.field.deviation_network.get_variance().detach()
-            m["inv_s"] = 1.0 / m["s_val"]
             if self.config.visibility_threshold == "learnable" and self.visibility_field is not None:
                 m["visibility_threshold"] = self.visibility_threshold.detach()
         return m

@@ -101,3 +101,25 @@ def test_ddf_loss_terms_and_gradients(circ, inv):
         assert a.shape == b.shape
         err = (a.cpu().double() - b).abs().max().item()
         assert err <= 3e-5 * max(b.abs().max().item(), 1e-12), (name, err)
+
+
+def test_train_metrics_kernel_matches_torch():
+    DEV = "cuda:0"
+    """hip.train_metrics against the torch expressions of neusky_model.py:1064-1072 and ddf_model.py:381-405"""
+    import torch.nn.functional as F
+    from neusky_amd import hip
+    g = torch.Generator().manual_seed(12)
+    rgb, image = torch.rand(1024, 3, generator=g), torch.rand(1024, 3, generator=g)
+    v = torch.tensor([0.3])
+    out = hip.train_metrics(rgb.to(DEV), image.to(DEV), None, 1.0, v.to(DEV)).cpu()
+    assert abs(float(out[0]) - float(-10.0 * torch.log10(F.mse_loss(rgb.double(), image.double())))) < 1e-4
+    s_val = torch.exp(v * 10.0).clip(1e-6, 1e6)
+    assert torch.allclose(out[1], s_val[0], rtol=1e-6) and torch.allclose(out[2], 1.0 / s_val[0], rtol=1e-6)
+    M = 262144 + 77
+    pred, gt = torch.rand(M, generator=g) * 2, torch.rand(M, 1, generator=g) * 2
+    mask = (torch.rand(M, 1, generator=g) > 0.3).float()
+    got = float(hip.train_metrics(pred.to(DEV), gt.to(DEV), mask.to(DEV), 4.0)[0])
+    want = float(10 * torch.log10(4.0 / F.mse_loss(pred.double().unsqueeze(1) * mask.double(), gt.double() * mask.double())))
+    assert abs(got - want) < 1e-4
+    # clip of the variance
+    assert float(hip.train_metrics(rgb.to(DEV), image.to(DEV), None, 1.0, torch.tensor([5.0], device=DEV))[1]) == 1e6
