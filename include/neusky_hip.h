@@ -232,6 +232,14 @@ int nsky_ray_reduce_bwd(const float* weights, const float* starts, const float* 
                         const float* d_accumulation, const float* d_normal, const float* d_albedo_acc, float* d_weights,
                         float* d_normals, float* d_albedo, nsky_stream_t stream);
 
+
+/* NeuS alphas of P isolated samples for three interval lengths each (the hash-grid density probe, neusky_model.py:715-732:
+ * nerfstudio SDFField.get_alpha with `deltas` = the three axis gaps broadcast against [P,1]): alphas [P,3]; backward to sdf [P],
+ * gradients [P,3] and the variance parameter (d_variance += ; may be NULL).  gap3_host: three floats in HOST memory. */
+int nsky_point_alphas_fwd(const float* sdf, const float* grad, const float* dirs, const float* gap3_host, const float* variance, float anneal,
+                          int32_t P, float* alphas, nsky_stream_t stream);
+int nsky_point_alphas_bwd(const float* sdf, const float* grad, const float* dirs, const float* gap3_host, const float* variance, float anneal,
+                          int32_t P, const float* d_alphas, float* d_sdf, float* d_grad, float* d_variance, nsky_stream_t stream);
 /* Points along rays: out[i] = origins[i] + sign t[i] dirs[i % n_dirs] (the DDF's predicted termination points: ddf_model.py:243,
  * neusky_model.py:1716-1724 with the R x Dv visibility rows sharing their Dv directions), and its backward
  * d_t[i] = sign <d_out[i], dirs[i % n_dirs]> (origins and directions carry no gradient on this path). */

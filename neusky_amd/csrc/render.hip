@@ -354,6 +354,60 @@ __global__ __launch_bounds__(256) void neus_weights_bwd_kernel(const float* __re
   if (lane == 0 && d_variance && invs_pass) atomicAdd(d_variance, gvar * inv_s * 10.0f);
 }
 
+// NeuS alphas of isolated samples for three interval lengths each (the hash-grid density probe: SDFField.get_alpha with `deltas` = the
+// three axis gaps broadcast against [P,1], neusky_model.py:715-732): alphas[p][a] for gap a, and the backward to sdf, gradients, variance.
+__global__ void point_alphas_fwd_kernel(const float* __restrict__ sdf, const float* __restrict__ grad, const float* __restrict__ dirs,
+                                        float g0, float g1, float g2, const float* __restrict__ variance, float anneal, int P,
+                                        float* __restrict__ alphas) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const float inv_s = fminf(fmaxf(expf(variance[0] * 10.0f), 1e-6f), 1e6f);
+  const float g[3] = {grad[3 * p], grad[3 * p + 1], grad[3 * p + 2]}, d[3] = {dirs[3 * p], dirs[3 * p + 1], dirs[3 * p + 2]};
+  const float gaps[3] = {g0, g1, g2};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) alphas[3 * p + a] = neus_alpha_terms(sdf[p], g, d, gaps[a], inv_s, anneal).alpha;
+}
+
+__global__ void point_alphas_bwd_kernel(const float* __restrict__ sdf, const float* __restrict__ grad, const float* __restrict__ dirs,
+                                        float g0, float g1, float g2, const float* __restrict__ variance, float anneal, int P,
+                                        const float* __restrict__ d_alphas, float* __restrict__ d_sdf, float* __restrict__ d_grad,
+                                        float* __restrict__ d_variance) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const float e10 = expf(variance[0] * 10.0f);
+  const float inv_s = fminf(fmaxf(e10, 1e-6f), 1e6f);
+  const bool invs_pass = (e10 >= 1e-6f && e10 <= 1e6f);
+  float gvar = 0.0f;
+  if (p < P) {
+    const float sd = sdf[p];
+    const float g[3] = {grad[3 * p], grad[3 * p + 1], grad[3 * p + 2]}, d[3] = {dirs[3 * p], dirs[3 * p + 1], dirs[3 * p + 2]};
+    const float gaps[3] = {g0, g1, g2};
+    float gs = 0.0f, gg[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const AlphaTerms t = neus_alpha_terms(sd, g, d, gaps[a], inv_s, anneal);
+      if (!t.clip_pass) continue;
+      const float galpha = d_alphas[3 * p + a];
+      const float den = t.prev_cdf + 1e-5f;
+      const float av = (t.prev_cdf - t.next_cdf + 1e-5f) / den;
+      const float gc = galpha * ((1.0f - av) / den) * t.prev_cdf * (1.0f - t.prev_cdf);
+      const float gn = galpha * (-1.0f / den) * t.next_cdf * (1.0f - t.next_cdf);
+      const float prv = sd - t.ic * gaps[a] * 0.5f, nxt = sd + t.ic * gaps[a] * 0.5f;
+      gs += (gc + gn) * inv_s;
+      gvar += gc * prv + gn * nxt;
+      const float gic = (gn - gc) * inv_s * gaps[a] * 0.5f;
+      float dic = 0.0f;
+      if (-t.cosv * 0.5f + 0.5f > 0.0f) dic += 0.5f * (1.0f - anneal);
+      if (-t.cosv > 0.0f) dic += anneal;
+      const float gcos = gic * dic;
+      gg[0] += gcos * d[0]; gg[1] += gcos * d[1]; gg[2] += gcos * d[2];
+    }
+    d_sdf[p] = gs;
+    d_grad[3 * p] = gg[0]; d_grad[3 * p + 1] = gg[1]; d_grad[3 * p + 2] = gg[2];
+  }
+  gvar = wave_sum(gvar);
+  if ((threadIdx.x & 63) == 0 && d_variance && invs_pass && gvar != 0.0f) atomicAdd(d_variance, gvar * inv_s * 10.0f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // DDF visibility ray set-up: thread per (ray, selected direction)
 // ------------------------------------------------------------------------------------------------
@@ -984,5 +1038,26 @@ extern "C" int nsky_ray_points_bwd(const float* dirs, int32_t n_dirs, float sign
   NSKY_CHECK_ARG(dirs && d_out && d_t && n > 0 && n_dirs > 0, "nsky_ray_points_bwd: bad argument");
   hipLaunchKernelGGL(ray_points_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, dirs, n_dirs, sign, d_out, (long)n, d_t);
   NSKY_CHECK_LAUNCH("nsky_ray_points_bwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_point_alphas_fwd(const float* sdf, const float* grad, const float* dirs, const float* gap3_host, const float* variance,
+                                     float anneal, int32_t P, float* alphas, nsky_stream_t stream) {
+  if (P == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(sdf && grad && dirs && gap3_host && variance && alphas && P > 0, "nsky_point_alphas_fwd: bad argument");
+  hipLaunchKernelGGL(point_alphas_fwd_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, (hipStream_t)stream, sdf, grad, dirs, gap3_host[0], gap3_host[1],
+                     gap3_host[2], variance, anneal, P, alphas);
+  NSKY_CHECK_LAUNCH("nsky_point_alphas_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_point_alphas_bwd(const float* sdf, const float* grad, const float* dirs, const float* gap3_host, const float* variance,
+                                     float anneal, int32_t P, const float* d_alphas, float* d_sdf, float* d_grad, float* d_variance,
+                                     nsky_stream_t stream) {
+  if (P == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(sdf && grad && dirs && gap3_host && variance && d_alphas && d_sdf && d_grad && P > 0, "nsky_point_alphas_bwd: bad argument");
+  hipLaunchKernelGGL(point_alphas_bwd_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, (hipStream_t)stream, sdf, grad, dirs, gap3_host[0], gap3_host[1],
+                     gap3_host[2], variance, anneal, P, d_alphas, d_sdf, d_grad, d_variance);
+  NSKY_CHECK_LAUNCH("nsky_point_alphas_bwd");
   return NSKY_OK;
 }

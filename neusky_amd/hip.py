@@ -704,6 +704,27 @@ def train_metrics(pred, gt, mask, peak_sq, variance=None):
     return out
 
 
+_point_alphas_fwd = _sig("nsky_point_alphas_fwd", C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_void_p, C.c_float, C.c_int32,
+                         C.c_void_p, C.c_void_p)
+_point_alphas_bwd = _sig("nsky_point_alphas_bwd", C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_void_p, C.c_float, C.c_int32,
+                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+
+
+def point_alphas_fwd(sdf, grad, dirs, gaps, variance, anneal, alphas):
+    P = sdf.numel()
+    assert sdf.is_contiguous() and grad.is_contiguous() and dirs.is_contiguous() and alphas.is_contiguous() and alphas.shape == (P, 3)
+    g3 = (C.c_float * 3)(*[float(v) for v in gaps])
+    check(_point_alphas_fwd(ptr(sdf), ptr(grad), ptr(dirs), g3, ptr(variance), float(anneal), P, ptr(alphas), stream_ptr()), "nsky_point_alphas_fwd")
+
+
+def point_alphas_bwd(sdf, grad, dirs, gaps, variance, anneal, d_alphas, d_sdf, d_grad, d_variance):
+    P = sdf.numel()
+    assert d_alphas.is_contiguous() and d_sdf.is_contiguous() and d_grad.is_contiguous()
+    g3 = (C.c_float * 3)(*[float(v) for v in gaps])
+    check(_point_alphas_bwd(ptr(sdf), ptr(grad), ptr(dirs), g3, ptr(variance), float(anneal), P, ptr(d_alphas), ptr(d_sdf), ptr(d_grad),
+                            ptr(d_variance), stream_ptr()), "nsky_point_alphas_bwd")
+
+
 class Segment(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int64)]
 

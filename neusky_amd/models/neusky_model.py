@@ -487,26 +487,17 @@ class NeuSkyFactoModel(ModelBase):
             else:  # the reference draws these on the CPU every step (:704-712); drawn in one kernel here (csrc/samplers.hip)
                 positions, gdir = torch.empty_like(self._grid_lattice), torch.empty_like(self._grid_lattice)
                 hip.grid_probe_points(self._grid_lattice, self._grid_gap_host, self._grid_rng[0], self._grid_rng[1], positions, gdir)
-            P = positions.shape[0]
-            grid_samples = RaySamples(frustums=Frustums(origins=positions, directions=gdir, starts=torch.zeros(P, 1, device=dev),
-                                                        ends=torch.zeros(P, 1, device=dev), pixel_area=None), deltas=gap)
             # (sic) the reference hands `deltas=gap` ([3]) to get_alpha, which broadcasts [P,1]*[3] -> three alphas
             # per point, one per axis gap (equal for the cubic scene box) (:715-724, :732)
-            out["grid_density"] = self._grid_alpha(grid_samples)
+            out["grid_density"] = self._grid_alpha(positions, gdir)
         return out
 
-    def _grid_alpha(self, grid_samples: RaySamples) -> torch.Tensor:
-        """three alphas per probe point, one per axis gap (SDFField.get_alpha on isolated samples, :715-732): the 3 P (point, gap)
-        pairs are 3 P one-sample rays of ONE NeuS launch (with a single sample the weight is the alpha)"""
-        x = grid_samples.frustums.origins
-        d = grid_samples.frustums.directions
-        sdf, grad, _ = self.field.field_values(x, want_albedo=False)
-        P = x.shape[0]
-        rep = lambda t, w: t.reshape(1, P, w).expand(3, P, w).reshape(3 * P, w)  # noqa: E731  (row a P + p = gap a, point p)
-        ends = grid_samples.deltas.reshape(3, 1, 1).expand(3, P, 1).reshape(3 * P, 1)
-        w, _, _, _ = ops.NeusWeightsFn.apply(rep(sdf, 1), rep(grad, 3).reshape(3 * P, 1, 3), rep(d, 3), ops.zeros(3 * P, 1, device=x.device), ends,
-                                             self.field.deviation_network.variance, self.field._cos_anneal_ratio)
-        return w.reshape(3, P).t()
+    def _grid_alpha(self, positions: torch.Tensor, directions: torch.Tensor) -> torch.Tensor:
+        """three alphas per probe point, one per axis gap (SDFField.get_alpha on isolated samples with `deltas` = the [3] gaps
+        broadcast against [P,1], :715-732) from one kernel each way (ops.PointAlphasFn)"""
+        sdf, grad, _ = self.field.field_values(positions, want_albedo=False)
+        return ops.PointAlphasFn.apply(sdf, grad, directions, self._grid_gap_host, self.field.deviation_network.variance,
+                                       self.field._cos_anneal_ratio)
 
     # ------------------------------------------------------------------ outputs
     def get_outputs(self, ray_bundle: RayBundle, batch=None, rotation=None, step=None, randoms=None) -> Dict[str, Any]:

@@ -1095,6 +1095,29 @@ class RENIOutputFn(torch.autograd.Function):
         return d_raw, d_scale, None, None, None
 
 
+class PointAlphasFn(torch.autograd.Function):
+    """NeuS alphas [P,3] of P isolated samples for three interval lengths (hip.point_alphas_*; the hash-grid density probe,
+    neusky_model.py:715-732); differentiable w.r.t. sdf, gradients and the variance parameter"""
+
+    @staticmethod
+    def forward(ctx, sdf, grad, dirs, gaps, variance, anneal):
+        s, g, d = sdf.detach().reshape(-1).contiguous(), grad.detach().reshape(-1, 3).contiguous(), dirs.detach().reshape(-1, 3).contiguous()
+        alphas = torch.empty(s.numel(), 3, device=s.device)
+        hip.point_alphas_fwd(s, g, d, gaps, variance, anneal, alphas)
+        ctx.save_for_backward(s, g, d, variance)
+        ctx.cfg = (tuple(float(v) for v in gaps), float(anneal), tuple(sdf.shape), tuple(grad.shape))
+        return alphas
+
+    @staticmethod
+    def backward(ctx, d_alphas):
+        s, g, d, variance = ctx.saved_tensors
+        gaps, anneal, sdf_shape, grad_shape = ctx.cfg
+        d_sdf, d_grad = torch.empty_like(s), torch.empty_like(g)
+        d_var = zeros_like(variance)
+        hip.point_alphas_bwd(s, g, d, gaps, variance, anneal, d_alphas.contiguous(), d_sdf, d_grad, d_var)
+        return d_sdf.view(sdf_shape), d_grad.view(grad_shape), None, None, d_var, None
+
+
 class TermPointsFn(torch.autograd.Function):
     """The DDF's predicted termination points of the visibility rows and (optionally) of the fit rays, in ONE [M + N, 3] buffer:
     sphere_pts[m] - sel_dirs[m % Dv] t_hat[m]  |  fit_pos[n] + fit_dirs[n] t_main[n]   (neusky_model.py:1716-1724, ddf_model.py:243);

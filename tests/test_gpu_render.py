@@ -264,3 +264,33 @@ def test_interlevel_kernel_matches_torch_formulation():
         got.backward()
         gref = wp64.grad
         assert (wp32.grad.double() - gref).abs().max().item() < 2e-5 * gref.abs().max().item()
+
+
+def test_point_alphas_match_neus_weights_of_single_samples():
+    """ops.PointAlphasFn (the hash-grid probe's three per-axis alphas) against ops.NeusWeightsFn on 3 P one-sample rays, values and
+    every gradient (with a single sample the weight is the alpha)"""
+    from neusky_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(21)
+    P = 777
+    sdf = (torch.randn(P, generator=g) * 0.05).to(dev)
+    grad = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1).to(dev)
+    dirs = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1).to(dev)
+    gaps = [0.2, 0.15, 0.3]
+    probe = torch.randn(P, 3, generator=g).to(dev)
+    outs = []
+    for which in (0, 1):
+        s, gr = sdf.clone().requires_grad_(True), grad.clone().requires_grad_(True)
+        var = torch.tensor([0.35], device=dev, requires_grad=True)
+        if which == 0:
+            a = ops.PointAlphasFn.apply(s, gr, dirs, gaps, var, 0.6)
+        else:
+            rep = lambda t, w: t.reshape(1, P, w).expand(3, P, w).reshape(3 * P, w)  # noqa: E731
+            ends = torch.tensor(gaps, device=dev).reshape(3, 1, 1).expand(3, P, 1).reshape(3 * P, 1)
+            w, _, _, _ = ops.NeusWeightsFn.apply(rep(s, 1), rep(gr, 3).reshape(3 * P, 1, 3), rep(dirs, 3), torch.zeros(3 * P, 1, device=dev),
+                                                 ends, var, 0.6)
+            a = w.reshape(3, P).t()
+        (a * probe).sum().backward()
+        outs.append((a.detach(), s.grad, gr.grad, var.grad))
+    for x, y in zip(*outs):
+        assert torch.allclose(x, y, rtol=1e-5, atol=2e-6 * float(y.abs().max())), float((x - y).abs().max())  # (the three gaps' terms sum in another order)
