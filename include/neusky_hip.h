@@ -500,6 +500,9 @@ int nsky_weight_norm_bwd(const float* d_out, int32_t ldo, const float* v, const 
  * kernel per parameter (nerfstudio Optimizers.zero_grad_all / optimizer_scheduler_step_all around neusky_config.py:216-237). */
 typedef struct { const float* src; float* dst; int64_t n; } nsky_segment;
 int nsky_gather_segments(const nsky_segment* segments, int32_t n_segments, nsky_stream_t stream);
+/* The same for byte runs of any element type (host arrays of device pointers and byte counts): the next step's input tensors into the
+ * static buffers a captured graph reads (nerfstudio's datamanager.next_train hand-over), one launch instead of one copy per tensor. */
+int nsky_copy_segments(const void* const* src, void* const* dst, const int64_t* nbytes, int32_t n_segments, nsky_stream_t stream);
 
 /* Adam update (torch.optim.Adam semantics, no weight decay / amsgrad) over a flat slab of n floats;
  * the five optimizer groups of neusky/configs/neusky_config.py:216-237.  grad_scale multiplies g first. */

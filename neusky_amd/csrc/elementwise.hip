@@ -296,26 +296,49 @@ __global__ __launch_bounds__(256) void softplus_tangent_bwd4_kernel(const float*
   }
 }
 
-// gradients autograd left in tensors of its own -> their places in the optimizer slab, one launch for all of them
+// Many small device-to-device copies as ONE launch (byte runs): the parameter gradients autograd left in tensors of its own -> their
+// places in the optimizer slab; the next step's input tensors -> the static buffers a captured graph reads.
 constexpr int GATHER_MAX = 64;
 struct GatherArgs {
-  const float* src[GATHER_MAX];
-  float* dst[GATHER_MAX];
-  long n[GATHER_MAX];
+  const unsigned char* src[GATHER_MAX];
+  unsigned char* dst[GATHER_MAX];
+  long n[GATHER_MAX];  // bytes
 };
 __global__ __launch_bounds__(256) void gather_segments_kernel(const GatherArgs a) {
   const int s = blockIdx.y;
-  const float* __restrict__ src = a.src[s];
-  float* __restrict__ dst = a.dst[s];
+  const unsigned char* __restrict__ src = a.src[s];
+  unsigned char* __restrict__ dst = a.dst[s];
   const long n = a.n[s];
   const long stride = (long)gridDim.x * 256, t0 = (long)blockIdx.x * 256 + threadIdx.x;
-  if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+  const uintptr_t both = (uintptr_t)src | (uintptr_t)dst;
+  if ((both & 15) == 0) {
+    const long n16 = n >> 4;
+    for (long i = t0; i < n16; i += stride) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    for (long i = 16 * n16 + t0; i < n; i += stride) dst[i] = src[i];
+  } else if ((both & 3) == 0) {
     const long n4 = n >> 2;
-    for (long i = t0; i < n4; i += stride) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    for (long i = t0; i < n4; i += stride) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(src)[i];
     for (long i = 4 * n4 + t0; i < n; i += stride) dst[i] = src[i];
   } else {
     for (long i = t0; i < n; i += stride) dst[i] = src[i];
   }
+}
+
+static int copy_segments_launch(const void* const* src, void* const* dst, const int64_t* nbytes, int count, hipStream_t stream, const char* who) {
+  for (int s0 = 0; s0 < count; s0 += GATHER_MAX) {
+    const int cnt = count - s0 < GATHER_MAX ? count - s0 : GATHER_MAX;
+    GatherArgs a;
+    long longest = 0;
+    for (int i = 0; i < cnt; ++i) {
+      NSKY_CHECK_ARG(nbytes[s0 + i] >= 0 && (nbytes[s0 + i] == 0 || (src[s0 + i] && dst[s0 + i])), "%s: segment %d", who, s0 + i);
+      a.src[i] = static_cast<const unsigned char*>(src[s0 + i]); a.dst[i] = static_cast<unsigned char*>(dst[s0 + i]); a.n[i] = nbytes[s0 + i];
+      longest = a.n[i] > longest ? a.n[i] : longest;
+    }
+    if (longest == 0) continue;
+    const long bx = (longest / 16 + 2047) / 2048;  // ~8 x 16 bytes per thread
+    hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)(bx < 1 ? 1 : (bx > 256 ? 256 : bx)), cnt), dim3(256), 0, stream, a);
+  }
+  return NSKY_OK;
 }
 
 }  // namespace
@@ -424,21 +447,19 @@ extern "C" int nsky_bins_to_samples(const float* sbins, const float* nears, cons
 }
 
 extern "C" int nsky_gather_segments(const nsky_segment* segments, int32_t n_segments, nsky_stream_t stream) {
-  NSKY_CHECK_ARG(n_segments >= 0 && (n_segments == 0 || segments), "nsky_gather_segments: bad argument");
-  for (int s0 = 0; s0 < n_segments; s0 += GATHER_MAX) {
-    const int cnt = n_segments - s0 < GATHER_MAX ? n_segments - s0 : GATHER_MAX;
-    GatherArgs a;
-    long longest = 0;
-    for (int i = 0; i < cnt; ++i) {
-      const nsky_segment& g = segments[s0 + i];
-      NSKY_CHECK_ARG(g.n >= 0 && (g.n == 0 || (g.src && g.dst)), "nsky_gather_segments: segment %d", s0 + i);
-      a.src[i] = g.src; a.dst[i] = g.dst; a.n[i] = g.n;
-      longest = g.n > longest ? g.n : longest;
-    }
-    if (longest == 0) continue;
-    const long bx = (longest / 4 + 2047) / 2048;  // ~8 float4 per thread
-    hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)(bx < 1 ? 1 : (bx > 256 ? 256 : bx)), cnt), dim3(256), 0, (hipStream_t)stream, a);
-  }
+  NSKY_CHECK_ARG(n_segments >= 0 && n_segments <= 4096 && (n_segments == 0 || segments), "nsky_gather_segments: bad argument");
+  if (n_segments == 0) return NSKY_OK;
+  const void* src[4096]; void* dst[4096]; int64_t nb[4096];
+  for (int i = 0; i < n_segments; ++i) { src[i] = segments[i].src; dst[i] = segments[i].dst; nb[i] = segments[i].n * (int64_t)sizeof(float); }
+  if (int rc = copy_segments_launch(src, dst, nb, n_segments, (hipStream_t)stream, "nsky_gather_segments")) return rc;
   NSKY_CHECK_LAUNCH("nsky_gather_segments");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_copy_segments(const void* const* src, void* const* dst, const int64_t* nbytes, int32_t n_segments, nsky_stream_t stream) {
+  NSKY_CHECK_ARG(n_segments >= 0 && (n_segments == 0 || (src && dst && nbytes)), "nsky_copy_segments: bad argument");
+  if (n_segments == 0) return NSKY_OK;
+  if (int rc = copy_segments_launch(src, dst, nbytes, n_segments, (hipStream_t)stream, "nsky_copy_segments")) return rc;
+  NSKY_CHECK_LAUNCH("nsky_copy_segments");
   return NSKY_OK;
 }

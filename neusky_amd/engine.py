@@ -240,17 +240,19 @@ class GraphedTrainStep:
         return loss.detach(), {k: v.detach() for k, v in loss_dict.items()}, metrics
 
     def load(self, ray_bundle, batch, sky=None) -> None:
-        """device-to-device copies of the next step's inputs into the graph's static buffers"""
-        self.rb.origins.copy_(ray_bundle.origins, non_blocking=True)
-        self.rb.directions.copy_(ray_bundle.directions, non_blocking=True)
-        self.rb.camera_indices.copy_(ray_bundle.camera_indices, non_blocking=True)
-        for k, v in ray_bundle.metadata.items():
-            self.rb.metadata[k].copy_(v, non_blocking=True)
-        self.batch["image"].copy_(batch["image"], non_blocking=True)
-        self.batch["mask"].copy_(batch["mask"], non_blocking=True)
+        """the next step's inputs into the graph's static buffers: ONE launch for all of them when they are already on the device
+        (hip.copy_segments), otherwise a copy per tensor (host batches)"""
+        pairs = [(ray_bundle.origins, self.rb.origins), (ray_bundle.directions, self.rb.directions),
+                 (ray_bundle.camera_indices, self.rb.camera_indices)]
+        pairs += [(v, self.rb.metadata[k]) for k, v in ray_bundle.metadata.items()]
+        pairs += [(batch["image"], self.batch["image"]), (batch["mask"], self.batch["mask"])]
         if sky is not None:
-            self.sky.origins.copy_(sky.origins, non_blocking=True)
-            self.sky.directions.copy_(sky.directions, non_blocking=True)
+            pairs += [(sky.origins, self.sky.origins), (sky.directions, self.sky.directions)]
+        if all(s.is_cuda and s.is_contiguous() and d.is_contiguous() and s.dtype == d.dtype and s.shape == d.shape for s, d in pairs):
+            hip.copy_segments(pairs)
+        else:
+            for s, d in pairs:
+                d.copy_(s, non_blocking=True)
 
     def step(self, step: int, ray_bundle=None, batch=None, sky=None):
         if ray_bundle is not None:

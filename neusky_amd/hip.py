@@ -743,6 +743,21 @@ def gather_segments(pairs):
     check(_gather_segments(arr, len(pairs), stream_ptr()), "nsky_gather_segments")
 
 
+_copy_segments = _sig("nsky_copy_segments", C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_void_p)
+
+
+def copy_segments(pairs):
+    """pairs: [(src, dst)] contiguous device tensors of equal dtype and numel: dst <- src for all of them in ONE launch"""
+    if not pairs:
+        return
+    n = len(pairs)
+    src, dst, nb = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_int64 * n)()
+    for i, (s_, d_) in enumerate(pairs):
+        assert s_.is_cuda and d_.is_cuda and s_.is_contiguous() and d_.is_contiguous() and s_.dtype == d_.dtype and s_.numel() == d_.numel()
+        src[i], dst[i], nb[i] = s_.data_ptr(), d_.data_ptr(), s_.numel() * s_.element_size()
+    check(_copy_segments(src, dst, nb, n, stream_ptr()), "nsky_copy_segments")
+
+
 class SdfNet(C.Structure):
     _fields_ = [("in_dim", C.c_int32), ("hidden", C.c_int32),
                 ("w0", C.c_void_p), ("ld0", C.c_int32), ("b0", C.c_void_p),

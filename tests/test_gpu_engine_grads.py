@@ -69,3 +69,19 @@ def test_optimizers_collect_grads_equals_accumulate_grad():
     opt.collect_grads()
     for p, f in zip(params, first):
         assert torch.allclose(p.grad, 2 * f, rtol=1e-5, atol=1e-7)
+
+
+def test_copy_segments_mixed_element_types():
+    """hip.copy_segments: byte runs of any dtype (the graphed step's input hand-over), aligned or not, one launch"""
+    from neusky_amd import hip
+    g = torch.Generator().manual_seed(3)
+    base = torch.randn(5000, generator=g).to(DEV)
+    srcs = [torch.randn(1024, 3, generator=g).to(DEV), torch.randint(0, 99, (1024, 1), generator=g).to(DEV),
+            (torch.rand(1024, 4, generator=g) > 0.5).to(DEV), torch.randn(1024, 1, generator=g).to(DEV),
+            base[1:4001], (torch.rand(333, generator=g) > 0.5).to(DEV), torch.randint(0, 255, (777,), generator=g, dtype=torch.uint8).to(DEV)]
+    dsts = [torch.zeros_like(s) for s in srcs]
+    dsts[4] = torch.zeros(4003, device=DEV)[3:]  # 4-byte aligned only
+    hip.copy_segments(list(zip(srcs, dsts)))
+    torch.cuda.synchronize()
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(s, d)
