@@ -340,7 +340,7 @@ int nsky_encode_fwd(const nsky_hashgrid_desc* g, const float* x, int32_t P, int3
 
 /* Backward of nsky_encode_fwd.  dY [P,lddy] = gradient w.r.t. the rows; dT (optional) [3][P][lddy] =
  * gradient w.r.t. the tangent rows (second-order path: eikonal / normals).  Accumulates (float adds, order not
- * fixed) into dtable [offset[L]][2]; dx (optional, [P,3], overwritten) = dY . d(row)/dx.
+ * fixed) into dtable [offset[L]][2] (NULL: a frozen table, only dx is formed); dx (optional, [P,3], overwritten) = dY . d(row)/dx.
  * workspace (optional): nsky_encode_bwd_workspace_bytes(g, P, dT != NULL) bytes of scratch, 256-byte aligned; with it, and at
  * least NSKY_ENCODE_BWD_OWNER_MIN_POINTS points, the table gradient is accumulated by chunk-owning workgroups in LDS
  * instead of by global atomics (same result up to the order of the float adds). */

@@ -824,11 +824,13 @@ extern "C" int nsky_encode_bwd(const nsky_hashgrid_desc* d, const float* x, int3
   Grid g;
   if (int rc = make_grid(d, g, "nsky_encode_bwd")) return rc;
   if (P == 0) return NSKY_OK;
-  NSKY_CHECK_ARG(x && dY && dtable && P > 0, "nsky_encode_bwd: null argument");
+  NSKY_CHECK_ARG(x && dY && (dtable || dx) && P > 0, "nsky_encode_bwd: null argument");
   NSKY_CHECK_ARG(mode >= 0 && mode <= 2 && pe_freqs >= 0 && pe_freqs <= 6, "nsky_encode_bwd: bad mode/pe_freqs");
   hipStream_t s = (hipStream_t)stream;
   const int feat0 = (include_x ? 3 : 0) + 6 * pe_freqs;
-  if (workspace != nullptr && P >= NSKY_ENCODE_BWD_OWNER_MIN_POINTS && owner_geometry_ok(g)) {
+  if (!dtable) {
+    // a frozen table: the input gradient alone
+  } else if (workspace != nullptr && P >= NSKY_ENCODE_BWD_OWNER_MIN_POINTS && owner_geometry_ok(g)) {
     // Many points: chunk owners for EVERY level (LDS accumulation, above).
     OwnerArgs oa;
     oa.g = g; oa.x = x; oa.dY = dY; oa.dT = dT; oa.dtable = dtable; oa.P = P; oa.mode = mode; oa.feat0 = feat0; oa.lddy = lddy;

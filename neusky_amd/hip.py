@@ -201,10 +201,10 @@ def encode_bwd(geom, table, x, mode, include_x, pe_freqs, pe_max_exp, dY, dT, dt
     P = x.shape[0]
     if dT is not None:
         assert dT.shape == (3, P, dY.shape[1]) and dT.is_contiguous() and dY.is_contiguous()
-    assert dtable.shape == table.shape and dtable.is_contiguous()
+    assert dtable is None or (dtable.shape == table.shape and dtable.is_contiguous())
     desc = grid_desc(geom, table)
     if isinstance(workspace, str):
-        nbytes = _encode_bwd_ws(C.byref(desc), P, int(dT is not None))
+        nbytes = _encode_bwd_ws(C.byref(desc), P, int(dT is not None)) if dtable is not None else 0
         workspace = torch.empty(nbytes // 4, dtype=torch.int32, device=x.device) if nbytes > 0 else None
     check(_encode_bwd(C.byref(desc), ptr(x), P, mode, int(include_x), pe_freqs, pe_max_exp, ptr(dY), ld(dY),
                       ptr(dT), ptr(dtable), ptr(dx), ptr(workspace), stream_ptr()), "nsky_encode_bwd")

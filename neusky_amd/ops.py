@@ -333,6 +333,12 @@ class HashEncodeFn(torch.autograd.Function):
     def backward(ctx, d_out):
         x, table = ctx.saved_tensors
         geom, mode, include_x, pe_freqs, pe_max_exp, tangents, need_dx, P, ldy = ctx.cfg
+        if not ctx.needs_input_grad[1]:  # a frozen table (the eval-latent fit): only the input gradient, no scatter
+            if not need_dx:
+                return None, None, None, None, None, None, None, None, None
+            dx = torch.empty(P, 3, device=x.device)
+            hip.encode_bwd(geom, table, x, mode, include_x, pe_freqs, pe_max_exp, d_out.contiguous()[:P], None, None, dx)
+            return dx, None, None, None, None, None, None, None, None
         d_out = d_out.contiguous()
         sink = ctx.sink
         accumulate = sink is not None and sink.grad is not None and sink.grad.is_contiguous() and sink.grad.numel() == table.numel()

@@ -155,3 +155,23 @@ def test_empty_and_bad_args():
     hip.encode_fwd(geom, table.to(DEV), x, 0, True, 0, 0.0, Y)  # P == 0 is a no-op
     with pytest.raises(hip.NeuSkyHipError):
         hip.encode_fwd(geom, table.to(DEV), torch.zeros(4, 3, device=DEV), 0, True, 0, 0.0, torch.zeros(4, 8, device=DEV))
+
+
+def test_frozen_table_backward_forms_only_the_input_gradient():
+    """a table that does not require grad (the eval-latent fit): no scatter, dx as with a trainable table"""
+    from neusky_amd import ops
+    from neusky_amd.encoding import HashGridGeometry
+    geom = HashGridGeometry(smoothstep=True)
+    torch.manual_seed(0)
+    table = ((torch.rand(geom.n_params, 2) * 2 - 1) * 1e-2).to("cuda:0")
+    x = (torch.rand(40000, 3) * 1.6 - 0.8).to("cuda:0")
+    probe = torch.randn(40000, 76).to("cuda:0")
+    outs = []
+    for trainable in (True, False):
+        t = table.clone().requires_grad_(trainable)
+        xi = x.clone().requires_grad_(True)
+        y = ops.HashEncodeFn.apply(xi, t, geom, 1, True, 6, 5.0, False, True)
+        (y * probe[:, :y.shape[1]]).sum().backward()
+        outs.append(xi.grad)
+        assert (t.grad is not None) == trainable
+    assert torch.equal(outs[0], outs[1])
