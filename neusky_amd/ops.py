@@ -849,6 +849,7 @@ class SDFValueFn(torch.autograd.Function):
     def _backward_fused(ctx, g_sdf):
         E, A0, A1, W0, b0, W1, b1, W2, b2 = ctx.saved_tensors
         M, Hd, Kin, GF, beta, train_w = ctx.cfg
+        train_w = train_w and any(ctx.needs_input_grad[1:7])  # (frozen weights -- the eval-latent fit -- take no gradient)
         dev = E.device
         net, stream, table = _sdf_stream(W0, b0, W1, b1, W2, b2, GF, beta, 1)
         Mp = hip.film_rows(M)
@@ -879,6 +880,7 @@ class SDFValueFn(torch.autograd.Function):
             return SDFValueFn._backward_fused(ctx, g_sdf)
         E, A0, S0, A1, S1, W0, b0, W1, b1, W2, b2 = ctx.saved_tensors
         M, Hd, Kin, GF, beta, train_w = ctx.cfg
+        train_w = train_w and any(ctx.needs_input_grad[1:7])
         dev = E.device
         g = zeros(M, 4, device=dev)
         g[:, 0] = g_sdf
