@@ -240,6 +240,11 @@ int nsky_point_alphas_fwd(const float* sdf, const float* grad, const float* dirs
                           int32_t P, float* alphas, nsky_stream_t stream);
 int nsky_point_alphas_bwd(const float* sdf, const float* grad, const float* dirs, const float* gap3_host, const float* variance, float anneal,
                           int32_t P, const float* d_alphas, float* d_sdf, float* d_grad, float* d_variance, nsky_stream_t stream);
+
+/* The DDF's output activation (neusky/fields/directional_distance_field.py:297-299): t [n] = scale sigmoid(raw[:, 0]) on the padded
+ * [n, ld] head output of the chain; backward d_raw [n, ld] = (d_t scale s (1 - s) | 0 ...). */
+int nsky_sigmoid_column_fwd(const float* raw, int32_t ld, int64_t n, float scale, float* t, nsky_stream_t stream);
+int nsky_sigmoid_column_bwd(const float* raw, int32_t ld, int64_t n, float scale, const float* d_t, float* d_raw, nsky_stream_t stream);
 /* Points along rays: out[i] = origins[i] + sign t[i] dirs[i % n_dirs] (the DDF's predicted termination points: ddf_model.py:243,
  * neusky_model.py:1716-1724 with the R x Dv visibility rows sharing their Dv directions), and its backward
  * d_t[i] = sign <d_out[i], dirs[i % n_dirs]> (origins and directions carry no gradient on this path). */

@@ -826,6 +826,22 @@ __global__ void normalize3_bwd_kernel(const float* __restrict__ g, const float* 
   }
 }
 
+// the DDF's output activation (directional_distance_field.py:297-299): t = scale sigmoid(raw[:, 0]) on the chain's padded [M, 4] head
+// output, and its backward as one [M, 4] matrix (columns 1..3 zero)
+__global__ void sigmoid_column_fwd_kernel(const float* __restrict__ raw, int ld, long n, float scale, float* __restrict__ t) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  t[i] = scale * sigmoidf_(raw[i * ld]);
+}
+__global__ void sigmoid_column_bwd_kernel(const float* __restrict__ raw, int ld, long n, float scale, const float* __restrict__ d_t,
+                                          float* __restrict__ d_raw) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float sg = sigmoidf_(raw[i * ld]);
+  d_raw[i * ld] = d_t[i] * scale * sg * (1.0f - sg);
+  for (int c = 1; c < ld; ++c) d_raw[i * ld + c] = 0.0f;
+}
+
 // points along rays: out[i] = o[i] + sign t[i] d[i % n_dirs] (the DDF's predicted termination points, ddf_model.py:243 and
 // neusky_model.py:1716-1724: sphere point minus the direction to the sun-side sample times the predicted distance), and d t
 __global__ void ray_points_fwd_kernel(const float* __restrict__ o, const float* __restrict__ d, int n_dirs, float sign,
@@ -1059,5 +1075,21 @@ extern "C" int nsky_point_alphas_bwd(const float* sdf, const float* grad, const 
   hipLaunchKernelGGL(point_alphas_bwd_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, (hipStream_t)stream, sdf, grad, dirs, gap3_host[0], gap3_host[1],
                      gap3_host[2], variance, anneal, P, d_alphas, d_sdf, d_grad, d_variance);
   NSKY_CHECK_LAUNCH("nsky_point_alphas_bwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_sigmoid_column_fwd(const float* raw, int32_t ld, int64_t n, float scale, float* t, nsky_stream_t stream) {
+  if (n == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(raw && t && ld >= 1 && n > 0, "nsky_sigmoid_column_fwd: bad argument");
+  hipLaunchKernelGGL(sigmoid_column_fwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, raw, ld, (long)n, scale, t);
+  NSKY_CHECK_LAUNCH("nsky_sigmoid_column_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_sigmoid_column_bwd(const float* raw, int32_t ld, int64_t n, float scale, const float* d_t, float* d_raw, nsky_stream_t stream) {
+  if (n == 0) return NSKY_OK;
+  NSKY_CHECK_ARG(raw && d_t && d_raw && ld >= 1 && ld <= 8 && n > 0, "nsky_sigmoid_column_bwd: bad argument");
+  hipLaunchKernelGGL(sigmoid_column_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, raw, ld, (long)n, scale, d_t, d_raw);
+  NSKY_CHECK_LAUNCH("nsky_sigmoid_column_bwd");
   return NSKY_OK;
 }

@@ -84,8 +84,8 @@ class DirectionalDistanceField(FieldBase):
         """fast path: xrow [M,16] already encoded (nsky_visibility_rays) -> expected termination distance [M]"""
         cond = ops.HashEncodeFn.apply(sphere_positions, self.position_encoding.table, self.geom, hip.MODE_RAW, True, 0, 0.0,
                                       False, False)  # [p | hash(p)] :267-268
-        out = self.ddf(xrow, cond)
-        return torch.sigmoid(out[:, 0]) * (2 * self.ddf_radius)  # :297-299
+        out = self.ddf(xrow, cond, padded_output=True)
+        return ops.SigmoidColumnFn.apply(out, 2 * self.ddf_radius)  # :297-299
 
     def get_outputs(self, ray_samples: RaySamples) -> Dict:
         origins = ray_samples.frustums.origins.reshape(-1, 3).contiguous()

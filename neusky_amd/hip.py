@@ -725,6 +725,20 @@ def point_alphas_bwd(sdf, grad, dirs, gaps, variance, anneal, d_alphas, d_sdf, d
                             ptr(d_variance), stream_ptr()), "nsky_point_alphas_bwd")
 
 
+_sig_col_fwd = _sig("nsky_sigmoid_column_fwd", C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_void_p)
+_sig_col_bwd = _sig("nsky_sigmoid_column_bwd", C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p)
+
+
+def sigmoid_column_fwd(raw, scale, t):
+    assert raw.dim() == 2 and raw.stride(1) == 1 and t.is_contiguous() and t.numel() == raw.shape[0]
+    check(_sig_col_fwd(ptr(raw), ld(raw), raw.shape[0], float(scale), ptr(t), stream_ptr()), "nsky_sigmoid_column_fwd")
+
+
+def sigmoid_column_bwd(raw, scale, d_t, d_raw):
+    assert d_raw.shape == raw.shape and d_raw.is_contiguous() and raw.is_contiguous() and d_t.is_contiguous()
+    check(_sig_col_bwd(ptr(raw), ld(raw), raw.shape[0], float(scale), ptr(d_t), ptr(d_raw), stream_ptr()), "nsky_sigmoid_column_bwd")
+
+
 class Segment(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int64)]
 

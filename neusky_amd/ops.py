@@ -1126,6 +1126,27 @@ class PointAlphasFn(torch.autograd.Function):
         return d_sdf.view(sdf_shape), d_grad.view(grad_shape), None, None, d_var, None
 
 
+class SigmoidColumnFn(torch.autograd.Function):
+    """t [M] = scale * sigmoid(raw[:, 0]) on a chain's padded [M, 4] head output (the DDF's termination distance,
+    directional_distance_field.py:297-299), one kernel each way (hip.sigmoid_column_*)"""
+
+    @staticmethod
+    def forward(ctx, raw, scale):
+        raw = raw.contiguous()
+        t = torch.empty(raw.shape[0], device=raw.device)
+        hip.sigmoid_column_fwd(raw, scale, t)
+        ctx.save_for_backward(raw)
+        ctx.scale = float(scale)
+        return t
+
+    @staticmethod
+    def backward(ctx, d_t):
+        raw, = ctx.saved_tensors
+        d_raw = torch.empty_like(raw)
+        hip.sigmoid_column_bwd(raw, ctx.scale, d_t.contiguous(), d_raw)
+        return d_raw, None
+
+
 class TermPointsFn(torch.autograd.Function):
     """The DDF's predicted termination points of the visibility rows and (optionally) of the fit rays, in ONE [M + N, 3] buffer:
     sphere_pts[m] - sel_dirs[m % Dv] t_hat[m]  |  fit_pos[n] + fit_dirs[n] t_main[n]   (neusky_model.py:1716-1724, ddf_model.py:243);

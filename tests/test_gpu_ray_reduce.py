@@ -97,3 +97,19 @@ def test_term_points_match_torch_autograd():
     # visibility rows only
     out2 = ops.TermPointsFn.apply(sp.to(DEV), sel.to(DEV), th.detach(), None, None, None)
     assert torch.equal(out2, out[:M].detach())
+
+
+def test_sigmoid_column_matches_torch():
+    """ops.SigmoidColumnFn (directional_distance_field.py:297-299) against torch.sigmoid(raw[:, 0]) * scale, values and gradient"""
+    from neusky_amd import ops
+    g = torch.Generator().manual_seed(31)
+    raw = torch.randn(5001, 4, generator=g) * 3
+    probe = torch.randn(5001, generator=g)
+    a = raw.to(DEV).requires_grad_(True)
+    t = ops.SigmoidColumnFn.apply(a, 2.5)
+    (t * probe.to(DEV)).sum().backward()
+    b = raw.double().requires_grad_(True)
+    ref = torch.sigmoid(b[:, 0]) * 2.5
+    (ref * probe.double()).sum().backward()
+    assert torch.allclose(t.detach().cpu().double(), ref.detach(), atol=1e-6)
+    assert torch.allclose(a.grad.cpu().double(), b.grad, atol=1e-6) and bool((a.grad[:, 1:] == 0).all())
