@@ -245,6 +245,17 @@ int nsky_point_alphas_bwd(const float* sdf, const float* grad, const float* dirs
  * [n, ld] head output of the chain; backward d_raw [n, ld] = (d_t scale s (1 - s) | 0 ...). */
 int nsky_sigmoid_column_fwd(const float* raw, int32_t ld, int64_t n, float scale, float* t, nsky_stream_t stream);
 int nsky_sigmoid_column_bwd(const float* raw, int32_t ld, int64_t n, float scale, const float* d_t, float* d_raw, nsky_stream_t stream);
+
+/* The proposal networks' density MLP (nerfstudio HashMLPDensityField, hidden_dim 16: Linear(in_dim, 16) + ReLU -> Linear(16, 1); called
+ * through ProposalNetworkSampler at neusky/models/neusky_model.py:561) on P hash-encoded rows feat [P, ldf]: raw [P] = the density
+ * head's pre-activation, both layers in registers.  Backward: d_raw [P] -> d_feat [P, ldf] (optional; pad columns zeroed) and the
+ * parameter gradients, ADDED into dw0 [16, ldw0] / db0 [16] / dw1 [16] / db1 [1] (caller zero-fills).  w0 [16, ldw0], w1 [16]: torch
+ * nn.Linear layout; hidden must be 16, in_dim <= 12. */
+int nsky_proposal_mlp_fwd(const float* feat, int32_t ldf, int64_t P, int32_t in_dim, int32_t hidden, const float* w0, int32_t ldw0,
+                          const float* b0, const float* w1, const float* b1, float* raw, nsky_stream_t stream);
+int nsky_proposal_mlp_bwd(const float* feat, int32_t ldf, int64_t P, int32_t in_dim, int32_t hidden, const float* w0, int32_t ldw0,
+                          const float* b0, const float* w1, const float* b1, const float* d_raw, float* d_feat, float* dw0, float* db0,
+                          float* dw1, float* db1, nsky_stream_t stream);
 /* Points along rays: out[i] = origins[i] + sign t[i] dirs[i % n_dirs] (the DDF's predicted termination points: ddf_model.py:243,
  * neusky_model.py:1716-1724 with the R x Dv visibility rows sharing their Dv directions), and its backward
  * d_t[i] = sign <d_out[i], dirs[i % n_dirs]> (origins and directions carry no gradient on this path). */

@@ -739,6 +739,32 @@ def sigmoid_column_bwd(raw, scale, d_t, d_raw):
     check(_sig_col_bwd(ptr(raw), ld(raw), raw.shape[0], float(scale), ptr(d_t), ptr(d_raw), stream_ptr()), "nsky_sigmoid_column_bwd")
 
 
+_prop_fwd = _sig("nsky_proposal_mlp_fwd", C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                 C.c_void_p, C.c_void_p, C.c_void_p)
+_prop_bwd = _sig("nsky_proposal_mlp_bwd", C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+
+
+def proposal_mlp_supported(in_dim: int, hidden: int) -> bool:
+    return hidden == 16 and 1 <= in_dim <= 12
+
+
+def proposal_mlp_fwd(feat, w0, b0, w1, b1, raw):
+    """feat [P, ld >= in_dim] -> raw [P]; w0 [16, in_dim], b0 [16], w1 [1, 16] or [16], b1 [1] (torch nn.Linear tensors)"""
+    P, in_dim = feat.shape[0], w0.shape[1]
+    assert feat.stride(1) == 1 and w0.is_contiguous() and w1.is_contiguous() and raw.is_contiguous() and raw.numel() == P
+    check(_prop_fwd(ptr(feat), ld(feat), P, in_dim, w0.shape[0], ptr(w0), ld(w0), ptr(b0), ptr(w1), ptr(b1), ptr(raw), stream_ptr()),
+          "nsky_proposal_mlp_fwd")
+
+
+def proposal_mlp_bwd(feat, w0, b0, w1, b1, d_raw, d_feat, dw0, db0, dw1, db1):
+    P, in_dim = feat.shape[0], w0.shape[1]
+    assert d_raw.is_contiguous() and d_raw.numel() == P and (d_feat is None or (d_feat.shape == feat.shape and d_feat.is_contiguous() and feat.is_contiguous()))
+    assert dw0.shape == w0.shape and dw0.is_contiguous()
+    check(_prop_bwd(ptr(feat), ld(feat), P, in_dim, w0.shape[0], ptr(w0), ld(w0), ptr(b0), ptr(w1), ptr(b1), ptr(d_raw), ptr(d_feat), ptr(dw0),
+                    ptr(db0), ptr(dw1), ptr(db1), stream_ptr()), "nsky_proposal_mlp_bwd")
+
+
 class Segment(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int64)]
 

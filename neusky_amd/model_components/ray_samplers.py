@@ -50,6 +50,9 @@ class HashMLPDensityField(nn.Module):
         """positions [R,n,3] -> pre-activation of the density head, [R*n, 4] (column 0; columns 1-3 are padding)"""
         x = positions.reshape(-1, 3).detach()
         feat = ops.HashEncodeFn.apply(x, self.encoding.table, self.geom, self.mode, False, 0, 0.0, False, False)
+        if feat.is_cuda and hip.proposal_mlp_supported(self.lin0.in_features, self.lin0.out_features) and self.lin1.out_features == 1:
+            # both layers in registers, one kernel each way (csrc/proposal.hip) -> [R*n, 1]
+            return ops.ProposalMLPFn.apply(feat, self.lin0.weight, self.lin0.bias, self.lin1.weight, self.lin1.bias)
         w0, b0, w1, b1 = self._padded()
         h = ops.DenseFn.apply(feat, w0, b0, self.lin0.out_features, "relu", True)
         return ops.DenseFn.apply(h, w1, b1, 1, "none", True)

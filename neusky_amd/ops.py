@@ -1270,6 +1270,31 @@ class InterlevelFn(torch.autograd.Function):
         return None, None, None, d_wp
 
 
+class ProposalMLPFn(torch.autograd.Function):
+    """the proposal networks' density MLP (Linear + ReLU -> Linear(., 1)) on hash-encoded rows, both layers in registers
+    (hip.proposal_mlp_*): feat [P, ld], lin0 weight / bias, lin1 weight / bias (unpadded torch parameters) -> raw [P, 1]"""
+
+    @staticmethod
+    def forward(ctx, feat, w0, b0, w1, b1):
+        feat = feat.contiguous()
+        w0c, w1c = w0.detach().contiguous(), w1.detach().contiguous()
+        raw = torch.empty(feat.shape[0], 1, device=feat.device)
+        hip.proposal_mlp_fwd(feat, w0c, b0.detach(), w1c, b1.detach(), raw)
+        ctx.save_for_backward(feat, w0c, b0.detach(), w1c, b1.detach())
+        return raw
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        feat, w0, b0, w1, b1 = ctx.saved_tensors
+        flat = zeros(w0.numel() + b0.numel() + w1.numel() + 4, device=feat.device)
+        n0, nb = w0.numel(), b0.numel()
+        dw0, db0 = flat[:n0].view_as(w0), flat[n0:n0 + nb]
+        dw1, db1 = flat[n0 + nb:n0 + nb + w1.numel()].view_as(w1), flat[n0 + nb + w1.numel():n0 + nb + w1.numel() + 1]
+        d_feat = torch.empty_like(feat) if ctx.needs_input_grad[0] else None
+        hip.proposal_mlp_bwd(feat, w0, b0, w1, b1, d_raw.contiguous(), d_feat, dw0, db0, dw1, db1)
+        return d_feat, dw0, db0, dw1, db1
+
+
 class DensityWeightsFn(torch.autograd.Function):
     """proposal-network weights from the raw density head: raw [R*n, ld] (column 0), ebins [R,n+1] -> weights [R,n]
     (trunc_exp density + RaySamples.get_weights in one launch each way; see include/neusky_hip.h)"""

@@ -241,3 +241,30 @@ def test_grid_probe_points_distribution():
     p2, d2 = torch.empty_like(lattice), torch.empty_like(lattice)
     hip.grid_probe_points(lattice, gap, 1234, c2, p2, d2)
     assert torch.equal((p2 - lattice).cpu(), draws[0][0]) and torch.equal(d2.cpu(), draws[0][1])
+
+
+@pytest.mark.parametrize("P,in_dim,ldf", [(5000, 10, 12), (262144, 10, 12), (777, 12, 12), (1500, 7, 8)])
+def test_proposal_mlp_matches_torch(P, in_dim, ldf):
+    """ops.ProposalMLPFn (nerfstudio HashMLPDensityField's Linear + ReLU -> Linear head) against torch in float64: values and every gradient"""
+    from neusky_amd import ops
+    g = torch.Generator().manual_seed(P + in_dim)
+    feat = torch.zeros(P, ldf)
+    feat[:, :in_dim] = torch.randn(P, in_dim, generator=g)
+    lin0, lin1 = torch.nn.Linear(in_dim, 16), torch.nn.Linear(16, 1)
+    with torch.no_grad():
+        lin0.bias.uniform_(-0.5, 0.5)
+    probe = torch.randn(P, 1, generator=g)
+    fd = feat.to(DEV).requires_grad_(True)
+    ps = [p.detach().clone().to(DEV).requires_grad_(True) for p in (lin0.weight, lin0.bias, lin1.weight, lin1.bias)]
+    raw = ops.ProposalMLPFn.apply(fd, *ps)
+    assert raw.shape == (P, 1)
+    (raw * probe.to(DEV)).sum().backward()
+    f64 = feat.double().requires_grad_(True)
+    q = [p.detach().double().requires_grad_(True) for p in (lin0.weight, lin0.bias, lin1.weight, lin1.bias)]
+    ref = torch.relu(f64[:, :in_dim] @ q[0].T + q[1]) @ q[2].T + q[3]
+    (ref * probe.double()).sum().backward()
+    assert torch.allclose(raw.detach().cpu().double(), ref.detach(), atol=2e-5)
+    assert torch.allclose(fd.grad.cpu().double()[:, :in_dim], f64.grad[:, :in_dim], atol=1e-5) and bool((fd.grad[:, in_dim:] == 0).all())
+    for a, b, n in zip(ps, q, ("dW0", "db0", "dW1", "db1")):
+        tol = (2e-5 + 1e-9 * P) * max(1.0, float(b.grad.abs().max()))  # (fp32 sums of P terms, order not fixed)
+        assert torch.allclose(a.grad.cpu().double(), b.grad, atol=tol), (n, float((a.grad.cpu().double() - b.grad).abs().max()))
