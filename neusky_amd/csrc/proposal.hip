@@ -52,15 +52,9 @@ __global__ __launch_bounds__(256) void proposal_mlp_fwd_kernel(const float* __re
 // Backward: SIXTEEN lanes per point (lane i of a group = hidden unit i), four points per wave step.  A lane keeps its unit's weight row
 // in registers; the point's features (lane j of the group loads feature j: one coalesced row) reach every unit by 16-lane broadcasts;
 // dW0 += dh^T f is then ONE v_mfma_f32_16x16x4_f32 per step with both operands already where the instruction wants them (A: unit i of
-// point k in lane i + 16 k, B: feature j of point k in lane j + 16 k), exact fp32; d_feat = W0^T dh by 16-lane sums.  The sums of a
+// point k in lane i + 16 k, B: feature j of point k in lane j + 16 k), exact fp32; d_feat = W0^T dh by four more of them.  The sums of a
 // block meet in LDS and leave as one atomic per value and block.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float group_sum16(float v) {
-#pragma unroll
-  for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
-  return v;
-}
 
 __global__ __launch_bounds__(256) void proposal_mlp_bwd_kernel(const float* __restrict__ feat, int ldf, long P, ProposalMlp m,
                                                                const float* __restrict__ d_raw, float* __restrict__ d_feat, float* __restrict__ dw0,
@@ -73,32 +67,58 @@ __global__ __launch_bounds__(256) void proposal_mlp_bwd_kernel(const float* __re
 #pragma unroll
   for (int j = 0; j < PIN; ++j) wrow[j] = j < m.in_dim ? m.w0[(long)i * m.ldw0 + j] : 0.0f;
   const float bi = m.b0[i], w1i = m.w1[i];
+  float w0t[4];  // A operand of the d_feat products: W0[4 mm + lane / 16][lane % 16]
+#pragma unroll
+  for (int mm = 0; mm < 4; ++mm) w0t[mm] = i < m.in_dim ? m.w0[(long)(4 * mm + k) * m.ldw0 + i] : 0.0f;
   __syncthreads();
   f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
   float ab0 = 0.0f, aw1 = 0.0f, ab1 = 0.0f;
   const long wave = (long)blockIdx.x * 4 + (tid >> 6), n_waves = (long)gridDim.x * 4;
   const long steps = (P + 3) / 4;
-  for (long st = wave; st < steps; st += n_waves) {
-    const long p = 4 * st + k;
-    const bool live = p < P;
-    const float fval = (live && i < m.in_dim) ? feat[p * ldf + i] : 0.0f;
-    const float g = live ? d_raw[p] : 0.0f;
-    float h = bi;
+  // eight steps' loads are issued before their arithmetic (one wave per SIMD: a step is ~300 clocks of work behind a ~2000-clock load)
+  constexpr int U = 8;
+  for (long st0 = wave; st0 < steps; st0 += U * n_waves) {
+    float f_[U], g_[U];
 #pragma unroll
-    for (int j = 0; j < PIN; ++j) h = fmaf(wrow[j], __shfl(fval, j, 16), h);
-    const float dh = h > 0.0f ? g * w1i : 0.0f;
-    ab0 += dh;
-    aw1 = fmaf(g, fmaxf(h, 0.0f), aw1);
-    if (i == 0) ab1 += g;
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dh, fval, acc, 0, 0, 0);
-    if (d_feat) {
-      float mine = 0.0f;  // lane j of the group ends up with d_feat[p][j]
+    for (int u = 0; u < U; ++u) {
+      const long pn = 4 * (st0 + u * n_waves) + k;
+      f_[u] = (pn < P && i < m.in_dim) ? feat[pn * ldf + i] : 0.0f;
+      g_[u] = pn < P ? d_raw[pn] : 0.0f;
+    }
 #pragma unroll
-      for (int j = 0; j < PIN; ++j) {
-        const float s = group_sum16(wrow[j] * dh);
-        mine = i == j ? s : mine;
+    for (int u = 0; u < U; ++u) {
+      const long st = st0 + u * n_waves;
+      if (st >= steps) break;
+      const long p = 4 * st + k;
+      const bool live = p < P;
+      const float fval = f_[u], g = g_[u];
+      float h = bi;
+#pragma unroll
+      for (int j = 0; j < PIN; ++j) h = fmaf(wrow[j], __shfl(fval, j, 16), h);
+      const float dh = h > 0.0f ? g * w1i : 0.0f;
+      ab0 += dh;
+      aw1 = fmaf(g, fmaxf(h, 0.0f), aw1);
+      if (i == 0) ab1 += g;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dh, fval, acc, 0, 0, 0);
+      if (d_feat) {
+        // d_feat^T [feature j][point n] = sum over units of W0[unit][j] dh_unit(point n): four more MFMAs (K = 4 units each), A = W0^T from
+        // registers, B = the step's dh values moved to (lane % 16 = point, lane / 16 = unit within the K slice) by one permute each
+        f32x4_t df = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+          const float b = __shfl(dh, (4 * mm + k) + 16 * (i & 3), 64);
+          df = __builtin_amdgcn_mfma_f32_16x16x4f32(w0t[mm], i < 4 ? b : 0.0f, df, 0, 0, 0);
+        }
+        // lane (c = i, q = k) holds features 4 q + r of point c (c < 4)
+        const long pc = 4 * st + i;
+        if (i < 4 && pc < P) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = 4 * k + r;
+            if (j < ldf) d_feat[pc * ldf + j] = j < m.in_dim ? df[r] : 0.0f;
+          }
+        }
       }
-      if (live && i < ldf) d_feat[p * ldf + i] = i < m.in_dim ? mine : 0.0f;
     }
   }
   // accumulator tile: lane (c = lane & 15, q = lane >> 4) holds rows 4 q + r, column c
@@ -154,7 +174,7 @@ extern "C" int nsky_proposal_mlp_bwd(const float* feat, int32_t ldf, int64_t P, 
   NSKY_CHECK_ARG(d_raw && dw0 && db0 && dw1 && db1, "nsky_proposal_mlp_bwd: null argument");
   const ProposalMlp m{w0, ldw0, b0, w1, b1, in_dim};
   NSKY_CHECK_ARG(!d_feat || ldf <= 16, "nsky_proposal_mlp_bwd: ldf %d (<= 16 with d_feat)", ldf);
-  const long blocks = (P + 1023) / 1024;  // >= 64 steps of four points per wave
+  const long blocks = (P + 1023) / 1024;  // >= 64 steps of four points per wave; <= 512 blocks end with 289 atomics each
   hipLaunchKernelGGL(proposal_mlp_bwd_kernel, dim3((unsigned)(blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks))), dim3(256), 0, (hipStream_t)stream, feat,
                      ldf, (long)P, m, d_raw, d_feat, dw0, db0, dw1, db1);
   NSKY_CHECK_LAUNCH("nsky_proposal_mlp_bwd");
