@@ -270,15 +270,24 @@ class SDFAlbedoField(FieldBase):
         return w  # with a single sample, weight == alpha
 
     def get_outputs(self, ray_samples: RaySamples, density_embedding=None, return_alphas: bool = False,
-                    want_albedo: bool = True) -> Dict:
+                    want_albedo: bool = True, extra_points: Optional[torch.Tensor] = None) -> Dict:
         """sdf_albedo_field.py:211-269.  Besides the reference keys, `weights` [R,S,1], `bg_transmittance` [R,1],
-        `accumulation` [R,1] and `p2p_dist` [R,1] come out of the same fused NeuS kernel when return_alphas."""
+        `accumulation` [R,1] and `p2p_dist` [R,1] come out of the same fused NeuS kernel when return_alphas.
+        extra_points [P,3]: isolated points evaluated in the same pass; their sdf / gradients come back as `extra_sdf` [P] and
+        `extra_gradients` [P,3]."""
         if ray_samples.camera_indices is None:
             raise AttributeError("Camera indices are not provided.")
         fr = ray_samples.frustums
         R, S = fr.origins.shape[:2]
         x = fr.get_start_positions().reshape(-1, 3)
+        n_main = x.shape[0]
+        if extra_points is not None:  # isolated points evaluated in the same pass (tail rows): the model's hash-grid density probe
+            x = torch.cat([x, extra_points.reshape(-1, 3)], 0)
         sdf, grad, albedo = self.field_values(x, want_albedo)
+        extra = None
+        if extra_points is not None:
+            extra = (sdf[n_main:], grad[n_main:])
+            sdf, grad, albedo = sdf[:n_main], grad[:n_main], albedo[:n_main]
         outputs = {
             NeuSkyFieldHeadNames.ALBEDO: albedo.view(R, S, 3),
             FieldHeadNames.SDF: sdf.view(R, S, 1),
@@ -294,8 +303,10 @@ class SDFAlbedoField(FieldBase):
             outputs["bg_transmittance"] = tbg[:, None]
             outputs["accumulation"] = acc[:, None]
             outputs["p2p_dist_unclipped"] = dep[:, None]
+        if extra is not None:
+            outputs["extra_sdf"], outputs["extra_gradients"] = extra
         return outputs
 
     def forward(self, ray_samples: RaySamples, compute_normals: bool = False, return_alphas: bool = False,
-                want_albedo: bool = True) -> Dict:
-        return self.get_outputs(ray_samples, return_alphas=return_alphas, want_albedo=want_albedo)
+                want_albedo: bool = True, extra_points: Optional[torch.Tensor] = None) -> Dict:
+        return self.get_outputs(ray_samples, return_alphas=return_alphas, want_albedo=want_albedo, extra_points=extra_points)

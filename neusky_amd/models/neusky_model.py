@@ -433,7 +433,8 @@ class NeuSkyFactoModel(ModelBase):
             with torch.cuda.stream(side):
                 dirs, cam_colours, cam_of_ray, hdr_bg = self.sample_illumination_compact(cam, ray_bundle.directions, rotation, randoms)
         ray_samples, weights_list, sbins_list, sbins, inds_list = self._sample(ray_bundle, randoms, want_inds=randoms is not None)
-        field_outputs = self.field(ray_samples, return_alphas=True)
+        probe = self._grid_probe_points(ray_bundle.origins.device, randoms)
+        field_outputs = self.field(ray_samples, return_alphas=True, extra_points=None if probe is None else probe[0])
         weights = field_outputs["weights"]
         weights_list = weights_list + [weights[..., 0]]
         sbins_list = sbins_list + [sbins]
@@ -465,39 +466,40 @@ class NeuSkyFactoModel(ModelBase):
                                                              self.visibility_threshold, self.sigmoid_scale,
                                                              sel=getattr(self, "_upper_sel", None))
             out.update(p2p_dist=p2p_dist, depth=depth, accumulation=accumulation)
-        if self.training and self.config.loss_inclusions["hashgrid_density_loss"]["enabled"]:  # :672-734
-            res = self.config.loss_inclusions["hashgrid_density_loss"]["grid_resolution"]
-            aabb = self.scene_box["aabb"] if isinstance(self.scene_box, dict) else self.scene_box.aabb
-            mn, mx = aabb[0], aabb[1]
-            dev = ray_bundle.origins.device
-            key = (res, str(dev))
-            if getattr(self, "_grid_cache_key", None) != key:  # lattice + gaps built once, kept on the device
-                lin = [torch.linspace(float(mn[i]), float(mx[i]), res) for i in range(3)]
-                X, Y, Z = torch.meshgrid(*lin, indexing="ij")
-                self._grid_lattice = torch.stack((X, Y, Z), -1).reshape(-1, 3).to(dev)
-                self._grid_gap_host = [(float(mx[i]) - float(mn[i])) / res for i in range(3)]
-                self._grid_gap = torch.tensor(self._grid_gap_host).to(dev)
-                self._grid_rng = (device_rng_seed(3), torch.zeros(1, dtype=torch.int64, device=dev))
-                self._grid_cache_key = key
-            gap = self._grid_gap
-            if randoms is not None and "grid_perturb" in randoms:
-                perturb, gdir = randoms["grid_perturb"].to(dev), randoms["grid_dirs"].to(dev)
-                positions = self._grid_lattice + (perturb * gap - gap / 2)
-                gdir = gdir / torch.norm(gdir, dim=-1, keepdim=True)
-            else:  # the reference draws these on the CPU every step (:704-712); drawn in one kernel here (csrc/samplers.hip)
-                positions, gdir = torch.empty_like(self._grid_lattice), torch.empty_like(self._grid_lattice)
-                hip.grid_probe_points(self._grid_lattice, self._grid_gap_host, self._grid_rng[0], self._grid_rng[1], positions, gdir)
+        if probe is not None:
             # (sic) the reference hands `deltas=gap` ([3]) to get_alpha, which broadcasts [P,1]*[3] -> three alphas
-            # per point, one per axis gap (equal for the cubic scene box) (:715-724, :732)
-            out["grid_density"] = self._grid_alpha(positions, gdir)
+            # per point, one per axis gap (equal for the cubic scene box) (:715-724, :732).  The probe points rode through the field
+            # behind the batch's own samples (one pass instead of a second one over 1000 points: every kernel of a pass costs its
+            # 25-40 us whatever the row count); their sdf / gradients come back as the tail rows.
+            out["grid_density"] = ops.PointAlphasFn.apply(field_outputs["extra_sdf"], field_outputs["extra_gradients"], probe[1], self._grid_gap_host,
+                                                          self.field.deviation_network.variance, self.field._cos_anneal_ratio)
         return out
 
-    def _grid_alpha(self, positions: torch.Tensor, directions: torch.Tensor) -> torch.Tensor:
-        """three alphas per probe point, one per axis gap (SDFField.get_alpha on isolated samples with `deltas` = the [3] gaps
-        broadcast against [P,1], :715-732) from one kernel each way (ops.PointAlphasFn)"""
-        sdf, grad, _ = self.field.field_values(positions, want_albedo=False)
-        return ops.PointAlphasFn.apply(sdf, grad, directions, self._grid_gap_host, self.field.deviation_network.variance,
-                                       self.field._cos_anneal_ratio)
+    def _grid_probe_points(self, dev, randoms):
+        """the hash-grid density probe's points and directions (:672-724), or None when the loss is off"""
+        if not (self.training and self.config.loss_inclusions["hashgrid_density_loss"]["enabled"]):
+            return None
+        res = self.config.loss_inclusions["hashgrid_density_loss"]["grid_resolution"]
+        aabb = self.scene_box["aabb"] if isinstance(self.scene_box, dict) else self.scene_box.aabb
+        mn, mx = aabb[0], aabb[1]
+        key = (res, str(dev))
+        if getattr(self, "_grid_cache_key", None) != key:  # lattice + gaps built once, kept on the device
+            lin = [torch.linspace(float(mn[i]), float(mx[i]), res) for i in range(3)]
+            X, Y, Z = torch.meshgrid(*lin, indexing="ij")
+            self._grid_lattice = torch.stack((X, Y, Z), -1).reshape(-1, 3).to(dev)
+            self._grid_gap_host = [(float(mx[i]) - float(mn[i])) / res for i in range(3)]
+            self._grid_gap = torch.tensor(self._grid_gap_host).to(dev)
+            self._grid_rng = (device_rng_seed(3), torch.zeros(1, dtype=torch.int64, device=dev))
+            self._grid_cache_key = key
+        gap = self._grid_gap
+        if randoms is not None and "grid_perturb" in randoms:
+            perturb, gdir = randoms["grid_perturb"].to(dev), randoms["grid_dirs"].to(dev)
+            positions = self._grid_lattice + (perturb * gap - gap / 2)
+            gdir = gdir / torch.norm(gdir, dim=-1, keepdim=True)
+        else:  # the reference draws these on the CPU every step (:704-712); drawn in one kernel here (csrc/samplers.hip)
+            positions, gdir = torch.empty_like(self._grid_lattice), torch.empty_like(self._grid_lattice)
+            hip.grid_probe_points(self._grid_lattice, self._grid_gap_host, self._grid_rng[0], self._grid_rng[1], positions, gdir)
+        return positions, gdir
 
     # ------------------------------------------------------------------ outputs
     def get_outputs(self, ray_bundle: RayBundle, batch=None, rotation=None, step=None, randoms=None) -> Dict[str, Any]:
