@@ -26,9 +26,19 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0) -> int:
         if id(t) in seen:
             continue
         seen.add(id(t))
-        dist.broadcast(t.data, src=src)
+        _broadcast(t.data, src)
         n += 1
     return n
+
+
+def _broadcast(t: torch.Tensor, src: int) -> None:
+    """RCCL broadcasts device tensors in place; under gloo (two ranks sharing one GPU in tests) a device tensor goes through the host"""
+    if t.is_cuda and dist.get_backend() != "nccl":
+        host = t.cpu()
+        dist.broadcast(host, src=src)
+        t.copy_(host)
+    else:
+        dist.broadcast(t, src=src)
 
 
 class GradientAllReduce:
@@ -48,7 +58,7 @@ class GradientAllReduce:
             broadcast_module_state(self.module, src)
             return
         for p in self.params:
-            dist.broadcast(p.data, src=src)
+            _broadcast(p.data, src)
 
     def barrier(self) -> None:
         dist.barrier()

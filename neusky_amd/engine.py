@@ -161,6 +161,10 @@ class Optimizers:
             return
         if dist.get_backend() == "nccl":
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.AVG)
+        elif self.flat_g.is_cuda:  # gloo with device gradients (two ranks sharing one GPU in tests): staged through the host
+            host = self.flat_g.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            self.flat_g.copy_(host.div_(self.world_size))
         else:  # gloo (CPU tests) has no AVG
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
             self.flat_g.div_(self.world_size)

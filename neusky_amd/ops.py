@@ -60,8 +60,8 @@ class _PadFn(torch.autograd.Function):
     incoming gradient backward (torch's F.pad costs a pad kernel each way)"""
 
     @staticmethod
-    def forward(ctx, w, shape):
-        out = zeros(shape, device=w.device)
+    def forward(ctx, w, shape, persistent=False):
+        out = torch.zeros(shape, device=w.device) if persistent else zeros(shape, device=w.device)
         if w.dim() == 2:
             out[:w.shape[0], :w.shape[1]].copy_(w)
         else:
@@ -72,21 +72,22 @@ class _PadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         o = ctx.orig
-        return (g[:o[0], :o[1]] if len(o) == 2 else g[:o[0]]), None
+        return (g[:o[0], :o[1]] if len(o) == 2 else g[:o[0]]), None, None
 
 
-def pad_weight(w: torch.Tensor) -> torch.Tensor:
-    """[out, in] -> zero padded [pad4(out), pad4(in)] (autograd-tracked)."""
+def pad_weight(w: torch.Tensor, persistent: bool = False) -> torch.Tensor:
+    """[out, in] -> zero padded [pad4(out), pad4(in)] (autograd-tracked).  persistent: the copy outlives the step (a frozen
+    network's cache): it gets an allocation of its own instead of a region of the step's zero arena."""
     o, i = w.shape
     if o % 4 == 0 and i % 4 == 0:
         return w if w.is_contiguous() else w.contiguous()
-    return _PadFn.apply(w, (pad4(o), pad4(i)))
+    return _PadFn.apply(w, (pad4(o), pad4(i)), persistent)
 
 
-def pad_bias(b: torch.Tensor) -> torch.Tensor:
+def pad_bias(b: torch.Tensor, persistent: bool = False) -> torch.Tensor:
     if b.shape[0] % 4 == 0:
         return b if b.is_contiguous() else b.contiguous()
-    return _PadFn.apply(b, (pad4(b.shape[0]),))
+    return _PadFn.apply(b, (pad4(b.shape[0]),), persistent)
 
 
 WGRAD_STREAM_MIN_ROWS = 32768
@@ -393,6 +394,12 @@ FUSED_FILM_MIN_ROWS = 4096  # below: a handful of workgroups each walking a ~0.2
 _FILM_STREAMS: dict = {}
 
 
+def forget_film_streams(wb) -> None:
+    """drop the packed streams built from the padded weight list `wb` (FiLMSiren.invalidate_weight_cache)"""
+    for key in [k for k, hit in _FILM_STREAMS.items() if hit[0] and wb and hit[0][0] is wb[0]]:
+        del _FILM_STREAMS[key]
+
+
 def _film_fused_ok(M, H, Hm, n_map, n_film, mw, fw, ow, x, cond) -> bool:
     return (FWD_PRECISION == hip.PREC_F16X2 and M >= FUSED_FILM_MIN_ROWS and x.is_cuda and ld(x) <= 16
             and hip.film_supported(H, Hm, n_map, n_film, mw[0].shape[1], fw[0].shape[1], ow.shape[0])
@@ -505,6 +512,7 @@ class FilmSirenFn(torch.autograd.Function):
         tile-native matrix (F / phase are re-formed in registers: no [M, 2 n_film H] matrix is read or recomputed through HBM)
         and d_cond; the parameter gradients are weight-gradient GEMMs straight over those matrices."""
         n_map, n_film, train_w, need_dcond, M, H, Hm = ctx.cfg
+        train_w = train_w and any(ctx.needs_input_grad[6:])  # (frozen weights -- the eval-latent fit -- take no gradient)
         dev = x.device
         Mp = hip.film_rows(M)
         d_res = d_res.contiguous()
@@ -566,6 +574,7 @@ class FilmSirenFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_res):
         n_map, n_film, train_w, need_dcond, M, H, Hm = ctx.cfg
+        train_w = train_w and any(ctx.needs_input_grad[6:])  # (frozen weights -- the eval-latent fit -- take no gradient)
         sv = ctx.saved_tensors
         x, cond, FP = sv[0], sv[1], sv[2]
         hs = list(sv[3:3 + n_map])

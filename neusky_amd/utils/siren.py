@@ -63,8 +63,15 @@ class FiLMSiren(nn.Module):
     def invalidate_weight_cache(self) -> None:
         """once per optimisation step -- unless every weight is frozen (the RENI++ decoder): its padded copies and, through them,
         its packed weight streams (ops._film_stream) then stay valid from step to step"""
-        if getattr(self, "_wcache", None) and not any(p.requires_grad for p in self.parameters()):
+        c = getattr(self, "_wcache", None)
+        frozen = not any(p.requires_grad for p in self.parameters())
+        # kept only when the copies were BUILT while the network was frozen and it still is: a cache filled during a train step
+        # (trainable weights, updated since through raw pointers by hip.adam_step) must not survive a later freeze -- the
+        # eval-latent fit freezes every other parameter for its duration (NeuSkyFactoModel.fit_latent_codes_for_eval)
+        if c and c.get("frozen", False) and frozen:
             return
+        if c and "wb" in c:
+            ops.forget_film_streams(c["wb"])  # packed streams keyed by the dropped copies (frozen ones are not purged by begin_step)
         self._wcache = {}
 
     def padded_weights(self):
@@ -75,15 +82,18 @@ class FiLMSiren(nn.Module):
         wb = self._padded_weights_uncached()
         if c is not None:
             c["wb"], c["grad"], c["ver"] = wb, torch.is_grad_enabled(), ver
+            c["frozen"] = not any(p.requires_grad for p in self.parameters())
         return wb
 
     def _padded_weights_uncached(self):
+        # copies of a frozen network live across steps: they get allocations of their own, not regions of one step's zero arena
+        keep = not any(p.requires_grad for p in self.parameters())
         wb = []
         for lin in self.mapping_network.linears():
-            wb += [ops.pad_weight(lin.weight), ops.pad_bias(lin.bias)]
+            wb += [ops.pad_weight(lin.weight, keep), ops.pad_bias(lin.bias, keep)]
         for l in self.net:
-            wb += [ops.pad_weight(l.layer.weight), ops.pad_bias(l.layer.bias)]
-        wb += [ops.pad_weight(self.final_layer.weight), ops.pad_bias(self.final_layer.bias)]
+            wb += [ops.pad_weight(l.layer.weight, keep), ops.pad_bias(l.layer.bias, keep)]
+        wb += [ops.pad_weight(self.final_layer.weight, keep), ops.pad_bias(self.final_layer.bias, keep)]
         return wb
 
     def forward(self, x: torch.Tensor, conditioning_input: torch.Tensor, train_weights: bool = True, padded_output: bool = False) -> torch.Tensor:

@@ -652,6 +652,24 @@ def neusky_losses(out: Dict[str, Tensor], image: Tensor, mask: Tensor, threshold
     return ld
 
 
+def neusky_eval_losses(rgb: Tensor, hdr_bg: Tensor, image: Tensor, mask: Tensor, sky_alpha: float = 0.1, rgb_l2: bool = False,
+                       cosine_colour: bool = False, sky_pixel: bool = True) -> Dict[str, Tensor]:
+    """neusky/models/neusky_model.py:1036-1059: the evaluation / eval-latent-fitting branch of get_loss_dict, UNSCALED (PINNED by
+    G7's `evalloss_*` / `evalall_*` / `evalosr_*` vectors).  The `neusky` config includes rgb_l1 and the sky-pixel term only
+    (neusky_config.py:102-126); sky_pixel=False is the 'nerf_osr_envmap' method (:1048)."""
+    sky = mask[..., 3].to(image.dtype)
+    keep = (1 - sky)[:, None]
+    im, pred = image * keep, rgb * keep
+    ld: Dict[str, Tensor] = {"rgb_l1_loss": F.l1_loss(im, pred)}  # :1038-1043
+    if rgb_l2:
+        ld["rgb_l2_loss"] = F.mse_loss(im, pred)  # :1044-1045
+    if cosine_colour:
+        ld["cosine_colour_loss"] = torch.mean(1 - F.cosine_similarity(im, pred, dim=1))  # :1046-1048
+    if sky_pixel:
+        ld["sky_pixel_loss"] = sky_pixel_loss(linear_to_srgb(hdr_bg), image, sky[:, None].expand(-1, 3), sky_alpha)  # :1051-1058
+    return ld
+
+
 def ddf_losses(expected: Tensor, gt_term: Tensor, mask: Tensor, distance_weight: Tensor, sdf_at_term: Tensor,
                mv_expected: Tensor, mv_gt: Tensor, sky_expected: Tensor, sky_gt: Tensor) -> Dict[str, Tensor]:
     """neusky/models/ddf_model.py:407-493 with the `neusky` config (:178-205): mask_to_circumference=False,
@@ -763,15 +781,14 @@ def field_pass(p, cfg: StepCfg, origins, directions, ebins):
     return fo
 
 
-def neusky_train_step(p: Dict[str, Tensor], cfg: StepCfg, origins: Tensor, directions: Tensor, cam_idx: Tensor,
-                      image: Tensor, mask: Tensor, rnd: Dict[str, Tensor], light_dirs: Tensor):
-    """Forward of one full training step -> (scaled loss dict, outputs).  All randomness is explicit:
-    rnd = {jitters: [L+1 x [R,1]], grid_perturb [G,3], grid_dirs [G,3], ddf_rays (o,d), ddf_jitters, mv_points [Mv,3],
-    sky_o, sky_d}; light_dirs [D,3] is the (already rotated) illumination direction set."""
-    dt = origins.dtype
-    R = origins.shape[0]
+def neusky_forward_rays(p: Dict[str, Tensor], cfg: StepCfg, origins: Tensor, directions: Tensor, cam_idx: Tensor, jitters,
+                        light_dirs: Tensor):
+    """The per-ray part of the training forward (neusky_model.py:553-631, 797-805): proposal sampling, field, illumination,
+    depth, DDF visibility (+ the sdf probe at the predicted termination points) and the Lambertian render.  Every output row
+    depends on its own ray only (its camera's latents, its jitters, the shared direction set), so a SLICE of a large batch can be
+    checked on its own (tests/test_gpu_full_size.py).  -> (samp, field outputs, bg, p2p, visibility dict, rgb)"""
     nears, fars = sphere_collider(origins, directions, cfg.radius)  # neusky_model.py:440-441
-    samp = proposal_sample(origins, directions, nears, fars, p, cfg.prop_grids, cfg.num_prop, cfg.num_final, rnd["jitters"], cfg.anneal)
+    samp = proposal_sample(origins, directions, nears, fars, p, cfg.prop_grids, cfg.num_prop, cfg.num_final, jitters, cfg.anneal)
     ebins = samp["ebins"]
     fo = field_pass(p, cfg, origins, directions, ebins)  # :563-568
     weights = fo["weights"]
@@ -787,6 +804,19 @@ def neusky_train_step(p: Dict[str, Tensor], cfg: StepCfg, origins: Tensor, direc
     vis = compute_visibility(origins, directions, p2p.detach(), light_dirs, p["visibility_threshold"], cfg.sigmoid_scale,
                              cfg.radius, vis_field, True, True)  # :624-630 ('depth' stop-gradient mode)
     rgb = lambertian_render(fo["albedo"], fo["normals"], light_dirs, cols, inverse, vis["visibility"], bg, weights)  # :797-805
+    return samp, fo, bg, p2p, vis, rgb
+
+
+def neusky_train_step(p: Dict[str, Tensor], cfg: StepCfg, origins: Tensor, directions: Tensor, cam_idx: Tensor,
+                      image: Tensor, mask: Tensor, rnd: Dict[str, Tensor], light_dirs: Tensor):
+    """Forward of one full training step -> (scaled loss dict, outputs).  All randomness is explicit:
+    rnd = {jitters: [L+1 x [R,1]], grid_perturb [G,3], grid_dirs [G,3], ddf_rays (o,d), ddf_jitters, mv_points [Mv,3],
+    sky_o, sky_d}; light_dirs [D,3] is the (already rotated) illumination direction set."""
+    dt = origins.dtype
+    R = origins.shape[0]
+    samp, fo, bg, p2p, vis, rgb = neusky_forward_rays(p, cfg, origins, directions, cam_idx, rnd["jitters"], light_dirs)
+    ebins, weights = samp["ebins"], fo["weights"]
+    ddf_fn = lambda sp, dd: ddf_query(sp, dd, p, cfg.ddf_grid, cfg.radius)
     # hash-grid density probe (:672-734): jittered res^3 lattice over the scene box, alpha per axis gap
     res = cfg.grid_res
     lin = torch.linspace(-cfg.radius, cfg.radius, res, dtype=dt)
@@ -876,11 +906,8 @@ def neusky_eval_fit_loss(p: Dict[str, Tensor], cfg: StepCfg, origins: Tensor, di
         vis = compute_visibility(origins, directions, p2p, light_dirs, pc["visibility_threshold"], cfg.sigmoid_scale, cfg.radius,
                                  lambda sp, dd: {"expected_termination_dist": ddf_query(sp, dd, pc, cfg.ddf_grid, cfg.radius)}, True, True)
     rgb = lambertian_render(fo["albedo"], fo["normals"], light_dirs, cols, inverse, vis["visibility"], bg, weights)
-    sky = mask[:, 3].to(rgb.dtype)
-    keep = (1 - sky)[:, None]
-    loss = F.l1_loss(image * keep, rgb * keep)  # :1038-1043
-    loss = loss + sky_pixel_loss(linear_to_srgb(bg), image, sky[:, None].expand(-1, 3), 0.1)  # :1051-1058, cosine_weight 0.1
-    return loss
+    ld = scale_dict(neusky_eval_losses(rgb, bg, image, mask), NEUSKY_LOSS_COEFFICIENTS)  # :1036-1059, both coefficients 1
+    return ld["rgb_l1_loss"] + ld["sky_pixel_loss"]
 
 
 def adam_fit(params, loss_fn, steps: int, lr: float, lr_final: float, eps: float = 1e-15, betas=(0.9, 0.999)):

@@ -304,9 +304,21 @@ def g7_losses():
     batch = {"image": T(image), "mask": T(mask)}
     # neusky/models/neusky_model.py:933-1035 (train branch)
     ld = rnm.NeuSkyFactoModel.get_loss_dict(self, outputs, batch)
+    # neusky/models/neusky_model.py:1036-1059 (the other branch: evaluation / eval-latent fitting, per-image latents)
+    self.fitting_eval_latents = True
+    self.config.eval_latent_optimise_method = "per_image"
+    self.rgb_l2_loss = torch.nn.MSELoss()
+    self.cosine_colour_loss = torch.nn.CosineSimilarity(dim=1)
+    ld_eval = rnm.NeuSkyFactoModel.get_loss_dict(self, outputs, batch)
+    incl2 = dict(incl, rgb_l2_loss=True, cosine_colour_loss=True)  # every term the branch can emit
+    self.config.loss_inclusions = incl2
+    ld_eval_all = rnm.NeuSkyFactoModel.get_loss_dict(self, outputs, batch)
+    self.config.eval_latent_optimise_method = "nerf_osr_envmap"  # :1048: no sky-pixel term
+    ld_eval_osr = rnm.NeuSkyFactoModel.get_loss_dict(self, outputs, batch)
     save("g7_losses", rgb=rgb, image=image, mask=mask, eik=eik, w=w, normal=normal, hdr_bg=hdr_bg,
          grid_density=grid_density, sdf_term=sdf_term, sky_direct=sky_val,
-         **{f"loss_{k}": v for k, v in ld.items()})
+         **{f"loss_{k}": v for k, v in ld.items()}, **{f"evalloss_{k}": v for k, v in ld_eval.items()},
+         **{f"evalall_{k}": v for k, v in ld_eval_all.items()}, **{f"evalosr_{k}": v for k, v in ld_eval_osr.items()})
 
 
 # ----------------------------------------------------------------------------- G8 FiLM-SIREN

@@ -107,3 +107,53 @@ def test_fit_graph_replay_equals_eager():
     t = m.fit_latent_codes_for_eval(pipe.datamanager, 10_000, steps=40, bundles=bundles, log_every=1)
     t = torch.stack(t).cpu()
     assert torch.isfinite(t).all() and t[-5:].mean() < t[:3].mean()
+
+
+def test_fit_after_a_train_step_uses_the_current_frozen_weights():
+    """a train step leaves padded DDF weights cached from BEFORE the Adam update (which writes through raw
+    pointers, so no version counter moves); the fit then freezes the DDF.  The cache must not survive that freeze: the weights the
+    fit evaluates visibility with are the current ones, and no gradient work reaches the frozen DDF parameters."""
+    from neusky_amd.engine import Optimizers, neusky_optimizers, train_iteration
+    from util_step import make_randoms, randoms_to
+    torch.manual_seed(0)
+    R = 32
+    pipe = small_pipeline_config(R=R, num_prop=(24, 12), S=8, D=24, images=4).setup(device=DEV)
+    pipe.train()
+    randomise(pipe)
+    m = pipe.model
+    opt = Optimizers(neusky_optimizers(), pipe.get_param_groups())
+    for g in opt.groups:  # a visible update of every group
+        g.opt.lr = 1e-2
+        g.sched = None
+    rb, batch = pipe.datamanager.next_train(0)
+    train_iteration(pipe, opt, 10_000, ray_bundle=rb, batch=batch, randoms=randoms_to(make_randoms(pipe, R), DEV))
+    ddf = m.visibility_field.field.ddf
+    stale = [t.detach().clone() for t in ddf.padded_weights()]  # the train step's cache: built before the update
+    bundles = [pipe.datamanager.get_eval_image_half_bundle("full_image", image_index=0, num_rays=R)]
+    grads_before = [None if p.grad is None else p.grad.detach().clone() for p in ddf.parameters()]
+    seen = {}
+    orig = type(ddf).padded_weights
+
+    def spy(self):
+        wb = orig(self)
+        if self is ddf and not any(p.requires_grad for p in self.parameters()):
+            seen["wb"] = [t.detach().clone() for t in wb]
+            seen["rg"] = [t.requires_grad for t in wb]
+        return wb
+
+    type(ddf).padded_weights = spy
+    try:
+        m.fit_latent_codes_for_eval(pipe.datamanager, 10_000, steps=3, bundles=bundles, use_graph=False)
+    finally:
+        type(ddf).padded_weights = orig
+    assert "wb" in seen, "the fit never evaluated the (frozen) DDF"
+    with torch.no_grad():
+        fresh = ddf._padded_weights_uncached()
+    assert any(not torch.equal(a, b) for a, b in zip(stale, fresh)), "the train step did not move the DDF weights: test is vacuous"
+    for a, b in zip(seen["wb"], fresh):
+        assert torch.equal(a, b), "the fit ran on weights cached before the optimizer update"
+    assert not any(seen["rg"]), "frozen DDF copies still carry requires_grad: the fit would run the DDF weight-gradient backward"
+    for p, g0 in zip(ddf.parameters(), grads_before):
+        assert p.requires_grad  # restored
+        if g0 is not None:
+            assert torch.equal(p.grad, g0), "a gradient reached the frozen DDF parameters during the fit"

@@ -123,3 +123,27 @@ def test_train_metrics_kernel_matches_torch():
     assert abs(got - want) < 1e-4
     # clip of the variance
     assert float(hip.train_metrics(rgb.to(DEV), image.to(DEV), None, 1.0, torch.tensor([5.0], device=DEV))[1]) == 1e6
+
+
+def test_eval_branch_matches_the_reference_golden(golden_dir):
+    """the evaluation / eval-latent-fitting branch of get_loss_dict (neusky_model.py:1036-1059) through the fused loss kernel,
+    against the G7 vectors produced by the REFERENCE's own get_loss_dict (tests/golden/make_golden.py: `evalloss_*`) and against
+    the oracle's restatement with its float64 input gradients"""
+    import os
+    import numpy as np
+    from neusky_amd import ops
+    from oracle import neusky_oracle as O
+    dev = "cuda:0"
+    g = np.load(os.path.join(golden_dir, "g7_losses.npz"))
+    T = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    rgb, hdr = T("rgb").to(dev).requires_grad_(True), T("hdr_bg").to(dev).requires_grad_(True)
+    out = ops.MainLossesFn.apply(rgb, T("image").to(dev), T("mask").float().to(dev), None, None, None, hdr, None, None, None, 0.1, 0.1)
+    assert abs(float(out[0]) - float(g["evalloss_rgb_l1_loss"])) < 2e-5 * abs(float(g["evalloss_rgb_l1_loss"]))
+    assert abs(float(out[5]) - float(g["evalloss_sky_pixel_loss"])) < 2e-5 * abs(float(g["evalloss_sky_pixel_loss"]))
+    assert float(out[[1, 2, 3, 4, 6, 7]].abs().sum()) == 0.0
+    r64, h64 = T("rgb").double().requires_grad_(True), T("hdr_bg").double().requires_grad_(True)
+    ld = O.neusky_eval_losses(r64, h64, T("image").double(), T("mask"))
+    gref = torch.autograd.grad(ld["rgb_l1_loss"] + 1.3 * ld["sky_pixel_loss"], [r64, h64])
+    ggpu = torch.autograd.grad(out[0] + 1.3 * out[5], [rgb, hdr])
+    for a, b in zip(ggpu, gref):
+        assert (a.cpu().double() - b).abs().max().item() <= 2e-5 * b.abs().max().item()

@@ -1,6 +1,7 @@
 """Device datamanager against a plain numpy restatement of the pinhole / mask semantics.
 Runs on CPU (device='cpu'); the same code path runs on the GPU inside the pipeline."""
 import numpy as np
+import pytest
 import torch
 
 from neusky_amd.data.image_datamanager import DeviceImageDataManager
@@ -55,6 +56,33 @@ def test_eval_half_bundle_and_uniformity():
 
 
 def test_pixel_sets_and_collation_match_the_reference_sampler():
+    _check_against_the_reference_sampler("cpu")
+
+
+@pytest.mark.gpu
+def test_pixel_sets_and_collation_match_the_reference_sampler_on_the_gpu():
+    """SURVEY 8(f)1 under -m gpu: the same golden comparison with the images, masks, pixel tables and draws resident on cuda:0
+    (the device the train step samples on), plus the ray maths of a drawn batch against the numpy pinhole restatement"""
+    _check_against_the_reference_sampler("cuda:0")
+    images, masks, c2w = _scene()
+    dm = DeviceImageDataManager(images, masks, c2w, fx=20.0, fy=21.0, cx=8.0, cy=6.0, train_num_rays_per_batch=500, device="cuda:0")
+    rb, batch = dm.next_train(0)
+    assert rb.origins.is_cuda and batch["image"].is_cuda and batch["indices"].is_cuda
+    idx = batch["indices"].cpu().numpy()
+    assert masks.numpy()[idx[:, 0], idx[:, 1], idx[:, 2], 0].all()
+    np.testing.assert_array_equal(batch["image"].cpu().numpy(), images.numpy()[idx[:, 0], idx[:, 1], idx[:, 2]])
+    np.testing.assert_array_equal(batch["mask"].cpu().numpy(), masks.numpy()[idx[:, 0], idx[:, 1], idx[:, 2]])
+    c, y, x = idx[:, 0], idx[:, 1].astype(np.float64), idx[:, 2].astype(np.float64)
+    d_cam = np.stack([(x + 0.5 - 8.0) / 20.0, -(y + 0.5 - 6.0) / 21.0, -np.ones_like(x)], -1)
+    d = np.einsum("rij,rj->ri", c2w.numpy().astype(np.float64)[c, :, :3], d_cam)
+    n = np.linalg.norm(d, axis=-1, keepdims=True)
+    np.testing.assert_allclose(rb.directions.cpu().numpy(), d / n, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rb.origins.cpu().numpy(), c2w.numpy()[c, :, 3], rtol=0, atol=0)
+    sky = dm.get_sky_ray_bundle(256)
+    assert sky.origins.is_cuda and sky.origins.shape == (256, 3)
+
+
+def _check_against_the_reference_sampler(device):
     """golden from the reference's own NeuSkyPixelSampler (tests/golden/make_golden_sampler.py; nerfstudio's random draw replaced
     by an enumeration of the admissible pixels): the pixels THIS datamanager may draw in each mode are exactly the reference's,
     and a batch is collated the same way (values by [c, y, x], indices[:, 0] remapped through image_idx)"""
@@ -64,11 +92,11 @@ def test_pixel_sets_and_collation_match_the_reference_sampler():
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pixel_sampler.npz"))
     N, H, W = g["image"].shape[:3]
     c2w = torch.eye(4)[:3][None].repeat(N, 1, 1)
-    dm = DeviceImageDataManager(torch.from_numpy(g["image"]), torch.from_numpy(g["mask"]), c2w, 10.0, 10.0, W / 2, H / 2, device="cpu",
+    dm = DeviceImageDataManager(torch.from_numpy(g["image"]), torch.from_numpy(g["mask"]), c2w, 10.0, 10.0, W / 2, H / 2, device=device,
                                 train_num_rays_per_batch=16, image_idx=torch.from_numpy(g["image_idx"]))
     key = lambda a: sorted(map(tuple, np.asarray(a).tolist()))  # noqa: E731
-    remap = lambda p: torch.stack([dm.image_idx[p[:, 0]], p[:, 1], p[:, 2]], 1).numpy()  # noqa: E731
-    assert key(dm.static_pixels.numpy()) == key(g["train_pixels"])                      # neusky_pixel_sampler.py:36-46
+    remap = lambda p: torch.stack([dm.image_idx[p[:, 0]], p[:, 1], p[:, 2]], 1).cpu().numpy()  # noqa: E731
+    assert key(dm.static_pixels.cpu().numpy()) == key(g["train_pixels"])                      # neusky_pixel_sampler.py:36-46
     assert key(remap(dm.sky_pixels)) == key(g["sky_pixels_remapped"])                   # :58-62
     for region in ("left_image_half", "right_image_half", "full_image"):                # :128-146
         assert key(remap(dm.half_pixels(region))) == key(g[f"{region}_pixels_remapped"]), region
@@ -77,11 +105,12 @@ def test_pixel_sets_and_collation_match_the_reference_sampler():
     for name in ("sky", "left_image_half", "full_image"):
         ref_idx = g[f"{name}_batch_indices"]
         stack = torch.from_numpy(np.stack([[pos[int(r[0])] for r in ref_idx], ref_idx[:, 1], ref_idx[:, 2]], 1))
-        b = dm.collate(stack)
-        assert torch.equal(b["indices"], torch.from_numpy(ref_idx)) and torch.equal(b["image"], torch.from_numpy(g[f"{name}_batch_image"]))
-        assert torch.equal(b["mask"].float(), torch.from_numpy(g[f"{name}_batch_mask"]))
+        b = dm.collate(stack.to(device))
+        assert str(b["image"].device) == str(torch.device(device))
+        assert torch.equal(b["indices"].cpu(), torch.from_numpy(ref_idx)) and torch.equal(b["image"].cpu(), torch.from_numpy(g[f"{name}_batch_image"]))
+        assert torch.equal(b["mask"].float().cpu(), torch.from_numpy(g[f"{name}_batch_mask"]))
     # and what the manager actually draws stays inside those sets
     rb, batch = dm.next_train(0)
-    assert set(map(tuple, batch["indices"].tolist())) <= set(key(remap(dm.static_pixels)))
+    assert set(map(tuple, batch["indices"].cpu().tolist())) <= set(key(remap(dm.static_pixels)))
     sky = dm._draw(dm.sky_pixels, 64)
     assert set(map(tuple, remap(sky).tolist())) <= set(key(g["sky_pixels_remapped"]))

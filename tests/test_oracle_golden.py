@@ -127,12 +127,21 @@ def test_g7_losses():
            "hdr_background_colours": T(g["hdr_bg"]), "grid_density": T(g["grid_density"]),
            "sdf_at_termination": T(g["sdf_term"])}
     ld = O.neusky_losses(out, T(g["image"]), T(g["mask"]), torch.tensor(2.0))
-    keys = [k[5:] for k in g if k.startswith("loss_")]
+    keys = [k[5:] for k in g if k.startswith("loss_")]  # (the train branch; "evalloss_" etc. below)
     assert sorted(keys) == sorted(ld.keys())
     for k in keys:
         close(ld[k], g["loss_" + k], rtol=1e-5, atol=1e-7)
     m3 = T(g["mask"][:, 3].astype(np.float32))[:, None].expand(-1, 3)
     close(O.sky_pixel_loss(O.linear_to_srgb(T(g["hdr_bg"])), T(g["image"]), m3, 0.1), g["sky_direct"], rtol=1e-6)
+    # the evaluation / eval-latent-fitting branch (neusky_model.py:1036-1059), the `neusky` inclusions, every optional term, and
+    # the nerf_osr_envmap method (no sky-pixel term)
+    for tag, kw in (("evalloss_", {}), ("evalall_", dict(rgb_l2=True, cosine_colour=True)),
+                    ("evalosr_", dict(rgb_l2=True, cosine_colour=True, sky_pixel=False))):
+        le = O.neusky_eval_losses(T(g["rgb"]), T(g["hdr_bg"]), T(g["image"]), T(g["mask"]), **kw)
+        ekeys = [k[len(tag):] for k in g if k.startswith(tag)]
+        assert sorted(ekeys) == sorted(le.keys()), (tag, ekeys, sorted(le))
+        for k in ekeys:
+            close(le[k], g[tag + k], rtol=1e-5, atol=1e-7)
     # coefficient quirk: 'eikonal_loss' is NOT scaled by the 'eikonal loss' coefficient
     sc = O.scale_dict(ld, O.NEUSKY_LOSS_COEFFICIENTS)
     assert float(sc["eikonal_loss"]) == float(ld["eikonal_loss"])
