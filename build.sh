@@ -9,7 +9,7 @@ pids=""
 for f in $SRCS; do
   o="build/$(basename $f).o"
   OBJS="$OBJS $o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ include/neusky_hip.h -nt "$o" ] || [ neusky_amd/csrc/common.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ include/neusky_hip.h -nt "$o" ] || [ neusky_amd/csrc/common.h -nt "$o" ] || [ neusky_amd/csrc/chain.h -nt "$o" ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$f" -o "$o" &
     pids="$pids $!"
   fi

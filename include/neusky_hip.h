@@ -216,8 +216,72 @@ typedef struct {
    * product, no pre-scaling).  All problems of one launch are of the same kind.  bias_rows > 0: db sums only the first bias_rows rows
    * (stacked value + tangent rows: only the value rows carry a bias). */
   int32_t lda, ldb, width_a, width_b, bias_rows;
+  /* tile-native operands only: width_a / width_b > 0 = features of dZ / X that exist (dW is [width_a, width_b], ldw >= width_b; the
+   * tiles beyond are walked but their outputs dropped); bias_row_mod = 4: db sums the rows with row % 4 == 0 only (quad-native
+   * matrices of the SDF field, nsky_field_geo_bwd: row 4 n + j is row-set j of point n and only the value rows carry a bias). */
+  int32_t bias_row_mod;
 } nsky_wgrad_problem;
 int nsky_wgrad_native_batch(const nsky_wgrad_problem* problems, int32_t n_problems, int32_t rows, nsky_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SDF / albedo field as chain kernels (csrc/field_chain.hip).  Replaces SDFAlbedoField.get_outputs / get_colors,
+ * neusky/fields/sdf_albedo_field.py:185-269: the geometry network it inherits from nerfstudio's SDFField ([x | PE6 | hash] -> Linear +
+ * Softplus(beta) -> Linear + Softplus(beta) -> Linear -> [sdf | feat]), torch.autograd.grad(sdf, x, create_graph=True) (:231-238; here the
+ * encode row's three tangent rows ride through the layers in forward mode) and the colour network (:147-161,199-207), forward and
+ * backward (the reference's double backward) as two kernels each on the weight-stream machinery of the FiLM-SIREN chain.
+ *
+ * Packed weight streams of arbitrary layer lists: a layer is a [rows, K] matrix (transposed = 0: W[r][k] = W[r * ld + k]; transposed = 1:
+ * W[r][k] = W[k * ld + r], i.e. the torch [out, in] matrix walked by input feature), cut into ceil(rows / 32) tiles of 32 output rows,
+ * K <= 320.  nsky_chain_pack writes the stream and one reciprocal power-of-two scale per tile (scales[n_tiles]).
+ */
+#define NSKY_CHAIN_MAX_LAYERS 8
+typedef struct { const float* W; int32_t ld, rows, K, transposed; } nsky_chain_layer;
+int nsky_chain_stream_layout(const nsky_chain_layer* layers, int32_t n_layers, int64_t* stream_bytes, int32_t* n_tiles, int32_t* n_groups);
+int nsky_chain_pack(const nsky_chain_layer* layers, int32_t n_layers, void* stream_buf, float* scales, nsky_stream_t stream);
+/* The small vectors of the field the kernels keep in LDS (hidden width 256, geometric feature width 256).  The weight matrices come as
+ * packed streams (total_groups = their n_groups), in this order:
+ *   geo_fwd    : W0 [256, in_dim], W1 [256, 256]
+ *   colour_fwd : W2f [256, 256] (feature rows of the last geometry layer), Wc0 [256, 300] (columns [feat 256 | 0 0 0 0 | x PE | 0]), Wc1 [256, 256]
+ *   colour_bwd : Wc1^T, Wc0^T (rows = its 300 input columns), W2f^T      (transposed = 1)
+ *   geo_bwd    : W1^T, W0^T (rows = in_dim)                              (transposed = 1) */
+typedef struct nsky_field_net {
+  int32_t in_dim;                         /* width of an encode row (multiple of 4; 68..80): [x | PE | hash] */
+  int32_t npe;                            /* its leading x / PE columns that also feed the colour net (<= 39) */
+  float beta;                             /* Softplus beta (sdf_albedo_field.py:163) */
+  const float* b0; const float* b1;       /* [256] biases of the two hidden geometry layers */
+  const float* w_sdf; const float* b_sdf; /* the sdf row [256] of the last geometry layer and its bias [1] (may be null) */
+  const float* b2f;                       /* [256] bias of its feature rows */
+  const float* bc0; const float* bc1;     /* [256] */
+  const float* wc2; int32_t ldc2; const float* bc2;  /* output layer of the colour net [3, 256] (row stride ldc2), [3] */
+} nsky_field_net;
+/* QUAD-NATIVE matrices: tile-native [ceil32(4 N), width] whose row 4 n + j is row-set j of point n (j = 0: value, j = 1..3: d/dx_k).
+ * ET: the stacked encode matrix [4 N, ldE] of nsky_encode_fwd (row j N + n).  Outputs: sdf [N], grad [N, 3] (d sdf / dx), a0q / a1q
+ * (the two hidden layers' outputs, quad-native, width 256), Eq (optional; quad-native copy of the encode rows, width 128, for the first
+ * layer's weight gradient), a1max [N] (optional: largest |a1| of each value row, the colour path's operand scale). */
+int nsky_field_geo_fwd(const nsky_field_net* net, const void* stream_buf, const float* scales, int32_t total_groups, const float* ET,
+                       int32_t ldE, int32_t N, float* a0q, float* a1q, float* Eq, float* a1max, float* sdf, float* grad, nsky_stream_t stream);
+/* feat = W2f a1 + b2f; albedo = sigmoid(Wc2 relu(Wc1 relu(Wc0 [feat | x PE] + bc0) + bc1) + bc2) -> alb [N, 4] (3 used).  Saves (tile-
+ * native, rows = points): a1v [ceil32(N), 256] (optional: value rows of a1), feat [ceil32(N), 256] and xpe [ceil32(N), 128] (columns 0..255
+ * and 256..303 of the colour net's input; xpe's columns 48.. are not written), c0, c1 [ceil32(N), 256]. */
+int nsky_field_colour_fwd(const nsky_field_net* net, const void* stream_buf, const float* scales, int32_t total_groups, const float* ET,
+                          int32_t ldE, int32_t N, const float* a1q, const float* a1max, float* a1v, float* feat, float* xpe, float* c0, float* c1,
+                          float* alb, nsky_stream_t stream);
+/* g_alb [N, 3] -> dpc2 [N, 4] (output layer's pre-activation gradient, row-major), dpc1 / dpc0 / dfeat (tile-native pre-activation
+ * gradients: weight-gradient operands), dxpe [N, 40] (optional: gradient of the encode row's x / PE columns), da1v (tile-native: gradient
+ * of a1's value rows from the feature rows), gmax [3] = max |dpc1|, |dpc0|, |dfeat| (caller zero-fills). */
+int nsky_field_colour_bwd(const nsky_field_net* net, const void* stream_buf, const float* scales, int32_t total_groups, int32_t N,
+                          const float* g_alb, const float* alb, const float* c0, const float* c1, float* dpc2, float* dpc1, float* dpc0,
+                          float* dfeat, float* dxpe, float* da1v, float* gmax, nsky_stream_t stream);
+/* g_sdf [N], g_grad [N, 3], da1v, dxpe (each optional) -> d1q / d0q (quad-native pre-activation gradients of the two hidden layers),
+ * dET [4 N, ldE] (stacked, optional), gmax [2] = max |d1q|, |d0q| (caller zero-fills). */
+int nsky_field_geo_bwd(const nsky_field_net* net, const void* stream_buf, const float* scales, int32_t total_groups, int32_t N,
+                       const float* g_sdf, const float* g_grad, const float* da1v, const float* dxpe, const float* a0q, const float* a1q,
+                       float* d1q, float* d0q, float* dET, int32_t ldE, float* gmax, nsky_stream_t stream);
+/* out[o][f] += sum_rows w[row][o] X[row][f] (o < n_out <= 4) over a tile-native X [rows, 32 nt]; bias[o] += sum_rows w[row][o] (optional):
+ * the weight gradients of the field's narrow output layers.  w4 [rows, 4] row-major, or (w4 null, n_out 1) the quad form over a
+ * quad-native X: w(row) = g_sdf[row / 4] on value rows (the only ones that count for the bias), g_grad[row / 4][row % 4 - 1] on tangent rows. */
+int nsky_native_weighted_colsum(const float* X, int32_t nt, int32_t rows, const float* w4, int32_t n_out, const float* g_sdf,
+                                const float* g_grad, float* out, int32_t ldo, float* bias, nsky_stream_t stream);
 
 /* Per-ray reductions of the renderers, one pass each way: expected depth clipped to the global [min, max] of the sample mid
  * points and, if max_clamp > 0, to max_clamp (nerfstudio DepthRenderer('expected'); neusky_model.py:591, :1342-1353),

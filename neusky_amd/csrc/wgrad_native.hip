@@ -45,6 +45,7 @@ struct WgradProblem {
   int lda, ldb;     // row-major operands: leading dimensions (floats)
   int wa, wb;       // features that exist (dW is [wa, wb]); native: 32 nnt
   int bias_rows;    // db sums the first bias_rows rows only
+  int bias_mod;     // > 1: db sums the rows with row % bias_mod == 0 only (quad-native gradients: the value rows)
 };
 struct WgradArgs {
   WgradProblem p[NSKY_WGRAD_MAX_PROBLEMS];
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void wgrad_nati
     const float s = op == 0 ? a_scale : b_scale;
     const int row = row0 + (RM ? 8 * u + rq : c);
     const bool live = row_block_live && row < a.rows && (!RM || (op == 0 ? fa_ok : fb_ok));
-    const bool bias_on = op == 0 && row < P.bias_rows;
+    const bool bias_on = op == 0 && row < P.bias_rows && (P.bias_mod <= 1 || (row % P.bias_mod) == 0);
     float v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void wgrad_nati
         float v = bias[u][i];
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);  // over the 32 rows of this lane half
-        if (c == 0) atomicAdd(P.db + (nb * NT + wave) * 32 + 8 * u + 4 * hh + i, v * a_inv);
+        if (c == 0 && (nb * NT + wave) * 32 + 8 * u + 4 * hh + i < P.wa) atomicAdd(P.db + (nb * NT + wave) * 32 + 8 * u + 4 * hh + i, v * a_inv);
       }
   }
 }
@@ -321,7 +322,9 @@ extern "C" int nsky_wgrad_native_batch(const nsky_wgrad_problem* problems, int32
       NSKY_CHECK_ARG(q.nnt_a > 0 && q.nnt_b > 0 && q.nnt_a % 4 == 0 && q.nnt_b % 4 == 0,
                      "nsky_wgrad_native_batch: problem %d: both operands need a multiple of 128 features (got %d and %d tiles of 32)", i,
                      q.nnt_a, q.nnt_b);
-      NSKY_CHECK_ARG(q.ldw >= 32 * q.nnt_b, "nsky_wgrad_native_batch: problem %d: ldw %d < %d", i, q.ldw, 32 * q.nnt_b);
+      NSKY_CHECK_ARG(q.width_a >= 0 && q.width_a <= 32 * q.nnt_a && q.width_b >= 0 && q.width_b <= 32 * q.nnt_b,
+                     "nsky_wgrad_native_batch: problem %d: widths %d / %d exceed the tiles", i, q.width_a, q.width_b);
+      NSKY_CHECK_ARG(q.ldw >= (q.width_b > 0 ? q.width_b : 32 * q.nnt_b), "nsky_wgrad_native_batch: problem %d: ldw %d too small", i, q.ldw);
       int e = 0;
       NSKY_CHECK_ARG(q.b_scale > 0.0f && frexpf(q.b_scale, &e) == 0.5f, "nsky_wgrad_native_batch: problem %d: b_scale must be a power of two", i);
       wide = wide && q.nnt_a % 8 == 0 && q.nnt_b % 8 == 0;
@@ -338,9 +341,10 @@ extern "C" int nsky_wgrad_native_batch(const nsky_wgrad_problem* problems, int32
     P.nnt_b = rm ? ceil_div(q.width_b, 32 * NT) * NT : q.nnt_b;
     P.ldw = q.ldw; P.tile0 = tiles;
     P.lda = q.lda; P.ldb = q.ldb;
-    P.wa = rm ? q.width_a : 32 * q.nnt_a;
-    P.wb = rm ? q.width_b : 32 * q.nnt_b;
+    P.wa = (rm || q.width_a > 0) ? q.width_a : 32 * q.nnt_a;
+    P.wb = (rm || q.width_b > 0) ? q.width_b : 32 * q.nnt_b;
     P.bias_rows = q.bias_rows > 0 ? q.bias_rows : rows;
+    P.bias_mod = rm ? 0 : q.bias_row_mod;
     tiles += (P.nnt_a / NT) * (P.nnt_b / NT);
   }
   a.n_problems = n_problems; a.rows = rows; a.n_tiles = tiles;

@@ -235,7 +235,7 @@ class SDFAlbedoField(FieldBase):
         """sdf [N], gradients [N,3], albedo [N,3] at flat positions (sdf_albedo_field.py:225-246).  want_albedo=False: the
         colour net is skipped each way and albedo comes back as zeros (geometry-only passes: DDF-fit ground truth, grid probe)."""
         ET = self._encode(positions_flat.detach(), True, False)
-        return ops.SDFAlbedoFn.apply(ET, *self._geo_weights(), *self._colour_weights(), self.softplus_beta, want_albedo)
+        return ops.field_apply(ET, *self._geo_weights(), *self._colour_weights(), self.softplus_beta, want_albedo)
 
     def get_colors(self, points: torch.Tensor, geo_features: torch.Tensor) -> torch.Tensor:
         """sdf_albedo_field.py:185-209: albedo of the colour network at `points` given their geometric features:

@@ -52,7 +52,7 @@ class GemmDesc(C.Structure):
 
 _lib.nsky_last_error.restype = C.c_char_p
 _lib.nsky_abi_version.restype = C.c_int
-ABI_VERSION = 9  # the ctypes structures below mirror this version of include/neusky_hip.h
+ABI_VERSION = 10  # the ctypes structures below mirror this version of include/neusky_hip.h
 if _lib.nsky_abi_version() != ABI_VERSION:
     raise NeuSkyHipError(f"libneusky_hip.so has ABI version {_lib.nsky_abi_version()}, this package binds version {ABI_VERSION}: rebuild (build.sh)")
 
@@ -605,17 +605,22 @@ _wgrad_native = _sig("nsky_wgrad_native", C.c_void_p, C.c_int32, C.c_void_p, C.c
 class WgradProblem(C.Structure):
     _fields_ = [("dZ", C.c_void_p), ("nnt_a", C.c_int32), ("X", C.c_void_p), ("nnt_b", C.c_int32), ("dW", C.c_void_p), ("ldw", C.c_int32),
                 ("db", C.c_void_p), ("a_scale_max", C.c_void_p), ("b_scale", C.c_float),
-                ("lda", C.c_int32), ("ldb", C.c_int32), ("width_a", C.c_int32), ("width_b", C.c_int32), ("bias_rows", C.c_int32)]
+                ("lda", C.c_int32), ("ldb", C.c_int32), ("width_a", C.c_int32), ("width_b", C.c_int32), ("bias_rows", C.c_int32),
+                ("bias_row_mod", C.c_int32)]
 
 
 WGRAD_MAX_PROBLEMS = 16
 _wgrad_native_batch = _sig("nsky_wgrad_native_batch", C.POINTER(WgradProblem), C.c_int32, C.c_int32, C.c_void_p)
 
 
-def wgrad_problem(dZ, nnt_a, X, nnt_b, rows, dW, db=None, a_scale_max=None, b_scale=64.0) -> WgradProblem:
-    assert dW.stride(1) == 1 and dW.shape[0] >= 32 * nnt_a and dW.shape[1] >= 32 * nnt_b
+def wgrad_problem(dZ, nnt_a, X, nnt_b, rows, dW, db=None, a_scale_max=None, b_scale=64.0, width_a=0, width_b=0, bias_row_mod=0) -> WgradProblem:
+    """width_a / width_b: features of dZ / X that exist when fewer than the tiles walked (dW is then [width_a, width_b]);
+    bias_row_mod = 4: db sums the value rows (row % 4 == 0) of a quad-native dZ only"""
+    wa, wb = width_a or 32 * nnt_a, width_b or 32 * nnt_b
+    assert dW.stride(1) == 1 and dW.shape[0] >= wa and dW.shape[1] >= wb
     assert dZ.numel() >= film_rows(rows) * 32 * nnt_a and X.numel() >= film_rows(rows) * 32 * nnt_b
-    return WgradProblem(ptr(dZ), nnt_a, ptr(X), nnt_b, ptr(dW), ld(dW), ptr(db), ptr(a_scale_max), float(b_scale))
+    return WgradProblem(ptr(dZ), nnt_a, ptr(X), nnt_b, ptr(dW), ld(dW), ptr(db), ptr(a_scale_max), float(b_scale), 0, 0, int(width_a), int(width_b), 0,
+                        int(bias_row_mod))
 
 
 def wgrad_problem_rowmajor(dZ, n_out, X, k_in, rows, dW, db=None, bias_rows=0) -> WgradProblem:
@@ -843,6 +848,95 @@ def sdf_chain_fwd(net: SdfNet, stream_buf, table, E, M, a0_save, a1_save, sdf):
 def sdf_chain_bwd(net: SdfNet, stream_buf, table, M, g_sdf, a0_save, a1_save, dz1, dz0, dE, dw2, db2, gmax):
     check(_sdf_bwd(C.byref(net), ptr(stream_buf), ptr(table), M, ptr(g_sdf), ptr(a0_save), ptr(a1_save), ptr(dz1), ptr(dz0),
                    ptr(dE), 0 if dE is None else ld(dE), ptr(dw2), ptr(db2), ptr(gmax), stream_ptr()), "nsky_sdf_chain_bwd")
+
+
+# ------------------------------------------------------------------------------------------ SDF / albedo field chain
+CHAIN_MAX_LAYERS = 8
+
+
+class ChainLayer(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("ld", C.c_int32), ("rows", C.c_int32), ("K", C.c_int32), ("transposed", C.c_int32)]
+
+
+class FieldNet(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("npe", C.c_int32), ("beta", C.c_float),
+                ("b0", C.c_void_p), ("b1", C.c_void_p), ("w_sdf", C.c_void_p), ("b_sdf", C.c_void_p), ("b2f", C.c_void_p),
+                ("bc0", C.c_void_p), ("bc1", C.c_void_p), ("wc2", C.c_void_p), ("ldc2", C.c_int32), ("bc2", C.c_void_p)]
+
+
+_chain_layout = _sig("nsky_chain_stream_layout", C.POINTER(ChainLayer), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32))
+_chain_pack = _sig("nsky_chain_pack", C.POINTER(ChainLayer), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p)
+_field_geo_fwd = _sig("nsky_field_geo_fwd", C.POINTER(FieldNet), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_field_col_fwd = _sig("nsky_field_colour_fwd", C.POINTER(FieldNet), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_field_col_bwd = _sig("nsky_field_colour_bwd", C.POINTER(FieldNet), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_field_geo_bwd = _sig("nsky_field_geo_bwd", C.POINTER(FieldNet), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p)
+_native_wcolsum = _sig("nsky_native_weighted_colsum", C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                       C.c_int32, C.c_void_p, C.c_void_p)
+
+
+def chain_layer(W, rows, K, transposed=False) -> ChainLayer:
+    """one layer of a packed weight stream: W[r][k] = W[r * ld + k] (transposed: W[k * ld + r]), r < rows, k < K"""
+    return ChainLayer(ptr(W), ld(W), int(rows), int(K), int(bool(transposed)))
+
+
+def chain_pack(layers, device):
+    """-> (stream bytes tensor, per-tile reciprocal scales, number of groups); see include/neusky_hip.h"""
+    arr = (ChainLayer * len(layers))(*layers)
+    nbytes, ntiles, ngroups = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+    check(_chain_layout(arr, len(layers), C.byref(nbytes), C.byref(ntiles), C.byref(ngroups)), "nsky_chain_stream_layout")
+    stream = torch.zeros(nbytes.value, dtype=torch.uint8, device=device)  # (pad slabs of partial groups are streamed, never multiplied)
+    scales = torch.empty(max(ntiles.value, 4), device=device)
+    check(_chain_pack(arr, len(layers), ptr(stream), ptr(scales), stream_ptr()), "nsky_chain_pack")
+    return stream, scales, ngroups.value
+
+
+def field_supported(in_dim: int, hidden: int, geo_feat: int, hidden_colour: int, colour_in: int) -> bool:
+    """shapes the fused field kernels are built for (the `neusky` method's, neusky_config.py:66-77)"""
+    return hidden == 256 and geo_feat == 256 and hidden_colour == 256 and 68 <= in_dim <= 80 and in_dim % 4 == 0 and colour_in == 300
+
+
+def field_net(in_dim, npe, beta, b0, b1, w_sdf, b_sdf, b2f=None, bc0=None, bc1=None, wc2=None, bc2=None) -> FieldNet:
+    return FieldNet(in_dim=in_dim, npe=npe, beta=float(beta), b0=ptr(b0), b1=ptr(b1), w_sdf=ptr(w_sdf), b_sdf=ptr(b_sdf), b2f=ptr(b2f),
+                    bc0=ptr(bc0), bc1=ptr(bc1), wc2=ptr(wc2), ldc2=0 if wc2 is None else ld(wc2), bc2=ptr(bc2))
+
+
+def field_geo_fwd(net: FieldNet, pack, ET, N, a0q, a1q, Eq, a1max, sdf, grad):
+    stream, scales, groups = pack
+    check(_field_geo_fwd(C.byref(net), ptr(stream), ptr(scales), groups, ptr(ET), ld(ET), N, ptr(a0q), ptr(a1q), ptr(Eq), ptr(a1max), ptr(sdf),
+                         ptr(grad), stream_ptr()), "nsky_field_geo_fwd")
+
+
+def field_colour_fwd(net: FieldNet, pack, ET, N, a1q, a1max, a1v, feat, xpe, c0, c1, alb):
+    stream, scales, groups = pack
+    check(_field_col_fwd(C.byref(net), ptr(stream), ptr(scales), groups, ptr(ET), ld(ET), N, ptr(a1q), ptr(a1max), ptr(a1v), ptr(feat), ptr(xpe),
+                         ptr(c0), ptr(c1), ptr(alb), stream_ptr()), "nsky_field_colour_fwd")
+
+
+def field_colour_bwd(net: FieldNet, pack, N, g_alb, alb, c0, c1, dpc2, dpc1, dpc0, dfeat, dxpe, da1v, gmax):
+    stream, scales, groups = pack
+    check(_field_col_bwd(C.byref(net), ptr(stream), ptr(scales), groups, N, ptr(g_alb), ptr(alb), ptr(c0), ptr(c1), ptr(dpc2), ptr(dpc1), ptr(dpc0),
+                         ptr(dfeat), ptr(dxpe), ptr(da1v), ptr(gmax), stream_ptr()), "nsky_field_colour_bwd")
+
+
+def field_geo_bwd(net: FieldNet, pack, N, g_sdf, g_grad, da1v, dxpe, a0q, a1q, d1q, d0q, dET, gmax):
+    stream, scales, groups = pack
+    check(_field_geo_bwd(C.byref(net), ptr(stream), ptr(scales), groups, N, ptr(g_sdf), ptr(g_grad), ptr(da1v), ptr(dxpe), ptr(a0q), ptr(a1q),
+                         ptr(d1q), ptr(d0q), ptr(dET), 0 if dET is None else ld(dET), ptr(gmax), stream_ptr()), "nsky_field_geo_bwd")
+
+
+def native_weighted_colsum(X, nt, rows, out, bias=None, w4=None, n_out=1, g_sdf=None, g_grad=None):
+    """out[o] += sum_rows w[row][o] X[row] over a tile-native X [rows, 32 nt]; w4 [rows, 4], or the quad form (g_sdf / g_grad)"""
+    check(_native_wcolsum(ptr(X), nt, rows, ptr(w4), n_out, ptr(g_sdf), ptr(g_grad), ptr(out), ld(out) if out.dim() == 2 else out.shape[0],
+                          ptr(bias), stream_ptr()), "nsky_native_weighted_colsum")
+
+
+def quad_native_to_rows(buf, N: int, width: int):
+    """quad-native [ceil32(4 N), width] -> [4, N, width] (row-set major; tests)"""
+    return film_native_to_rows(buf, 4 * N, width).reshape(N, 4, width).permute(1, 0, 2)
 
 
 def _ptr_array(ts, n):

@@ -232,9 +232,23 @@ def zeros_like(t: torch.Tensor) -> torch.Tensor:
     return zeros(tuple(t.shape), device=t.device)
 
 
+_STEP_SEQ = [0]  # bumped by begin_step: cache entries remember the step they were prepared in
+
+
+def _order_after(hit_stream, hit_seq) -> None:
+    """a cached weight preparation (planes / packed stream) made on another stream of THIS step: order the current stream after it.
+    An entry that survives from an earlier step (a frozen network's stream) needs no edge -- steps are ordered by their caller --
+    and must not get one: the stream it was made on may be the legacy stream, which a capturing stream cannot wait for."""
+    cur = torch.cuda.current_stream()
+    if hit_seq == _STEP_SEQ[0] and hit_stream != cur:
+        cur.wait_stream(hit_stream)
+
+
 def begin_step(device=None) -> None:
+    _STEP_SEQ[0] += 1
     _PLANES.clear()
     _SDF_STREAMS.clear()
+    _FIELD_STREAMS.clear()
     for key in [k for k, hit in _FILM_STREAMS.items() if any(t.requires_grad for t in hit[0])]:
         del _FILM_STREAMS[key]  # (streams packed from frozen weights -- keyed by storage and version -- stay)
     a = _ARENA
@@ -246,11 +260,10 @@ def begin_step(device=None) -> None:
 def _planes(W, n_rows, n_k, transpose, precision):
     key = (W.data_ptr(), W._version, ld(W), n_rows, n_k, transpose, precision)
     hit = _PLANES.get(key)
-    cur = torch.cuda.current_stream()
     if hit is None:
-        hit = _PLANES[key] = (W, hip.split_planes(W, n_rows, n_k, transpose, precision), cur)
-    elif hit[2] != cur:  # split on another stream (parallel passes of one step share the weights): order this stream after it
-        cur.wait_stream(hit[2])
+        hit = _PLANES[key] = (W, hip.split_planes(W, n_rows, n_k, transpose, precision), torch.cuda.current_stream(), _STEP_SEQ[0])
+    else:  # split on another stream (parallel passes of one step share the weights): order this stream after it
+        _order_after(hit[2], hit[3])
     return hit[1]
 
 
@@ -411,7 +424,6 @@ def _film_stream(wb, n_map, n_film, mw, mb, mwo, mbo, fw, fb, ow, ob, direction=
     dropped by begin_step when any of its weights is trainable: the optimiser changed them) -> (descriptor, stream bytes, bias / scale table)"""
     key = (wb[0].data_ptr(), wb[0]._version, wb[-2].data_ptr(), n_map, n_film, direction)
     hit = _FILM_STREAMS.get(key)
-    cur = torch.cuda.current_stream()
     if hit is None:
         net = hip.film_net(mw[0].shape[1], fw[0].shape[1], ow.shape[0], mw, mb, mwo, mbo, fw, fb, ow, ob)
         nbytes, _ = hip.film_stream_layout(net, direction)
@@ -419,9 +431,9 @@ def _film_stream(wb, n_map, n_film, mw, mb, mwo, mbo, fw, fb, ow, ob, direction=
         stream = torch.zeros(nbytes, dtype=torch.uint8, device=wb[0].device)
         table = torch.empty(hip.FILM_TABLE_FLOATS, device=wb[0].device)
         hip.film_pack(net, stream, table, direction)
-        hit = _FILM_STREAMS[key] = (list(wb), net, stream, table, cur)
-    elif hit[4] != cur:  # packed on another stream of the same step: order this stream after it
-        cur.wait_stream(hit[4])
+        hit = _FILM_STREAMS[key] = (list(wb), net, stream, table, torch.cuda.current_stream(), _STEP_SEQ[0])
+    else:  # packed on another stream of the same step: order this stream after it
+        _order_after(hit[4], hit[5])
     return hit[1], hit[2], hit[3]
 
 
@@ -802,6 +814,133 @@ class SDFAlbedoFn(torch.autograd.Function):
                 k(f_c1, dWc1), k(f_c1, dbc1), k(f_c2, dWc2), k(f_c2, dbc2), None, None)
 
 
+# =============================================================================================
+# SDF + albedo field as chain kernels (csrc/field_chain.hip)
+# =============================================================================================
+FUSED_FIELD_MIN_POINTS = 1024  # 4096 stacked value + tangent rows: below, a handful of workgroups walk a serial chain
+_FIELD_STREAMS: dict = {}
+
+
+def _field_pack(kind, weights, layers_fn):
+    """per-step cache of one packed weight stream of the field (dropped by begin_step) -> (stream, scales, groups)"""
+    key = (kind,) + tuple((w.data_ptr(), w._version) for w in weights)
+    hit = _FIELD_STREAMS.get(key)
+    if hit is None:
+        hit = _FIELD_STREAMS[key] = (weights, hip.chain_pack(layers_fn(), weights[0].device), torch.cuda.current_stream(), _STEP_SEQ[0])
+    else:
+        _order_after(hit[2], hit[3])
+    return hit[1]
+
+
+def field_fused_ok(ET, W0, W1, W2, Wc0, Wc1) -> bool:
+    return (FWD_PRECISION == hip.PREC_F16X2 and ET.is_cuda and ET.shape[0] // 4 >= FUSED_FIELD_MIN_POINTS and ld(ET) == W0.shape[1]
+            and hip.field_supported(W0.shape[1], W0.shape[0], W2.shape[0] - 4, Wc1.shape[0], Wc0.shape[1]))
+
+
+class FieldChainFn(torch.autograd.Function):
+    """SDFAlbedoFn's contract (same arguments, same outputs) on the fused field kernels: geometry network with forward-mode tangents
+    in the quad layout, colour path, and the hand-derived reverse of both; every product fp32-grade (fp16 hi + residual planes on
+    power-of-two pre-scaled operands), weight gradients by the streaming tile-native kernel."""
+
+    NPE = 39  # x (3) + PE6 (36): the leading columns of an encode row that also feed the colour net
+
+    @staticmethod
+    def forward(ctx, ET, W0, b0, W1, b1, W2, b2, Wc0, bc0, Wc1, bc1, Wc2, bc2, beta, want_albedo=True):
+        N = ET.shape[0] // 4
+        dev = ET.device
+        GF = W2.shape[0] - 4
+        Kin = W0.shape[1]
+        save = any(ctx.needs_input_grad)
+        w_sdf, b_sdf = W2[GF], b2[GF:GF + 1]
+        net = hip.field_net(Kin, FieldChainFn.NPE, beta, b0, b1, w_sdf, b_sdf, b2[:GF], bc0, bc1, Wc2, bc2)
+        Mq, Mp = hip.film_rows(4 * N), hip.film_rows(N)
+        a0q, a1q = torch.empty(Mq, 256, device=dev), torch.empty(Mq, 256, device=dev)
+        Eq = torch.empty(Mq, 128, device=dev) if save else None
+        a1max = torch.empty(N, device=dev)
+        sdf, grad = torch.empty(N, device=dev), torch.empty(N, 3, device=dev)
+        pk = _field_pack("geo_fwd", (W0, W1), lambda: [hip.chain_layer(W0, 256, Kin), hip.chain_layer(W1, 256, 256)])
+        hip.field_geo_fwd(net, pk, ET, N, a0q, a1q, Eq, a1max, sdf, grad)
+        if want_albedo:
+            a1v = torch.empty(Mp, 256, device=dev) if save else None
+            feat, c0, c1 = torch.empty(Mp, 256, device=dev), torch.empty(Mp, 256, device=dev), torch.empty(Mp, 256, device=dev)
+            xpe = torch.empty(Mp, 128, device=dev)
+            alb = torch.empty(N, 4, device=dev)
+            pk = _field_pack("col_fwd", (W2, Wc0, Wc1), lambda: [hip.chain_layer(W2, 256, 256), hip.chain_layer(Wc0, 256, Wc0.shape[1]),
+                                                                  hip.chain_layer(Wc1, 256, 256)])
+            hip.field_colour_fwd(net, pk, ET, N, a1q, a1max, a1v, feat, xpe, c0, c1, alb)
+        else:
+            a1v = feat = xpe = c0 = c1 = alb = None
+        ctx.want_albedo = want_albedo
+        ctx.cfg = (N, GF, Kin, beta)
+        ctx.set_materialize_grads(False)
+        if save:
+            e = ET.new_empty(0)
+            ctx.save_for_backward(ET, a0q, a1q, Eq, *((a1v, feat, xpe, c0, c1, alb) if want_albedo else (e, e, e, e, e, e)),
+                                  W0, b0, W1, b1, W2, b2, Wc0, bc0, Wc1, bc1, Wc2, bc2)
+        if not want_albedo:
+            out_alb = zeros(N, 3, device=dev)
+            ctx.mark_non_differentiable(out_alb)
+            return sdf, grad, out_alb
+        return sdf, grad, alb[:, :3].contiguous()
+
+    @staticmethod
+    def backward(ctx, g_sdf, g_grad, g_alb):
+        ET, a0q, a1q, Eq, a1v, feat, xpe, c0, c1, alb, W0, b0, W1, b1, W2, b2, Wc0, bc0, Wc1, bc1, Wc2, bc2 = ctx.saved_tensors
+        N, GF, Kin, beta = ctx.cfg
+        dev = ET.device
+        colour = ctx.want_albedo and g_alb is not None
+        net = hip.field_net(Kin, FieldChainFn.NPE, beta, b0, b1, W2[GF], b2[GF:GF + 1], b2[:GF], bc0, bc1, Wc2, bc2)
+        Mq, Mp = hip.film_rows(4 * N), hip.film_rows(N)
+        gmax = zeros(8, device=dev)
+        g_sdf = None if g_sdf is None else g_sdf.contiguous()
+        g_grad = None if g_grad is None else g_grad.contiguous()
+        da1v = dxpe = None
+        if colour:
+            dpc2 = torch.empty(N, 4, device=dev)
+            dpc1, dpc0, dfeat, da1v = (torch.empty(Mp, 256, device=dev) for _ in range(4))
+            dxpe = torch.empty(N, 40, device=dev)
+            pk = _field_pack("col_bwd", (Wc1, Wc0, W2), lambda: [hip.chain_layer(Wc1, 256, 256, True), hip.chain_layer(Wc0, Wc0.shape[1], 256, True),
+                                                                  hip.chain_layer(W2, 256, 256, True)])
+            hip.field_colour_bwd(net, pk, N, g_alb.contiguous(), alb, c0, c1, dpc2, dpc1, dpc0, dfeat, dxpe, da1v, gmax[:3])
+        d1q, d0q = torch.empty(Mq, 256, device=dev), torch.empty(Mq, 256, device=dev)
+        dET = torch.empty(4 * N, ld(ET), device=dev) if ctx.needs_input_grad[0] else None
+        pk = _field_pack("geo_bwd", (W1, W0), lambda: [hip.chain_layer(W1, 256, 256, True), hip.chain_layer(W0, Kin, 256, True)])
+        hip.field_geo_bwd(net, pk, N, g_sdf, g_grad, da1v, dxpe, a0q, a1q, d1q, d0q, dET, gmax[4:6])
+        none6 = (None,) * 6
+        if not any(ctx.needs_input_grad[1:13]):  # frozen field (the eval-latent fit): only the encode rows' gradient
+            return (dET, *none6, *none6, None, None)
+        # ---- parameter gradients: every dense layer's by the streaming tile-native kernel (value rows only for the biases of the
+        # quad-native gradients), the two narrow output layers' by weighted column sums
+        dW2, db2, f_2 = shared_grad(W2, b2)
+        dW1, db1, f_1 = shared_grad(W1, b1)
+        dW0, db0, f_0 = shared_grad(W0, b0)
+        R4 = 4 * N
+        hip.wgrad_native_batch([hip.wgrad_problem(d1q, 8, a0q, 8, R4, dW1, db1, gmax[4:5], 8.0, bias_row_mod=4)], R4)
+        hip.wgrad_native_batch([hip.wgrad_problem(d0q, 8, Eq, 4, R4, dW0, db0, gmax[5:6], 64.0, width_b=Kin, bias_row_mod=4)], R4)
+        hip.native_weighted_colsum(a1q, 8, R4, dW2[GF], db2[GF:GF + 1], g_sdf=g_sdf, g_grad=g_grad)
+        k = lambda first, t: t if first else None  # noqa: E731  later nodes of the pass added in place
+        if not colour:
+            return (dET, k(f_0, dW0), k(f_0, db0), k(f_1, dW1), k(f_1, db1), k(f_2, dW2), k(f_2, db2), *none6, None, None)
+        dWc2, dbc2, f_c2 = shared_grad(Wc2, bc2)
+        dWc1, dbc1, f_c1 = shared_grad(Wc1, bc1)
+        dWc0, dbc0, f_c0 = shared_grad(Wc0, bc0)
+        hip.wgrad_native_batch([hip.wgrad_problem(dfeat, 8, a1v, 8, N, dW2[:GF], db2[:GF], gmax[2:3], 8.0),
+                                hip.wgrad_problem(dpc1, 8, c0, 8, N, dWc1, dbc1, gmax[0:1], 8.0),
+                                hip.wgrad_problem(dpc0, 8, feat, 8, N, dWc0[:, :GF], dbc0, gmax[1:2], 8.0)], N)
+        hip.wgrad_native_batch([hip.wgrad_problem(dpc0, 8, xpe, 4, N, dWc0[:, GF:], None, gmax[1:2], 64.0, width_b=Wc0.shape[1] - GF)], N)
+        hip.native_weighted_colsum(c1, 8, N, dWc2, dbc2, w4=dpc2, n_out=3)
+        return (dET, k(f_0, dW0), k(f_0, db0), k(f_1, dW1), k(f_1, db1), k(f_2, dW2), k(f_2, db2), k(f_c0, dWc0), k(f_c0, dbc0),
+                k(f_c1, dWc1), k(f_c1, dbc1), k(f_c2, dWc2), k(f_c2, dbc2), None, None)
+
+
+def field_apply(ET, *args):
+    """the field on stacked encode rows: the fused chain kernels where they apply, otherwise the per-layer path"""
+    W0, _, W1, _, W2, _, Wc0, _, Wc1 = args[:9]
+    if field_fused_ok(ET, W0, W1, W2, Wc0, Wc1):
+        return FieldChainFn.apply(ET, *args)
+    return SDFAlbedoFn.apply(ET, *args)
+
+
 FUSED_SDF_MIN_ROWS = 4096
 _SDF_STREAMS: dict = {}
 
@@ -810,7 +949,6 @@ def _sdf_stream(W0, b0, W1, b1, W2, b2, GF, beta, direction):
     """per-step cache of the packed weight stream of the sdf value chain (direction 0 forward, 1 backward; dropped by begin_step)"""
     key = (W0.data_ptr(), W0._version, W1.data_ptr(), W2.data_ptr(), GF, direction)
     hit = _SDF_STREAMS.get(key)
-    cur = torch.cuda.current_stream()
     if hit is None:
         keep = (W0, b0, W1, b1, W2, b2, W2[GF], b2[GF:GF + 1])
         net = hip.sdf_net(W0, b0, W1, b1, keep[6], keep[7], beta)
@@ -818,9 +956,9 @@ def _sdf_stream(W0, b0, W1, b1, W2, b2, GF, beta, direction):
         stream = torch.zeros(nbytes, dtype=torch.uint8, device=W0.device)
         table = torch.empty(hip.FILM_TABLE_FLOATS, device=W0.device)
         hip.sdf_pack(net, stream, table, direction)
-        hit = _SDF_STREAMS[key] = (keep, net, stream, table, cur)
-    elif hit[4] != cur:
-        cur.wait_stream(hit[4])
+        hit = _SDF_STREAMS[key] = (keep, net, stream, table, torch.cuda.current_stream(), _STEP_SEQ[0])
+    else:
+        _order_after(hit[4], hit[5])
     return hit[1], hit[2], hit[3]
 
 

@@ -77,10 +77,14 @@ def main():
     torch.cuda.synchronize()
     eager = named_grads(pipe)
     slab_eager = opt.flat_g.detach().cpu().numpy().copy()
+    # nothing of the eager iteration's autograd graph may outlive it: a live loss tensor keeps the parameters' AccumulateGrad nodes,
+    # which remember the (legacy) stream they were made on and would run on it inside the capture below
+    loss_eager = float(loss)
+    del loss, ld
     # ---- the same iteration captured in a HIP graph, replayed, all-reduced, Adam-stepped
     before = {n: p.detach().clone() for n, p in pipe.named_parameters() if p.requires_grad}
     stepper = GraphedTrainStep(pipe, opt, rbs, bs, warmup=1, start_step=10_000, randoms=rs)
-    gl, _, _ = stepper.step(10_000)
+    gl, _, _ = stepper.step(10_000, rbs, bs, rs["sky_ray_bundle"])  # (the sky rays of the eager iteration: the stepper drew its own)
     torch.cuda.synchronize()
     slab_graph = opt.flat_g.detach().cpu().numpy().copy()
     moved = sum(int(not torch.equal(p.detach(), before[n])) for n, p in pipe.named_parameters() if p.requires_grad)
@@ -90,7 +94,7 @@ def main():
         dist.all_gather(both, sums)
         assert all(torch.equal(b, both[0]) for b in both), "ranks hold different slabs after the all-reduce"
     if rank == 0:
-        np.savez(out, loss=float(loss), graph_loss=float(gl), slab_eager=slab_eager, slab_graph=slab_graph, moved=moved,
+        np.savez(out, loss=loss_eager, graph_loss=float(gl), slab_eager=slab_eager, slab_graph=slab_graph, moved=moved,
                  **{"g:" + k: v for k, v in eager.items()})
     if world > 1:
         dist.barrier()
