@@ -106,10 +106,11 @@ struct WStream {
 };
 
 // PW = 1 KB pieces of a 16 KB group this wave moves: 4 with four waves per workgroup, 2 with eight
-template <int PW = 4>
+// RG: groups in the LDS ring (a power of two; 8 = 128 KB with one workgroup per CU, 4 = 64 KB with two)
+template <int PW = 4, int RG = RING_GROUPS>
 __device__ __forceinline__ void ws_issue(const WStream& w, int group) {
   const unsigned char* s = w.src + (long)group * GROUP;
-  const uint32_t d = w.dst + (uint32_t)(group & (RING_GROUPS - 1)) * GROUP;
+  const uint32_t d = w.dst + (uint32_t)(group & (RG - 1)) * GROUP;
 #pragma unroll
   for (int p = 0; p < PW; ++p) {
     glds16(s + p * 1024, d + p * 1024);
@@ -117,10 +118,10 @@ __device__ __forceinline__ void ws_issue(const WStream& w, int group) {
 }
 
 // the same for a stream that is walked cyclically: the ring slot follows the running group count, the source wraps
-template <int PW = 4>
+template <int PW = 4, int RG = RING_GROUPS>
 __device__ __forceinline__ void ws_issue_wrap(WStream& w, int group) {
   const unsigned char* s = w.src + (long)w.sg * GROUP;
-  const uint32_t d = w.dst + (uint32_t)(group & (RING_GROUPS - 1)) * GROUP;
+  const uint32_t d = w.dst + (uint32_t)(group & (RG - 1)) * GROUP;
 #pragma unroll
   for (int p = 0; p < PW; ++p) {
     glds16(s + p * 1024, d + p * 1024);
@@ -139,8 +140,9 @@ __device__ __forceinline__ void frag_wait(f16x8& h, f16x8& l) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(h), "+v"(l) : "n"(N) : "memory");
 }
 
+template <int RG = RING_GROUPS>
 __device__ __forceinline__ uint32_t ws_addr(const WStream& w, int group, int slab) {
-  return w.lds_lane + (uint32_t)(group & (RING_GROUPS - 1)) * GROUP + slab * SLAB;
+  return w.lds_lane + (uint32_t)(group & (RG - 1)) * GROUP + slab * SLAB;
 }
 
 template <int PW = 4>
@@ -155,42 +157,42 @@ __device__ __forceinline__ void ws_begin(WStream& w) {
   frag_wait<0>(w.ch, w.cl);
 }
 
-template <int PW = 4>
+template <int PW = 4, int RG = RING_GROUPS>
 __device__ __forceinline__ void ws_begin_wrap(WStream& w, int total_groups) {
   w.total = total_groups;
   w.sg = 0;
 #pragma unroll
-  for (int g = 0; g < RING_GROUPS; ++g) ws_issue_wrap<PW>(w, g);
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PW * (RING_GROUPS - 2)) : "memory");  // groups 0 and 1 landed
+  for (int g = 0; g < RG; ++g) ws_issue_wrap<PW, RG>(w, g);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PW * (RG - 2)) : "memory");  // groups 0 and 1 landed
   w.g = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) { w.ch[j] = (_Float16)0.0f; w.cl[j] = (_Float16)0.0f; }
-  frag_read(w.ch, w.cl, ws_addr(w, 0, 0));
+  frag_read(w.ch, w.cl, ws_addr<RG>(w, 0, 0));
   frag_wait<0>(w.ch, w.cl);
 }
 
-template <int PW = 4, bool WRAP = false>
+template <int PW = 4, bool WRAP = false, int RG = RING_GROUPS>
 __device__ __forceinline__ void ws_transition(WStream& w, int from_group) {
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PW * (RING_GROUPS - 3)) : "memory");
-  if (WRAP) ws_issue_wrap<PW>(w, from_group + RING_GROUPS);
-  else ws_issue<PW>(w, from_group + RING_GROUPS);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PW * (RG - 3)) : "memory");
+  if (WRAP) ws_issue_wrap<PW, RG>(w, from_group + RG);
+  else ws_issue<PW, RG>(w, from_group + RG);
 }
 
 // what a wave WITHOUT a row tile does in place of a product (the last round of a persistent workgroup): its share of the group
 // hand-shakes (counted wait, barrier, DMA pieces of the refill) and nothing else -- the same number of barriers as product<KS>
-template <int KS, int PW, bool WRAP>
+template <int KS, int PW, bool WRAP, int RG = RING_GROUPS>
 __device__ __forceinline__ void product_skip(WStream& w) {
   constexpr int NG = (KS + GSLABS - 1) / GSLABS;
   const int g0 = w.g;
 #pragma unroll
-  for (int i = 0; i < NG; ++i) ws_transition<PW, WRAP>(w, g0 + i);
+  for (int i = 0; i < NG; ++i) ws_transition<PW, WRAP, RG>(w, g0 + i);
   w.g = g0 + NG;
 }
 
 // acc += W_tile X over KS k-steps, B planes in registers.  One wave per SIMD issues in order, so everything that is not an
 // MFMA is placed in the shadow of one: the LDS requests of k-step ks + 2 (and a group transition: barrier + 4 DMA pieces) right
 // behind the first MFMA of k-step ks, the counted wait for the fragments of ks + 1 behind the third.
-template <int KS, int PW = 4, bool WRAP = false>
+template <int KS, int PW = 4, bool WRAP = false, int RG = RING_GROUPS>
 __device__ __forceinline__ void product(WStream& w, const f16x8 (&bh)[KS], const f16x8 (&bl)[KS], f32x16& acc) {
   constexpr int NG = (KS + GSLABS - 1) / GSLABS;  // groups of this tile; slab index KS stands for slab 0 of the next tile
   f16x8 fh[3], fl[3];
@@ -200,8 +202,8 @@ __device__ __forceinline__ void product(WStream& w, const f16x8 (&bh)[KS], const
   for (int j = 0; j < 8; ++j) { fh[1][j] = fh[2][j] = fl[1][j] = fl[2][j] = (_Float16)0.0f; }
   const int g0 = w.g;
   auto request = [&](int s) {  // s static
-    if (s < KS) frag_read(fh[s % 3], fl[s % 3], ws_addr(w, g0 + s / GSLABS, s % GSLABS));
-    else frag_read(fh[s % 3], fl[s % 3], ws_addr(w, g0 + NG, 0));
+    if (s < KS) frag_read(fh[s % 3], fl[s % 3], ws_addr<RG>(w, g0 + s / GSLABS, s % GSLABS));
+    else frag_read(fh[s % 3], fl[s % 3], ws_addr<RG>(w, g0 + NG, 0));
   };
   request(1);
 #pragma unroll
@@ -210,7 +212,7 @@ __device__ __forceinline__ void product(WStream& w, const f16x8 (&bh)[KS], const
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks % 3], bl[ks], acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (ks + 2 <= KS) request(ks + 2);  // into the buffer of k-step ks - 1, whose MFMAs have been issued
-    if ((ks & (GSLABS - 1)) == GSLABS - 1 || ks == KS - 1) ws_transition<PW, WRAP>(w, g0 + ks / GSLABS);
+    if ((ks & (GSLABS - 1)) == GSLABS - 1 || ks == KS - 1) ws_transition<PW, WRAP, RG>(w, g0 + ks / GSLABS);
     __builtin_amdgcn_sched_barrier(0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks % 3], bh[ks], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks % 3], bh[ks], acc, 0, 0, 0);

@@ -30,7 +30,11 @@
 
 namespace {
 
-constexpr int H = 256, NT = 8, KS = 16, PW = 2;
+constexpr int H = 256, NT = 8, KS = 16;
+// Workgroup shape: WAVES waves share one weight stream through a ring of RG groups; 8 / WAVES workgroups are resident per CU (two waves
+// per SIMD either way).  With two 4-wave workgroups per CU the two waves of a SIMD belong to different workgroups: no barrier couples
+// them, so one's epilogue arithmetic runs beside the other's MFMAs instead of both alternating in lockstep.
+constexpr int WAVES = 4, PW = 16 / WAVES, RG = WAVES == 8 ? 8 : 4, RING = RG * GROUP, THREADS = 64 * WAVES, WGS_PER_CU = 8 / WAVES;
 
 // ---------------------------------------------------------------------------------------------------------------------
 // generic packed stream: a list of layers, each ceil(rows / 32) tiles of groups_of(K) groups
@@ -65,21 +69,38 @@ __global__ __launch_bounds__(256) void chain_pack_kernel(ChainLayers L, unsigned
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Cross-lane moves must execute with the whole quad enabled: never inside an arm of a `c ? a : b` whose condition differs between the
-// lanes of a quad (the arm runs under its own EXEC mask and the DPP move reads zeros from the disabled lanes).  Their operands and
-// results are additionally pinned by empty asm statements so that no later transformation moves them next to a single user.
-__device__ __forceinline__ float pin(float v) {
-  asm volatile("" : "+v"(v));
+// lanes of a quad (the arm runs under its own EXEC mask and the DPP move reads zeros from the disabled lanes): every quad move below
+// is a statement of its own, ahead of the selects that use it.
+template <int G>
+__device__ __forceinline__ float quad_bcast(float v) {  // the value of the quad's lane G in all four lanes
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), G * 0x55, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float quad_bcast0(float v) { return quad_bcast<0>(v); }
+__device__ __forceinline__ float quad_sum(float v) {  // sum over the quad, in all four lanes
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
   return v;
 }
-__device__ __forceinline__ float quad_bcast0(float v) {  // the value of the quad's lane 0 in all four lanes
-  return pin(__int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(pin(v)), 0x00, 0xf, 0xf, true)));
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true)));
+  return v;
 }
-__device__ __forceinline__ float quad_sum(float v) {  // sum over the quad, in all four lanes
-  v = pin(v);
-  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
-  v = pin(v);
-  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
-  return pin(v);
+// registers 4 j .. 4 j + 3 of the quad's lane 0 (the value lane) in lane j: the value row's sixteen features of a tile are worked on by
+// the four lanes of its quad, four each (the transcendental work of a softplus layer is needed for the value row only)
+__device__ __forceinline__ void quad_scatter_value(const float (&x)[16], int j, float (&mine)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float b0 = quad_bcast0(x[q]), b1 = quad_bcast0(x[4 + q]), b2 = quad_bcast0(x[8 + q]), b3 = quad_bcast0(x[12 + q]);
+    mine[q] = j == 0 ? b0 : (j == 1 ? b1 : (j == 2 ? b2 : b3));
+  }
+}
+// the reverse: element q of lane g -> register 4 g + q of every lane
+__device__ __forceinline__ void quad_gather_all(const float (&mine)[4], float (&all)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    all[q] = quad_bcast<0>(mine[q]); all[4 + q] = quad_bcast<1>(mine[q]); all[8 + q] = quad_bcast<2>(mine[q]); all[12 + q] = quad_bcast<3>(mine[q]);
+  }
 }
 
 // softplus(beta; threshold 20) and sigmoid(beta v) from one exp / rcp / log
@@ -120,15 +141,15 @@ __device__ __forceinline__ void prod(WStream& ws, const f16x8 (&bh)[KSN], const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   }
-  if (ACTIVE) product<KSN, PW, true>(ws, bh, bl, acc);
-  else product_skip<KSN, PW, true>(ws);
+  if (ACTIVE) product<KSN, PW, true, RG>(ws, bh, bl, acc);
+  else product_skip<KSN, PW, true, RG>(ws);
 }
 
 __device__ __forceinline__ void ws_setup(WStream& ws, const unsigned char* stream, unsigned char* smem, int wave, int lane, int total_groups) {
   ws.src = stream + wave * (PW * 1024) + lane * 16;
   ws.dst = (uint32_t)(uintptr_t)smem + wave * (PW * 1024);
   ws.lds_lane = (uint32_t)(uintptr_t)smem + lane * 16;
-  ws_begin_wrap<PW>(ws, total_groups);
+  ws_begin_wrap<PW, RG>(ws, total_groups);
 }
 
 // =====================================================================================================================
@@ -143,6 +164,53 @@ struct GeoFwdArgs {
   float* a1max;               // [N] largest |a1| of the value row (optional)
   float* sdf; float* grad;    // [N], [N, 3]
 };
+
+// Epilogue of one 32-feature tile of a forward-mode softplus layer in the quad layout.  acc: this column's accumulator; inv: its
+// un-scale; bias_t / w_t: the layer's bias and (DOT) the sdf row, at the tile's first feature.  The value row's pre-activations are
+// spread over the quad (lane g: features 8 g + 4 h ..), softplus and sigmoid are evaluated there, the value row's outputs are stored
+// by the lanes that computed them, the sigmoids return to every lane for the tangent rows ta_k = tz_k sigmoid(beta z).
+// m: running row maximum of this lane's column; part_v / part_t: running dots with the sdf row (value row: quad partials).
+template <bool DOT>
+__device__ __forceinline__ void geo_fwd_epilogue(const f32x16& acc, float inv, const float* bias_t, const float* w_t, float beta, float inv_beta, int lane,
+                                                 float* blk_t, float& m, float& part_v, float& part_t) {
+  const int c = lane & 31, h = lane >> 5, j = c & 3;
+  float x[16], zv[4], sp[4], sg[4], S[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[r] = acc[r] * inv;
+  quad_scatter_value(x, j, zv);
+  const float4 b4 = *reinterpret_cast<const float4*>(bias_t + 8 * j + 4 * h);
+  const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+  float mv = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    softplus_sig(zv[q] + bb[q], beta, inv_beta, sp[q], sg[q]);
+    mv = fmaxf(mv, sp[q]);
+  }
+  quad_gather_all(sg, S);
+  mv = quad_max(mv);
+  float mt = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    x[r] *= S[r];  // tangent rows (the value lane's own x is not used past this point)
+    mt = fmaxf(mt, fabsf(x[r]));
+  }
+  m = fmaxf(m, j == 0 ? mv : mt);
+  if (DOT) {
+    const float4 wv = *reinterpret_cast<const float4*>(w_t + 8 * j + 4 * h);
+    part_v = fmaf(sp[0], wv.x, fmaf(sp[1], wv.y, fmaf(sp[2], wv.z, fmaf(sp[3], wv.w, part_v))));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 w4 = *reinterpret_cast<const float4*>(w_t + 8 * g + 4 * h);
+      part_t = fmaf(x[4 * g], w4.x, fmaf(x[4 * g + 1], w4.y, fmaf(x[4 * g + 2], w4.z, fmaf(x[4 * g + 3], w4.w, part_t))));
+    }
+  }
+  // the value row's piece g (features 8 g + 4 h ..) from lane g of the quad; the tangent rows from their own lanes
+  stg4(blk_t + j * 256 + ((c & ~3) + 32 * h) * 4, make_float4(sp[0], sp[1], sp[2], sp[3]));
+  if (j != 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) stg4(blk_t + g * 256 + lane * 4, make_float4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]));
+  }
+}
 
 template <int KS0, bool ACTIVE>
 __device__ __forceinline__ void geo_fwd_tile(const GeoFwdArgs& a, WStream& ws, const float* bl, const float* sl, long tile, int lane) {
@@ -192,30 +260,11 @@ __device__ __forceinline__ void geo_fwd_tile(const GeoFwdArgs& a, WStream& ws, c
   float* a0blk = a.a0q + tile * NT * 1024;
   float* a1blk = a.a1q + tile * NT * 1024;
   // ---- layer 0
-  float m = 0.0f;
+  float m = 0.0f, part_v = 0.0f, part_t = 0.0f;
   for (int t = 0; t < NT; ++t) {
     f32x16 acc;
     prod<KS0, ACTIVE>(ws, eh, el, acc);
-    if (ACTIVE) {
-      const float inv = e_inv * sl[t];
-      float v[16];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 b4 = *reinterpret_cast<const float4*>(bl + 32 * t + 8 * g + 4 * h);
-        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float z = fmaf(acc[4 * g + q], inv, j == 0 ? bb[q] : 0.0f);
-          float sp, sg;
-          softplus_sig(z, beta, inv_beta, sp, sg);
-          const float sq = quad_bcast0(sg);  // (outside the conditional: every lane of the quad takes part)
-          const float o = j == 0 ? sp : z * sq;
-          v[4 * g + q] = o;
-          m = fmaxf(m, fabsf(o));
-        }
-      }
-      store_tile(a0blk + t * 1024, lane, v);
-    }
+    if (ACTIVE) geo_fwd_epilogue<false>(acc, e_inv * sl[t], bl + 32 * t, nullptr, beta, inv_beta, lane, a0blk + t * 1024, m, part_v, part_t);
   }
   f16x8 ah[KS], al[KS];
   float a_inv = 1.0f;
@@ -226,34 +275,14 @@ __device__ __forceinline__ void geo_fwd_tile(const GeoFwdArgs& a, WStream& ws, c
   }
   // ---- layer 1 + the sdf row of layer 2
   m = 0.0f;
-  float part = 0.0f;
   for (int t = 0; t < NT; ++t) {
     f32x16 acc;
     prod<KS, ACTIVE>(ws, ah, al, acc);
-    if (ACTIVE) {
-      const float inv = a_inv * sl[NT + t];
-      float v[16];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 b4 = *reinterpret_cast<const float4*>(bl + H + 32 * t + 8 * g + 4 * h);
-        const float4 w4 = *reinterpret_cast<const float4*>(bl + 2 * H + 32 * t + 8 * g + 4 * h);
-        const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float z = fmaf(acc[4 * g + q], inv, j == 0 ? bb[q] : 0.0f);
-          float sp, sg;
-          softplus_sig(z, beta, inv_beta, sp, sg);
-          const float sq = quad_bcast0(sg);  // (outside the conditional: every lane of the quad takes part)
-          const float o = j == 0 ? sp : z * sq;
-          v[4 * g + q] = o;
-          m = fmaxf(m, fabsf(o));
-          part = fmaf(o, ww[q], part);
-        }
-      }
-      store_tile(a1blk + t * 1024, lane, v);
-    }
+    if (ACTIVE) geo_fwd_epilogue<true>(acc, a_inv * sl[NT + t], bl + H + 32 * t, bl + 2 * H + 32 * t, beta, inv_beta, lane, a1blk + t * 1024, m, part_v, part_t);
   }
   if (ACTIVE) {
+    const float pq = quad_sum(part_v);  // the value row's dot: partials in the four lanes of the quad
+    float part = j == 0 ? pq : part_t;
     part += __shfl_xor(part, 32, 64);  // the two lane halves hold different features of the same column
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     if (live && h == 0) {
@@ -268,21 +297,21 @@ __device__ __forceinline__ void geo_fwd_tile(const GeoFwdArgs& a, WStream& ws, c
 }
 
 template <int KS0>
-__global__ __launch_bounds__(512, 2) void field_geo_fwd_kernel(const GeoFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + (3 * H + 4 + 32) * 4];
-  float* bl = reinterpret_cast<float*>(smem + RING_BYTES);  // b0 | b1 | w_sdf | b_sdf
+__global__ __launch_bounds__(THREADS, 2) void field_geo_fwd_kernel(const GeoFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING + (3 * H + 4 + 32) * 4];
+  float* bl = reinterpret_cast<float*>(smem + RING);  // b0 | b1 | w_sdf | b_sdf
   float* sl = bl + 3 * H + 4;                               // 2 NT tile scales
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < H; i += 512) { bl[i] = a.net.b0[i]; bl[H + i] = a.net.b1[i]; bl[2 * H + i] = a.net.w_sdf[i]; }
+  for (int i = tid; i < H; i += THREADS) { bl[i] = a.net.b0[i]; bl[H + i] = a.net.b1[i]; bl[2 * H + i] = a.net.w_sdf[i]; }
   if (tid == 0) bl[3 * H] = a.net.b_sdf ? a.net.b_sdf[0] : 0.0f;
-  for (int i = tid; i < 2 * NT; i += 512) sl[i] = a.scales[i];
+  for (int i = tid; i < 2 * NT; i += THREADS) sl[i] = a.scales[i];
   __syncthreads();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   WStream ws;
   ws_setup(ws, a.stream, smem, wave, lane, a.total_groups);
   const long G = gridDim.x;
-  for (long base = 0; base < a.n_tiles; base += 8 * G) {
+  for (long base = 0; base < a.n_tiles; base += WAVES * G) {
     const long tile = base + wave * G + blockIdx.x;
     if (tile < a.n_tiles) geo_fwd_tile<KS0, true>(a, ws, bl, sl, tile, lane);
     else geo_fwd_tile<KS0, false>(a, ws, bl, sl, 0, lane);
@@ -459,24 +488,24 @@ __device__ __forceinline__ void col_fwd_tile(const ColFwdArgs& a, WStream& ws, c
   }
 }
 
-__global__ __launch_bounds__(512, 2) void field_colour_fwd_kernel(const ColFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + (6 * H + 4 + 32) * 4];
-  float* bl = reinterpret_cast<float*>(smem + RING_BYTES);  // b2f | bc0 | bc1 | wc2[0..2] | bc2
+__global__ __launch_bounds__(THREADS, 2) void field_colour_fwd_kernel(const ColFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING + (6 * H + 4 + 32) * 4];
+  float* bl = reinterpret_cast<float*>(smem + RING);  // b2f | bc0 | bc1 | wc2[0..2] | bc2
   float* sl = bl + 6 * H + 4;                               // 3 NT tile scales
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < H; i += 512) {
+  for (int i = tid; i < H; i += THREADS) {
     bl[i] = a.net.b2f[i]; bl[H + i] = a.net.bc0[i]; bl[2 * H + i] = a.net.bc1[i];
     for (int k = 0; k < 3; ++k) bl[(3 + k) * H + i] = a.net.wc2[(long)k * a.net.ldc2 + i];
   }
   if (tid < 3) bl[6 * H + tid] = a.net.bc2[tid];
-  for (int i = tid; i < 3 * NT; i += 512) sl[i] = a.scales[i];
+  for (int i = tid; i < 3 * NT; i += THREADS) sl[i] = a.scales[i];
   __syncthreads();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   WStream ws;
   ws_setup(ws, a.stream, smem, wave, lane, a.total_groups);
   const long G = gridDim.x;
-  for (long base = 0; base < a.n_tiles; base += 8 * G) {
+  for (long base = 0; base < a.n_tiles; base += WAVES * G) {
     const long tile = base + wave * G + blockIdx.x;
     if (tile < a.n_tiles) col_fwd_tile<true>(a, ws, bl, sl, tile, lane);
     else col_fwd_tile<false>(a, ws, bl, sl, 0, lane);
@@ -522,9 +551,14 @@ __device__ __forceinline__ void col_bwd_tile(const ColBwdArgs& a, WStream& ws, c
       dp[k] = live ? a.g_alb[nc * 3 + k] * al * (1.0f - al) : 0.0f;
     }
     if (live && h == 0) stg4(a.dpc2 + n * 4, make_float4(dp[0], dp[1], dp[2], 0.0f));
+    float cvn[16];
+    load_tile(a.c1 + (tile * NT) * 1024, lane, cvn);
+#pragma unroll 2
     for (int t = 0; t < NT; ++t) {
       float cv[16], dv[16];
-      load_tile(a.c1 + (tile * NT + t) * 1024, lane, cv);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cv[r] = cvn[r];
+      if (t + 1 < NT) load_tile(a.c1 + (tile * NT + t + 1) * 1024, lane, cvn);  // one tile ahead
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int fo = 32 * t + 8 * g + 4 * h;
@@ -551,22 +585,29 @@ __device__ __forceinline__ void col_bwd_tile(const ColBwdArgs& a, WStream& ws, c
   m = 0.0f;
   for (int u = 0; u < NT; ++u) {
     f32x16 acc;
+    f32x4 cq[4];
+    if (ACTIVE) {  // the saved c0 tile, requested ahead of the product with hidden loads (counted wait behind it)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) cq[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) hidden_load4(cq[g], a.c0 + (tile * NT + u) * 1024 + g * 256 + lane * 4);
+    }
     prod<KS, ACTIVE>(ws, ph, pl, acc);
     if (ACTIVE) {
+      hidden_wait<((KS + GSLABS - 1) / GSLABS) * PW>(cq);
       const float inv = p_inv * sl[u];
-      float cv[16], dv[16];
-      load_tile(a.c0 + (tile * NT + u) * 1024, lane, cv);
+      float dv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        dv[r] = cv[r] > 0.0f ? acc[r] * inv : 0.0f;
+        dv[r] = cq[r >> 2][r & 3] > 0.0f ? acc[r] * inv : 0.0f;
         m = fmaxf(m, fabsf(dv[r]));
       }
       store_tile(d0blk + u * 1024, lane, dv);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // compiler-visible loads: none pending across the next product
     }
   }
   if (ACTIVE) {
     publish_max(a.gmax + 1, m, live, true, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's dpc0 stores have left before it reads them back
     p_inv = planes_from_tiles<NT>(d0blk, lane, m, ph, pl);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -614,21 +655,21 @@ __device__ __forceinline__ void col_bwd_tile(const ColBwdArgs& a, WStream& ws, c
   }
 }
 
-__global__ __launch_bounds__(512, 2) void field_colour_bwd_kernel(const ColBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + (3 * H + 32) * 4];
-  float* wl = reinterpret_cast<float*>(smem + RING_BYTES);  // wc2[0..2]
+__global__ __launch_bounds__(THREADS, 2) void field_colour_bwd_kernel(const ColBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING + (3 * H + 32) * 4];
+  float* wl = reinterpret_cast<float*>(smem + RING);  // wc2[0..2]
   float* sl = wl + 3 * H;                                   // 3 NT + 2 tile scales
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < H; i += 512)
+  for (int i = tid; i < H; i += THREADS)
     for (int k = 0; k < 3; ++k) wl[k * H + i] = a.net.wc2[(long)k * a.net.ldc2 + i];
-  for (int i = tid; i < 3 * NT + 2; i += 512) sl[i] = a.scales[i];
+  for (int i = tid; i < 3 * NT + 2; i += THREADS) sl[i] = a.scales[i];
   __syncthreads();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   WStream ws;
   ws_setup(ws, a.stream, smem, wave, lane, a.total_groups);
   const long G = gridDim.x;
-  for (long base = 0; base < a.n_tiles; base += 8 * G) {
+  for (long base = 0; base < a.n_tiles; base += WAVES * G) {
     const long tile = base + wave * G + blockIdx.x;
     if (tile < a.n_tiles) col_bwd_tile<true>(a, ws, wl, sl, tile, lane);
     else col_bwd_tile<false>(a, ws, wl, sl, 0, lane);
@@ -652,12 +693,22 @@ struct GeoBwdArgs {
   float* gmax;                 // [2]: max |d1q|, |d0q| (caller zero-fills)
 };
 
-// reverse of one forward-mode softplus layer on a tile: av = the saved layer output (value lane: a, tangent lanes: ta_k), gin = the
-// incoming gradient of that output -> the pre-activation gradient (value lane: dz, tangent lanes: dtz_k)
-__device__ __forceinline__ float softplus_rev(float av, float gin, float beta, int j) {
-  const float sq = quad_bcast0(-expm1f(-beta * av));  // sigmoid(beta z) of the point, recovered from its softplus output
-  const float cross = quad_sum(j == 0 ? 0.0f : gin * av * beta * (1.0f - sq));
-  return j == 0 ? fmaf(gin, sq, cross) : gin * sq;
+// reverse of one forward-mode softplus layer on a tile.  av: the saved layer outputs of this lane's column (value lane: a, tangent lanes:
+// ta_k); gin: the incoming gradient of those outputs -> dv: the pre-activation gradients (value lane: dz = da s + sum_k dta_k ta_k
+// beta (1 - s), tangent lanes: dtz_k = dta_k s), s = sigmoid(beta z) = 1 - exp(-beta a) recovered from the value row's saved output:
+// the exponentials are taken by the four lanes of the quad, four features each, and handed back to every lane.
+__device__ __forceinline__ void softplus_rev_tile(const float (&av)[16], const float (&gin)[16], float beta, int j, float (&dv)[16]) {
+  float a4[4], e4[4], E[16];
+  quad_scatter_value(av, j, a4);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) e4[q] = __expf(-beta * a4[q]);  // 1 - sigmoid(beta z)
+  quad_gather_all(e4, E);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float cross = quad_sum(j == 0 ? 0.0f : gin[r] * av[r] * (beta * E[r]));
+    const float s = 1.0f - E[r];
+    dv[r] = j == 0 ? fmaf(gin[r], s, cross) : gin[r] * s;
+  }
 }
 
 template <bool ACTIVE>
@@ -676,23 +727,37 @@ __device__ __forceinline__ void geo_bwd_tile(const GeoBwdArgs& a, WStream& ws, c
     float gq = 0.0f;
     if (live) gq = j == 0 ? (a.g_sdf ? a.g_sdf[nc] : 0.0f) : (a.g_grad ? a.g_grad[nc * 3 + (j - 1)] : 0.0f);
     const float* dap = a.da1v ? a.da1v + ((nc >> 5) * NT) * 1024 + ((int)(nc & 31) + 32 * h) * 4 : nullptr;
+    float avn[16];
+    float4 ddn[4];
+    auto request = [&](int t) {  // tile t's saved outputs and (value lane) the colour path's gradient: one tile ahead of their use
+      load_tile(a.a1q + (tile * NT + t) * 1024, lane, avn);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        ddn[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dap && j == 0) ddn[g] = ldg4(dap + t * 1024 + g * 256);
+      }
+    };
+    request(0);
+#pragma unroll 2
     for (int t = 0; t < NT; ++t) {
-      float av[16], dv[16];
-      load_tile(a.a1q + (tile * NT + t) * 1024, lane, av);
+      float av[16], dv[16], gin[16];
+      float4 dd4[4];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) av[r] = avn[r];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) dd4[g] = ddn[g];
+      if (t + 1 < NT) request(t + 1);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 w4 = *reinterpret_cast<const float4*>(wl + 32 * t + 8 * g + 4 * h);
         const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
-        float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (dap && j == 0) d4 = ldg4(dap + t * 1024 + g * 256);
-        const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+        const float dd[4] = {dd4[g].x, dd4[g].y, dd4[g].z, dd4[g].w};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int r = 4 * g + q;
-          dv[r] = softplus_rev(av[r], fmaf(gq, ww[q], dd[q]), beta, j);
-          m = fmaxf(m, fabsf(live ? dv[r] : 0.0f));
-        }
+        for (int q = 0; q < 4; ++q) gin[4 * g + q] = fmaf(gq, ww[q], dd[q]);
       }
+      softplus_rev_tile(av, gin, beta, j, dv);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(live ? dv[r] : 0.0f));
       store_tile(d1blk + t * 1024, lane, dv);
     }
     publish_max(a.gmax, m, live, true, lane);
@@ -704,22 +769,33 @@ __device__ __forceinline__ void geo_bwd_tile(const GeoBwdArgs& a, WStream& ws, c
   m = 0.0f;
   for (int u = 0; u < NT; ++u) {
     f32x16 acc;
+    f32x4 aq[4];
+    if (ACTIVE) {  // the tile's saved outputs, requested ahead of its product with loads the compiler does not see (a visible load
+      // would be waited for with vmcnt(0): the whole DMA ring); only the product's own DMA pieces are younger
+#pragma unroll
+      for (int g = 0; g < 4; ++g) aq[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) hidden_load4(aq[g], a.a0q + (tile * NT + u) * 1024 + g * 256 + lane * 4);
+    }
     prod<KS, ACTIVE>(ws, ph, pl, acc);
     if (ACTIVE) {
+      hidden_wait<((KS + GSLABS - 1) / GSLABS) * PW>(aq);
       const float inv = p_inv * sl[u];
-      float av[16], dv[16];
-      load_tile(a.a0q + (tile * NT + u) * 1024, lane, av);
+      float av[16], dv[16], gin[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        dv[r] = softplus_rev(av[r], acc[r] * inv, beta, j);
-        m = fmaxf(m, fabsf(live ? dv[r] : 0.0f));
+        av[r] = aq[r >> 2][r & 3];
+        gin[r] = acc[r] * inv;
       }
+      softplus_rev_tile(av, gin, beta, j, dv);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(live ? dv[r] : 0.0f));
       store_tile(d0blk + u * 1024, lane, dv);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
   if (ACTIVE) {
     publish_max(a.gmax + 1, m, live, true, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's d0 stores have left before it reads them back
     p_inv = planes_from_tiles<NT>(d0blk, lane, m, ph, pl);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -747,21 +823,21 @@ __device__ __forceinline__ void geo_bwd_tile(const GeoBwdArgs& a, WStream& ws, c
   }
 }
 
-__global__ __launch_bounds__(512, 2) void field_geo_bwd_kernel(const GeoBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + (H + 32) * 4];
-  float* wl = reinterpret_cast<float*>(smem + RING_BYTES);  // w_sdf
+__global__ __launch_bounds__(THREADS, 2) void field_geo_bwd_kernel(const GeoBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING + (H + 32) * 4];
+  float* wl = reinterpret_cast<float*>(smem + RING);  // w_sdf
   float* sl = wl + H;                                       // NT + ct tile scales
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ct = (a.net.in_dim + 31) / 32;
-  for (int i = tid; i < H; i += 512) wl[i] = a.net.w_sdf[i];
-  for (int i = tid; i < NT + ct; i += 512) sl[i] = a.scales[i];
+  for (int i = tid; i < H; i += THREADS) wl[i] = a.net.w_sdf[i];
+  for (int i = tid; i < NT + ct; i += THREADS) sl[i] = a.scales[i];
   __syncthreads();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   WStream ws;
   ws_setup(ws, a.stream, smem, wave, lane, a.total_groups);
   const long G = gridDim.x;
-  for (long base = 0; base < a.n_tiles; base += 8 * G) {
+  for (long base = 0; base < a.n_tiles; base += WAVES * G) {
     const long tile = base + wave * G + blockIdx.x;
     if (tile < a.n_tiles) geo_bwd_tile<true>(a, ws, wl, sl, tile, lane, ct);
     else geo_bwd_tile<false>(a, ws, wl, sl, 0, lane, ct);
@@ -794,31 +870,43 @@ __global__ __launch_bounds__(512) void native_weighted_colsum_kernel(const Colsu
     for (int o = 0; o < 4; ++o)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[o][r] = 0.0f;
-    for (int b = b0; b < b1; ++b) {
-      const long row = (long)b * 32 + c;
-      float w[4] = {0.f, 0.f, 0.f, 0.f};
-      if (row < a.rows) {
-        if (a.w4) {
-          const float4 q = ldg4(a.w4 + row * 4);
-          w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+    for (int bb = b0; bb < b1; bb += 4) {  // four row blocks in flight per wave
+      float v[4][16], w[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int b = bb + u;
+        const long row = (long)b * 32 + c;
+        w[u][0] = w[u][1] = w[u][2] = w[u][3] = 0.0f;
+        if (b < b1) {
+          load_tile(a.X + ((long)b * a.nt + t) * 1024, lane, v[u]);
+          if (row < a.rows) {
+            if (a.w4) {
+              const float4 q = ldg4(a.w4 + row * 4);
+              w[u][0] = q.x; w[u][1] = q.y; w[u][2] = q.z; w[u][3] = q.w;
+            } else {
+              const int j = (int)(row & 3);
+              const long n = row >> 2;
+              w[u][0] = j == 0 ? (a.g_sdf ? a.g_sdf[n] : 0.0f) : (a.g_grad ? a.g_grad[n * 3 + (j - 1)] : 0.0f);
+              if (j == 0) bs[0] += w[u][0];
+            }
+          }
         } else {
-          const int j = (int)(row & 3);
-          const long n = row >> 2;
-          w[0] = j == 0 ? (a.g_sdf ? a.g_sdf[n] : 0.0f) : (a.g_grad ? a.g_grad[n * 3 + (j - 1)] : 0.0f);
-          if (j == 0) bs[0] += w[0];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[u][r] = 0.0f;
         }
       }
-      if (a.w4) {
 #pragma unroll
-        for (int o = 0; o < 4; ++o) bs[o] += w[o];
+      for (int u = 0; u < 4; ++u) {
+        if (a.w4) {
+#pragma unroll
+          for (int o = 0; o < 4; ++o) bs[o] += w[u][o];
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+          if (o < a.n_out)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[o][r] = fmaf(w[u][o], v[u][r], acc[o][r]);
       }
-      float v[16];
-      load_tile(a.X + ((long)b * a.nt + t) * 1024, lane, v);
-#pragma unroll
-      for (int o = 0; o < 4; ++o)
-        if (o < a.n_out)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[o][r] = fmaf(w[o], v[r], acc[o][r]);
     }
 #pragma unroll
     for (int o = 0; o < 4; ++o)
@@ -854,8 +942,8 @@ int persistent_grid(int n_tiles) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
     return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
   }();
-  const int wgs = (n_tiles + 7) / 8;
-  return wgs < cus ? wgs : cus;
+  const int wgs = (n_tiles + WAVES - 1) / WAVES;
+  return wgs < cus * WGS_PER_CU ? wgs : cus * WGS_PER_CU;
 }
 
 }  // namespace
@@ -904,7 +992,7 @@ extern "C" int nsky_field_geo_fwd(const nsky_field_net* net, const void* stream_
   a.net = *net; a.stream = (const unsigned char*)stream_buf; a.scales = scales; a.total_groups = total_groups; a.ET = ET; a.ldE = ldE; a.N = N;
   a.n_tiles = ceil_div(N, 8); a.a0q = a0q; a.a1q = a1q; a.Eq = Eq; a.a1max = a1max; a.sdf = sdf; a.grad = grad;
   const dim3 grid(persistent_grid(a.n_tiles));
-  hipLaunchKernelGGL((field_geo_fwd_kernel<5>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((field_geo_fwd_kernel<5>), grid, dim3(THREADS), 0, (hipStream_t)stream, a);
   NSKY_CHECK_LAUNCH("nsky_field_geo_fwd");
   return NSKY_OK;
 }
@@ -921,7 +1009,7 @@ extern "C" int nsky_field_colour_fwd(const nsky_field_net* net, const void* stre
   ColFwdArgs a;
   a.net = *net; a.stream = (const unsigned char*)stream_buf; a.scales = scales; a.total_groups = total_groups; a.ET = ET; a.ldE = ldE; a.N = N;
   a.n_tiles = ceil_div(N, 32); a.a1q = a1q; a.a1max = a1max; a.a1v = a1v; a.feat = feat; a.xpe = xpe; a.c0 = c0; a.c1 = c1; a.alb = alb;
-  hipLaunchKernelGGL(field_colour_fwd_kernel, dim3(persistent_grid(a.n_tiles)), dim3(512), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(field_colour_fwd_kernel, dim3(persistent_grid(a.n_tiles)), dim3(THREADS), 0, (hipStream_t)stream, a);
   NSKY_CHECK_LAUNCH("nsky_field_colour_fwd");
   return NSKY_OK;
 }
@@ -938,7 +1026,7 @@ extern "C" int nsky_field_colour_bwd(const nsky_field_net* net, const void* stre
   ColBwdArgs a;
   a.net = *net; a.stream = (const unsigned char*)stream_buf; a.scales = scales; a.total_groups = total_groups; a.N = N; a.n_tiles = ceil_div(N, 32);
   a.g_alb = g_alb; a.alb = alb; a.c0 = c0; a.c1 = c1; a.dpc2 = dpc2; a.dpc1 = dpc1; a.dpc0 = dpc0; a.dfeat = dfeat; a.dxpe = dxpe; a.da1v = da1v; a.gmax = gmax;
-  hipLaunchKernelGGL(field_colour_bwd_kernel, dim3(persistent_grid(a.n_tiles)), dim3(512), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(field_colour_bwd_kernel, dim3(persistent_grid(a.n_tiles)), dim3(THREADS), 0, (hipStream_t)stream, a);
   NSKY_CHECK_LAUNCH("nsky_field_colour_bwd");
   return NSKY_OK;
 }
@@ -955,7 +1043,7 @@ extern "C" int nsky_field_geo_bwd(const nsky_field_net* net, const void* stream_
   GeoBwdArgs a;
   a.net = *net; a.stream = (const unsigned char*)stream_buf; a.scales = scales; a.total_groups = total_groups; a.N = N; a.n_tiles = ceil_div(N, 8);
   a.g_sdf = g_sdf; a.g_grad = g_grad; a.da1v = da1v; a.dxpe = dxpe; a.a0q = a0q; a.a1q = a1q; a.d1q = d1q; a.d0q = d0q; a.dET = dET; a.ldE = ldE; a.gmax = gmax;
-  hipLaunchKernelGGL(field_geo_bwd_kernel, dim3(persistent_grid(a.n_tiles)), dim3(512), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(field_geo_bwd_kernel, dim3(persistent_grid(a.n_tiles)), dim3(THREADS), 0, (hipStream_t)stream, a);
   NSKY_CHECK_LAUNCH("nsky_field_geo_bwd");
   return NSKY_OK;
 }
@@ -968,7 +1056,7 @@ extern "C" int nsky_native_weighted_colsum(const float* X, int32_t nt, int32_t r
   ColsumArgs a;
   a.X = X; a.nt = nt; a.rows = rows; a.w4 = w4; a.n_out = n_out; a.g_sdf = g_sdf; a.g_grad = g_grad; a.out = out; a.ldo = ldo; a.bias = bias;
   const int row_blocks = ceil_div(rows, 32);
-  a.blocks_per_wg = ceil_div(row_blocks, 512);
+  a.blocks_per_wg = ceil_div(row_blocks, 256);  // one workgroup per CU: every one ends with 512 n_out atomics onto the same 256 n_out addresses
   hipLaunchKernelGGL(native_weighted_colsum_kernel, dim3(ceil_div(row_blocks, a.blocks_per_wg)), dim3(512), 0, (hipStream_t)stream, a);
   NSKY_CHECK_LAUNCH("nsky_native_weighted_colsum");
   return NSKY_OK;
