@@ -426,6 +426,7 @@ struct BwdFilmArgs {
   float* dfp_rowmax;               // [ceil32(M)] max |dfp| per batch row
   float* gmax;                     // zero-initialised by the caller: [i] = max |dz_save[i]|, [n_film] = max |dfp|
   float* d_x; int ldx;             // optional [M, ldx]: gradient w.r.t. the FiLM input rows (pad columns zeroed)
+  int full_wgs, tail_wgs, tail_k;  // tail_plan of the launch
 };
 
 
@@ -434,9 +435,213 @@ struct BwdFilmArgs {
 // each.  That budget is met by keeping NO per-layer matrix in registers across the tile loop: the incoming gradient dY of a
 // layer waits, tile-native, in that layer's dz buffer (written by the layer above, overwritten tile by tile with dz), and the
 // W^T products of the layer read the finished dz tiles back (the lane that stored a piece loads it).
+// Tail workgroups.  A launch of n wave tiles (32 rows each) on C CUs runs F = floor(n / (8 C)) C full workgroups of eight tiles; the
+// remaining R = n - 8 F tiles (less than one workgroup round) do not get a round of full workgroups on a few CUs: they are dealt k =
+// ceil(R / C) to a workgroup (T = ceil(R / k) "tail" workgroups, FIRST in the grid), whose other waves only take part in the ring's
+// hand-shakes (product_skip).  A tail workgroup is done sooner than a full one and the dispatcher hands its CU the next workgroup, so
+// the remainder costs its share of a round instead of a whole one (263 456 DDF rows = 8233 tiles: 1024 full + 41 one-tile workgroups
+// instead of 1030 full ones = five rounds of time for 4.02 of work).
+struct TailPlan { int full_wgs, tail_wgs, tail_k; };
+inline TailPlan tail_plan(long n_tiles, int cus) {
+  TailPlan p;
+  p.full_wgs = (int)(n_tiles / (8L * cus)) * cus;
+  const long rem = n_tiles - 8L * p.full_wgs;
+  if (rem >= 8L * cus - cus) {  // nearly a whole round: full workgroups
+    p.full_wgs += (int)((rem + 7) / 8); p.tail_wgs = 0; p.tail_k = 0;
+    return p;
+  }
+  p.tail_k = (int)((rem + cus - 1) / cus);
+  p.tail_wgs = p.tail_k ? (int)((rem + p.tail_k - 1) / p.tail_k) : 0;
+  return p;
+}
+// wave tile of this wave, or -1 (a wave of a tail workgroup without one)
+__device__ __forceinline__ long tail_tile(int full_wgs, int tail_wgs, int tail_k, long n_tiles, int wave) {
+  const int b = blockIdx.x;
+  if (b >= tail_wgs) return (long)(b - tail_wgs) * 8 + wave;
+  const long t = 8L * full_wgs + (long)b * tail_k + wave;
+  return (wave < tail_k && t < n_tiles) ? t : -1;
+}
+
+// product of a wave WITH a row tile, or (ACTIVE = false) its share of the ring's hand-shakes
+template <int KSN, int PWN, bool ACTIVE>
+__device__ __forceinline__ void prodw(WStream& ws, const f16x8 (&bh)[KSN], const f16x8 (&bl)[KSN], f32x16& acc) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  if (ACTIVE) product<KSN, PWN>(ws, bh, bl, acc);
+  else product_skip<KSN, PWN, false>(ws);
+}
+
+template <int H, bool ACTIVE>
+__device__ __forceinline__ void film_bwd_tile(const BwdFilmArgs& a, WStream& ws, const float* bl, const float* sl, const float* wo, long rt, int lane) {
+  constexpr int NT = H / 32, KS = H / 16, GH = (KS + GSLABS - 1) / GSLABS, PW = 2;
+  const nsky_film_net& net = a.net;
+  const int c = lane & 31, h = lane >> 5;
+  const long row = rt * 32 + c;
+  const bool live = ACTIVE && row < a.M;
+  const long rowc = row < a.M ? row : a.M - 1;
+  const int n_film = net.n_film;
+  float h_inv = 1.0f, h_scale = 1.0f;
+  if (ACTIVE) {
+    // row scale of the last mapping activation
+    float m = 0.0f;
+    for (int t = 0; t < NT; ++t) {
+      float hv[16];
+      load_tile(a.h_last + (rt * NT + t) * 1024, lane, hv);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(hv[r]));
+    }
+    h_scale = row_scale(m, h_inv);
+    // head gradient -> dY of the last FiLM layer, parked in its dz buffer
+    const float4 dr = ldg4(a.d_res + rowc * a.ldres);
+    float* dst = a.dz_save[n_film - 1] + rt * NT * 1024 + lane * 4;
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int fo = 32 * t + 8 * g + 4 * h;
+        const float4 w0 = *reinterpret_cast<const float4*>(wo + fo), w1 = *reinterpret_cast<const float4*>(wo + H + fo);
+        const float4 w2 = *reinterpret_cast<const float4*>(wo + 2 * H + fo), w3 = *reinterpret_cast<const float4*>(wo + 3 * H + fo);
+        stg4(dst + t * 1024 + g * 256, make_float4(dr.x * w0.x + dr.y * w1.x + dr.z * w2.x + dr.w * w3.x, dr.x * w0.y + dr.y * w1.y + dr.z * w2.y + dr.w * w3.y,
+                                                    dr.x * w0.z + dr.y * w1.z + dr.z * w2.z + dr.w * w3.z, dr.x * w0.w + dr.y * w1.w + dr.z * w2.w + dr.w * w3.w));
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's dY stores have left before it reads them back
+  }
+  const float* bias_mo = bl + net.n_map * H;
+  float fp_max = 0.0f;
+  int tile = 0;
+  for (int i = n_film - 1; i >= 0; --i) {
+    const float* bF = bias_mo + i * H;
+    const float* bP = bias_mo + (n_film + i) * H;
+    const float* zp = a.z_save[i] + rt * NT * 1024 + lane * 4;
+    float* dzp = a.dz_save[i] + rt * NT * 1024 + lane * 4;   // holds dY on entry
+    float* dFp = a.dfp + (rt * (2 * n_film * NT) + (long)i * NT) * 1024 + lane * 4;
+    float* dPp = a.dfp + (rt * (2 * n_film * NT) + (long)(n_film + i) * NT) * 1024 + lane * 4;
+    float dz_max = 0.0f;
+    f16x8 hh[KS], hl[KS];
+    if (ACTIVE) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float hv[16];
+        load_tile(a.h_last + (rt * NT + t) * 1024, lane, hv);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float x8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x8[j] = hv[8 * u + j] * h_scale;
+          split8(x8, hh[2 * t + u], hl[2 * t + u]);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // compiler-visible loads: none pending when the hidden loads are counted
+    }
+    // ---- pass 1: dz, dF, dphase tile by tile
+    for (int t = 0; t < NT; ++t) {
+      f32x4 zq[4], yq[4];
+      if (ACTIVE) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { zq[g] = f32x4{0.f, 0.f, 0.f, 0.f}; yq[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) hidden_load4(zq[g], zp + t * 1024 + g * 256);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) hidden_load4_nt(yq[g], dzp + t * 1024 + g * 256);
+      }
+      f32x16 aF, aP;
+      prodw<KS, PW, ACTIVE>(ws, hh, hl, aF);
+      prodw<KS, PW, ACTIVE>(ws, hh, hl, aP);
+      if (ACTIVE) {
+        hidden_wait8<2 * GH * PW>(zq, yq);  // requested just before the two products: only their 2 GH transitions x PW pieces are younger
+        const float iF = h_inv * sl[tile], iP = h_inv * sl[tile + 1];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int fo = 32 * t + 8 * g + 4 * h;
+          const float4 b4F = *reinterpret_cast<const float4*>(bF + fo);
+          const float4 b4P = *reinterpret_cast<const float4*>(bP + fo);
+          const float bf[4] = {b4F.x, b4F.y, b4F.z, b4F.w}, bp[4] = {b4P.x, b4P.y, b4P.z, b4P.w};
+          float dzv[4], dFv[4], dPv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int r = 4 * g + q;
+            const float F = fmaf(aF[r], iF, bf[q]), P = fmaf(aP[r], iP, bp[q]), z = zq[g][q];
+            const float f = fmaf(15.0f, F, 30.0f);
+            float sn, cs;
+            sincos_cw(fmaf(f, z, P), sn, cs);
+            const float gc = yq[g][q] * cs;
+            dzv[q] = gc * f;
+            dFv[q] = 15.0f * gc * z;
+            dPv[q] = gc;
+            dz_max = fmaxf(dz_max, fabsf(dzv[q]));
+            fp_max = fmaxf(fp_max, fmaxf(fabsf(dFv[q]), fabsf(gc)));
+          }
+          // 1 KB-contiguous per wave instruction
+          stg4(dzp + t * 1024 + g * 256, make_float4(dzv[0], dzv[1], dzv[2], dzv[3]));
+          stg4(dFp + t * 1024 + g * 256, make_float4(dFv[0], dFv[1], dFv[2], dFv[3]));
+          stg4(dPp + t * 1024 + g * 256, make_float4(dPv[0], dPv[1], dPv[2], dPv[3]));
+        }
+      }
+      tile += 2;
+    }
+    // ---- pass 2: dY of the layer below = W_i^T dz (i = 0: the gradient w.r.t. the input rows, one tile)
+    {
+      float dz_inv = 1.0f;
+      f16x8 dh_[KS], dl_[KS];
+      if (ACTIVE) {
+        publish_max(a.gmax + i, dz_max, live, true, lane);
+        const float s = row_scale(dz_max, dz_inv);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's dz stores have left before it reads them back
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          float x8[8];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const float4 q = ldg4_nt(dzp + (ks >> 1) * 1024 + (2 * (ks & 1) + u) * 256);
+            x8[4 * u] = q.x * s; x8[4 * u + 1] = q.y * s; x8[4 * u + 2] = q.z * s; x8[4 * u + 3] = q.w * s;
+          }
+          split8(x8, dh_[ks], dl_[ks]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (i > 0) {
+        float* nxt = a.dz_save[i - 1] + rt * NT * 1024 + lane * 4;
+        for (int u = 0; u < NT; ++u) {
+          f32x16 acc;
+          prodw<KS, PW, ACTIVE>(ws, dh_, dl_, acc);
+          if (ACTIVE) {
+            const float inv = dz_inv * sl[tile];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              stg4(nxt + u * 1024 + g * 256, make_float4(acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv, acc[4 * g + 3] * inv));
+          }
+          ++tile;
+        }
+      } else {
+        f32x16 acc;
+        prodw<KS, PW, ACTIVE>(ws, dh_, dl_, acc);
+        if (ACTIVE && a.d_x && live) {
+          const float inv = dz_inv * sl[tile];
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+            if (8 * g + 4 * h < a.ldx)
+              stg4(a.d_x + row * a.ldx + 8 * g + 4 * h, make_float4(acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv, acc[4 * g + 3] * inv));
+        }
+        ++tile;
+      }
+      if (ACTIVE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next layer's hidden loads read what was just stored
+    }
+  }
+  if (ACTIVE) {
+    fp_max = fmaxf(fp_max, __shfl_xor(fp_max, 32, 64));
+    if (h == 0) a.dfp_rowmax[row] = fp_max;
+    publish_max(a.gmax + n_film, fp_max, live, true, lane);
+  }
+}
+
+// Eight waves per workgroup (two per SIMD: the matrix pipe of one wave's products overlaps the epilogue arithmetic of the
+// other; 256 batch rows share one weight stream, half the L2 -> LDS traffic per row of the four-wave forward), 256 registers
+// each.  That budget is met by keeping NO per-layer matrix in registers across the tile loop: the incoming gradient dY of a
+// layer waits, tile-native, in that layer's dz buffer (written by the layer above, overwritten tile by tile with dz), and the
+// W^T products of the layer read the finished dz tiles back (the lane that stored a piece loads it).
+// The remainder of the last round runs in tail workgroups (tail_plan above).
 template <int H>
 __global__ __launch_bounds__(512, 2) void film_bwd_kernel(const BwdFilmArgs a) {
-  constexpr int NT = H / 32, KS = H / 16, GH = (KS + GSLABS - 1) / GSLABS, PW = 2;
+  constexpr int PW = 2;
   __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + (BIAS_FLOATS + SCALE_FLOATS) * 4 + 4 * H * 4];
   float* bl = reinterpret_cast<float*>(smem + RING_BYTES);
   float* sl = bl + BIAS_FLOATS;
@@ -444,7 +649,6 @@ __global__ __launch_bounds__(512, 2) void film_bwd_kernel(const BwdFilmArgs a) {
   const nsky_film_net& net = a.net;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 31, h = lane >> 5;
   {
     constexpr int N4 = (BIAS_FLOATS + SCALE_FLOATS) / 4;
     float4 q[(N4 + 511) / 512];
@@ -457,169 +661,16 @@ __global__ __launch_bounds__(512, 2) void film_bwd_kernel(const BwdFilmArgs a) {
     for (int i = tid; i < 4 * H; i += 512) wo[i] = (i / H) < net.out_dim ? net.out_w[(long)(i / H) * net.out_ld + (i % H)] : 0.0f;
   }
   __syncthreads();
-  const long rt = (long)blockIdx.x * 8 + wave;
-  const long row = rt * 32 + c;
-  const bool live = row < a.M;
-  const long rowc = live ? row : a.M - 1;
-  const bool wave_live = rt * 32 < a.M;
-  const long rts = wave_live ? rt : 0;  // a wave wholly beyond M works on tile 0's data (in bounds) and stores nothing
-  const int n_film = net.n_film;
-
-  // row scale of the last mapping activation
-  float h_inv, h_scale;
-  {
-    float m = 0.0f;
-    for (int t = 0; t < NT; ++t) {
-      float hv[16];
-      load_tile(a.h_last + (rts * NT + t) * 1024, lane, hv);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(hv[r]));
-    }
-    h_scale = row_scale(m, h_inv);
-  }
-  // head gradient -> dY of the last FiLM layer, parked in its dz buffer
-  {
-    const float4 dr = ldg4(a.d_res + rowc * a.ldres);
-    float* dst = a.dz_save[n_film - 1] + rt * NT * 1024 + lane * 4;
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int fo = 32 * t + 8 * g + 4 * h;
-        const float4 w0 = *reinterpret_cast<const float4*>(wo + fo), w1 = *reinterpret_cast<const float4*>(wo + H + fo);
-        const float4 w2 = *reinterpret_cast<const float4*>(wo + 2 * H + fo), w3 = *reinterpret_cast<const float4*>(wo + 3 * H + fo);
-        if (wave_live)
-          stg4(dst + t * 1024 + g * 256, make_float4(dr.x * w0.x + dr.y * w1.x + dr.z * w2.x + dr.w * w3.x, dr.x * w0.y + dr.y * w1.y + dr.z * w2.y + dr.w * w3.y,
-                                                      dr.x * w0.z + dr.y * w1.z + dr.z * w2.z + dr.w * w3.z, dr.x * w0.w + dr.y * w1.w + dr.z * w2.w + dr.w * w3.w));
-      }
-  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every compiler-visible memory operation is done before the DMA stream starts
   WStream ws;
   ws.src = a.stream + wave * (PW * 1024) + lane * 16;
   ws.dst = (uint32_t)(uintptr_t)smem + wave * (PW * 1024);
   ws.lds_lane = (uint32_t)(uintptr_t)smem + lane * 16;
   ws_begin<PW>(ws);
-
-  const float* bias_mo = bl + net.n_map * H;
-  float fp_max = 0.0f;
-  int tile = 0;
-  for (int i = n_film - 1; i >= 0; --i) {
-    const float* bF = bias_mo + i * H;
-    const float* bP = bias_mo + (n_film + i) * H;
-    const float* zp = a.z_save[i] + rts * NT * 1024 + lane * 4;
-    float* dzp = a.dz_save[i] + rts * NT * 1024 + lane * 4;   // holds dY on entry
-    float* dFp = a.dfp + (rts * (2 * n_film * NT) + (long)i * NT) * 1024 + lane * 4;
-    float* dPp = a.dfp + (rts * (2 * n_film * NT) + (long)(n_film + i) * NT) * 1024 + lane * 4;
-    float dz_max = 0.0f;
-    f16x8 hh[KS], hl[KS];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      float hv[16];
-      load_tile(a.h_last + (rts * NT + t) * 1024, lane, hv);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        float x8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x8[j] = hv[8 * u + j] * h_scale;
-        split8(x8, hh[2 * t + u], hl[2 * t + u]);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // compiler-visible loads: none pending when the hidden loads are counted
-    // ---- pass 1: dz, dF, dphase tile by tile
-    for (int t = 0; t < NT; ++t) {
-      f32x4 zq[4], yq[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) { zq[g] = f32x4{0.f, 0.f, 0.f, 0.f}; yq[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) hidden_load4(zq[g], zp + t * 1024 + g * 256);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) hidden_load4_nt(yq[g], dzp + t * 1024 + g * 256);
-      f32x16 aF, aP;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { aF[r] = 0.0f; aP[r] = 0.0f; }
-      product<KS, PW>(ws, hh, hl, aF);
-      product<KS, PW>(ws, hh, hl, aP);
-      hidden_wait8<2 * GH * PW>(zq, yq);  // requested just before the two products: only their 2 GH transitions x PW pieces are younger
-      const float iF = h_inv * sl[tile], iP = h_inv * sl[tile + 1];
-      tile += 2;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int fo = 32 * t + 8 * g + 4 * h;
-        const float4 b4F = *reinterpret_cast<const float4*>(bF + fo);
-        const float4 b4P = *reinterpret_cast<const float4*>(bP + fo);
-        const float bf[4] = {b4F.x, b4F.y, b4F.z, b4F.w}, bp[4] = {b4P.x, b4P.y, b4P.z, b4P.w};
-        float dzv[4], dFv[4], dPv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int r = 4 * g + q;
-          const float F = fmaf(aF[r], iF, bf[q]), P = fmaf(aP[r], iP, bp[q]), z = zq[g][q];
-          const float f = fmaf(15.0f, F, 30.0f);
-          float sn, cs;
-          sincos_cw(fmaf(f, z, P), sn, cs);
-          const float gc = yq[g][q] * cs;
-          dzv[q] = gc * f;
-          dFv[q] = 15.0f * gc * z;
-          dPv[q] = gc;
-          dz_max = fmaxf(dz_max, fabsf(dzv[q]));
-          fp_max = fmaxf(fp_max, fmaxf(fabsf(dFv[q]), fabsf(gc)));
-        }
-        if (wave_live) {  // 1 KB-contiguous per wave instruction
-          stg4(dzp + t * 1024 + g * 256, make_float4(dzv[0], dzv[1], dzv[2], dzv[3]));
-          stg4(dFp + t * 1024 + g * 256, make_float4(dFv[0], dFv[1], dFv[2], dFv[3]));
-          stg4(dPp + t * 1024 + g * 256, make_float4(dPv[0], dPv[1], dPv[2], dPv[3]));
-        }
-      }
-    }
-    publish_max(a.gmax + i, dz_max, live, wave_live, lane);
-    // ---- pass 2: dY of the layer below = W_i^T dz (i = 0: the gradient w.r.t. the input rows, one tile)
-    {
-      float dz_inv;
-      const float s = row_scale(dz_max, dz_inv);
-      f16x8 dh_[KS], dl_[KS];
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's dz stores have left before it reads them back
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        float x8[8];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const float4 q = ldg4_nt(dzp + (ks >> 1) * 1024 + (2 * (ks & 1) + u) * 256);
-          x8[4 * u] = q.x * s; x8[4 * u + 1] = q.y * s; x8[4 * u + 2] = q.z * s; x8[4 * u + 3] = q.w * s;
-        }
-        split8(x8, dh_[ks], dl_[ks]);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (i > 0) {
-        float* nxt = a.dz_save[i - 1] + rts * NT * 1024 + lane * 4;
-        for (int u = 0; u < NT; ++u) {
-          f32x16 acc;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-          product<KS, PW>(ws, dh_, dl_, acc);
-          const float inv = dz_inv * sl[tile++];
-          if (wave_live) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-              stg4(nxt + u * 1024 + g * 256, make_float4(acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv, acc[4 * g + 3] * inv));
-          }
-        }
-      } else {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        product<KS, PW>(ws, dh_, dl_, acc);
-        const float inv = dz_inv * sl[tile++];
-        if (a.d_x && live) {
-#pragma unroll
-          for (int g = 0; g < 2; ++g)
-            if (8 * g + 4 * h < a.ldx)
-              stg4(a.d_x + row * a.ldx + 8 * g + 4 * h, make_float4(acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv, acc[4 * g + 3] * inv));
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next layer's hidden loads read what was just stored
-    }
-  }
-  fp_max = fmaxf(fp_max, __shfl_xor(fp_max, 32, 64));
-  if (wave_live && h == 0) a.dfp_rowmax[row] = fp_max;
-  publish_max(a.gmax + n_film, fp_max, live, wave_live, lane);
+  const long n_tiles = (a.M + 31) / 32;
+  const long rt = tail_tile(a.full_wgs, a.tail_wgs, a.tail_k, n_tiles, wave);
+  if (rt >= 0 && rt < n_tiles) film_bwd_tile<H, true>(a, ws, bl, sl, wo, rt, lane);
+  else film_bwd_tile<H, false>(a, ws, bl, sl, wo, 0, lane);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
@@ -639,40 +690,21 @@ struct BwdMapArgs {
   float* dpre_save[MAXL];    // native [ceil32(M), H]
   float* d_cond; int ldcond; // [M, ldcond] or NULL
   float* gmax;               // zero-initialised by the caller: [l] = max |dpre_save[l]|
+  int full_wgs, tail_wgs, tail_k;  // tail_plan of the launch
 };
 
-template <int H>
-__global__ __launch_bounds__(512, 2) void film_bwd_map_kernel(const BwdMapArgs a) {
-  // Eight waves (two per SIMD, 256 registers each) share one weight stream over 256 batch rows.  The register budget is met as in
-  // the FiLM backward: the head product runs as two passes over the 2 n_film H head rows with NT / 2 accumulator tiles each, and no
-  // layer's matrix stays in registers -- a finished tile of dpre is stored (tile-native, also the weight gradient's operand) and the
-  // layer below reads the tiles back (the lane that stored a piece loads it).
+template <int H, bool ACTIVE>
+__device__ __forceinline__ void film_bwd_map_tile(const BwdMapArgs& a, WStream& ws, const float* sl, long rt, int lane) {
   constexpr int NT = H / 32, KS = H / 16, NH = NT / 2, PW = 2;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + SCALE_FLOATS * 4];
-  float* sl = reinterpret_cast<float*>(smem + RING_BYTES);
   const nsky_film_net& net = a.net;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5;
-  for (int i = tid; i < SCALE_FLOATS; i += 512) sl[i] = a.table[BIAS_FLOATS + i];
-  const long rt = (long)blockIdx.x * 8 + wave;
   const long row = rt * 32 + c;
-  const bool live = row < a.M;
-  const bool wave_live = rt * 32 < a.M;
-  const long rts = wave_live ? rt : 0;
+  const bool live = ACTIVE && row < a.M;
   const int nkg = 2 * net.n_film * H / 128, ntot = 2 * net.n_film * NT;
-  float f_inv;
-  const float f_scale = row_scale(a.dfp_rowmax[rts * 32 + c], f_inv);  // both lane halves read the same row: the shuffle is a no-op
-  __syncthreads();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  WStream ws;
-  ws.src = a.stream + wave * (PW * 1024) + lane * 16;
-  ws.dst = (uint32_t)(uintptr_t)smem + wave * (PW * 1024);
-  ws.lds_lane = (uint32_t)(uintptr_t)smem + lane * 16;
-  ws_begin<PW>(ws);
-
+  float f_inv = 1.0f, f_scale = 1.0f;
+  if (ACTIVE) f_scale = row_scale(a.dfp_rowmax[rt * 32 + c], f_inv);  // both lane halves read the same row: the shuffle is a no-op
   int tile = 0;
-  const float* fblk = a.dfp + rts * ntot * 1024;
+  const float* fblk = a.dfp + rt * ntot * 1024;
   const int top = net.n_map - 1;
   float m = 0.0f;  // largest |dpre_top| of this lane's row half
   f32x4 fq[16];    // 128 head rows = 4 native tiles x 4 pieces, one k-group ahead
@@ -688,24 +720,26 @@ __global__ __launch_bounds__(512, 2) void film_bwd_map_kernel(const BwdMapArgs a
     for (int u = 0; u < NH; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dh[u][r] = 0.0f;
+    if (ACTIVE) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) fq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 16; ++j) fq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 16; ++j) hidden_load4(fq[j], fblk + (j >> 2) * 1024 + (j & 3) * 256 + lane * 4);
-    NSKY_FQ_WAIT(0);  // first group of the pass (everything older lands with it)
+      for (int j = 0; j < 16; ++j) hidden_load4(fq[j], fblk + (j >> 2) * 1024 + (j & 3) * 256 + lane * 4);
+      NSKY_FQ_WAIT(0);  // first group of the pass (everything older lands with it)
+    }
     for (int kg = 0; kg < nkg; ++kg) {
       f16x8 ph[8], pl[8];
+      if (ACTIVE) {
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        float x8[8];
+        for (int ks = 0; ks < 8; ++ks) {
+          float x8[8];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const f32x4 q = fq[(ks >> 1) * 4 + 2 * (ks & 1) + u];
-          x8[4 * u] = q[0] * f_scale; x8[4 * u + 1] = q[1] * f_scale; x8[4 * u + 2] = q[2] * f_scale; x8[4 * u + 3] = q[3] * f_scale;
+          for (int u = 0; u < 2; ++u) {
+            const f32x4 q = fq[(ks >> 1) * 4 + 2 * (ks & 1) + u];
+            x8[4 * u] = q[0] * f_scale; x8[4 * u + 1] = q[1] * f_scale; x8[4 * u + 2] = q[2] * f_scale; x8[4 * u + 3] = q[3] * f_scale;
+          }
+          split8(x8, ph[ks], pl[ks]);
         }
-        split8(x8, ph[ks], pl[ks]);
-      }
-      {
         const int kn = kg + 1 < nkg ? kg + 1 : kg;  // the last group re-requests itself (same count of operations in flight)
 #pragma unroll
         for (int j = 0; j < 16; ++j) hidden_load4(fq[j], fblk + (long)(4 * kn + (j >> 2)) * 1024 + (j & 3) * 256 + lane * 4);
@@ -713,81 +747,85 @@ __global__ __launch_bounds__(512, 2) void film_bwd_map_kernel(const BwdMapArgs a
 #pragma unroll
       for (int u = 0; u < NH; ++u) {
         f32x16 acc;
+        prodw<8, PW, ACTIVE>(ws, ph, pl, acc);
+        if (ACTIVE) {
+          const float inv = f_inv * sl[tile];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        product<8, PW>(ws, ph, pl, acc);
-        const float inv = f_inv * sl[tile++];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dh[u][r] = fmaf(acc[r], inv, dh[u][r]);
+          for (int r = 0; r < 16; ++r) dh[u][r] = fmaf(acc[r], inv, dh[u][r]);
+        }
+        ++tile;
       }
       // the next group's 16 pieces were requested before this group's NH products (NH transitions x PW DMA pieces)
-      NSKY_FQ_WAIT(PW * NH);
+      if (ACTIVE) NSKY_FQ_WAIT(PW * NH);
     }
     // dpre of the top mapping layer for this half of the features: dh * leaky'(h_top) (the activation keeps the sign of the
     // pre-activation), stored tile by tile
+    if (ACTIVE) {
 #pragma unroll
-    for (int u = 0; u < NH; ++u) {
-      const int t = pass * NH + u;
-      float hv[16];
-      load_tile(a.h_save[top] + (rts * NT + t) * 1024, lane, hv);
+      for (int u = 0; u < NH; ++u) {
+        const int t = pass * NH + u;
+        float hv[16];
+        load_tile(a.h_save[top] + (rt * NT + t) * 1024, lane, hv);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        dh[u][r] = hv[r] > 0.0f ? dh[u][r] : 0.2f * dh[u][r];
-        m = fmaxf(m, fabsf(dh[u][r]));
+        for (int r = 0; r < 16; ++r) {
+          dh[u][r] = hv[r] > 0.0f ? dh[u][r] : 0.2f * dh[u][r];
+          m = fmaxf(m, fabsf(dh[u][r]));
+        }
+        store_tile(a.dpre_save[top] + (rt * NT + t) * 1024, lane, dh[u]);
       }
-      if (wave_live) store_tile(a.dpre_save[top] + (rt * NT + t) * 1024, lane, dh[u]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 #undef NSKY_FQ_WAIT
 
   for (int l = top; l >= 0; --l) {
-    publish_max(a.gmax + l, m, live, wave_live, lane);
-    float d_inv;
-    const float s = row_scale(m, d_inv);
-    // B planes of dpre_l: its NT tiles come back from where this wave stored them
+    float d_inv = 1.0f;
     f16x8 ph[KS], pl[KS];
+    if (ACTIVE) {
+      publish_max(a.gmax + l, m, live, true, lane);
+      const float s = row_scale(m, d_inv);
+      // B planes of dpre_l: its NT tiles come back from where this wave stored them
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
-      float dv[16];
-      load_tile(a.dpre_save[l] + (rts * NT + u) * 1024, lane, dv);
+      for (int u = 0; u < NT; ++u) {
+        float dv[16];
+        load_tile(a.dpre_save[l] + (rt * NT + u) * 1024, lane, dv);
 #pragma unroll
-      for (int v = 0; v < 2; ++v) {
-        float x8[8];
+        for (int v = 0; v < 2; ++v) {
+          float x8[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x8[j] = dv[8 * v + j] * s;
-        split8(x8, ph[2 * u + v], pl[2 * u + v]);
+          for (int j = 0; j < 8; ++j) x8[j] = dv[8 * v + j] * s;
+          split8(x8, ph[2 * u + v], pl[2 * u + v]);
+        }
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // compiler-visible loads: none may be pending across the products
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // compiler-visible loads: none may be pending across the products
     m = 0.0f;
     if (l > 0) {
       for (int u = 0; u < NT; ++u) {
         f32x16 acc;
+        prodw<KS, PW, ACTIVE>(ws, ph, pl, acc);
+        if (ACTIVE) {
+          const float inv = d_inv * sl[tile];
+          float hv[16], dv[16];
+          load_tile(a.h_save[l - 1] + (rt * NT + u) * 1024, lane, hv);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        product<KS, PW>(ws, ph, pl, acc);
-        const float inv = d_inv * sl[tile++];
-        float hv[16], dv[16];
-        load_tile(a.h_save[l - 1] + (rts * NT + u) * 1024, lane, hv);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float g = acc[r] * inv;
-          dv[r] = hv[r] > 0.0f ? g : 0.2f * g;
-          m = fmaxf(m, fabsf(dv[r]));
+          for (int r = 0; r < 16; ++r) {
+            const float g = acc[r] * inv;
+            dv[r] = hv[r] > 0.0f ? g : 0.2f * g;
+            m = fmaxf(m, fabsf(dv[r]));
+          }
+          store_tile(a.dpre_save[l - 1] + (rt * NT + u) * 1024, lane, dv);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (wave_live) store_tile(a.dpre_save[l - 1] + (rt * NT + u) * 1024, lane, dv);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ++tile;
       }
     } else {
       const int ct = (net.cond_dim + 31) / 32;
       for (int u = 0; u < ct; ++u) {
         f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        product<KS, PW>(ws, ph, pl, acc);
-        const float inv = d_inv * sl[tile++];
-        if (a.d_cond && live) {
+        prodw<KS, PW, ACTIVE>(ws, ph, pl, acc);
+        if (ACTIVE && a.d_cond && live) {
+          const float inv = d_inv * sl[tile];
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int fo = 32 * u + 8 * g + 4 * h;
@@ -795,9 +833,35 @@ __global__ __launch_bounds__(512, 2) void film_bwd_map_kernel(const BwdMapArgs a
               stg4(a.d_cond + row * a.ldcond + fo, make_float4(acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv, acc[4 * g + 3] * inv));
           }
         }
+        ++tile;
       }
     }
   }
+}
+
+template <int H>
+__global__ __launch_bounds__(512, 2) void film_bwd_map_kernel(const BwdMapArgs a) {
+  // Eight waves (two per SIMD, 256 registers each) share one weight stream over 256 batch rows.  The register budget is met as in
+  // the FiLM backward: the head product runs as two passes over the 2 n_film H head rows with NT / 2 accumulator tiles each, and no
+  // layer's matrix stays in registers -- a finished tile of dpre is stored (tile-native, also the weight gradient's operand) and the
+  // layer below reads the tiles back (the lane that stored a piece loads it).  The remainder of the last round runs in tail workgroups.
+  constexpr int PW = 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + SCALE_FLOATS * 4];
+  float* sl = reinterpret_cast<float*>(smem + RING_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < SCALE_FLOATS; i += 512) sl[i] = a.table[BIAS_FLOATS + i];
+  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WStream ws;
+  ws.src = a.stream + wave * (PW * 1024) + lane * 16;
+  ws.dst = (uint32_t)(uintptr_t)smem + wave * (PW * 1024);
+  ws.lds_lane = (uint32_t)(uintptr_t)smem + lane * 16;
+  ws_begin<PW>(ws);
+  const long n_tiles = (a.M + 31) / 32;
+  const long rt = tail_tile(a.full_wgs, a.tail_wgs, a.tail_k, n_tiles, wave);
+  if (rt >= 0 && rt < n_tiles) film_bwd_map_tile<H, true>(a, ws, sl, rt, lane);
+  else film_bwd_map_tile<H, false>(a, ws, sl, 0, lane);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
@@ -1074,6 +1138,16 @@ __global__ __launch_bounds__(512, 2) void sdf_bwd_kernel(const SdfBwdArgs a) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
+int device_cus() {
+  static int cus = [] {
+    hipDeviceProp_t p;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+    return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+  }();
+  return cus;
+}
+
 int check_sdf_net(const nsky_sdf_net* n, const char* who) {
   NSKY_CHECK_ARG(n, "%s: null network", who);
   NSKY_CHECK_ARG(n->hidden == 256 && n->in_dim >= 4 && n->in_dim <= 80 && n->in_dim % 4 == 0, "%s: hidden %d (256) / in_dim %d (4..80, multiple of 4)", who,
@@ -1171,7 +1245,9 @@ extern "C" int nsky_film_chain_bwd_film(const nsky_film_net* net, const void* st
     a.dz_save[l] = l < net->n_film ? dz_save[l] : nullptr;
     if (l < net->n_film) NSKY_CHECK_ARG(a.z_save[l] && a.dz_save[l] && ((uintptr_t)a.z_save[l] % 16) == 0 && ((uintptr_t)a.dz_save[l] % 16) == 0, "nsky_film_chain_bwd_film: z_save / dz_save[%d]", l);
   }
-  const dim3 grid(ceil_div(M, 256));
+  const TailPlan tp = tail_plan(ceil_div(M, 32), device_cus());
+  a.full_wgs = tp.full_wgs; a.tail_wgs = tp.tail_wgs; a.tail_k = tp.tail_k;
+  const dim3 grid(tp.full_wgs + tp.tail_wgs);
   if (net->hidden == 256) hipLaunchKernelGGL((film_bwd_kernel<256>), grid, dim3(512), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((film_bwd_kernel<128>), grid, dim3(512), 0, (hipStream_t)stream, a);
   NSKY_CHECK_LAUNCH("nsky_film_chain_bwd_film");
@@ -1194,7 +1270,9 @@ extern "C" int nsky_film_chain_bwd_map(const nsky_film_net* net, const void* str
     a.dpre_save[l] = l < net->n_map ? dpre_save[l] : nullptr;
     if (l < net->n_map) NSKY_CHECK_ARG(a.h_save[l] && a.dpre_save[l] && ((uintptr_t)a.h_save[l] % 16) == 0 && ((uintptr_t)a.dpre_save[l] % 16) == 0, "nsky_film_chain_bwd_map: h_save / dpre_save[%d]", l);
   }
-  const dim3 grid(ceil_div(M, 256));
+  const TailPlan tp = tail_plan(ceil_div(M, 32), device_cus());
+  a.full_wgs = tp.full_wgs; a.tail_wgs = tp.tail_wgs; a.tail_k = tp.tail_k;
+  const dim3 grid(tp.full_wgs + tp.tail_wgs);
   if (net->hidden == 256) hipLaunchKernelGGL((film_bwd_map_kernel<256>), grid, dim3(512), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((film_bwd_map_kernel<128>), grid, dim3(512), 0, (hipStream_t)stream, a);
   NSKY_CHECK_LAUNCH("nsky_film_chain_bwd_map");
