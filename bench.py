@@ -67,7 +67,7 @@ class KernelTimer:
     def install(self):
         from neusky_amd import hip
         self._orig = {n: getattr(hip, n) for n in ("gemm", "gemm_planes", "film_chain_fwd", "film_chain_bwd_film", "film_chain_bwd_map",
-                                                   "wgrad_native_batch")}
+                                                   "wgrad_native_batch", "field_geo_fwd", "field_colour_fwd", "field_colour_bwd", "field_geo_bwd")}
         o, t = self._orig, self
 
         def gemm(A, B, Cout, M, N, K, **kw):
@@ -107,8 +107,8 @@ class KernelTimer:
             return t._timed(f"film_bwd_map_kernel<{H}>", o["film_chain_bwd_map"], fl, fl, net, stream, table, M, *a, nbytes=by, **kw)
 
         def wgrad(problems, rows):
-            wa = lambda q: q.width_a if q.lda > 0 else 32 * q.nnt_a  # noqa: E731
-            wb = lambda q: q.width_b if q.ldb > 0 else 32 * q.nnt_b  # noqa: E731
+            wa = lambda q: q.width_a if (q.lda > 0 or q.width_a > 0) else 32 * q.nnt_a  # noqa: E731
+            wb = lambda q: q.width_b if (q.ldb > 0 or q.width_b > 0) else 32 * q.nnt_b  # noqa: E731
             fl = sum(2.0 * rows * wa(q) * wb(q) for q in problems)
             # algorithmic bytes: every operand matrix once (the layer input shared by the blocks of a wide layer counts once)
             seen, by = set(), 0.0
@@ -118,10 +118,32 @@ class KernelTimer:
                         seen.add(p_)
                         by += 4.0 * rows * w
             kind = "row-major, bf16 x2" if problems[0].lda > 0 else "tile-native, fp16 split"
-            return t._timed(f"wgrad_native_kernel ({kind})", o["wgrad_native_batch"], fl, fl, problems, rows, nbytes=by)
+            return t._timed(f"wgrad_native_kernel ({kind}, {rows} rows)", o["wgrad_native_batch"], fl, fl, problems, rows, nbytes=by)
+
+        # fused SDF / albedo field (csrc/field_chain.hip): products of the layers they replace; bytes = inputs, saves and outputs once each
+        def geo_fwd(net, pack, ET, N, a0q, a1q, Eq, *a, **kw):
+            fl = 2.0 * 4 * N * (net.in_dim * 256 + 256 * 256 + 256)
+            by = 4.0 * 4 * N * (ET.shape[1] + 256 + 256 + (128 if Eq is not None else 0)) + 4.0 * N * 5
+            return t._timed("field_geo_fwd_kernel", o["field_geo_fwd"], fl, fl, net, pack, ET, N, a0q, a1q, Eq, *a, nbytes=by, **kw)
+
+        def col_fwd(net, pack, ET, N, *a, **kw):
+            fl = 2.0 * N * (256 * 256 + 300 * 256 + 256 * 256 + 3 * 256)
+            by = 4.0 * N * (256 + 40 + 256 * 4 + 128 + 4)
+            return t._timed("field_colour_fwd_kernel", o["field_colour_fwd"], fl, fl, net, pack, ET, N, *a, nbytes=by, **kw)
+
+        def col_bwd(net, pack, N, *a, **kw):
+            fl = 2.0 * N * (256 * 256 + 300 * 256 + 256 * 256 + 3 * 256)
+            by = 4.0 * N * (3 + 4 + 256 * 2 + 4 + 256 * 4 + 40)
+            return t._timed("field_colour_bwd_kernel", o["field_colour_bwd"], fl, fl, net, pack, N, *a, nbytes=by, **kw)
+
+        def geo_bwd(net, pack, N, g_sdf, g_grad, da1v, *a, **kw):
+            fl = 2.0 * 4 * N * (256 * 256 + net.in_dim * 256)
+            by = 4.0 * 4 * N * (256 * 4 + 72) + 4.0 * N * (4 + (256 + 40 if da1v is not None else 0))
+            return t._timed("field_geo_bwd_kernel", o["field_geo_bwd"], fl, fl, net, pack, N, g_sdf, g_grad, da1v, *a, nbytes=by, **kw)
 
         hip.gemm, hip.gemm_planes, hip.film_chain_fwd, hip.film_chain_bwd_film, hip.film_chain_bwd_map = gemm, gemm_planes, fwd, bwd_film, bwd_map
         hip.wgrad_native_batch = wgrad
+        hip.field_geo_fwd, hip.field_colour_fwd, hip.field_colour_bwd, hip.field_geo_bwd = geo_fwd, col_fwd, col_bwd, geo_bwd
 
     def uninstall(self):
         from neusky_amd import hip
@@ -141,6 +163,93 @@ class KernelTimer:
                 d["achieved_GBs"] = sum(r[4] for r in recs) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             out.append(d)
         return sorted(out, key=lambda d: -d["total_ms"])
+
+
+def _timed_ms(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def forward_only_line(pipe, device):
+    """BASELINE configs[1]: NeuSky SDF + albedo forward only, 1024 rays x 96 samples, hash L=16 F=2, no autograd: the whole field pass
+    (hash encode with tangents -> fused geometry net + SDF normals -> colour net) and its hash-encode kernel alone against the HBM
+    roofline (algorithmic bytes per point: position + 16 levels x 8 corners x 2 x 4 B gathered + the rows written)."""
+    from neusky_amd import hip
+    field = pipe.model.field
+    P = RAYS * SAMPLES
+    g = torch.Generator().manual_seed(0)
+    x = ((torch.rand(P, 3, generator=g) * 2 - 1) * 0.8).to(device)
+    with torch.no_grad():
+        pipe.model.begin_step()
+        whole = _timed_ms(lambda: field.field_values(x, want_albedo=True))
+        geom, table = field.geom, field.encoding.table
+        ldy = (3 + 6 * 6 + geom.n_levels * 2 + 3) // 4 * 4
+        Y, T = torch.empty(P, ldy, device=device), torch.empty(3, P, ldy, device=device)
+        enc_t = _timed_ms(lambda: hip.encode_fwd(geom, table, x, field.grid_mode, True, 6, 5.0, Y, T))
+    nbytes = P * (12 + geom.n_levels * 8 * 2 * 4 + 4 * ldy * 4)
+    return {"workload": "SDF+albedo forward only, 1024 rays x 96 samples, hash L=16 F=2 (BASELINE configs[1])", "ms": whole,
+            "rays_per_s": RAYS / whole * 1e3, "points_per_s": P / whole * 1e3,
+            "encode_fwd": {"ms": enc_t, "algorithmic_bytes": nbytes, "achieved_GBs": nbytes / enc_t / 1e6, "peak_GBs": HBM_PEAK_GBS,
+                           "frac": nbytes / enc_t / 1e6 / HBM_PEAK_GBS, "bound": "hbm (the 48.8 MB table is Infinity-Cache resident)"}}
+
+
+def render_1080p_line(pipe, device, chunk=4096):
+    """BASELINE configs[4]: relighting render pass, one 1920 x 1080 frame, 512 illumination directions = 256 upper-hemisphere DDF
+    visibility queries per ray, static chunks replayed from a HIP graph (publication/render_animation.py:118-119,196-207;
+    neusky_model.py:1369-1501).  The frame's wall time includes the graph capture of the first chunk; the dominant kernel's MFMA
+    fraction comes from HIP events around one eagerly launched chunk."""
+    from neusky_amd.cameras.rays import RayBundle
+    H, W = 1080, 1920
+    pipe.eval()
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    d_cam = torch.stack([(xs - W / 2) / 1100.0, (ys - H / 2) / 1100.0, torch.ones(H, W)], -1)
+    cR, cp = pipe.datamanager.cam_R[0], pipe.datamanager.cam_pos[0]
+    d = torch.einsum("ij,hwj->hwi", cR, d_cam)
+    d = d / d.norm(dim=-1, keepdim=True)
+    mk = lambda o, dd, h, w: RayBundle(origins=o.to(device), directions=dd.to(device), pixel_area=torch.ones(h, w, 1, device=device),  # noqa: E731
+                                       camera_indices=torch.zeros(h, w, 1, dtype=torch.long, device=device),
+                                       metadata={"directions_norm": torch.ones(h, w, 1, device=device)})
+    rb = mk(cp.expand(H, W, 3).contiguous(), d, H, W)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = pipe.model.get_outputs_for_camera_ray_bundle(rb, camera_index=0, chunk=chunk, use_graph=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer = KernelTimer()
+    timer.install()
+    try:
+        rows = chunk // W + 1
+        small = mk(cp.expand(rows, W, 3).contiguous(), d[:rows].contiguous(), rows, W)
+        pipe.model.get_outputs_for_camera_ray_bundle(small, camera_index=0, chunk=chunk, use_graph=False)
+        torch.cuda.synchronize()
+    finally:
+        timer.uninstall()
+    ks = timer.summary()
+    dom = ks[0] if ks else None
+    peak = PEAK_BF16_MFMA_TFLOPS / 3.0
+    res = {"workload": "relighting render pass, 1920x1080, 512 directions (256 DDF visibility queries/ray), HIP-graph-replayed chunks (BASELINE configs[4])",
+           "ms_per_frame": dt * 1e3, "rays_per_s": H * W / dt, "chunk_rays": chunk, "rgb_mean": float(out["rgb"].mean())}
+    if dom is not None:
+        res["dominant_kernel"] = {"kernel": dom["kernel"], "avg_launch_ms": dom["avg_launch_ms"], "achieved_tflops": dom["achieved_tflops"],
+                                  "frac_of_833_tflops": dom["achieved_tflops"] / peak}
+    pipe.train()
+    return res
+
+
+def _sources_sha(paths) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(paths):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_model() -> str:
@@ -213,6 +322,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured HIP graph")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the three extra eager steps under the exact-fp32 policy")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the forward-only (configs[1]) and 1080p render (configs[4]) lines")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -325,17 +435,22 @@ def main():
         peak = PEAK_BF16_MFMA_TFLOPS / 3.0
         for k in kernels:
             k["frac_of_833_tflops"] = k["achieved_tflops"] / peak
-        traffic, tsrc = None, os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        traffic, tsrc, traffic_note = None, os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"), ""
         dom = kernels[0]
         if os.path.exists(tsrc):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_bench.sh; not re-collected live)
             tj = json.load(open(tsrc))
             traffic = tj.get("bytes_per_launch", {}).get(dom["kernel"].split(" ")[0])
+            so = os.path.join(ROOT, "neusky_amd", "libneusky_hip.so")
+            srcs = [os.path.join(ROOT, "neusky_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "neusky_amd", "csrc"))]
+            if max(os.path.getmtime(f) for f in srcs) > os.path.getmtime(tsrc) + 60 and tj.get("kernel_sources_sha") != _sources_sha(srcs):
+                traffic_note = " (STALE: the kernel sources changed after the counters were collected)"
+                print("bench.py: warning: profiles/r03_pmc_traffic.json predates the kernel sources; re-run tools/pmc_bench.sh", file=sys.stderr)
         roof = {"bound": "mfma", "achieved": dom["achieved_tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["achieved_tflops"] / peak}
         if "algorithmic_bytes_per_launch" in dom and dom["algorithmic_bytes_per_launch"] / (HBM_PEAK_GBS * 1e9) > dom["algorithmic_flops_per_launch"] / (peak * 1e12):
             roof = {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["achieved_GBs"] / HBM_PEAK_GBS}
-        fwd = "fp16 hi + residual split, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate (~2^-22; chains: power-of-two pre-scaled operands, one accumulator; field layers: 2^11-scaled residual, two accumulators)"
-        bwd = ("FiLM-SIREN chains (83 % of the step's FLOPs) and their weight gradients: the same fp16 split on per-row / per-matrix pre-scaled gradients (fp32-grade); "
-               "SDF / colour layers: 2-term bf16 split (2^-16 per product); proposal layers and all N <= 64 heads: exact fp32 MFMA")
+        fwd = "fp16 hi + residual split, 3 x v_mfma_f32_32x32x16_f16 per product on power-of-two pre-scaled operands, one fp32 accumulator (~2^-22): FiLM-SIREN chains and the SDF / albedo field alike"
+        bwd = ("the same fp16 split on per-row / per-matrix pre-scaled gradients (fp32-grade) for the FiLM-SIREN chains, the SDF / albedo field and all their weight gradients; "
+               "proposal layers and all N <= 64 heads: exact fp32 MFMA")
         line = {
             "metric": "train rays/sec on NeRF-OSR lk2 @1024 rays x 96 samples",
             "value": rays_total / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -348,7 +463,7 @@ def main():
                        "parallelism": f"ray-sharded dp{world}", "final_loss": final_loss,
                        "launch": "HIP graph replay (1 graph/step + all-reduce + 5 Adam launches)" if use_graph else "eager (host launches every kernel)" + graph_note},
             "roofline": {**roof, "traffic": traffic,
-                         "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r02_pmc_traffic.json)",
+                         "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r03_pmc_traffic.json)" + traffic_note,
                          "kernel": dom["kernel"] + " = the kernel family with the largest total time in the three eager timing iterations",
                          "peak_note": ("HBM3E ~8 TB/s; achieved = algorithmic bytes (inputs, saved activations and outputs once each) / launch time; "
                                        "the kernel's byte floor exceeds its flop floor at 833.3 TFLOP/s") if roof["bound"] == "hbm" else
@@ -360,6 +475,9 @@ def main():
             "kernels": kernels[:8],
             "fp32_exact": exact,
         }
+        if world == 1 and not args.no_extra_configs:
+            line["forward_only"] = forward_only_line(pipe, device)
+            line["render_1080p"] = render_1080p_line(pipe, device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

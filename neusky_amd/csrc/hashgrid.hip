@@ -12,6 +12,15 @@
 
 namespace {
 
+// two consecutive floats of a gradient row: the hash columns start at column feat0 of the row, which is odd for the SDF field
+// ([x | PE6 | hash]: feat0 = 39), so the pair is only 4-byte aligned -- no float2 dereference
+__device__ __forceinline__ float2 load2(const float* p) {
+  float2 v;
+  __builtin_memcpy(&v, p, sizeof(v));
+  return v;
+}
+
+
 constexpr int PB = 64;         // points per workgroup
 constexpr int MAXW = 72;       // widest row: 3 + 36 + 32 = 71 -> 72
 constexpr int LDS_LD = MAXW + 1;
@@ -254,13 +263,13 @@ __global__ __launch_bounds__(256) void encode_bwd_kernel(Grid g, const float* __
     if (!valid) continue;
     Cell c;
     locate(g, level, pos, c);
-    const float2 gy = *reinterpret_cast<const float2*>(dY + (long)p * lddy + feat0 + 2 * level);
+    const float2 gy = load2(dY + (long)p * lddy + feat0 + 2 * level);
     // gradient w.r.t. d feat / d pos_a, pulled back through J from the tangent-row gradients
     float2 gpa[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     if (TANGENTS) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const float2 gt = *reinterpret_cast<const float2*>(dT + ((long)k * P + p) * lddy + feat0 + 2 * level);
+        const float2 gt = load2(dT + ((long)k * P + p) * lddy + feat0 + 2 * level);
 #pragma unroll
         for (int a = 0; a < 3; ++a) { gpa[a].x = fmaf(gt.x, J[a][k], gpa[a].x); gpa[a].y = fmaf(gt.y, J[a][k], gpa[a].y); }
       }
@@ -458,10 +467,10 @@ __global__ __launch_bounds__(256) void owner_pack_kernel(const float* __restrict
   const int l = lane & 15;
   if (p >= P || l >= n_levels) return;
   const long o = p * lddy + feat0 + 2 * l;
-  const float2 gy = *reinterpret_cast<const float2*>(dY + o);
-  const float2 g0 = *reinterpret_cast<const float2*>(dT + o);
-  const float2 g1 = *reinterpret_cast<const float2*>(dT + (long)P * lddy + o);
-  const float2 g2 = *reinterpret_cast<const float2*>(dT + 2l * P * lddy + o);
+  const float2 gy = load2(dY + o);
+  const float2 g0 = load2(dT + o);
+  const float2 g1 = load2(dT + (long)P * lddy + o);
+  const float2 g2 = load2(dT + 2l * P * lddy + o);
   float4* dst = reinterpret_cast<float4*>(packed + ((long)l * P + p) * 8);
   dst[0] = make_float4(gy.x, gy.y, g0.x, g0.y);
   dst[1] = make_float4(g1.x, g1.y, g2.x, g2.y);
@@ -709,7 +718,7 @@ __global__ __launch_bounds__(OWN_THREADS) void encode_bwd_owner_kernel(OwnerArgs
           gy[j] = make_float2(r0.x, r0.y);
           gt[j][0] = make_float2(r0.z, r0.w); gt[j][1] = make_float2(r1.x, r1.y); gt[j][2] = make_float2(r1.z, r1.w);
         } else {
-          gy[j] = *reinterpret_cast<const float2*>(a.dY + (long)p * a.lddy + col);
+          gy[j] = load2(a.dY + (long)p * a.lddy + col);
 #pragma unroll
           for (int k = 0; k < 3; ++k) gt[j][k] = make_float2(0.f, 0.f);
         }

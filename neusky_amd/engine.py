@@ -115,6 +115,9 @@ class Optimizers:
         self._backward_seen = False
 
     def zero_grad_all(self) -> None:
+        """zero the gradient slab.  Between this call and collect_grads() the .grad of a parameter that no kernel accumulates into the
+        slab directly is None or an autograd-owned temporary: anything that reads .grad (clipping, logging, an optimizer step) must run
+        AFTER collect_grads() -- all_reduce_gradients() and optimizer_scheduler_step_all() call it themselves."""
         self.flat_g.zero_()
         # Parameters whose gradient no kernel writes into the slab itself (everything behind weight norm / padding / plain torch
         # ops) start the backward with an undefined .grad: autograd's AccumulateGrad then keeps the incoming tensor instead of
@@ -138,8 +141,9 @@ class Optimizers:
             hip.gather_segments(pairs)
 
     def state_dict(self) -> Dict[str, Dict]:
-        """per group: Adam moments, bias-correction step count and the flat parameter slab (what nerfstudio's trainer keeps
-        under "optimizers" / "schedulers" in step-%09d.ckpt; the schedulers here are pure functions of the global step)"""
+        """per group: Adam moments and the bias-correction step count (what nerfstudio's trainer keeps under "optimizers" /
+        "schedulers" in step-%09d.ckpt; the schedulers here are pure functions of the global step).  The parameters themselves
+        travel in the pipeline's state dict: on load they are copied IN PLACE into the flat slabs they are views of."""
         return {g.name: {"m": g.m.detach().clone(), "v": g.v.detach().clone(), "steps": g.steps, "numel": g.numel}
                 for g in self.groups}
 

@@ -9,7 +9,7 @@ from typing import Optional, Type
 import torch
 
 from ..cameras.rays import RayBundle
-from ..utils.utils import device_rng_seed, to_device_async
+from ..utils.utils import device_rng, to_device_async
 
 
 @dataclass
@@ -89,13 +89,13 @@ class VMFDDFSampler:
         n = num_positions * num_directions
         st = getattr(self, "_dev_state", None)
         if st is None or st["n"] != n or st["ones"].device != dev:
-            st = self._dev_state = {"n": n, "counter": torch.zeros(1, dtype=torch.int64, device=dev), "seed": device_rng_seed(0),
-                                    "ones": torch.ones(n, 1, device=dev), "norm": torch.ones(n, 1, device=dev),
+            st = self._dev_state = {"n": n, "ones": torch.ones(n, 1, device=dev), "norm": torch.ones(n, 1, device=dev),
                                     "cam": torch.zeros(n, 1, device=dev, dtype=torch.int64)}
         origins = torch.empty(n, 3, device=dev)
         directions = torch.empty(n, 3, device=dev)
+        seed, counter = device_rng("ddf_vmf_samples", 0, dev)  # (registered: a checkpoint stores and restores the call counter)
         hip.ddf_vmf_samples(num_positions, num_directions, self.concentration, self.ddf_sphere_radius,
-                            self.config.only_sample_upper_hemisphere, st["seed"], st["counter"], origins, directions)
+                            self.config.only_sample_upper_hemisphere, seed, counter, origins, directions)
         return RayBundle(origins=origins, directions=directions, pixel_area=st["ones"], camera_indices=st["cam"],
                          metadata={"directions_norm": st["norm"]})
 

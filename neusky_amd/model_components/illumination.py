@@ -160,11 +160,8 @@ class IcosahedronSampler:
                 and (rotation is None or rotation.dim() == 2):
             # one kernel: rotation (drawn in the kernel, or the caller's), rotated set and its upper half (csrc/samplers.hip)
             from .. import hip
-            from ..utils.utils import device_rng_seed
-            ckey = key + ":rng"
-            if ckey not in self._dev_cache:
-                self._dev_cache[ckey] = (device_rng_seed(2), torch.zeros(1, dtype=torch.int64, device=base.device))
-            seed, counter = self._dev_cache[ckey]
+            from ..utils.utils import device_rng
+            seed, counter = device_rng("illumination_directions", 2, base.device)
             dirs = torch.empty(D, 3, device=base.device)
             sel = torch.empty(D // 2, dtype=torch.int32, device=base.device)
             self.last_rotation = torch.empty(3, 3, device=base.device)

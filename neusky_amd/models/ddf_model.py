@@ -19,7 +19,7 @@ from .. import ops
 from ..model_components.losses import LossDict, scale_dict
 
 _COEF_VECTORS: Dict[tuple, torch.Tensor] = {}
-from ..utils.utils import device_rng_seed, ray_sphere_intersection
+from ..utils.utils import device_rng, ray_sphere_intersection
 from ..plugin import ModelBase
 
 
@@ -90,9 +90,8 @@ class DDFModel(ModelBase):
         directions = ray_bundle.directions.reshape(-1, 3).contiguous()
         want_mv = bool(c.loss_inclusions["multi_view_loss"] and self.training and batch is not None)
         want_sky = bool(c.loss_inclusions["sky_ray_loss"] and self.training and batch is not None)
-        rng = getattr(self, "_query_rng", None)
-        if rng is None or rng["counter"].device != positions.device:
-            rng = self._query_rng = {"counter": torch.zeros(1, dtype=torch.int64, device=positions.device), "seed": device_rng_seed(1)}
+        q_seed, q_counter = device_rng("ddf_query_rows", 1, positions.device)
+        rng = {"counter": q_counter, "seed": q_seed}
         sky = batch["sky_ray_bundle"] if want_sky else None
         return {"positions": positions, "directions": directions, "term_dist": batch["termination_dist"] if batch is not None else None,
                 "want_mv": want_mv, "mv_points_in": None if mv_points is None else mv_points.to(positions).contiguous(),

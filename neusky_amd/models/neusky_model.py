@@ -33,7 +33,7 @@ from ..model_components.illumination import IcosahedronSamplerConfig, RENIFieldC
 from ..model_components.losses import LossDict, RENISkyPixelLoss, interlevel_loss, monosdf_normal_loss, scale_dict, total_loss
 from ..model_components.ray_samplers import HashMLPDensityField, ProposalNetworkSampler
 from ..model_components.renderers import RGBLambertianRendererWithVisibility
-from ..utils.utils import device_rng_seed, linear_to_sRGB, to_device_async
+from ..utils.utils import device_rng, device_rng_seed, linear_to_sRGB, to_device_async
 from ..plugin import ModelBase
 
 
@@ -489,7 +489,6 @@ class NeuSkyFactoModel(ModelBase):
             self._grid_lattice = torch.stack((X, Y, Z), -1).reshape(-1, 3).to(dev)
             self._grid_gap_host = [(float(mx[i]) - float(mn[i])) / res for i in range(3)]
             self._grid_gap = torch.tensor(self._grid_gap_host).to(dev)
-            self._grid_rng = (device_rng_seed(3), torch.zeros(1, dtype=torch.int64, device=dev))
             self._grid_cache_key = key
         gap = self._grid_gap
         if randoms is not None and "grid_perturb" in randoms:
@@ -498,7 +497,8 @@ class NeuSkyFactoModel(ModelBase):
             gdir = gdir / torch.norm(gdir, dim=-1, keepdim=True)
         else:  # the reference draws these on the CPU every step (:704-712); drawn in one kernel here (csrc/samplers.hip)
             positions, gdir = torch.empty_like(self._grid_lattice), torch.empty_like(self._grid_lattice)
-            hip.grid_probe_points(self._grid_lattice, self._grid_gap_host, self._grid_rng[0], self._grid_rng[1], positions, gdir)
+            g_seed, g_counter = device_rng("grid_probe_points", 3, dev)
+            hip.grid_probe_points(self._grid_lattice, self._grid_gap_host, g_seed, g_counter, positions, gdir)
         return positions, gdir
 
     # ------------------------------------------------------------------ outputs

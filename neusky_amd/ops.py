@@ -356,8 +356,10 @@ class HashEncodeFn(torch.autograd.Function):
         d_out = d_out.contiguous()
         sink = ctx.sink
         accumulate = sink is not None and sink.grad is not None and sink.grad.is_contiguous() and sink.grad.numel() == table.numel()
-        if accumulate:
-            sink._nsky_sunk = True  # (engine.Optimizers.zero_grad_all: this parameter's .grad stays its slab view)
+        if accumulate or (sink is not None and sink.grad is None):
+            # engine.Optimizers.zero_grad_all: this parameter's .grad stays its slab view.  (A parameter first used after step 0 -- a
+            # loss enabled later -- arrives here with .grad dropped: it takes the slow path once and sinks from the next step on.)
+            sink._nsky_sunk = True
         dtable = sink.grad.view_as(table) if accumulate else zeros_like(table)
         dx = torch.empty(P, 3, device=x.device) if need_dx else None
         dT = d_out[P:].view(3, P, ldy) if tangents else None
@@ -549,6 +551,8 @@ class FilmSirenFn(torch.autograd.Function):
                 if sk is not None and sk.grad is not None and sk.grad.shape == t.shape and sk.grad.is_contiguous():
                     grads[idx], sunk[idx] = sk.grad, True
                     sk._nsky_sunk = True
+                elif sk is not None and sk.grad is None:
+                    sk._nsky_sunk = True  # (first used after step 0: sinks from the next zero_grad_all on)
             sizes = [0 if sunk[idx] else (t.numel() + 3) // 4 * 4 for idx, t in enumerate(wb)]
             flat = zeros(max(sum(sizes), 4), device=dev)
             off = 0
@@ -609,6 +613,8 @@ class FilmSirenFn(torch.autograd.Function):
                 if sk is not None and sk.grad is not None and sk.grad.shape == t.shape and sk.grad.is_contiguous():
                     grads[idx], sunk[idx] = sk.grad, True
                     sk._nsky_sunk = True
+                elif sk is not None and sk.grad is None:
+                    sk._nsky_sunk = True  # (first used after step 0: sinks from the next zero_grad_all on)
             sizes = [0 if sunk[idx] else (t.numel() + 3) // 4 * 4 for idx, t in enumerate(wb)]
             flat = zeros(max(sum(sizes), 4), device=dev)
             off = 0

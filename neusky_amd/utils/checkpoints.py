@@ -11,11 +11,20 @@ by torch itself:
   _model.field.{glin,clin}{l}.parametrizations.weight.original{0,1}   (new style: g, v)
   _model.field.deviation_network.variance
   _model.visibility_field.field.position_encoding.params
-  _model.{train,eval}_illumination_latents, _model.{train,eval}_scale, _model.visibility_threshold
+  _model.visibility_field.field.ddf.{mapping_network.network.{2 l}, net.{i}.layer, final_layer}.{weight,bias}
+                                                    the DDF FiLM-SIREN under the module names of neusky/utils/siren.py:108-208 (the only
+                                                    in-tree statement of that network; this package's FiLMSiren keeps the same names)
+  _model.proposal_networks.{i}.mlp_base.0.tcnn_encoding.params | .encoding.tcnn_encoding.params | .encoding.params
+                                                    proposal hash tables in tcnn's level-major layout
+  _model.proposal_networks.{i}.mlp_base.1.layers.{l}.{weight,bias} | .network.layers.{l}.{weight,bias}
+                                                    proposal density MLPs in their fp32 torch form (nerfstudio MLP, implementation="torch")
+                                                    [UNVERIFIED-UPSTREAM key names: nerfstudio's source is absent from the reference tree]
+  _model.{train,eval}_illumination_latents, _model.{train,eval}_scale, _model.eval_rotation, _model.visibility_threshold
+  any other key that is the name of a parameter / buffer of THIS package's pipeline (its own checkpoints; the illumination decoder)
 
-Not mapped (their tensor layouts live in packages whose source is absent from the reference tree - SURVEY F2): the
-proposal networks (`tcnn.NetworkWithInputEncoding` packs MLP + grid into one fp16 blob), the DDF FiLM-SIREN
-(`reni.field_components.film_siren.FiLMSiren` parameter names) and the RENI++ decoder.  They are returned in `unmapped`.
+Not mapped (their tensor layouts live in packages whose source is absent from the reference tree - SURVEY F2): proposal networks
+saved as ONE packed fp16 blob (`tcnn.NetworkWithInputEncoding`), nerfstudio's torch hash table (fixed 2^k entries per level, no dense
+levels: not tcnn's indexing) and the real RENI++ decoder.  They are returned in `unmapped`.
 """
 from __future__ import annotations
 
@@ -47,11 +56,27 @@ def load_reference_pipeline_state(pipeline, state: Dict[str, torch.Tensor], stri
             targets[base + "bias"] = lin.bias
             targets[base + "parametrizations.weight.original0"] = lin.weight_g
             targets[base + "parametrizations.weight.original1"] = lin.weight_v
-    for name in ("train_illumination_latents", "train_scale", "eval_illumination_latents", "eval_scale"):
-        targets["_model." + name] = getattr(model, name)
+    for name in ("train_illumination_latents", "train_scale", "eval_illumination_latents", "eval_scale", "eval_rotation"):
+        if hasattr(model, name):
+            targets["_model." + name] = getattr(model, name)
     if model.visibility_field is not None:
         targets["_model.visibility_threshold"] = model.visibility_threshold
-        targets["_model.visibility_field.field.position_encoding.params"] = model.visibility_field.field.position_encoding.params
+        vf = model.visibility_field.field
+        targets["_model.visibility_field.field.position_encoding.params"] = vf.position_encoding.params
+        for n, p_ in vf.ddf.named_parameters():  # mapping_network.network.{2l}.*, net.{i}.layer.*, final_layer.* (siren.py:108-208)
+            targets["_model.visibility_field.field.ddf." + n] = p_
+    for i, net in enumerate(model.proposal_networks):
+        base = f"_model.proposal_networks.{i}."
+        for k in ("mlp_base.0.tcnn_encoding.params", "encoding.tcnn_encoding.params", "encoding.params"):
+            targets[base + k] = net.encoding.params
+        for l, lin in enumerate((net.lin0, net.lin1)):
+            for stem in (f"mlp_base.1.layers.{l}.", f"network.layers.{l}.", f"lin{l}."):
+                targets[base + stem + "weight"] = lin.weight
+                targets[base + stem + "bias"] = lin.bias
+    own = dict(pipeline.named_parameters())
+    own.update(dict(pipeline.named_buffers()))
+    for k, v in own.items():  # this package's own names (its checkpoints; the illumination decoder)
+        targets.setdefault(k, v)
     loaded, unmapped = [], []
     for k, v in state.items():
         if k in targets:
@@ -64,6 +89,8 @@ def load_reference_pipeline_state(pipeline, state: Dict[str, torch.Tensor], stri
                 unmapped.append(k)
         elif k.startswith("_model."):
             unmapped.append(k)
+    if loaded and hasattr(model, "begin_step") and next(model.parameters()).is_cuda:
+        model.begin_step()  # prepared (weight-normed / padded / packed) copies of the old weights are stale
     return loaded, unmapped
 
 
@@ -76,12 +103,18 @@ def checkpoint_path(base_dir, step: int):
 
 
 def save_checkpoint(base_dir, step: int, pipeline, optimizers=None) -> str:
-    """{"step", "pipeline": state_dict, "optimizers": Adam moments + step counts per group, "schedulers": {}} (the
+    """{"step", "pipeline": state_dict, "optimizers": Adam moments + step counts per group, "schedulers": {}, "rng": ...} (the
     schedulers are pure functions of the global step and carry no state).  Returns the file written."""
     import os
     path = checkpoint_path(base_dir, step)
     os.makedirs(os.path.dirname(path), exist_ok=True)
+    from .utils import device_rng_state
+    dm_gen = getattr(getattr(pipeline, "datamanager", None), "_gen", None)
     ckpt = {"step": int(step), "pipeline": {k: v.detach().cpu().clone() for k, v in pipeline.state_dict().items()},
+            # what an exact resume needs besides parameters and Adam state: the call counters of the in-kernel generators, the
+            # datamanager's host generator and the step of the last eval-latent fit (neusky_pipeline.py:202-210)
+            "rng": {"device": device_rng_state(), "datamanager": None if dm_gen is None else dm_gen.get_state(),
+                    "step_of_last_latent_optimisation": int(getattr(pipeline, "step_of_last_latent_optimisation", 0))},
             "optimizers": {} if optimizers is None else {k: {kk: (vv.cpu() if torch.is_tensor(vv) else vv) for kk, vv in st.items()}
                                                         for k, st in optimizers.state_dict().items()},
             "schedulers": {}}
@@ -98,6 +131,15 @@ def load_checkpoint(path, pipeline, optimizers=None) -> int:
         if not ckpt.get("optimizers"):
             raise ValueError(f"{path}: no optimizer state to resume from")
         optimizers.load_state_dict(ckpt["optimizers"])
+    rng = ckpt.get("rng")
+    if rng:
+        from .utils import load_device_rng_state
+        load_device_rng_state(rng.get("device", {}))
+        dm_gen = getattr(getattr(pipeline, "datamanager", None), "_gen", None)
+        if dm_gen is not None and rng.get("datamanager") is not None:
+            dm_gen.set_state(rng["datamanager"])
+        if hasattr(pipeline, "step_of_last_latent_optimisation"):
+            pipeline.step_of_last_latent_optimisation = int(rng.get("step_of_last_latent_optimisation", 0))
     if hasattr(pipeline.model, "begin_step"):
         pipeline.model.begin_step()  # prepared (weight-normed / padded / split) copies of the old weights are stale
     return int(ckpt["step"])

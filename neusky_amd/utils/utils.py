@@ -47,3 +47,36 @@ def device_rng_seed(stream_id: int = 0) -> int:
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     return (torch.initial_seed() + 7919 * rank + 104729 * stream_id) & (2**63 - 1)
+
+
+# ---- device RNG registry: every in-kernel generator of a run is (seed, call counter on the device); a checkpoint stores and restores them
+_DEVICE_RNGS: dict = {}
+
+
+def device_rng(name: str, stream_id: int, device) -> tuple:
+    """(seed, int64 device counter) of the named in-kernel generator: created on first use, or -- after utils.checkpoints.load_checkpoint
+    -- resumed from the saved seed and call count, so that a resumed run continues the random sequence instead of redrawing step 0's"""
+    key = (name, str(torch.device(device)))
+    hit = _DEVICE_RNGS.get(key)
+    if hit is None:
+        pend = _DEVICE_RNGS.pop(("pending", name), None)
+        seed = device_rng_seed(stream_id) if pend is None else int(pend[0])
+        counter = torch.zeros(1, dtype=torch.int64, device=device)
+        if pend is not None:
+            counter.fill_(int(pend[1]))
+        hit = _DEVICE_RNGS[key] = (seed, counter)
+    return hit
+
+
+def device_rng_state() -> dict:
+    return {k[0]: (int(v[0]), int(v[1].item())) for k, v in _DEVICE_RNGS.items() if k[0] != "pending"}
+
+
+def load_device_rng_state(state: dict) -> None:
+    for name, (seed, count) in state.items():
+        live = [k for k in _DEVICE_RNGS if k[0] == name]
+        if live:
+            for k in live:
+                _DEVICE_RNGS[k] = (int(seed), _DEVICE_RNGS[k][1].fill_(int(count)))
+        else:
+            _DEVICE_RNGS[("pending", name)] = (int(seed), int(count))

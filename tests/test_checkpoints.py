@@ -25,9 +25,28 @@ def test_load_reference_state_dict_cpu():
         "_model.visibility_field.field.ddf.net.0.linear.weight": torch.zeros(4),
         "datamanager.something": torch.zeros(1),
     }
+    # the DDF FiLM-SIREN under the module names of neusky/utils/siren.py:108-208 and the proposal networks' fp32 torch form
+    ddf = pipe.model.visibility_field.field.ddf
+    pn = pipe.model.proposal_networks[1]
+    extra = {
+        "_model.visibility_field.field.ddf.mapping_network.network.0.weight": torch.rand(ddf.mapping_network.network[0].weight.shape, generator=g),
+        "_model.visibility_field.field.ddf.mapping_network.network.2.bias": torch.rand(ddf.mapping_network.network[2].bias.shape, generator=g),
+        "_model.visibility_field.field.ddf.net.0.layer.weight": torch.rand(ddf.net[0].layer.weight.shape, generator=g),
+        "_model.visibility_field.field.ddf.net.3.layer.bias": torch.rand(ddf.net[3].layer.bias.shape, generator=g),
+        "_model.visibility_field.field.ddf.final_layer.weight": torch.rand(ddf.final_layer.weight.shape, generator=g),
+        "_model.proposal_networks.1.mlp_base.0.tcnn_encoding.params": (torch.rand(pn.encoding.params.shape, generator=g) * 1e-2).half(),
+        "_model.proposal_networks.1.mlp_base.1.layers.0.weight": torch.rand(pn.lin0.weight.shape, generator=g),
+        "_model.proposal_networks.1.mlp_base.1.layers.1.bias": torch.rand(pn.lin1.bias.shape, generator=g),
+        "_model.eval_rotation": torch.rand(pipe.model.eval_rotation.shape, generator=g),
+    }
+    state.update(extra)
     loaded, unmapped = load_reference_pipeline_state(pipe, state)
     assert sorted(unmapped) == ["_model.proposal_networks.0.mlp_base.params", "_model.visibility_field.field.ddf.net.0.linear.weight"]
-    assert len(loaded) == 9
+    assert len(loaded) == 9 + len(extra)
+    assert torch.equal(ddf.net[0].layer.weight.detach(), extra["_model.visibility_field.field.ddf.net.0.layer.weight"])
+    assert torch.equal(ddf.mapping_network.network[2].bias.detach(), extra["_model.visibility_field.field.ddf.mapping_network.network.2.bias"])
+    assert torch.equal(pn.lin0.weight.detach(), extra["_model.proposal_networks.1.mlp_base.1.layers.0.weight"])
+    assert torch.equal(pn.encoding.params.detach(), extra["_model.proposal_networks.1.mlp_base.0.tcnn_encoding.params"].float())
     assert torch.equal(f.encoding.params.detach(), state["_model.field.encoding.params"].float())
     assert torch.equal(f.glin1.weight_v.detach(), state["_model.field.glin1.parametrizations.weight.original1"])
     assert abs(float(pipe.model.visibility_threshold) - 0.77) < 1e-6 and abs(float(f.deviation_network.variance) - 0.42) < 1e-6
@@ -68,3 +87,46 @@ def test_save_resume_round_trip_cpu(tmp_path):
     assert [grp.flat_p.data_ptr() for grp in opt2.groups] == slab_ptrs
     for grp in opt2.groups:
         assert grp.params[0].data_ptr() == grp.flat_p.data_ptr()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_saved_state_loads_into_a_fresh_pipeline_and_renders_identically(tmp_path):
+    """SURVEY 8(f)3 end to end on the GPU: a checkpoint in the reference's wire format ({"pipeline": state_dict} at
+    nerfstudio_models/step-%09d.ckpt, neusky_pipeline.py:174-194) is loaded key by key (field, both proposal networks, the DDF
+    FiLM-SIREN, illumination latents and decoder) into a differently initialised pipeline, which then renders the same frame"""
+    from neusky_amd.cameras.rays import RayBundle
+    from neusky_amd.utils.checkpoints import load_reference_pipeline_state, save_checkpoint
+    from util_step import randomise
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    cfg = dict(R=32, num_prop=(24, 12), S=8, D=24, images=4)
+    pipe = small_pipeline_config(**cfg).setup(device=dev)
+    randomise(pipe)
+    path = save_checkpoint(tmp_path, 7, pipe)
+    torch.manual_seed(123)
+    pipe2 = small_pipeline_config(**cfg).setup(device=dev)
+    randomise(pipe2, seed=5)
+    state = torch.load(path, weights_only=False)["pipeline"]
+    loaded, unmapped = load_reference_pipeline_state(pipe2, state)
+    assert not unmapped, unmapped
+    trainable = [n for n, _ in pipe2.named_parameters()]
+    assert set(trainable) <= set(loaded)
+    for (n, a), (_, b) in zip(pipe.named_parameters(), pipe2.named_parameters()):
+        assert torch.equal(a.detach(), b.detach()), n
+    H, W = 6, 8
+    g = torch.Generator().manual_seed(2)
+    d = torch.randn(H, W, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    mk = lambda: RayBundle(origins=(torch.rand(H, W, 3, generator=torch.Generator().manual_seed(3)) * 0.2 - 0.1).to(dev), directions=d.to(dev),  # noqa: E731
+                           pixel_area=torch.ones(H, W, 1, device=dev), camera_indices=torch.zeros(H, W, 1, dtype=torch.long, device=dev),
+                           metadata={"directions_norm": torch.ones(H, W, 1, device=dev)})
+    outs = []
+    for p_ in (pipe, pipe2):
+        p_.eval()
+        with torch.no_grad():
+            outs.append(p_.model.get_outputs_for_camera_ray_bundle(mk(), camera_index=0, chunk=64, use_graph=False))
+    for k in ("rgb", "depth", "normal", "albedo"):
+        assert torch.equal(outs[0][k], outs[1][k]), k

@@ -11,6 +11,6 @@ if [ "$1" = "snapshot" ]; then
 fi
 for i in 1 2 3; do
   for d in $R/scratch/base $R; do
-    (cd $d && python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-exact-f32 2>/dev/null | tail -1 | python -c "import sys,json; print('$d'.replace('$R','.') or '.', json.loads(sys.stdin.read())['ms_per_step'])")
+    (cd $d && python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-exact-f32 --no-extra-configs 2>/dev/null | tail -1 | python -c "import sys,json; print('$d'.replace('$R','.') or '.', json.loads(sys.stdin.read())['ms_per_step'])")
   done
 done

@@ -14,10 +14,10 @@ python tools/bench_forward_only.py > $O/forward_only.json 2> $O/forward_only.err
 python tools/bench_render.py > $O/bench_render.log 2>&1; tail -2 $O/bench_render.log
 python tools/train_sanity.py 300 > $O/train_sanity.log 2>&1; tail -3 $O/train_sanity.log
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact-f32 > $O/prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact-f32 --no-extra-configs > $O/prof_bench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_render -- python3 $R/tools/bench_render.py 270 480 > $O/prof_render.log 2>&1
 find $O -name "*kernel_trace.csv" -delete
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_bench_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-exact-f32 > $R/gpurun_out/pmc_bench_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_bench_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-exact-f32 --no-extra-configs > $R/gpurun_out/pmc_bench_$c.log 2>&1
 done
 find $O -name "*_stats.csv" | head
