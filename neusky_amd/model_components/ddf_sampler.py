@@ -93,7 +93,7 @@ class VMFDDFSampler:
                                     "cam": torch.zeros(n, 1, device=dev, dtype=torch.int64)}
         origins = torch.empty(n, 3, device=dev)
         directions = torch.empty(n, 3, device=dev)
-        seed, counter = device_rng("ddf_vmf_samples", 0, dev)  # (registered: a checkpoint stores and restores the call counter)
+        seed, counter = device_rng(self, "ddf_vmf_samples", 0, dev)  # (registered: a checkpoint stores and restores the call counter)
         hip.ddf_vmf_samples(num_positions, num_directions, self.concentration, self.ddf_sphere_radius,
                             self.config.only_sample_upper_hemisphere, seed, counter, origins, directions)
         return RayBundle(origins=origins, directions=directions, pixel_area=st["ones"], camera_indices=st["cam"],

@@ -90,7 +90,7 @@ class DDFModel(ModelBase):
         directions = ray_bundle.directions.reshape(-1, 3).contiguous()
         want_mv = bool(c.loss_inclusions["multi_view_loss"] and self.training and batch is not None)
         want_sky = bool(c.loss_inclusions["sky_ray_loss"] and self.training and batch is not None)
-        q_seed, q_counter = device_rng("ddf_query_rows", 1, positions.device)
+        q_seed, q_counter = device_rng(self, "ddf_query_rows", 1, positions.device)
         rng = {"counter": q_counter, "seed": q_seed}
         sky = batch["sky_ray_bundle"] if want_sky else None
         return {"positions": positions, "directions": directions, "term_dist": batch["termination_dist"] if batch is not None else None,

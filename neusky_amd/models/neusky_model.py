@@ -497,7 +497,7 @@ class NeuSkyFactoModel(ModelBase):
             gdir = gdir / torch.norm(gdir, dim=-1, keepdim=True)
         else:  # the reference draws these on the CPU every step (:704-712); drawn in one kernel here (csrc/samplers.hip)
             positions, gdir = torch.empty_like(self._grid_lattice), torch.empty_like(self._grid_lattice)
-            g_seed, g_counter = device_rng("grid_probe_points", 3, dev)
+            g_seed, g_counter = device_rng(self, "grid_probe_points", 3, dev)
             hip.grid_probe_points(self._grid_lattice, self._grid_gap_host, g_seed, g_counter, positions, gdir)
         return positions, gdir
 

@@ -49,34 +49,45 @@ def device_rng_seed(stream_id: int = 0) -> int:
     return (torch.initial_seed() + 7919 * rank + 104729 * stream_id) & (2**63 - 1)
 
 
-# ---- device RNG registry: every in-kernel generator of a run is (seed, call counter on the device); a checkpoint stores and restores them
-_DEVICE_RNGS: dict = {}
+# ---- in-kernel generators: (seed, call counter on the device) held by the object that draws, listed here for checkpoints
+import weakref
+
+_RNG_OWNERS: dict = {}    # name -> weak reference to the object holding the generator's state
+_RNG_PENDING: dict = {}   # name -> (seed, calls) loaded from a checkpoint before the generator exists
 
 
-def device_rng(name: str, stream_id: int, device) -> tuple:
-    """(seed, int64 device counter) of the named in-kernel generator: created on first use, or -- after utils.checkpoints.load_checkpoint
-    -- resumed from the saved seed and call count, so that a resumed run continues the random sequence instead of redrawing step 0's"""
-    key = (name, str(torch.device(device)))
-    hit = _DEVICE_RNGS.get(key)
-    if hit is None:
-        pend = _DEVICE_RNGS.pop(("pending", name), None)
-        seed = device_rng_seed(stream_id) if pend is None else int(pend[0])
-        counter = torch.zeros(1, dtype=torch.int64, device=device)
+def device_rng(owner, name: str, stream_id: int, device) -> tuple:
+    """(seed, int64 device counter) of `owner`'s in-kernel generator `name`: created at its first use (seed: device_rng_seed, counter 0)
+    or, after utils.checkpoints.load_checkpoint, resumed from the saved seed and call count -- a resumed run continues the random
+    sequence instead of redrawing step 0's."""
+    attr = "_nsky_rng_" + name
+    st = getattr(owner, attr, None)
+    if st is None or st[1].device != torch.device(device):
+        pend = _RNG_PENDING.pop(name, None)
+        st = (device_rng_seed(stream_id) if pend is None else int(pend[0]), torch.zeros(1, dtype=torch.int64, device=device))
         if pend is not None:
-            counter.fill_(int(pend[1]))
-        hit = _DEVICE_RNGS[key] = (seed, counter)
-    return hit
+            st[1].fill_(int(pend[1]))
+        object.__setattr__(owner, attr, st)
+        _RNG_OWNERS[name] = weakref.ref(owner)
+    return st
 
 
 def device_rng_state() -> dict:
-    return {k[0]: (int(v[0]), int(v[1].item())) for k, v in _DEVICE_RNGS.items() if k[0] != "pending"}
+    out = {}
+    for name, ref in _RNG_OWNERS.items():
+        o = ref()
+        st = getattr(o, "_nsky_rng_" + name, None) if o is not None else None
+        if st is not None:
+            out[name] = (int(st[0]), int(st[1].item()))
+    return out
 
 
 def load_device_rng_state(state: dict) -> None:
     for name, (seed, count) in state.items():
-        live = [k for k in _DEVICE_RNGS if k[0] == name]
-        if live:
-            for k in live:
-                _DEVICE_RNGS[k] = (int(seed), _DEVICE_RNGS[k][1].fill_(int(count)))
+        ref = _RNG_OWNERS.get(name)
+        o = ref() if ref is not None else None
+        st = getattr(o, "_nsky_rng_" + name, None) if o is not None else None
+        if st is not None:  # a live generator: same counter tensor (a captured graph reads it), checkpoint's seed and call count
+            object.__setattr__(o, "_nsky_rng_" + name, (int(seed), st[1].fill_(int(count))))
         else:
-            _DEVICE_RNGS[("pending", name)] = (int(seed), int(count))
+            _RNG_PENDING[name] = (int(seed), int(count))

@@ -559,6 +559,38 @@ def reni_decode(latents: Tensor, dirs: Tensor, scale: Tensor, p: Dict[str, Tenso
     return torch.exp(rgb) * scale[:, None]
 
 
+def reni_attention_decode(latents: Tensor, dirs: Tensor, scale: Tensor, p: Dict[str, Tensor], heads: int = 8, layers: int = 6) -> Tensor:
+    """THIS PROJECT'S restatement of the RENI++ attention-conditioned decoder (neusky_config.py:78-95: conditioning="Attention", VN /
+    SO2-about-z invariance, 8 heads x 6 layers, hidden 128; ns_reni source absent -> PARITY UNPINNED), in its plain per-pair form:
+    latents Z [B,L,3], dirs d [B,3], scale [B] -> HDR radiance [B,3].
+      token n:  t_n = E [z_xy . d_xy, z_x d_y - z_y d_x, z_z, |z_xy|] + e   (invariant under a joint rotation of Z and d about z)
+      query:    q = X [|d_xy|, d_z, NeRF2(|d_xy|, d_z)] + x
+      layer:    q += Wo MHA(LN1(q); K = Wk t + bk, V = Wv t + bv);  q += W2 relu(W1 LN2(q) + b1) + b2;  out = Wout LNf(q) + bout
+    The product forms every (pair, token) explicitly here; neusky_amd's AttentionDecoder uses the tokens' linearity in (d_x, d_y)."""
+    B, L, _ = latents.shape
+    zx, zy, zz = latents[..., 0], latents[..., 1], latents[..., 2]
+    dx, dy = dirs[:, 0:1], dirs[:, 1:2]
+    inv = torch.stack([zx * dx + zy * dy, zx * dy - zy * dx, zz, torch.sqrt(zx * zx + zy * zy + 1e-20)], -1)  # [B,L,4]
+    t = F.linear(inv, p["reni.attn.token_w"], p["reni.attn.token_b"])  # [B,L,H]
+    x = torch.stack([torch.sqrt(dirs[:, 0] ** 2 + dirs[:, 1] ** 2 + 1e-20), dirs[:, 2]], -1)
+    x = torch.cat([x, nerf_encoding(x, 2, 0.0, 2.0, False)], -1)
+    q = F.linear(x, p["reni.attn.query_w"], p["reni.attn.query_b"])  # [B,H]
+    H = q.shape[1]
+    dh = H // heads
+    ln = lambda v, k: F.layer_norm(v, (H,), p[k + "_w"], p[k + "_b"])  # noqa: E731
+    for l in range(layers):
+        k_ = f"reni.attn.l{l}."
+        Q = F.linear(ln(q, k_ + "ln1"), p[k_ + "wq_w"], p[k_ + "wq_b"]).reshape(B, heads, 1, dh)
+        K = F.linear(t, p[k_ + "wk_w"], p[k_ + "wk_b"]).reshape(B, L, heads, dh).transpose(1, 2)
+        V = F.linear(t, p[k_ + "wv_w"], p[k_ + "wv_b"]).reshape(B, L, heads, dh).transpose(1, 2)
+        a = torch.softmax(torch.matmul(Q, K.transpose(-1, -2)) / dh ** 0.5, -1)  # [B,heads,1,L]
+        o = torch.matmul(a, V).reshape(B, H)
+        q = q + F.linear(o, p[k_ + "wo_w"], p[k_ + "wo_b"])
+        q = q + F.linear(torch.relu(F.linear(ln(q, k_ + "ln2"), p[k_ + "ff1_w"], p[k_ + "ff1_b"])), p[k_ + "ff2_w"], p[k_ + "ff2_b"])
+    rgb = F.linear(ln(q, "reni.attn.lnf"), p["reni.attn.out_w"], p["reni.attn.out_b"])
+    return torch.exp(rgb) * scale[:, None]
+
+
 def sample_illumination(cam_idx: Tensor, ray_dirs: Tensor, dirs: Tensor, latents: Tensor, scales: Tensor, decode_fn):
     """neusky/models/neusky_model.py:445-551 on compact inputs.  cam_idx [R] (every sample of a ray has the
     ray's camera index), ray_dirs [R,3], dirs [D,3].  decode_fn(latents[B,L,3], dirs[B,3], scale[B]) -> [B,3].

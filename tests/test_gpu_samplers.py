@@ -45,11 +45,13 @@ def test_vmf_ddf_samples_distribution():
 
 def test_vmf_ddf_samples_advance_and_reproduce():
     s = _sampler(8, 16)
+    from neusky_amd.utils.utils import device_rng
     a = s()
     b = s()
     assert not torch.equal(a.directions, b.directions) and not torch.equal(a.origins, b.origins)
-    assert int(s._dev_state["counter"]) == 2
-    s._dev_state["counter"].zero_()
+    _, counter = device_rng(s, "ddf_vmf_samples", 0, DEV)  # the generator's call counter lives on the device (checkpointed, graph-safe)
+    assert int(counter) == 2
+    counter.zero_()
     c = s()
     assert torch.equal(a.directions, c.directions) and torch.equal(a.origins, c.origins)
 
