@@ -15,10 +15,11 @@ import torch
 
 from ..cameras.rays import RayBundle
 from ..utils.utils import to_device_async
+from ..plugin import ConfigBase
 
 
 @dataclass
-class SyntheticDataManagerConfig:
+class SyntheticDataManagerConfig(ConfigBase):
     _target: Type = field(default_factory=lambda: SyntheticDataManager)
     num_train_images: int = 300
     num_eval_images: int = 96

@@ -19,7 +19,7 @@ from ..encoding import HashGridGeometry
 from ..field_components.neusky_fieldheadnames import NeuSkyFieldHeadNames
 from ..utils.siren import FiLMSiren
 from .sdf_albedo_field import HashEncoding
-from ..plugin import FieldBase
+from ..plugin import ConfigBase, FieldBase
 
 
 def nerf_encoding(x: torch.Tensor, num_freq: int, max_exp: float, include_input: bool = False) -> torch.Tensor:
@@ -31,7 +31,7 @@ def nerf_encoding(x: torch.Tensor, num_freq: int, max_exp: float, include_input:
 
 
 @dataclass
-class DirectionalDistanceFieldConfig:
+class DirectionalDistanceFieldConfig(ConfigBase):
     """neusky/fields/directional_distance_field.py:47-91"""
 
     _target: Type = field(default_factory=lambda: DirectionalDistanceField)

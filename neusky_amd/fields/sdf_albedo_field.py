@@ -25,7 +25,7 @@ from .. import hip, ops
 from ..cameras.rays import RaySamples
 from ..encoding import HashGridGeometry
 from ..field_components.neusky_fieldheadnames import FieldHeadNames, NeuSkyFieldHeadNames
-from ..plugin import FieldBase
+from ..plugin import ConfigBase, FieldBase
 
 
 class HashEncoding(nn.Module):
@@ -70,7 +70,7 @@ class LearnedVariance(nn.Module):
 
 
 @dataclass
-class SDFAlbedoFieldConfig:
+class SDFAlbedoFieldConfig(ConfigBase):
     """neusky/fields/sdf_albedo_field.py:71-77 + the inherited nerfstudio SDFFieldConfig members the
     `neusky` method sets (neusky/configs/neusky_config.py:66-77)."""
 

@@ -10,10 +10,11 @@ import torch
 
 from ..cameras.rays import RayBundle
 from ..utils.utils import device_rng, to_device_async
+from ..plugin import ConfigBase
 
 
 @dataclass
-class VMFDDFSamplerConfig:
+class VMFDDFSamplerConfig(ConfigBase):
     _target: Type = field(default_factory=lambda: VMFDDFSampler)
     num_samples_on_sphere: int = 8
     num_rays_per_sample: int = 128

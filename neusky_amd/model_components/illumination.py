@@ -22,6 +22,7 @@ from torch import nn
 from ..fields.directional_distance_field import nerf_encoding
 from ..utils.siren import FiLMSiren
 from .. import ops
+from ..plugin import ConfigBase
 
 
 def fibonacci_sphere(n: int) -> torch.Tensor:
@@ -106,7 +107,7 @@ def random_rotation(generator: Optional[torch.Generator] = None) -> torch.Tensor
 
 
 @dataclass
-class IcosahedronSamplerConfig:
+class IcosahedronSamplerConfig(ConfigBase):
     _target: Type = field(default_factory=lambda: IcosahedronSampler)
     num_directions: int = 512
     apply_random_rotation: bool = True
@@ -203,7 +204,7 @@ class IcosahedronSampler:
 
 
 @dataclass
-class RENIFieldConfig:
+class RENIFieldConfig(ConfigBase):
     """subset of reni RENIFieldConfig used by neusky_config.py:78-96.  conditioning = "FiLM" (north star: 'RENI++ SIREN illumination
     decode'; what bench.py measures) or "Attention" (what neusky_config.py:79-80,90-91 selects: VN invariance, SO2 about z, transformer
     decoder with 8 heads x 6 layers, hidden 128)."""

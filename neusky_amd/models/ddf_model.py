@@ -20,11 +20,11 @@ from ..model_components.losses import LossDict, scale_dict
 
 _COEF_VECTORS: Dict[tuple, torch.Tensor] = {}
 from ..utils.utils import device_rng, ray_sphere_intersection
-from ..plugin import ModelBase
+from ..plugin import ConfigBase, ModelBase
 
 
 @dataclass
-class DDFModelConfig:
+class DDFModelConfig(ConfigBase):
     """neusky/models/ddf_model.py:53-86 with the values of neusky/configs/neusky_config.py:162-206"""
 
     _target: Type = field(default_factory=lambda: DDFModel)

@@ -34,7 +34,7 @@ from ..model_components.losses import LossDict, RENISkyPixelLoss, interlevel_los
 from ..model_components.ray_samplers import HashMLPDensityField, ProposalNetworkSampler
 from ..model_components.renderers import RGBLambertianRendererWithVisibility
 from ..utils.utils import device_rng, device_rng_seed, linear_to_sRGB, to_device_async
-from ..plugin import ModelBase
+from ..plugin import ConfigBase, ModelBase
 
 
 def _default_loss_inclusions() -> Dict[str, Any]:  # neusky/configs/neusky_config.py:102-126
@@ -60,7 +60,7 @@ def _default_loss_coefficients() -> Dict[str, float]:  # neusky/configs/neusky_c
 
 
 @dataclass
-class NeuSkyFactoModelConfig:
+class NeuSkyFactoModelConfig(ConfigBase):
     """neusky/models/neusky_model.py:81-169 + inherited NeuSFactoModelConfig members,
     defaults = the `neusky` method (neusky/configs/neusky_config.py:65-161)."""
 

@@ -18,16 +18,17 @@ import torch.nn.functional as F
 from . import hip
 
 
-# Arithmetic of the dense contractions (operands and results are fp32 in memory either way; see include/neusky_hip.h):
-#   forward GEMMs  : NSKY_PRECISION=splith (default) fp16 hi + 2^11-scaled fp16 residual, 3 fp16 MFMAs, ~2^-21 per product
-#                    (operands are bounded activations / weights, inside fp16's range); split = 3-term bf16 split
-#                    (6 bf16 MFMAs, ~2^-22, any range); split2 = 2-term bf16 (2^-16); f32 | mixed = exact fp32 MFMA
-#   backward GEMMs : 2-term bf16 split (3 bf16 MFMAs, ~2^-16 per product; gradients need bf16's exponent range)
-#                    unless NSKY_PRECISION=f32
+# Arithmetic of the dense contractions (operands and results are fp32 in memory either way; see include/neusky_hip.h).  Two policies:
+#   splith (default): every large contraction -- the FiLM-SIREN chains, the SDF / albedo field and all their weight gradients -- is
+#                    fp32-grade: fp16 hi + residual planes on power-of-two pre-scaled operands, three fp16 MFMAs per product (~2^-22).
+#                    The per-layer kernels that remain for SMALL row counts (< 4096 rows: tests, tiny batches) use the fp16 split
+#                    forward (2^11-scaled residual) and a 2-term bf16 split backward; proposal layers and N <= 64 heads: exact fp32 MFMA.
+#   f32            : every product on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), per-layer kernels only: the measurement reference
+#                    (bench.py's `fp32_exact` line).
 import os as _os
 
-_POLICIES = ("f32", "mixed", "split", "split2", "splith")
-_FWD = {"split": hip.PREC_BF16X3, "split2": hip.PREC_BF16X2, "splith": hip.PREC_F16X2}
+_POLICIES = ("f32", "splith")
+_FWD = {"splith": hip.PREC_F16X2}
 _POLICY = _os.environ.get("NSKY_PRECISION", "splith")
 if _POLICY not in _POLICIES:
     raise ValueError(f"NSKY_PRECISION={_POLICY!r}: expected one of {' | '.join(_POLICIES)}")

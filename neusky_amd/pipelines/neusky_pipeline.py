@@ -22,11 +22,11 @@ from ..model_components.ddf_sampler import VMFDDFSamplerConfig
 from ..model_components.losses import merge_loss_dicts
 from ..models.ddf_model import DDFModelConfig
 from ..models.neusky_model import NeuSkyFactoModelConfig
-from ..plugin import PipelineBase
+from ..plugin import ConfigBase, PipelineBase
 
 
 @dataclass
-class NeuSkyPipelineConfig:
+class NeuSkyPipelineConfig(ConfigBase):
     """neusky/pipelines/neusky_pipeline.py:61-96 with the `neusky` values (neusky_config.py:43-215)"""
 
     _target: Type = field(default_factory=lambda: NeuSkyPipeline)

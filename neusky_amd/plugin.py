@@ -3,7 +3,7 @@
 When `nerfstudio` is importable, the `neusky` method specification is built from nerfstudio's OWN types
 (`MethodSpecification(TrainerConfig(...))` with nerfstudio optimizer / scheduler / viewer configs, exactly the call forms of
 neusky/configs/neusky_config.py:33-242) and this package's Pipeline / Model / Field classes subclass nerfstudio's
-`Pipeline` / `Model` / `Field`, so `ns-train neusky` resolves the entry point, type-checks and drives the HIP pipeline with
+`Pipeline` / `Model` / `Field` and every config dataclass derives from nerfstudio's `InstantiateConfig`, so `ns-train neusky` resolves the entry point, type-checks and drives the HIP pipeline with
 nerfstudio's own Trainer.  When it is not (the build image has no nerfstudio), attribute-compatible stand-ins are used and
 `neusky_amd.engine` plays the trainer.  The constructors of this package never call the nerfstudio bases' `__init__`
 (`nn.Module.__init__` only): the bases contribute the type identity and their default helper methods, nothing else.
@@ -16,6 +16,7 @@ from typing import Any, Dict
 from torch import nn
 
 try:  # pragma: no cover - exercised by tests/test_plugin_seam.py through a stand-in package
+    from nerfstudio.configs.base_config import InstantiateConfig as ConfigBase
     from nerfstudio.configs.base_config import ViewerConfig
     from nerfstudio.engine.optimizers import AdamOptimizerConfig as NSAdamOptimizerConfig
     from nerfstudio.engine.schedulers import CosineDecaySchedulerConfig as NSCosineDecaySchedulerConfig
@@ -30,6 +31,11 @@ except ImportError:
     HAVE_NERFSTUDIO = False
     FieldBase = ModelBase = PipelineBase = nn.Module
     ViewerConfig = None
+
+    @dataclass
+    class ConfigBase:  # nerfstudio.configs.base_config.InstantiateConfig: `_target` + setup(**kwargs) -> _target(self, **kwargs)
+        def setup(self, **kwargs) -> Any:
+            return self._target(self, **kwargs)
 
     @dataclass
     class TrainerConfig:  # the members neusky_config.py:34-42,238-240 sets

@@ -85,7 +85,8 @@ def test_with_nerfstudio_importable_the_seam_uses_its_types(tmp_path):
     pkg = tmp_path / "nerfstudio"
     files = {
         "__init__.py": "",
-        "configs/__init__.py": "", "configs/base_config.py": "from dataclasses import dataclass\n@dataclass\nclass ViewerConfig:\n    num_rays_per_chunk: int = 32768\n",
+        "configs/__init__.py": "", "configs/base_config.py": ("from dataclasses import dataclass\nfrom typing import Any, Type\n@dataclass\nclass ViewerConfig:\n    num_rays_per_chunk: int = 32768\n"
+                                   "@dataclass\nclass InstantiateConfig:\n    _target: Type\n    def setup(self, **kwargs) -> Any:\n        return self._target(self, **kwargs)\n"),
         "engine/__init__.py": "",
         "engine/optimizers.py": "from dataclasses import dataclass\n@dataclass\nclass AdamOptimizerConfig:\n    lr: float = 1e-3\n    eps: float = 1e-8\n",
         "engine/schedulers.py": ("from dataclasses import dataclass\nfrom typing import Optional\n@dataclass\nclass CosineDecaySchedulerConfig:\n    warm_up_end: int = 0\n"
@@ -121,6 +122,12 @@ def test_with_nerfstudio_importable_the_seam_uses_its_types(tmp_path):
         from neusky_amd.fields.sdf_albedo_field import SDFAlbedoField
         assert issubclass(NeuSkyPipeline, BP.Pipeline) and issubclass(NeuSkyFactoModel, BM.Model) and issubclass(DDFModel, BM.Model)
         assert issubclass(SDFAlbedoField, BF.Field)
+        import nerfstudio.configs.base_config as BC
+        from neusky_amd.pipelines.neusky_pipeline import NeuSkyPipelineConfig
+        from neusky_amd.models.neusky_model import NeuSkyFactoModelConfig
+        from neusky_amd.fields.sdf_albedo_field import SDFAlbedoFieldConfig
+        assert all(issubclass(c, BC.InstantiateConfig) for c in (NeuSkyPipelineConfig, NeuSkyFactoModelConfig, SDFAlbedoFieldConfig))
+        assert isinstance(NeuSky.config.pipeline, BC.InstantiateConfig) and isinstance(NeuSky.config.pipeline.model, BC.InstantiateConfig)
         from util_step import small_pipeline_config
         pipe = small_pipeline_config(R=8, images=3).setup(device="cpu")   # what nerfstudio's trainer does with config.pipeline
         assert isinstance(pipe, BP.Pipeline) and isinstance(pipe.model, BM.Model) and isinstance(pipe.model.field, BF.Field)
