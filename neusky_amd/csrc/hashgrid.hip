@@ -177,12 +177,26 @@ __global__ __launch_bounds__(256) void encode_fwd_kernel(Grid g, const float* __
     }
   }
 
-  for (int level = wave; level < g.n_levels; level += 4) {
-    Cell c;
-    locate(g, level, pos, c);
-    float2 v[8];
+  // A wave owns levels wave, wave + 4, ... (at most ML of them: n_levels <= 16).  ALL their corner rows are requested before the first
+  // one is used -- 8 ML gathers of 8 bytes in flight per lane, finest (hashed: Infinity-Cache latency) levels first -- instead of one
+  // level's eight at a time behind the previous level's arithmetic.
+  constexpr int ML = 4;
+  Cell cs[ML];
+  float2 v[ML][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = reinterpret_cast<const float2*>(g.table)[c.idx[k]];
+  for (int i = ML - 1; i >= 0; --i) {
+    const int level = wave + 4 * i;
+    if (level < g.n_levels) {
+      locate(g, level, pos, cs[i]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[i][k] = reinterpret_cast<const float2*>(g.table)[cs[i].idx[k]];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ML; ++i) {
+    const int level = wave + 4 * i;
+    if (level >= g.n_levels) continue;
+    const Cell& c = cs[i];
     float f0 = 0.f, f1 = 0.f;
     float d0[3] = {0.f, 0.f, 0.f}, d1[3] = {0.f, 0.f, 0.f};  // d feat / d pos_a
 #pragma unroll
@@ -191,15 +205,15 @@ __global__ __launch_bounds__(256) void encode_fwd_kernel(Grid g, const float* __
       const float wy = (k & 2) ? c.w[1] : 1.0f - c.w[1];
       const float wz = (k & 4) ? c.w[2] : 1.0f - c.w[2];
       const float w = wx * wy * wz;
-      f0 = fmaf(w, v[k].x, f0);
-      f1 = fmaf(w, v[k].y, f1);
+      f0 = fmaf(w, v[i][k].x, f0);
+      f1 = fmaf(w, v[i][k].y, f1);
       if (TANGENTS) {
         const float gx = ((k & 1) ? c.dw[0] : -c.dw[0]) * wy * wz;
         const float gy = ((k & 2) ? c.dw[1] : -c.dw[1]) * wx * wz;
         const float gz = ((k & 4) ? c.dw[2] : -c.dw[2]) * wx * wy;
-        d0[0] = fmaf(gx, v[k].x, d0[0]); d1[0] = fmaf(gx, v[k].y, d1[0]);
-        d0[1] = fmaf(gy, v[k].x, d0[1]); d1[1] = fmaf(gy, v[k].y, d1[1]);
-        d0[2] = fmaf(gz, v[k].x, d0[2]); d1[2] = fmaf(gz, v[k].y, d1[2]);
+        d0[0] = fmaf(gx, v[i][k].x, d0[0]); d1[0] = fmaf(gx, v[i][k].y, d1[0]);
+        d0[1] = fmaf(gy, v[i][k].x, d0[1]); d1[1] = fmaf(gy, v[i][k].y, d1[1]);
+        d0[2] = fmaf(gz, v[i][k].x, d0[2]); d1[2] = fmaf(gz, v[i][k].y, d1[2]);
       }
     }
     S[0][lane][feat0 + 2 * level] = f0;

@@ -20,4 +20,6 @@ find $O -name "*kernel_trace.csv" -delete
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_bench_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-exact-f32 --no-extra-configs > $R/gpurun_out/pmc_bench_$c.log 2>&1
 done
+python3 $R/tools/pmc_step_traffic.py 0 ${TAG}_pmc_traffic.json > $O/pmc_traffic.txt 2>&1; cp $R/profiles/${TAG}_pmc_traffic.json $O/ 2>/dev/null
+bash $R/tools/trace_gaps.sh $TAG > /dev/null 2>&1; cp $R/gpurun_out/timeline_$TAG.txt $R/gpurun_out/trace_$TAG.txt $O/ 2>/dev/null
 find $O -name "*_stats.csv" | head

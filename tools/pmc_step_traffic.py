@@ -3,6 +3,7 @@ iteration = 4 iterations): 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; FETCH_SIZE
 import csv, glob, os, re, sys, collections, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 iters = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0
+out_name = sys.argv[2] if len(sys.argv) > 2 else "r03_pmc_traffic.json"
 tot = collections.defaultdict(lambda: [0.0, 0.0, 0])
 for c, idx in (("FETCH_SIZE", 0), ("WRITE_SIZE", 1)):
     files = glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_bench_{c}", "**", "*counter_collection.csv"), recursive=True)
@@ -33,4 +34,8 @@ out = {"command": "tools/pmc_bench.sh: rocprofv3 --kernel-trace --pmc <FETCH_SIZ
        "whole_step_GB": total / 1e9, "iterations": iters,
        "bytes_per_launch": {k: v[0] / max(v[1], 1) for k, v in fam.items() if v[1] > 0 and v[0] / iters > 5e7},
        "GB_per_iteration": {k: v[0] / iters / 1e9 for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:20]}}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"), "w"), indent=1)
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (for the source hash bench.py compares against: the counters describe THESE kernels)
+csrc = os.path.join(ROOT, "neusky_amd", "csrc")
+out["kernel_sources_sha"] = bench._sources_sha([os.path.join(csrc, f) for f in os.listdir(csrc)])
+json.dump(out, open(os.path.join(ROOT, "profiles", out_name), "w"), indent=1)
