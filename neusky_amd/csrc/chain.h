@@ -30,6 +30,7 @@ struct TileDesc {
   const float* W;
   int ld, row0, nrows, K, transposed, k0;
   long group;
+  int slab0 = 0;  // first slab inside the group (tiles of K <= 64 may share a group: product_pair)
 };
 
 // one block per tile: absmax -> power-of-two scale -> fp16 hi / residual planes in fragment order (tile = blockIdx.x)
@@ -60,7 +61,7 @@ __device__ __forceinline__ void pack_tile(const TileDesc& d, unsigned char* __re
     sc = ldexpf(1.0f, 15 - e);  // m sc < 2^15
   }
   if (tid == 0) scales[blockIdx.x] = 1.0f / sc;
-  unsigned char* base = stream + d.group * GROUP;
+  unsigned char* base = stream + d.group * GROUP + (long)d.slab0 * SLAB;
   const int KS = ksteps_of(d.K);
   for (int idx = tid; idx < KS * 64; idx += 256) {
     const int ks = idx >> 6, lane = idx & 63;
@@ -226,6 +227,42 @@ __device__ __forceinline__ void product(WStream& w, const f16x8 (&bh)[KS], const
   w.ch = fh[KS % 3];
   w.cl = fl[KS % 3];
   w.g = g0 + NG;
+}
+
+// Two tiles of K = 64 (four k-steps each) sharing one group and one set of B planes: slabs 0..3 accumulate into a0, slabs 4..7 into
+// a1.  The accumulators are NOT zeroed: the mapping backward's head product adds k-block after k-block into them.
+template <int PW = 4, int RG = RING_GROUPS>
+__device__ __forceinline__ void product_pair(WStream& w, const f16x8 (&bh)[4], const f16x8 (&bl)[4], f32x16& a0, f32x16& a1) {
+  constexpr int KS = 8;
+  f16x8 fh[3], fl[3];
+  fh[0] = w.ch;
+  fl[0] = w.cl;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { fh[1][j] = fh[2][j] = fl[1][j] = fl[2][j] = (_Float16)0.0f; }
+  const int g0 = w.g;
+  auto request = [&](int s) {  // s static
+    if (s < KS) frag_read(fh[s % 3], fl[s % 3], ws_addr<RG>(w, g0, s));
+    else frag_read(fh[s % 3], fl[s % 3], ws_addr<RG>(w, g0 + 1, 0));
+  };
+  auto step = [&](int ks, f32x16& acc) {  // ks static
+    __builtin_amdgcn_sched_barrier(0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks % 3], bl[ks & 3], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 2 <= KS) request(ks + 2);
+    if (ks == KS - 1) ws_transition<PW, false, RG>(w, g0);
+    __builtin_amdgcn_sched_barrier(0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks % 3], bh[ks & 3], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks % 3], bh[ks & 3], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 2 <= KS) frag_wait<2>(fh[(ks + 1) % 3], fl[(ks + 1) % 3]);
+    else frag_wait<0>(fh[(ks + 1) % 3], fl[(ks + 1) % 3]);
+  };
+  request(1);
+  step(0, a0); step(1, a0); step(2, a0); step(3, a0);
+  step(4, a1); step(5, a1); step(6, a1); step(7, a1);
+  w.ch = fh[KS % 3];
+  w.cl = fl[KS % 3];
+  w.g = g0 + 1;
 }
 
 // the same over the first ksn (wave-uniform, run time; >= 1) of KS k-steps: the mapping network's first layer.  No read-ahead

@@ -92,8 +92,9 @@ __device__ inline TileDesc fwd_tile(const nsky_film_net& n, const Layout& L, int
 
 // direction 1 (FiLM backward): for i = n_film-1 .. 0: for t: F tile, phase tile; if i > 0: for u: transposed FiLM weight tile
 //   (rows = input features 32 u .., k = output features).
-// direction 2 (mapping backward): mapping head transposed, k-group outer: for kg: for u: tile (rows = hidden features 32 u ..,
-//   k = head rows 128 kg .. 128 kg + 127); layers n_map-1 .. 1 transposed: for u; layer 0 transposed: ceil(cond_dim / 32) tiles.
+// direction 2 (mapping backward): mapping head transposed, k-block outer: for kb: for u: tile (rows = hidden features 32 u ..,
+//   k = head rows 64 kb .. 64 kb + 63; four slabs: two tiles per group); layers n_map-1 .. 1 transposed: for u; layer 0 transposed:
+//   ceil(cond_dim / 32) tiles.
 __host__ __device__ inline void bwd_film_layout(const nsky_film_net& n, long& total_groups, int& n_tiles) {
   const int NT = n.hidden / 32, Gh = groups_of(n.hidden);
   n_tiles = n.n_film * NT * 2 + (n.n_film - 1) * NT + 1;  // last: first FiLM layer transposed (rows = x features) -> d_x
@@ -101,9 +102,9 @@ __host__ __device__ inline void bwd_film_layout(const nsky_film_net& n, long& to
 }
 __host__ __device__ inline void bwd_map_layout(const nsky_film_net& n, long& total_groups, int& n_tiles) {
   const int NT = n.hidden / 32, Gh = groups_of(n.hidden);
-  const int nkg = 2 * n.n_film * n.hidden / 128, ct = (n.cond_dim + 31) / 32;
-  n_tiles = nkg * NT + (n.n_map - 1) * NT + ct;
-  total_groups = (long)nkg * NT + (long)((n.n_map - 1) * NT + ct) * Gh;
+  const int nkb = 2 * n.n_film * n.hidden / 64, ct = (n.cond_dim + 31) / 32;
+  n_tiles = nkb * NT + (n.n_map - 1) * NT + ct;
+  total_groups = (long)nkb * (NT / 2) + (long)((n.n_map - 1) * NT + ct) * Gh;
 }
 
 __device__ inline TileDesc bwd_film_tile(const nsky_film_net& n, int idx) {
@@ -131,16 +132,15 @@ __device__ inline TileDesc bwd_film_tile(const nsky_film_net& n, int idx) {
 __device__ inline TileDesc bwd_map_tile(const nsky_film_net& n, int idx) {
   TileDesc d;
   const int NT = n.hidden / 32, H = n.hidden, Gh = groups_of(H);
-  const int nkg = 2 * n.n_film * H / 128;
+  const int nkb = 2 * n.n_film * H / 64;
   d.nrows = 32; d.transposed = 1; d.k0 = 0;
-  if (idx < nkg * NT) {  // two passes over the k-groups, each for half of the output tiles (the kernel keeps NT / 2 accumulators)
-    const int NH = NT / 2;
-    const int pass = idx / (nkg * NH), kg = (idx % (nkg * NH)) / NH, u = pass * NH + idx % NH;
-    d.W = n.mo_w; d.ld = n.mo_ld; d.row0 = 32 * u; d.K = 128; d.k0 = 128 * kg; d.group = idx;
+  if (idx < nkb * NT) {  // k-block (64 head rows) outer, output tile inner; tiles 2 v and 2 v + 1 of a k-block share group kb NT / 2 + v
+    const int kb = idx / NT, u = idx % NT;
+    d.W = n.mo_w; d.ld = n.mo_ld; d.row0 = 32 * u; d.K = 64; d.k0 = 64 * kb; d.group = idx / 2; d.slab0 = 4 * (u & 1);
     return d;
   }
-  idx -= nkg * NT;
-  d.group = (long)nkg * NT + (long)idx * Gh;
+  idx -= nkb * NT;
+  d.group = (long)nkb * (NT / 2) + (long)idx * Gh;
   d.K = H;
   if (idx < (n.n_map - 1) * NT) {
     const int l = n.n_map - 1 - idx / NT, u = idx % NT;
@@ -675,8 +675,9 @@ __global__ __launch_bounds__(512, 2) void film_bwd_kernel(const BwdFilmArgs a) {
 }
 
 // =====================================================================================================================
-// Backward, mapping network.  dh = sum over the 2 n_film H head rows of Wmo^T dfp (k-group outer: 128 head rows of dfp are
-// fetched tile-native one group ahead with hidden loads, pre-scaled by the row's maximum over ALL of dfp and split), then the
+// Backward, mapping network.  dh = sum over the 2 n_film H head rows of Wmo^T dfp (k-block outer: 64 head rows of dfp are
+// fetched tile-native one block ahead with hidden loads, pre-scaled by the row's maximum over ALL of dfp and split; dfp is read
+// ONCE), then the
 // mapping layers backwards, hidden state in registers as in the forward: dpre = dh * leaky'(h) is stored tile-native (weight
 // gradients), split, and multiplied by the transposed weight tiles; the last product yields d_cond (row-major).
 struct BwdMapArgs {
@@ -695,86 +696,94 @@ struct BwdMapArgs {
 
 template <int H, bool ACTIVE>
 __device__ __forceinline__ void film_bwd_map_tile(const BwdMapArgs& a, WStream& ws, const float* sl, long rt, int lane) {
-  constexpr int NT = H / 32, KS = H / 16, NH = NT / 2, PW = 2;
+  constexpr int NT = H / 32, KS = H / 16, PW = 2;
   const nsky_film_net& net = a.net;
   const int c = lane & 31, h = lane >> 5;
   const long row = rt * 32 + c;
   const bool live = ACTIVE && row < a.M;
-  const int nkg = 2 * net.n_film * H / 128, ntot = 2 * net.n_film * NT;
+  const int nkb = 2 * net.n_film * H / 64, ntot = 2 * net.n_film * NT;
   float f_inv = 1.0f, f_scale = 1.0f;
   if (ACTIVE) f_scale = row_scale(a.dfp_rowmax[rt * 32 + c], f_inv);  // both lane halves read the same row: the shuffle is a no-op
   int tile = 0;
   const float* fblk = a.dfp + rt * ntot * 1024;
   const int top = net.n_map - 1;
   float m = 0.0f;  // largest |dpre_top| of this lane's row half
-  f32x4 fq[16];    // 128 head rows = 4 native tiles x 4 pieces, one k-group ahead
+  // ONE pass over the 2 n_film H head rows: all NT accumulator tiles of dh stay in registers (NT x 16), the head rows come 64 at a
+  // time (two native tiles = 8 pieces, one k-block ahead).  A k-block's weight tiles carry their own power-of-two scales; the
+  // accumulators are kept in units of the current tile's scale (an exact rescale by the ratio of two powers of two when it changes),
+  // so the MFMAs add straight into them.
+  f32x4 fq[8];
 #define NSKY_FQ_WAIT(N)                                                                                                         \
-  asm volatile("s_waitcnt vmcnt(%16)"                                                                                           \
-               : "+v"(fq[0]), "+v"(fq[1]), "+v"(fq[2]), "+v"(fq[3]), "+v"(fq[4]), "+v"(fq[5]), "+v"(fq[6]), "+v"(fq[7]), "+v"(fq[8]), \
-                 "+v"(fq[9]), "+v"(fq[10]), "+v"(fq[11]), "+v"(fq[12]), "+v"(fq[13]), "+v"(fq[14]), "+v"(fq[15])                \
+  asm volatile("s_waitcnt vmcnt(%8)"                                                                                            \
+               : "+v"(fq[0]), "+v"(fq[1]), "+v"(fq[2]), "+v"(fq[3]), "+v"(fq[4]), "+v"(fq[5]), "+v"(fq[6]), "+v"(fq[7])           \
                : "n"(N)                                                                                                         \
                : "memory")
-  for (int pass = 0; pass < 2; ++pass) {
-    float dh[NH][16];
+  f32x16 dh[NT];
 #pragma unroll
-    for (int u = 0; u < NH; ++u)
+  for (int u = 0; u < NT; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dh[u][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) dh[u][r] = 0.0f;
+  if (ACTIVE) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hidden_load4(fq[j], fblk + (j >> 2) * 1024 + (j & 3) * 256 + lane * 4);
+    NSKY_FQ_WAIT(0);  // first block (everything older lands with it)
+  }
+  for (int kb = 0; kb < nkb; ++kb) {
+    f16x8 ph[4], pl[4];
     if (ACTIVE) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) fq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < 4; ++ks) {
+        float x8[8];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) hidden_load4(fq[j], fblk + (j >> 2) * 1024 + (j & 3) * 256 + lane * 4);
-      NSKY_FQ_WAIT(0);  // first group of the pass (everything older lands with it)
+        for (int u = 0; u < 2; ++u) {
+          const f32x4 q = fq[(ks >> 1) * 4 + 2 * (ks & 1) + u];
+          x8[4 * u] = q[0] * f_scale; x8[4 * u + 1] = q[1] * f_scale; x8[4 * u + 2] = q[2] * f_scale; x8[4 * u + 3] = q[3] * f_scale;
+        }
+        split8(x8, ph[ks], pl[ks]);
+      }
+      const int kn = kb + 1 < nkb ? kb + 1 : kb;  // the last block re-requests itself (same count of operations in flight)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hidden_load4(fq[j], fblk + (long)(2 * kn + (j >> 2)) * 1024 + (j & 3) * 256 + lane * 4);
     }
-    for (int kg = 0; kg < nkg; ++kg) {
-      f16x8 ph[8], pl[8];
+#pragma unroll
+    for (int v = 0; v < NT / 2; ++v) {
       if (ACTIVE) {
+        if (kb > 0) {  // units of the previous block's tile scale -> units of this block's (reciprocal scales: exact powers of two)
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          float x8[8];
+          for (int e = 0; e < 2; ++e) {
+            const float ratio = __int_as_float(__float_as_int(sl[tile + e - NT]) - __float_as_int(sl[tile + e]) + 0x3f800000);
+            if (ratio != 1.0f)
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const f32x4 q = fq[(ks >> 1) * 4 + 2 * (ks & 1) + u];
-            x8[4 * u] = q[0] * f_scale; x8[4 * u + 1] = q[1] * f_scale; x8[4 * u + 2] = q[2] * f_scale; x8[4 * u + 3] = q[3] * f_scale;
+              for (int r = 0; r < 16; ++r) dh[2 * v + e][r] *= ratio;
           }
-          split8(x8, ph[ks], pl[ks]);
         }
-        const int kn = kg + 1 < nkg ? kg + 1 : kg;  // the last group re-requests itself (same count of operations in flight)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) hidden_load4(fq[j], fblk + (long)(4 * kn + (j >> 2)) * 1024 + (j & 3) * 256 + lane * 4);
+        product_pair<PW>(ws, ph, pl, dh[2 * v], dh[2 * v + 1]);
+      } else {
+        product_skip<8, PW, false>(ws);
       }
-#pragma unroll
-      for (int u = 0; u < NH; ++u) {
-        f32x16 acc;
-        prodw<8, PW, ACTIVE>(ws, ph, pl, acc);
-        if (ACTIVE) {
-          const float inv = f_inv * sl[tile];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dh[u][r] = fmaf(acc[r], inv, dh[u][r]);
-        }
-        ++tile;
-      }
-      // the next group's 16 pieces were requested before this group's NH products (NH transitions x PW DMA pieces)
-      if (ACTIVE) NSKY_FQ_WAIT(PW * NH);
+      tile += 2;
     }
-    // dpre of the top mapping layer for this half of the features: dh * leaky'(h_top) (the activation keeps the sign of the
-    // pre-activation), stored tile by tile
-    if (ACTIVE) {
+    // the next block's 8 pieces were requested before this block's NT / 2 pair products (one transition x PW DMA pieces each)
+    if (ACTIVE) NSKY_FQ_WAIT(PW * (NT / 2));
+  }
+  // dpre of the top mapping layer: dh * leaky'(h_top) (the activation keeps the sign of the pre-activation), stored tile by tile
+  if (ACTIVE) {
 #pragma unroll
-      for (int u = 0; u < NH; ++u) {
-        const int t = pass * NH + u;
-        float hv[16];
-        load_tile(a.h_save[top] + (rt * NT + t) * 1024, lane, hv);
+    for (int u = 0; u < NT; ++u) {
+      const float inv = f_inv * sl[tile - NT + u];
+      float hv[16], dv[16];
+      load_tile(a.h_save[top] + (rt * NT + u) * 1024, lane, hv);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          dh[u][r] = hv[r] > 0.0f ? dh[u][r] : 0.2f * dh[u][r];
-          m = fmaxf(m, fabsf(dh[u][r]));
-        }
-        store_tile(a.dpre_save[top] + (rt * NT + t) * 1024, lane, dh[u]);
+      for (int r = 0; r < 16; ++r) {
+        const float g = dh[u][r] * inv;
+        dv[r] = hv[r] > 0.0f ? g : 0.2f * g;
+        m = fmaxf(m, fabsf(dv[r]));
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      store_tile(a.dpre_save[top] + (rt * NT + u) * 1024, lane, dv);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 #undef NSKY_FQ_WAIT
 
@@ -842,7 +851,7 @@ __device__ __forceinline__ void film_bwd_map_tile(const BwdMapArgs& a, WStream& 
 template <int H>
 __global__ __launch_bounds__(512, 2) void film_bwd_map_kernel(const BwdMapArgs a) {
   // Eight waves (two per SIMD, 256 registers each) share one weight stream over 256 batch rows.  The register budget is met as in
-  // the FiLM backward: the head product runs as two passes over the 2 n_film H head rows with NT / 2 accumulator tiles each, and no
+  // the FiLM backward: the head product keeps its NT accumulator tiles and only 64 head rows of operand planes at a time, and no
   // layer's matrix stays in registers -- a finished tile of dpre is stored (tile-native, also the weight gradient's operand) and the
   // layer below reads the tiles back (the lane that stored a piece loads it).  The remainder of the last round runs in tail workgroups.
   constexpr int PW = 2;
