@@ -362,10 +362,8 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
         for (int q = 0; q < 4; ++q) {
           const int r = 4 * g + q;
           const float F = fmaf(aF[r], iF, bf[q]), P = fmaf(aP[r], iP, bp[q]), z = fmaf(aZ[r], iZ, bz[q]);
-          float sn, cs;
-          sincos_cw(fmaf(fmaf(15.0f, F, 30.0f), z, P), sn, cs);
           zz[r] = z;
-          yy[r] = sn;
+          yy[r] = sin_cw(fmaf(fmaf(15.0f, F, 30.0f), z, P));
         }
       }
       if (wave_live) {
@@ -561,9 +559,7 @@ __device__ __forceinline__ void film_bwd_tile(const BwdFilmArgs& a, WStream& ws,
             const int r = 4 * g + q;
             const float F = fmaf(aF[r], iF, bf[q]), P = fmaf(aP[r], iP, bp[q]), z = zq[g][q];
             const float f = fmaf(15.0f, F, 30.0f);
-            float sn, cs;
-            sincos_cw(fmaf(f, z, P), sn, cs);
-            const float gc = yq[g][q] * cs;
+            const float gc = yq[g][q] * cos_cw(fmaf(f, z, P));
             dzv[q] = gc * f;
             dFv[q] = 15.0f * gc * z;
             dPv[q] = gc;

@@ -988,6 +988,11 @@ class SDFValueFn(torch.autograd.Function):
             A0 = torch.empty(Mp, Hd, device=dev); A1 = torch.empty(Mp, Hd, device=dev)
             sdf = torch.empty(M, device=dev)
             hip.sdf_chain_fwd(net, stream, table, E, M, A0, A1, sdf)
+            if any(ctx.needs_input_grad):
+                # the backward's stream is packed here, in a quiet stretch of the step: launched from the backward, its 11 small
+                # workgroups (34 KB of LDS each) queue behind the illumination decoder's chain kernels on the second stream, which hold
+                # every CU's LDS (0.28 ms on the timeline for 10 us of work)
+                _sdf_stream(W0, b0, W1, b1, W2, b2, GF, beta, 1)
             ctx.save_for_backward(E, A0, A1, W0, b0, W1, b1, W2, b2)
             return sdf
         A0 = torch.empty(M, Hd, device=dev); S0 = torch.empty(M, Hd, device=dev)
