@@ -27,7 +27,7 @@ extern "C" {
 typedef void* nsky_stream_t; /* hipStream_t */
 
 const char* nsky_last_error(void);
-int nsky_abi_version(void); /* 9 (bumped when a struct layout or an entry point's signature changes) */
+int nsky_abi_version(void); /* 11 (bumped when a struct layout or an entry point's signature changes) */
 
 /* ------------------------------------------------------------------------------------------
  * Dense layer on the matrix cores: C[M,N] = epilogue( sum_k A(m,k) * B(n,k) + bias[n] )
@@ -625,6 +625,20 @@ int nsky_main_losses_bwd(const nsky_main_losses_desc* d, const float* wsum, cons
  * (neusky_model.py:1071-1072).  None of it is differentiated. */
 int nsky_train_metrics(const float* pred, const float* gt, const float* mask, int64_t n, float peak_sq, const float* variance, float* out,
                        nsky_stream_t stream);
+/* The step's objective: total = sum over segments of scale_s * sum_i coef_s[i] x_s[i] (coef NULL: 1).  Replaces the dozen scalar
+ * multiplies, sums and adds that scale and merge the loss dictionaries (nerfstudio scale_dict + functools.reduce(torch.add, ...),
+ * neusky_pipeline.py:283-289; interlevel_loss' mean, neusky_model.py:987-988) by one launch each way.  One workgroup; bwd writes
+ * grad_s[i] = g[0] * scale_s * coef_s[i] for every segment whose grad pointer is set. */
+#define NSKY_TOTAL_MAX_SEGMENTS 8
+typedef struct nsky_total_segment {
+  const float* x;      /* [n] */
+  const float* coef;   /* [n] or NULL */
+  float* grad;         /* [n] or NULL (bwd) */
+  int32_t n;
+  float scale;
+} nsky_total_segment;
+int nsky_weighted_total_fwd(const nsky_total_segment* segments, int32_t n_segments, float* total, nsky_stream_t stream);
+int nsky_weighted_total_bwd(const nsky_total_segment* segments, int32_t n_segments, const float* g, nsky_stream_t stream);
 /* DDF model, get_loss_dict, neusky/models/ddf_model.py:407-493:
  *   terms[5] = { depth L1 x scene-centre weight (:427-433), sdf L2, sdf L1, multi-view hinge^2 with the reference's
  *                [M] - [M,1] -> [M,M] broadcast (:475-483), sky-ray L1 (:485-490) }, unscaled. */

@@ -357,7 +357,59 @@ __global__ __launch_bounds__(1024) void train_metrics_kernel(const float* __rest
   }
 }
 
+struct TotalArgs { nsky_total_segment s[NSKY_TOTAL_MAX_SEGMENTS]; int n; };
+
+__global__ __launch_bounds__(1024) void weighted_total_fwd_kernel(TotalArgs a, float* __restrict__ total) {
+  __shared__ double red[16];
+  double acc = 0.0;
+  for (int k = 0; k < a.n; ++k) {
+    const nsky_total_segment& g = a.s[k];
+    float part = 0.0f;
+    for (int i = threadIdx.x; i < g.n; i += 1024) part += g.coef ? g.coef[i] * g.x[i] : g.x[i];
+    acc += (double)g.scale * (double)part;
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    total[0] = (float)t;
+  }
+}
+
+__global__ __launch_bounds__(256) void weighted_total_bwd_kernel(TotalArgs a, const float* __restrict__ g) {
+  const nsky_total_segment& s = a.s[blockIdx.y];
+  if (!s.grad) return;
+  const float gs = g[0] * s.scale;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < s.n; i += gridDim.x * 256) s.grad[i] = s.coef ? gs * s.coef[i] : gs;
+}
+
 }  // namespace
+
+extern "C" int nsky_weighted_total_fwd(const nsky_total_segment* segments, int32_t n_segments, float* total, nsky_stream_t stream) {
+  NSKY_CHECK_ARG(segments && total && n_segments > 0 && n_segments <= NSKY_TOTAL_MAX_SEGMENTS, "nsky_weighted_total_fwd: bad argument");
+  TotalArgs a;
+  a.n = n_segments;
+  for (int i = 0; i < n_segments; ++i) {
+    NSKY_CHECK_ARG(segments[i].x && segments[i].n >= 0, "nsky_weighted_total_fwd: bad segment");
+    a.s[i] = segments[i];
+  }
+  hipLaunchKernelGGL(weighted_total_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, total);
+  NSKY_CHECK_LAUNCH("nsky_weighted_total_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_weighted_total_bwd(const nsky_total_segment* segments, int32_t n_segments, const float* g, nsky_stream_t stream) {
+  NSKY_CHECK_ARG(segments && g && n_segments > 0 && n_segments <= NSKY_TOTAL_MAX_SEGMENTS, "nsky_weighted_total_bwd: bad argument");
+  TotalArgs a;
+  a.n = n_segments;
+  int nmax = 1;
+  for (int i = 0; i < n_segments; ++i) { a.s[i] = segments[i]; nmax = segments[i].n > nmax ? segments[i].n : nmax; }
+  hipLaunchKernelGGL(weighted_total_bwd_kernel, dim3((nmax + 255) / 256 > 64 ? 64 : (nmax + 255) / 256, n_segments), dim3(256), 0, (hipStream_t)stream, a, g);
+  NSKY_CHECK_LAUNCH("nsky_weighted_total_bwd");
+  return NSKY_OK;
+}
 
 extern "C" int nsky_main_losses_fwd(const nsky_main_losses_desc* d, float* terms, float* wsum, nsky_stream_t stream) {
   NSKY_CHECK_ARG(d && terms && d->R > 0 && d->mask && d->image, "nsky_main_losses_fwd: null argument");

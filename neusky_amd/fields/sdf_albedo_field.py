@@ -286,8 +286,14 @@ class SDFAlbedoField(FieldBase):
         sdf, grad, albedo = self.field_values(x, want_albedo)
         extra = None
         if extra_points is not None:
-            extra = (sdf[n_main:], grad[n_main:])
-            sdf, grad, albedo = sdf[:n_main], grad[:n_main], albedo[:n_main]
+            if sdf.is_cuda and sdf.requires_grad:
+                sdf, e_sdf = ops.SplitRowsFn.apply(sdf, n_main)
+                grad, e_grad = ops.SplitRowsFn.apply(grad, n_main)
+                albedo = ops.SplitRowsFn.apply(albedo, n_main)[0] if albedo.requires_grad else albedo[:n_main]
+                extra = (e_sdf, e_grad)
+            else:
+                extra = (sdf[n_main:], grad[n_main:])
+                sdf, grad, albedo = sdf[:n_main], grad[:n_main], albedo[:n_main]
         outputs = {
             NeuSkyFieldHeadNames.ALBEDO: albedo.view(R, S, 3),
             FieldHeadNames.SDF: sdf.view(R, S, 1),

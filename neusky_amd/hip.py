@@ -52,7 +52,7 @@ class GemmDesc(C.Structure):
 
 _lib.nsky_last_error.restype = C.c_char_p
 _lib.nsky_abi_version.restype = C.c_int
-ABI_VERSION = 10  # the ctypes structures below mirror this version of include/neusky_hip.h
+ABI_VERSION = 11  # the ctypes structures below mirror this version of include/neusky_hip.h
 if _lib.nsky_abi_version() != ABI_VERSION:
     raise NeuSkyHipError(f"libneusky_hip.so has ABI version {_lib.nsky_abi_version()}, this package binds version {ABI_VERSION}: rebuild (build.sh)")
 
@@ -532,6 +532,31 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
 
 
 # ------------------------------------------------------------------------------------------ fused loss terms
+TOTAL_MAX_SEGMENTS = 8
+
+
+class TotalSegment(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("coef", C.c_void_p), ("grad", C.c_void_p), ("n", C.c_int32), ("scale", C.c_float)]
+
+
+_total_fwd = _sig("nsky_weighted_total_fwd", C.POINTER(TotalSegment), C.c_int32, C.c_void_p, C.c_void_p)
+_total_bwd = _sig("nsky_weighted_total_bwd", C.POINTER(TotalSegment), C.c_int32, C.c_void_p, C.c_void_p)
+
+
+def weighted_total_fwd(parts, total):
+    """parts: [(x, coef | None, scale)] -> total[0] = sum_s scale_s sum_i coef_s[i] x_s[i] (one launch; include/neusky_hip.h)"""
+    assert 0 < len(parts) <= TOTAL_MAX_SEGMENTS
+    arr = (TotalSegment * len(parts))(*[TotalSegment(ptr(x), ptr(c), None, x.numel(), float(sc)) for x, c, sc in parts])
+    check(_total_fwd(arr, len(parts), ptr(total), stream_ptr()), "nsky_weighted_total_fwd")
+    return total
+
+
+def weighted_total_bwd(parts, g, grads):
+    """grads[s] (or None) = g[0] scale_s coef_s"""
+    arr = (TotalSegment * len(parts))(*[TotalSegment(ptr(x), ptr(c), ptr(d), x.numel(), float(sc)) for (x, c, sc), d in zip(parts, grads)])
+    check(_total_bwd(arr, len(parts), ptr(g), stream_ptr()), "nsky_weighted_total_bwd")
+
+
 class MainLossesDesc(C.Structure):
     _fields_ = [("R", C.c_int32), ("S", C.c_int32), ("P", C.c_int32), ("M", C.c_int32),
                 ("rgb", C.c_void_p), ("image", C.c_void_p), ("mask", C.c_void_p), ("eik", C.c_void_p), ("weights", C.c_void_p),
@@ -883,13 +908,18 @@ def chain_layer(W, rows, K, transposed=False) -> ChainLayer:
     return ChainLayer(ptr(W), ld(W), int(rows), int(K), int(bool(transposed)))
 
 
-def chain_pack(layers, device):
-    """-> (stream bytes tensor, per-tile reciprocal scales, number of groups); see include/neusky_hip.h"""
+def chain_pack(layers, device, buffers=None):
+    """-> (stream bytes tensor, per-tile reciprocal scales, number of groups); see include/neusky_hip.h.
+    buffers(nbytes, n_scales) -> (zero-initialised uint8 stream buffer, scales buffer): a caller's persistent pair (the pack writes
+    the real slabs only, so the pad slabs of a buffer that has held the same layout before are still zero)"""
     arr = (ChainLayer * len(layers))(*layers)
     nbytes, ntiles, ngroups = C.c_int64(0), C.c_int32(0), C.c_int32(0)
     check(_chain_layout(arr, len(layers), C.byref(nbytes), C.byref(ntiles), C.byref(ngroups)), "nsky_chain_stream_layout")
-    stream = torch.zeros(nbytes.value, dtype=torch.uint8, device=device)  # (pad slabs of partial groups are streamed, never multiplied)
-    scales = torch.empty(max(ntiles.value, 4), device=device)
+    if buffers is not None:
+        stream, scales = buffers(nbytes.value, max(ntiles.value, 4))
+    else:
+        stream = torch.zeros(nbytes.value, dtype=torch.uint8, device=device)  # (pad slabs of partial groups are streamed, never multiplied)
+        scales = torch.empty(max(ntiles.value, 4), device=device)
     check(_chain_pack(arr, len(layers), ptr(stream), ptr(scales), stream_ptr()), "nsky_chain_pack")
     return stream, scales, ngroups.value
 

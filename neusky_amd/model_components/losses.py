@@ -35,15 +35,20 @@ def _outer(t0_starts, t0_ends, t1_starts, t1_ends, y1):
     return torch.take_along_dim(cy1[..., 1:], idx_hi, dim=-1) - torch.take_along_dim(cy1[..., :-1], idx_lo, dim=-1)
 
 
+def interlevel_per_ray(weights_list: Sequence[torch.Tensor], sbins_list: Sequence[torch.Tensor]):
+    """per-ray interlevel sums of every proposal level ([R] each): interlevel_loss = sum of all of them / numel(final weights)"""
+    from .. import ops
+    c, w = sbins_list[-1].detach(), weights_list[-1].detach()
+    return [ops.InterlevelFn.apply(c, w, sb.detach(), wp) for sb, wp in zip(sbins_list[:-1], weights_list[:-1])]
+
+
 def interlevel_loss(weights_list: Sequence[torch.Tensor], sbins_list: Sequence[torch.Tensor]) -> torch.Tensor:
     """nerfstudio interlevel_loss (called neusky_model.py:987-988); weights [R,n], spacing bins [R,n+1]."""
     c, w = sbins_list[-1].detach(), weights_list[-1].detach()
     loss = 0.0
     if w.is_cuda:  # one launch per proposal level each way (ops.InterlevelFn) instead of ~45 small torch kernels
-        from .. import ops
-        for sb, wp in zip(sbins_list[:-1], weights_list[:-1]):
-            loss = loss + ops.InterlevelFn.apply(c, w, sb.detach(), wp).sum() / w.numel()
-        return loss
+        per_ray = interlevel_per_ray(weights_list, sbins_list)
+        return (per_ray[0] if len(per_ray) == 1 else torch.cat(per_ray)).sum() * (1.0 / w.numel())
     for sb, wp in zip(sbins_list[:-1], weights_list[:-1]):
         w_outer = _outer(c[..., :-1], c[..., 1:], sb[..., :-1], sb[..., 1:], wp)
         loss = loss + torch.mean(torch.clip(w - w_outer, min=0) ** 2 / (w + 1e-7))
@@ -51,9 +56,12 @@ def interlevel_loss(weights_list: Sequence[torch.Tensor], sbins_list: Sequence[t
 
 
 class LossDict(dict):
-    """scaled loss terms; `.total` = their sum from ONE stacked multiply + reduction (13 scalar adds and 12 scalar
-    multiplies, and as many again in backward, become 3 launches each way)"""
+    """scaled loss terms (differentiable entries: a trainer that sums the values, as nerfstudio's does, gets the same objective).
+    `.parts` = [(x, coef | None, scale)]: the UNSCALED tensors the entries come from; total_loss() forms the objective from them in
+    ONE launch each way (ops.TotalLossFn) instead of through the entries' multiplies, sums and adds (a dozen scalar launches each
+    way).  `.total`: the objective once formed (or set by a caller)."""
     total: Optional[torch.Tensor] = None
+    parts: Optional[list] = None
 
 
 _COEF_CACHE: Dict[tuple, torch.Tensor] = {}
@@ -61,13 +69,34 @@ _COEF_CACHE: Dict[tuple, torch.Tensor] = {}
 
 def total_loss(loss_dict: Dict[str, torch.Tensor]) -> torch.Tensor:
     t = getattr(loss_dict, "total", None)
-    return t if t is not None else sum(loss_dict.values())
+    if t is not None:
+        return t
+    parts = getattr(loss_dict, "parts", None)
+    if parts and len(parts) <= 8 and all(p[0].is_cuda for p in parts):
+        from .. import ops
+        metas, tensors = [], []
+        for x, c, sc in parts:
+            metas.append((c is not None, float(sc)))
+            tensors.append(x)
+            if c is not None:
+                tensors.append(c)
+        loss_dict.total = ops.TotalLossFn.apply(tuple(metas), *tensors)
+        return loss_dict.total
+    if parts:
+        t = sum(((x * c).sum() if c is not None else x.sum()) * sc for x, c, sc in parts)
+        loss_dict.total = t
+        return t
+    return sum(loss_dict.values())
 
 
 def merge_loss_dicts(a: Dict[str, torch.Tensor], b: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     out = LossDict({**a, **b})
     if not (set(a) & set(b)):
-        out.total = total_loss(a) + total_loss(b)
+        pa, pb = getattr(a, "parts", None), getattr(b, "parts", None)
+        if pa and pb and getattr(a, "total", None) is None and getattr(b, "total", None) is None:
+            out.parts = list(pa) + list(pb)  # the objective of both from one launch (total_loss)
+        else:
+            out.total = total_loss(a) + total_loss(b)
     return out
 
 

@@ -221,5 +221,5 @@ class DDFModel(ModelBase):
             cv = _COEF_VECTORS[key] = torch.tensor(key[0], dtype=torch.float32).to(terms.device)
         scaled = terms * cv
         out = LossDict({k: scaled[i] for i, (k, p) in enumerate(zip(names, present)) if p})
-        out.total = scaled.sum()
+        out.parts = [(terms, cv, 1.0)]  # (the objective: losses.total_loss, one launch for both models' terms)
         return out

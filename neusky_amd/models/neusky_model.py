@@ -30,7 +30,8 @@ from ..cameras.rays import Frustums, RayBundle, RaySamples
 from ..field_components.neusky_fieldheadnames import FieldHeadNames, NeuSkyFieldHeadNames
 from ..fields.sdf_albedo_field import SDFAlbedoFieldConfig
 from ..model_components.illumination import IcosahedronSamplerConfig, RENIFieldConfig
-from ..model_components.losses import LossDict, RENISkyPixelLoss, interlevel_loss, monosdf_normal_loss, scale_dict, total_loss
+from ..model_components.losses import (LossDict, RENISkyPixelLoss, interlevel_loss, interlevel_per_ray, monosdf_normal_loss, scale_dict,
+                                        total_loss)
 from ..model_components.ray_samplers import HashMLPDensityField, ProposalNetworkSampler
 from ..model_components.renderers import RGBLambertianRendererWithVisibility
 from ..utils.utils import device_rng, device_rng_seed, linear_to_sRGB, to_device_async
@@ -232,9 +233,12 @@ class NeuSkyFactoModel(ModelBase):
         o = ray_bundle.origins[:, None, :].expand(R, S, 3)
         d = ray_bundle.directions[:, None, :].expand(R, S, 3)
         cam = ray_bundle.camera_indices.reshape(R, 1, 1).expand(R, S, 1) if ray_bundle.camera_indices is not None else None
-        rs = RaySamples(frustums=Frustums(origins=o, directions=d, starts=ebins[:, :-1, None], ends=ebins[:, 1:, None],
+        # starts and ends as two CONTIGUOUS [R, S] matrices from one launch: as column slices of the bins every consumer kernel
+        # (NeuS weights, the per-ray reductions, twice each per step) first copied them
+        se = torch.stack((ebins[:, :-1], ebins[:, 1:])) if ebins.is_cuda else (ebins[:, :-1], ebins[:, 1:])
+        rs = RaySamples(frustums=Frustums(origins=o, directions=d, starts=se[0][..., None], ends=se[1][..., None],
                                           pixel_area=None),
-                        camera_indices=cam, deltas=(ebins[:, 1:] - ebins[:, :-1])[..., None],
+                        camera_indices=cam, deltas=(se[1] - se[0])[..., None],
                         spacing_starts=sbins[:, :-1, None], spacing_ends=sbins[:, 1:, None])
         return rs, weights_list, sbins_list, sbins, inds_list
 
@@ -582,12 +586,19 @@ class NeuSkyFactoModel(ModelBase):
             cv = _COEF_VECTORS[key] = torch.tensor(key[0], dtype=torch.float32).to(terms.device)
         scaled = terms * cv  # nerfstudio scale_dict: keys missing from the coefficient table ('eikonal_loss') stay unscaled
         ld = LossDict({k: scaled[i] for i, k in enumerate(self._FUSED_TERMS) if present[k]})
-        total = scaled.sum()
+        ld.parts = [(terms, cv, 1.0)]  # the objective is formed from the unscaled pieces in one launch (losses.total_loss)
         if train_branch and li["interlevel_loss"]:
-            il = interlevel_loss(outputs["weights_list"], outputs["sbins_list"]) * float(coefs.get("interlevel_loss", 1.0))  # :987-988
-            ld["interlevel_loss"] = il
-            total = total + il
-        ld.total = total
+            c_il = float(coefs.get("interlevel_loss", 1.0))
+            wl, sl_ = outputs["weights_list"], outputs["sbins_list"]
+            if terms.is_cuda:
+                per_ray = interlevel_per_ray(wl, sl_)
+                inv_n = c_il / wl[-1].numel()
+                ld["interlevel_loss"] = (per_ray[0] if len(per_ray) == 1 else torch.cat(per_ray)).sum() * inv_n  # :987-988
+                ld.parts += [(pr, None, inv_n) for pr in per_ray]
+            else:
+                il = interlevel_loss(wl, sl_) * c_il
+                ld["interlevel_loss"] = il
+                ld.parts, ld.total = None, scaled.sum() + il
         return ld
 
     def get_metrics_dict(self, outputs, batch) -> Dict[str, Any]:

@@ -236,6 +236,22 @@ def zeros_like(t: torch.Tensor) -> torch.Tensor:
 _STEP_SEQ = [0]  # bumped by begin_step: cache entries remember the step they were prepared in
 
 
+_STREAM_BUFS: dict = {}  # persistent (stream bytes, table) pairs of the packed weight streams, by (owner key, layout size)
+
+
+def _stream_buffers(key, nbytes, n_table, device):
+    """The packed weight stream of a network is re-packed every optimizer step INTO THE SAME BUFFER: zero-filled once (the pad slabs of
+    partial groups are streamed through LDS but never written by a pack, so they stay zero as long as the layout -- part of the key --
+    is the same), one fill launch per network and direction less per step, and a stable address under graph capture."""
+    k = (key, int(nbytes), int(n_table), str(device))
+    hit = _STREAM_BUFS.get(k)
+    if hit is None:
+        if len(_STREAM_BUFS) > 64:
+            _STREAM_BUFS.clear()
+        hit = _STREAM_BUFS[k] = (torch.zeros(int(nbytes), dtype=torch.uint8, device=device), torch.empty(int(n_table), device=device))
+    return hit
+
+
 def _order_after(hit_stream, hit_seq) -> None:
     """a cached weight preparation (planes / packed stream) made on another stream of THIS step: order the current stream after it.
     An entry that survives from an earlier step (a frozen network's stream) needs no edge -- steps are ordered by their caller --
@@ -430,9 +446,9 @@ def _film_stream(wb, n_map, n_film, mw, mb, mwo, mbo, fw, fb, ow, ob, direction=
     if hit is None:
         net = hip.film_net(mw[0].shape[1], fw[0].shape[1], ow.shape[0], mw, mb, mwo, mbo, fw, fb, ow, ob)
         nbytes, _ = hip.film_stream_layout(net, direction)
-        # zero-filled: the pad slabs of partial groups are streamed through LDS but never multiplied
-        stream = torch.zeros(nbytes, dtype=torch.uint8, device=wb[0].device)
-        table = torch.empty(hip.FILM_TABLE_FLOATS, device=wb[0].device)
+        # zero-filled once: the pad slabs of partial groups are streamed through LDS but never multiplied
+        stream, table = _stream_buffers(("film", wb[0].data_ptr(), wb[-2].data_ptr(), n_map, n_film, direction), nbytes, hip.FILM_TABLE_FLOATS,
+                                        wb[0].device)
         hip.film_pack(net, stream, table, direction)
         hit = _FILM_STREAMS[key] = (list(wb), net, stream, table, torch.cuda.current_stream(), _STEP_SEQ[0])
     else:  # packed on another stream of the same step: order this stream after it
@@ -833,7 +849,9 @@ def _field_pack(kind, weights, layers_fn):
     key = (kind,) + tuple((w.data_ptr(), w._version) for w in weights)
     hit = _FIELD_STREAMS.get(key)
     if hit is None:
-        hit = _FIELD_STREAMS[key] = (weights, hip.chain_pack(layers_fn(), weights[0].device), torch.cuda.current_stream(), _STEP_SEQ[0])
+        dev = weights[0].device
+        pk = hip.chain_pack(layers_fn(), dev, lambda nb, nt: _stream_buffers((kind,) + tuple(w.data_ptr() for w in weights), nb, nt, dev))
+        hit = _FIELD_STREAMS[key] = (weights, pk, torch.cuda.current_stream(), _STEP_SEQ[0])
     else:
         _order_after(hit[2], hit[3])
     return hit[1]
@@ -960,8 +978,7 @@ def _sdf_stream(W0, b0, W1, b1, W2, b2, GF, beta, direction):
         keep = (W0, b0, W1, b1, W2, b2, W2[GF], b2[GF:GF + 1])
         net = hip.sdf_net(W0, b0, W1, b1, keep[6], keep[7], beta)
         nbytes, _ = hip.sdf_stream_layout(net, direction)
-        stream = torch.zeros(nbytes, dtype=torch.uint8, device=W0.device)
-        table = torch.empty(hip.FILM_TABLE_FLOATS, device=W0.device)
+        stream, table = _stream_buffers(("sdf", W0.data_ptr(), W1.data_ptr(), GF, direction), nbytes, hip.FILM_TABLE_FLOATS, W0.device)
         hip.sdf_pack(net, stream, table, direction)
         hit = _SDF_STREAMS[key] = (keep, net, stream, table, torch.cuda.current_stream(), _STEP_SEQ[0])
     else:
@@ -1101,6 +1118,27 @@ class HemiCompositeFn(torch.autograd.Function):
         dbg = torch.empty_like(bg)
         hip.hemi_composite_bwd(a, n, w, dirs, cam_colours, cam_of_ray, vis, bg, lin, d_rgb.contiguous(), da, dn, dw, dcol, dvis, dbg)
         return da, dn, dw, None, dcol, None, dvis, dbg
+
+
+class SplitRowsFn(torch.autograd.Function):
+    """t [N, ...] -> (t[:n], t[n:]) as views; the backward is ONE concatenation.  (Two slices of a tensor that requires grad cost
+    autograd a zero fill and a copy each plus the add that joins them: 5 launches per tensor.)"""
+
+    @staticmethod
+    def forward(ctx, t, n):
+        ctx.n, ctx.rest = n, (t.shape[0] - n,) + tuple(t.shape[1:])
+        ctx.set_materialize_grads(False)
+        return t.narrow(0, 0, n), t.narrow(0, n, t.shape[0] - n)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None, None
+        if gb is None:
+            gb = zeros(*ctx.rest, device=ga.device)
+        if ga is None:
+            ga = zeros(ctx.n, *ctx.rest[1:], device=gb.device)
+        return torch.cat((ga, gb), 0), None
 
 
 class NeusWeightsFn(torch.autograd.Function):
@@ -1440,11 +1478,24 @@ class ProposalMLPFn(torch.autograd.Function):
         raw = torch.empty(feat.shape[0], 1, device=feat.device)
         hip.proposal_mlp_fwd(feat, w0c, b0.detach(), w1c, b1.detach(), raw)
         ctx.save_for_backward(feat, w0c, b0.detach(), w1c, b1.detach())
+        ctx.sinks = [t if getattr(t, "_nsky_grad_sink", False) else None for t in (w0, b0, w1, b1)]
         return raw
 
     @staticmethod
     def backward(ctx, d_raw):
         feat, w0, b0, w1, b1 = ctx.saved_tensors
+        sinks = ctx.sinks
+        if all(sk is not None and sk.grad is not None and sk.grad.is_contiguous() for sk in sinks):
+            # optimizer-slab parameters: the kernel accumulates straight into their .grad views of the (zero-filled) gradient slab --
+            # no AccumulateGrad copy per parameter, nothing for collect_grads to gather
+            for sk in sinks:
+                sk._nsky_sunk = True
+            d_feat = torch.empty_like(feat) if ctx.needs_input_grad[0] else None
+            hip.proposal_mlp_bwd(feat, w0, b0, w1, b1, d_raw.contiguous(), d_feat, sinks[0].grad, sinks[1].grad, sinks[2].grad, sinks[3].grad)
+            return d_feat, None, None, None, None
+        for sk in sinks:
+            if sk is not None and sk.grad is None:
+                sk._nsky_sunk = True  # (sinks from the next zero_grad_all on)
         flat = zeros(w0.numel() + b0.numel() + w1.numel() + 4, device=feat.device)
         n0, nb = w0.numel(), b0.numel()
         dw0, db0 = flat[:n0].view_as(w0), flat[n0:n0 + nb]
@@ -1493,6 +1544,40 @@ class TruncExpFn(torch.autograd.Function):
 # =============================================================================================
 def _c(t):
     return None if t is None else t.detach().contiguous().float()
+
+
+class TotalLossFn(torch.autograd.Function):
+    """total = sum_s scale_s sum_i coef_s[i] x_s[i] over up to 8 small tensors, one launch each way (hip.weighted_total_*): the step's
+    objective straight from the UNSCALED fused loss terms, the per-ray interlevel sums, ... -- what nerfstudio's scale_dict +
+    functools.reduce(torch.add, loss_dict.values()) + interlevel_loss' mean form with a dozen scalar launches each way.
+    args: metas [(has_coef, scale)], then the tensors x_0, (coef_0), x_1, ..."""
+
+    @staticmethod
+    def forward(ctx, metas, *tensors):
+        parts, k = [], 0
+        for has_coef, scale in metas:
+            x = tensors[k].contiguous()
+            c = tensors[k + 1].contiguous() if has_coef else None
+            k += 2 if has_coef else 1
+            parts.append((x, c, scale))
+        total = torch.empty(1, device=parts[0][0].device)
+        hip.weighted_total_fwd(parts, total)
+        ctx.parts, ctx.metas = parts, metas
+        return total[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.reshape(1).contiguous()
+        grads, out, k = [], [None], 0
+        for (x, c, sc), (has_coef, _) in zip(ctx.parts, ctx.metas):
+            d = torch.empty_like(x) if ctx.needs_input_grad[1 + k] else None
+            grads.append(d)
+            out.append(d)
+            if has_coef:
+                out.append(None)
+            k += 2 if has_coef else 1
+        hip.weighted_total_bwd(ctx.parts, g, grads)
+        return tuple(out)
 
 
 class MainLossesFn(torch.autograd.Function):
