@@ -194,7 +194,9 @@ class SDFAlbedoField(FieldBase):
                 self._wn_maps = {}
             o, i = lin.weight_v.shape
             maps = self._wn_maps[(key, str(dev))] = ops.weight_norm_maps(o, i, rows(o, i), cols(o, i), dev)
-        return ops.WeightNormFn.apply(lin.weight_v, lin.weight_g, *maps)
+        w = ops.WeightNormFn.apply(lin.weight_v, lin.weight_g, *maps)
+        w._nsky_src = ("wn", id(lin.weight_v), key)  # (the packed weight streams keep one persistent buffer per source parameter)
+        return w
 
     def _geo_weights_uncached(self):
         ident = lambda n, m: list(range(n))  # noqa: E731

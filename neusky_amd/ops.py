@@ -236,6 +236,12 @@ def zeros_like(t: torch.Tensor) -> torch.Tensor:
 _STEP_SEQ = [0]  # bumped by begin_step: cache entries remember the step they were prepared in
 
 
+def stable_id(t: torch.Tensor):
+    """identity of the PARAMETER a derived weight tensor (weight norm, padding) was made from, when its maker recorded one
+    (`_nsky_src`): unlike the data pointer of the per-step temporary it is the same in every step and inside a graph capture"""
+    return getattr(t, "_nsky_src", None) or t.data_ptr()
+
+
 _STREAM_BUFS: dict = {}  # persistent (stream bytes, table) pairs of the packed weight streams, by (owner key, layout size)
 
 
@@ -447,8 +453,7 @@ def _film_stream(wb, n_map, n_film, mw, mb, mwo, mbo, fw, fb, ow, ob, direction=
         net = hip.film_net(mw[0].shape[1], fw[0].shape[1], ow.shape[0], mw, mb, mwo, mbo, fw, fb, ow, ob)
         nbytes, _ = hip.film_stream_layout(net, direction)
         # zero-filled once: the pad slabs of partial groups are streamed through LDS but never multiplied
-        stream, table = _stream_buffers(("film", wb[0].data_ptr(), wb[-2].data_ptr(), n_map, n_film, direction), nbytes, hip.FILM_TABLE_FLOATS,
-                                        wb[0].device)
+        stream, table = _stream_buffers(("film", stable_id(wb[0]), n_map, n_film, direction), nbytes, hip.FILM_TABLE_FLOATS, wb[0].device)
         hip.film_pack(net, stream, table, direction)
         hit = _FILM_STREAMS[key] = (list(wb), net, stream, table, torch.cuda.current_stream(), _STEP_SEQ[0])
     else:  # packed on another stream of the same step: order this stream after it
@@ -850,7 +855,7 @@ def _field_pack(kind, weights, layers_fn):
     hit = _FIELD_STREAMS.get(key)
     if hit is None:
         dev = weights[0].device
-        pk = hip.chain_pack(layers_fn(), dev, lambda nb, nt: _stream_buffers((kind,) + tuple(w.data_ptr() for w in weights), nb, nt, dev))
+        pk = hip.chain_pack(layers_fn(), dev, lambda nb, nt: _stream_buffers((kind,) + tuple(stable_id(w) for w in weights), nb, nt, dev))
         hit = _FIELD_STREAMS[key] = (weights, pk, torch.cuda.current_stream(), _STEP_SEQ[0])
     else:
         _order_after(hit[2], hit[3])
@@ -978,7 +983,7 @@ def _sdf_stream(W0, b0, W1, b1, W2, b2, GF, beta, direction):
         keep = (W0, b0, W1, b1, W2, b2, W2[GF], b2[GF:GF + 1])
         net = hip.sdf_net(W0, b0, W1, b1, keep[6], keep[7], beta)
         nbytes, _ = hip.sdf_stream_layout(net, direction)
-        stream, table = _stream_buffers(("sdf", W0.data_ptr(), W1.data_ptr(), GF, direction), nbytes, hip.FILM_TABLE_FLOATS, W0.device)
+        stream, table = _stream_buffers(("sdf", stable_id(W0), stable_id(W1), GF, direction), nbytes, hip.FILM_TABLE_FLOATS, W0.device)
         hip.sdf_pack(net, stream, table, direction)
         hit = _SDF_STREAMS[key] = (keep, net, stream, table, torch.cuda.current_stream(), _STEP_SEQ[0])
     else:

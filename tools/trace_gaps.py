@@ -42,3 +42,11 @@ print(f"kernels < 10 us: {len(short)}, {sum(short)/1e6:.3f} ms")
 print("idle attributed to the following kernel:")
 for n, t in gaps.most_common(25):
     print(f"  {t/1e3:9.1f} us  {gapn[n]:5d} gaps  avg {t/gapn[n]/1e3:6.2f} us  {n}")
+native = collections.Counter()
+for s, e, n in step:
+    if "at::native" in n or "rocclr" in n or "at::cuda" in n:
+        key = "copyBuffer" if "rocclr" in n else n.split("at::native::")[-1][:90]
+        native[key] += 1
+print(f"torch-native / copy launches in the step: {sum(native.values())} of {len(step)}")
+for n, c in native.most_common(12):
+    print(f"  {c:4d}  {n}")

@@ -7,4 +7,4 @@ rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_$TAG -- pyth
 python3 $R/tools/trace_gaps.py $R/gpurun_out/trace_$TAG > $R/gpurun_out/trace_$TAG.txt 2>&1
 python3 $R/tools/trace_timeline.py $R/gpurun_out/trace_$TAG $2 $3 > $R/gpurun_out/timeline_$TAG.txt 2>&1
 find $R/gpurun_out/trace_$TAG -name "*kernel_trace.csv" -delete
-tail -40 $R/gpurun_out/trace_$TAG.txt
+tail -60 $R/gpurun_out/trace_$TAG.txt
