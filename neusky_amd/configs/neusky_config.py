@@ -6,7 +6,17 @@ reference's pyproject.toml:19-22) resolves.  With nerfstudio installed it is ner
 """
 from __future__ import annotations
 
+from ..data.dataparsers import NeRFOSRCityScapesDataParserConfig
+from ..data.image_datamanager import NeuSkyDataManagerConfig
 from ..pipelines.neusky_pipeline import NeuSkyPipelineConfig
 from ..plugin import MethodSpecification, TrainerConfig, build_method_specification  # noqa: F401  (re-exported types)
 
-NeuSky = build_method_specification(NeuSkyPipelineConfig())
+# the datamanager of neusky_config.py:46-64: NeRF-OSR scene parsed from disk (`ns-train neusky --data <NeRF-OSR/Data>`), every image and
+# mask resident on the device, 1024 train / eval rays per batch.  (bench.py and the tests build their pipelines on the synthetic
+# datamanager instead: no dataset in the image.)
+NeuSky = build_method_specification(NeuSkyPipelineConfig(datamanager=NeuSkyDataManagerConfig(
+    dataparser=NeRFOSRCityScapesDataParserConfig(scene="site1", auto_scale_poses=True, crop_to_equal_size=True, pad_to_equal_size=False,
+                                                 scene_scale=1.0, mask_vegetation=True, mask_out_of_view_frustum_objects=True,
+                                                 session_holdout_indices=[0, 0, 0, 0, 0]),
+    train_num_images_to_sample_from=-1, train_num_times_to_repeat_images=-1, images_on_gpu=True, masks_on_gpu=True,
+    train_num_rays_per_batch=1024, eval_num_rays_per_batch=1024)))

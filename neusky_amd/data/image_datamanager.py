@@ -117,3 +117,103 @@ class DeviceImageDataManager:
         n = num_rays or self.train_num_rays_per_batch
         idx = self._draw(self.half_pixels(sample_region, image_index), n)
         return self.generate_rays(idx), self.collate(idx)
+
+
+# =====================================================================================================================
+# The reference's datamanager seam (neusky/data/datamanagers/neusky_datamanager.py:56-288): a config with a dataparser, train / eval
+# datasets parsed from disk, every image and mask resident on the device (`images_on_gpu / masks_on_gpu`, neusky_config.py:60-61), and
+# the iterator functions the pipeline calls.  Built on DeviceImageDataManager: one instance for the train split, one for the eval split.
+from dataclasses import dataclass, field  # noqa: E402
+from pathlib import Path  # noqa: E402
+from typing import Any, Type  # noqa: E402
+
+from ..plugin import ConfigBase  # noqa: E402
+
+
+@dataclass
+class NeuSkyDataManagerConfig(ConfigBase):
+    """field names of the reference's NeuSkyDataManagerConfig / nerfstudio VanillaDataManagerConfig that the `neusky` method sets
+    (neusky_config.py:46-64)"""
+    _target: Type = field(default_factory=lambda: NeuSkyDataManager)
+    dataparser: Any = None                      # NeRFOSRCityScapesDataParserConfig / CustomNeuskyDataparserConfig (data/dataparsers.py)
+    data: Optional[Path] = None                 # overrides dataparser.data when set (ns-train --data)
+    train_num_rays_per_batch: int = 1024
+    eval_num_rays_per_batch: int = 1024
+    train_num_images_to_sample_from: int = -1   # -1: all images resident (the only mode built)
+    train_num_times_to_repeat_images: int = -1
+    images_on_gpu: bool = True
+    masks_on_gpu: bool = True
+    camera_res_scale_factor: float = 1.0
+
+    def setup(self, **kwargs):
+        return self._target(self, **kwargs)
+
+
+class NeuSkyDataManager:
+    """train / eval data of one scene on the device.  Surface used by NeuSkyPipeline (neusky_pipeline.py:146-148,241-291,356-455):
+    train_dataset / eval_dataset (len, scene_box, metadata), num_val / num_test, next_train, next_eval, next_eval_image,
+    eval_dataloader, get_sky_ray_bundle, get_eval_image_half_bundle, get_param_groups."""
+
+    def __init__(self, config: NeuSkyDataManagerConfig, device="cuda:0", test_mode: str = "val", world_size: int = 1, local_rank: int = 0, **_):
+        from .dataparsers import NeRFOSRCityScapesDataParserConfig, NeuSkyDataset
+        if config.train_num_images_to_sample_from != -1:
+            raise NotImplementedError("train_num_images_to_sample_from: every image is resident on the device (images_on_gpu)")
+        self.config, self.device, self.test_mode = config, device, test_mode
+        pc = config.dataparser if config.dataparser is not None else NeRFOSRCityScapesDataParserConfig()
+        if config.data is not None:
+            pc.data = Path(config.data)
+        self.dataparser = pc.setup()
+        eval_split = test_mode if test_mode in ("test", "val") else "val"
+        s = float(config.camera_res_scale_factor)
+        self.train_dataset = NeuSkyDataset(self.dataparser.get_dataparser_outputs(split="train"), scale_factor=s, split="train")
+        self.eval_dataset = NeuSkyDataset(self.dataparser.get_dataparser_outputs(split=eval_split), scale_factor=s, split=eval_split)
+        # every rank holds the whole scene and draws its own rays (ray-sharded data parallelism: the generator is seeded by the rank)
+        self.train = DeviceImageDataManager.from_dataset(self.train_dataset, train_num_rays_per_batch=config.train_num_rays_per_batch,
+                                                         device=device, seed=local_rank)
+        self.eval = DeviceImageDataManager.from_dataset(self.eval_dataset, train_num_rays_per_batch=config.eval_num_rays_per_batch,
+                                                        device=device, seed=100_003 + local_rank)
+        self.num_val = self.num_test = len(self.eval_dataset)
+
+    def get_param_groups(self) -> Dict:
+        return {}
+
+    def next_train(self, step: int) -> Tuple[RayBundle, Dict]:
+        return self.train.next_train(step)
+
+    def get_sky_ray_bundle(self, number_of_rays: int) -> RayBundle:
+        return self.train.get_sky_ray_bundle(number_of_rays)
+
+    def next_eval(self, step: int) -> Tuple[RayBundle, Dict]:
+        return self.eval.next_train(step)
+
+    def get_eval_image_half_bundle(self, sample_region: str = "full_image", image_index: int = 0, num_rays: Optional[int] = None):
+        return self.eval.get_eval_image_half_bundle(sample_region, image_index, num_rays)
+
+    def next_eval_image(self, idx: int):
+        """-> (image_idx, camera ray bundle [H, W], batch {image [H,W,3], mask [H,W,4], image_idx})"""
+        e = self.eval
+        i = int(idx) % e.N
+        yy, xx = torch.meshgrid(torch.arange(e.H, device=e.device), torch.arange(e.W, device=e.device), indexing="ij")
+        pix = torch.stack([torch.full_like(yy, i), yy, xx], -1).reshape(-1, 3)
+        rb = e.generate_rays(pix)
+        shape = lambda t: t.reshape(e.H, e.W, *t.shape[1:])  # noqa: E731
+        bundle = RayBundle(origins=shape(rb.origins), directions=shape(rb.directions), pixel_area=shape(rb.pixel_area),
+                           camera_indices=shape(rb.camera_indices), metadata={"directions_norm": shape(rb.metadata["directions_norm"])})
+        image_idx = int(e.image_idx[i])
+        return image_idx, bundle, {"image": e.images[i], "mask": e.masks[i], "image_idx": image_idx}
+
+    class _EvalLoader:
+        def __init__(self, dm):
+            self.dm = dm
+
+        def __len__(self):
+            return self.dm.eval.N
+
+        def __iter__(self):
+            for i in range(self.dm.eval.N):
+                _, rb, batch = self.dm.next_eval_image(i)
+                yield rb, batch
+
+    @property
+    def eval_dataloader(self):
+        return NeuSkyDataManager._EvalLoader(self)

@@ -186,3 +186,35 @@ def test_device_datamanager_from_dataset_cpu(osr_root):
     uneven = dp.NeuSkyDataset(osr_config(osr_root, crop_to_equal_size=False).setup().get_dataparser_outputs("train"))
     with pytest.raises(ValueError):
         dp.load_stacks(uneven)
+
+
+def test_neusky_datamanager_over_the_parsed_scene(osr_root):
+    """the reference's datamanager seam (neusky_datamanager.py:56-288, neusky_config.py:46-64) on the on-disk parser: train / eval datasets,
+    resident stacks, the iterator functions the pipeline calls; every batch value is the dataset's own pixel at batch['indices']"""
+    from neusky_amd.data.image_datamanager import NeuSkyDataManagerConfig
+    cfg = NeuSkyDataManagerConfig(dataparser=osr_config(osr_root), train_num_rays_per_batch=64, eval_num_rays_per_batch=32)
+    dm = cfg.setup(device="cpu", test_mode="val", world_size=1, local_rank=0)
+    assert len(dm.train_dataset) > 0 and len(dm.eval_dataset) > 0 and dm.num_val == len(dm.eval_dataset)
+    assert dm.train_dataset.scene_box["aabb"].shape == (2, 3) and dm.get_param_groups() == {}
+    rb, batch = dm.next_train(0)
+    assert rb.origins.shape == (64, 3) and rb.directions.shape == (64, 3) and batch["image"].shape == (64, 3) and batch["mask"].shape == (64, 4)
+    assert torch.allclose(rb.directions.norm(dim=-1), torch.ones(64), atol=1e-5)
+    assert int(rb.camera_indices.min()) >= 0 and int(rb.camera_indices.max()) < len(dm.train_dataset)
+    assert bool(batch["mask"][:, 0].all())  # train rays come from the static mask only (neusky_pixel_sampler.py:36-81)
+    idx = batch["indices"]
+    for r in range(0, 64, 7):  # the batch's values are the dataset's own pixels
+        c, y, x = (int(v) for v in idx[r])
+        img = torch.from_numpy(dm.train_dataset.get_numpy_image(c)).float() / 255.0
+        assert torch.allclose(batch["image"][r], img[y, x, :3], atol=1e-6)
+    erb, ebatch = dm.next_eval(0)
+    assert erb.origins.shape == (32, 3) and ebatch["image"].shape == (32, 3)
+    image_idx, cam_rb, full = dm.next_eval_image(0)
+    H, W = full["image"].shape[:2]
+    assert cam_rb.origins.shape == (H, W, 3) and cam_rb.camera_indices.shape == (H, W, 1) and full["mask"].shape == (H, W, 4)
+    assert 0 <= image_idx and len(dm.eval_dataloader) == len(dm.eval_dataset)
+    first = next(iter(dm.eval_dataloader))
+    assert first[0].directions.shape == (H, W, 3) and torch.equal(first[1]["image"], full["image"])
+    sky = dm.get_sky_ray_bundle(16)
+    assert sky.origins.shape == (16, 3)
+    hrb, hbatch = dm.get_eval_image_half_bundle("left_image_half", image_index=0, num_rays=8)
+    assert hrb.origins.shape == (8, 3) and int(hbatch["indices"][:, 2].max()) < W // 2

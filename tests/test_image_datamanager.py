@@ -114,3 +114,38 @@ def _check_against_the_reference_sampler(device):
     assert set(map(tuple, batch["indices"].cpu().tolist())) <= set(key(remap(dm.static_pixels)))
     sky = dm._draw(dm.sky_pixels, 64)
     assert set(map(tuple, remap(sky).tolist())) <= set(key(g["sky_pixels_remapped"]))
+
+
+@pytest.mark.gpu
+def test_pipeline_trains_on_the_parsed_nerfosr_fixture(tmp_path):
+    """the method's own datamanager (configs/neusky_config.py: NeuSkyDataManagerConfig over the NeRF-OSR parser, images and masks on the
+    device) under the pipeline: two train iterations on the on-disk fixture scene, finite falling-or-equal objective, gradients in every
+    optimizer group, and an eval batch / eval image through the same objects"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import dataset_fixture as fx
+    from neusky_amd.data import dataparsers as dp
+    from neusky_amd.data.image_datamanager import NeuSkyDataManagerConfig
+    from neusky_amd.engine import Optimizers, neusky_optimizers, train_iteration
+    from util_step import randomise, small_pipeline_config
+    root = fx.build_nerfosr(str(tmp_path))
+    cfg = small_pipeline_config(R=64, num_prop=(24, 12), S=8, D=24)
+    cfg.datamanager = NeuSkyDataManagerConfig(
+        dataparser=dp.NeRFOSRCityScapesDataParserConfig(data=root, scene="site1", crop_to_equal_size=True, mask_vegetation=True,
+                                                        session_holdout_indices=[0, 0, 0], mask_out_of_view_frustum_objects=True),
+        train_num_rays_per_batch=64, eval_num_rays_per_batch=32)
+    torch.manual_seed(0)
+    pipe = cfg.setup(device="cuda:0")
+    pipe.train()
+    randomise(pipe)
+    assert int(pipe.num_train_data) == len(pipe.datamanager.train_dataset) > 0
+    opt = Optimizers(neusky_optimizers(), pipe.get_param_groups())
+    losses = [float(train_iteration(pipe, opt, 1000 + i)[0]) for i in range(2)]
+    assert all(l == l and abs(l) < 1e6 for l in losses), losses
+    for g in opt.groups:
+        assert float(g.flat_g.abs().max()) > 0.0 or g.name == "visibility_sigmoid", g.name
+    rb, batch = pipe.datamanager.next_eval(0)
+    assert rb.origins.is_cuda and batch["image"].shape == (32, 3)
+    idx, cam_rb, full = pipe.datamanager.next_eval_image(0)
+    assert cam_rb.origins.shape[:2] == full["image"].shape[:2]
