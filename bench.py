@@ -33,9 +33,8 @@ RAYS, SAMPLES, DIRECTIONS, PROPOSAL = 1024, 96, 512, (256, 96)
 
 
 def build_pipeline(device, world_size, local_rank, rays=RAYS, samples=SAMPLES, directions=DIRECTIONS, proposal=PROPOSAL):
-    from neusky_amd.configs.neusky_config import NeuSky
-    import copy
-    cfg = copy.deepcopy(NeuSky.config.pipeline)
+    from neusky_amd.configs.neusky_config import synthetic_pipeline_config
+    cfg = synthetic_pipeline_config()  # the `neusky` method's pipeline, synthetic lk2-shaped data (no dataset in the image)
     cfg.model.num_neus_samples_per_ray = samples  # BASELINE.json fixes 96
     cfg.model.num_proposal_samples_per_ray = tuple(proposal)
     cfg.model.illumination_sampler.num_directions = directions
@@ -274,9 +273,8 @@ def cpu_baseline(seconds_budget=25.0):
     rays = 16
     pipe_cpu = None
     # parameters come from a CPU-resident copy of the product's initial state (host modules only; no HIP call)
-    import copy
-    from neusky_amd.configs.neusky_config import NeuSky
-    cfg = copy.deepcopy(NeuSky.config.pipeline)
+    from neusky_amd.configs.neusky_config import synthetic_pipeline_config
+    cfg = synthetic_pipeline_config()
     cfg.model.num_neus_samples_per_ray = SAMPLES
     cfg.model.illumination_sampler.num_directions = DIRECTIONS
     cfg.datamanager.train_num_rays_per_batch = rays

@@ -20,3 +20,13 @@ NeuSky = build_method_specification(NeuSkyPipelineConfig(datamanager=NeuSkyDataM
                                                  session_holdout_indices=[0, 0, 0, 0, 0]),
     train_num_images_to_sample_from=-1, train_num_times_to_repeat_images=-1, images_on_gpu=True, masks_on_gpu=True,
     train_num_rays_per_batch=1024, eval_num_rays_per_batch=1024)))
+
+
+def synthetic_pipeline_config():
+    """the method's pipeline config on the synthetic NeRF-OSR-lk2-shaped datamanager (300 train cameras, 1280 x 823 frames, random pixels):
+    what bench.py, the tools and the tests build their pipelines from -- there is no dataset in the image"""
+    import copy
+    from ..data.synthetic_datamanager import SyntheticDataManagerConfig
+    cfg = copy.deepcopy(NeuSky.config.pipeline)
+    cfg.datamanager = SyntheticDataManagerConfig()
+    return cfg

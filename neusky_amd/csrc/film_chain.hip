@@ -932,6 +932,7 @@ struct SdfFwdArgs {
   int M;
   float* a0; float* a1;      // native [ceil32(M), H] softplus outputs of the two hidden layers
   float* sdf;                // [M]
+  int full_wgs, tail_wgs, tail_k;  // tail_plan of the launch
 };
 
 
@@ -946,12 +947,15 @@ __global__ __launch_bounds__(512, 2) void sdf_fwd_kernel(const SdfFwdArgs a) {
   const int c = lane & 31, h = lane >> 5;
   for (int i = tid; i < 3 * H + 1; i += 512) bl[i] = a.table[i];
   for (int i = tid; i < 2 * NT; i += 512) sl[i] = a.table[BIAS_FLOATS + i];
-  const long rt = (long)blockIdx.x * 8 + wave;
+  // the remainder of the last round runs in tail workgroups (tail_plan): a wave of one without a row tile only takes part in the
+  // ring's hand-shakes (product_skip)
+  const long n_tiles = (a.M + 31) / 32;
+  const long rt0 = tail_tile(a.full_wgs, a.tail_wgs, a.tail_k, n_tiles, wave);
+  const bool wave_live = __builtin_amdgcn_readfirstlane((int)(rt0 >= 0 && rt0 < n_tiles)) != 0;
+  const long rt = wave_live ? rt0 : 0, rts = rt;
   const long row = rt * 32 + c;
-  const bool live = row < a.M;
-  const long rowc = live ? row : a.M - 1;
-  const bool wave_live = rt * 32 < a.M;
-  const long rts = wave_live ? rt : 0;  // a wave wholly beyond M works on tile 0's rows and stores nothing
+  const bool live = wave_live && row < a.M;
+  const long rowc = row < a.M ? row : a.M - 1;
   const float beta = a.net.beta, inv_beta = 1.0f / beta;
   f16x8 eh[KS0], el[KS0];
   const float e_inv = load_planes<KS0>(a.E + rowc * a.ldE, a.net.in_dim, KS0, h, eh, el);
@@ -970,45 +974,59 @@ __global__ __launch_bounds__(512, 2) void sdf_fwd_kernel(const SdfFwdArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    product<KS0, PW>(ws, eh, el, acc);
+    if (wave_live) product<KS0, PW>(ws, eh, el, acc);
+    else product_skip<KS0, PW, false>(ws);
     const float inv = e_inv * sl[tile++];
-    float v[16];
+    if (wave_live) {
+      float v[16];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 b4 = *reinterpret_cast<const float4*>(bl + 32 * t + 8 * g + 4 * h);
-      const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bl + 32 * t + 8 * g + 4 * h);
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        v[4 * g + q] = softplus_b(fmaf(acc[4 * g + q], inv, bb[q]), beta, inv_beta);
-        m = fmaxf(m, v[4 * g + q]);
+        for (int q = 0; q < 4; ++q) {
+          v[4 * g + q] = softplus_b(fmaf(acc[4 * g + q], inv, bb[q]), beta, inv_beta);
+          m = fmaxf(m, v[4 * g + q]);
+        }
       }
+      store_tile(a0blk + t * 1024, lane, v);
     }
-    if (wave_live) store_tile(a0blk + t * 1024, lane, v);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's a0 stores have left before it reads them back
   f16x8 ah[KS], al[KS];
-  const float a_inv = planes_from_tiles<NT>(a0blk, lane, m, ah, al);
+  float a_inv = 1.0f;
+  if (wave_live) {
+    a_inv = planes_from_tiles<NT>(a0blk, lane, m, ah, al);
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ah[ks][j] = (_Float16)0.0f; al[ks][j] = (_Float16)0.0f; }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   float part = 0.0f;
   for (int t = 0; t < NT; ++t) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    product<KS, PW>(ws, ah, al, acc);
+    if (wave_live) product<KS, PW>(ws, ah, al, acc);
+    else product_skip<KS, PW, false>(ws);
     const float inv = a_inv * sl[tile++];
-    float v[16];
+    if (wave_live) {
+      float v[16];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 b4 = *reinterpret_cast<const float4*>(bl + H + 32 * t + 8 * g + 4 * h);
-      const float4 w4 = *reinterpret_cast<const float4*>(bl + 2 * H + 32 * t + 8 * g + 4 * h);
-      const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bl + H + 32 * t + 8 * g + 4 * h);
+        const float4 w4 = *reinterpret_cast<const float4*>(bl + 2 * H + 32 * t + 8 * g + 4 * h);
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        v[4 * g + q] = softplus_b(fmaf(acc[4 * g + q], inv, bb[q]), beta, inv_beta);
-        part = fmaf(v[4 * g + q], ww[q], part);
+        for (int q = 0; q < 4; ++q) {
+          v[4 * g + q] = softplus_b(fmaf(acc[4 * g + q], inv, bb[q]), beta, inv_beta);
+          part = fmaf(v[4 * g + q], ww[q], part);
+        }
       }
+      store_tile_nt(a1blk + t * 1024, lane, v);
     }
-    if (wave_live) store_tile_nt(a1blk + t * 1024, lane, v);
   }
   part += __shfl_xor(part, 32, 64);  // the two lane halves hold different features of the same row
   if (live && h == 0) a.sdf[row] = part + bl[3 * H];
@@ -1027,6 +1045,7 @@ struct SdfBwdArgs {
   float* dw2;                // [H] += sum_rows g a1 (or NULL)
   float* db2;                // [1] += sum_rows g (with dw2)
   float* gmax;               // [2]: max |dz1|, max |dz0| (zero-initialised by the caller)
+  int full_wgs, tail_wgs, tail_k;  // tail_plan of the launch
 };
 
 template <int H>
@@ -1043,11 +1062,12 @@ __global__ __launch_bounds__(512, 2) void sdf_bwd_kernel(const SdfBwdArgs a) {
   for (int i = tid; i < H; i += 512) { w2[i] = a.table[2 * H + i]; dw2s[i] = 0.0f; }
   if (tid < 4) dw2s[H + tid] = 0.0f;
   for (int i = tid; i < NT + ct; i += 512) sl[i] = a.table[BIAS_FLOATS + i];
-  const long rt = (long)blockIdx.x * 8 + wave;
+  const long n_tiles = (a.M + 31) / 32;
+  const long rt0 = tail_tile(a.full_wgs, a.tail_wgs, a.tail_k, n_tiles, wave);  // tail workgroups: see sdf_fwd_kernel
+  const bool wave_live = __builtin_amdgcn_readfirstlane((int)(rt0 >= 0 && rt0 < n_tiles)) != 0;
+  const long rt = wave_live ? rt0 : 0, rts = rt;
   const long row = rt * 32 + c;
-  const bool live = row < a.M;
-  const bool wave_live = rt * 32 < a.M;
-  const long rts = wave_live ? rt : 0;
+  const bool live = wave_live && row < a.M;
   const float beta = a.net.beta;
   const float g = live ? a.g[row] : 0.0f;
   __syncthreads();
@@ -1068,7 +1088,7 @@ __global__ __launch_bounds__(512, 2) void sdf_bwd_kernel(const SdfBwdArgs a) {
   float* dz0blk = a.dz0 + rts * NT * 1024;
   // ---- dz1 = g w2 sigmoid(beta z1); dw2 += g a1
   float m = 0.0f;
-  for (int t = 0; t < NT; ++t) {
+  for (int t = 0; wave_live && t < NT; ++t) {
     float av[16], dv[16];
     load_tile(a.a1 + (rts * NT + t) * 1024, lane, av);
 #pragma unroll
@@ -1088,12 +1108,20 @@ __global__ __launch_bounds__(512, 2) void sdf_bwd_kernel(const SdfBwdArgs a) {
         }
       }
     }
-    if (wave_live) store_tile(dz1blk + t * 1024, lane, dv);
+    store_tile(dz1blk + t * 1024, lane, dv);
   }
   publish_max(a.gmax, m, live, wave_live, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   f16x8 ph[KS], pl[KS];
-  float p_inv = planes_from_tiles<NT>(dz1blk, lane, m, ph, pl);
+  float p_inv = 1.0f;
+  if (wave_live) {
+    p_inv = planes_from_tiles<NT>(dz1blk, lane, m, ph, pl);
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ph[ks][j] = (_Float16)0.0f; pl[ks][j] = (_Float16)0.0f; }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ---- dz0 = (W1^T dz1) sigmoid(beta z0)
   m = 0.0f;
@@ -1101,28 +1129,32 @@ __global__ __launch_bounds__(512, 2) void sdf_bwd_kernel(const SdfBwdArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    product<KS, PW>(ws, ph, pl, acc);
+    if (wave_live) product<KS, PW>(ws, ph, pl, acc);
+    else product_skip<KS, PW, false>(ws);
     const float inv = p_inv * sl[tile++];
-    float av[16], dv[16];
-    load_tile(a.a0 + (rts * NT + u) * 1024, lane, av);
+    if (wave_live) {
+      float av[16], dv[16];
+      load_tile(a.a0 + (rts * NT + u) * 1024, lane, av);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      dv[r] = acc[r] * inv * -expm1f(-beta * av[r]);
-      m = fmaxf(m, fabsf(dv[r]));
+      for (int r = 0; r < 16; ++r) {
+        dv[r] = acc[r] * inv * -expm1f(-beta * av[r]);
+        m = fmaxf(m, fabsf(dv[r]));
+      }
+      store_tile(dz0blk + u * 1024, lane, dv);
     }
-    if (wave_live) store_tile(dz0blk + u * 1024, lane, dv);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // compiler-visible loads: none pending across the next product
   }
   publish_max(a.gmax + 1, m, live, wave_live, lane);
   // ---- dE = W0^T dz0
   if (a.dE) {
-    p_inv = planes_from_tiles<NT>(dz0blk, lane, m, ph, pl);
+    if (wave_live) p_inv = planes_from_tiles<NT>(dz0blk, lane, m, ph, pl);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int u = 0; u < ct; ++u) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-      product<KS, PW>(ws, ph, pl, acc);
+      if (wave_live) product<KS, PW>(ws, ph, pl, acc);
+      else product_skip<KS, PW, false>(ws);
       const float inv = p_inv * sl[tile++];
       if (live) {
 #pragma unroll
@@ -1313,7 +1345,9 @@ extern "C" int nsky_sdf_chain_fwd(const nsky_sdf_net* net, const void* stream_bu
   SdfFwdArgs a;
   a.net = *net; a.stream = (const unsigned char*)stream_buf; a.table = table; a.E = E; a.ldE = ldE; a.M = M; a.a0 = a0_save; a.a1 = a1_save;
   a.sdf = sdf;
-  const dim3 grid(ceil_div(M, 256));
+  const TailPlan tp = tail_plan((M + 31) / 32, device_cus());
+  a.full_wgs = tp.full_wgs; a.tail_wgs = tp.tail_wgs; a.tail_k = tp.tail_k;
+  const dim3 grid(tp.full_wgs + tp.tail_wgs);
   const int ks0 = ksteps_of(net->in_dim);
 #define NSKY_SDF_FWD(KK) hipLaunchKernelGGL((sdf_fwd_kernel<256, KK>), grid, dim3(512), 0, (hipStream_t)stream, a)
   switch (ks0) {
@@ -1337,7 +1371,9 @@ extern "C" int nsky_sdf_chain_bwd(const nsky_sdf_net* net, const void* stream_bu
   SdfBwdArgs a;
   a.net = *net; a.stream = (const unsigned char*)stream_buf; a.table = table; a.M = M; a.g = g_sdf; a.a0 = a0_save; a.a1 = a1_save;
   a.dz1 = dz1; a.dz0 = dz0; a.dE = dE; a.ldE = ldE; a.dw2 = dw2; a.db2 = db2; a.gmax = gmax;
-  hipLaunchKernelGGL((sdf_bwd_kernel<256>), dim3(ceil_div(M, 256)), dim3(512), 0, (hipStream_t)stream, a);
+  const TailPlan tp = tail_plan((M + 31) / 32, device_cus());
+  a.full_wgs = tp.full_wgs; a.tail_wgs = tp.tail_wgs; a.tail_k = tp.tail_k;
+  hipLaunchKernelGGL((sdf_bwd_kernel<256>), dim3(tp.full_wgs + tp.tail_wgs), dim3(512), 0, (hipStream_t)stream, a);
   NSKY_CHECK_LAUNCH("nsky_sdf_chain_bwd");
   return NSKY_OK;
 }
