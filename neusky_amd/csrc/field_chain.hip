@@ -22,10 +22,10 @@
 //                    quad-native (weight-gradient operands) and d(encode rows) in the stacked [E; T0; T1; T2] layout of the encode
 //                    backward.
 //
-// Workgroups are PERSISTENT (one per CU, eight waves): the grid is at most the CU count, a workgroup walks the weight stream
-// cyclically, round r gives wave w the row tile r * 8 G + w * G + b (G workgroups, b = blockIdx.x), so the tiles of the last,
-// partial round are spread over the first waves of all workgroups and a wave without a tile only takes part in the ring's
-// hand-shakes (product_skip): no workgroup round is paid for a handful of tail tiles.
+// Workgroups are PERSISTENT (WAVES = 4 waves, two workgroups per CU with a 64 KB ring each): the grid is at most twice the CU count, a
+// workgroup walks the weight stream cyclically, round r gives wave w the row tile r * WAVES G + w * G + b (G workgroups, b =
+// blockIdx.x), so the tiles of the last, partial round are spread over the first waves of all workgroups and a wave without a tile
+// only takes part in the ring's hand-shakes (product_skip): no workgroup round is paid for a handful of tail tiles.
 #include "chain.h"
 
 namespace {
