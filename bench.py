@@ -341,11 +341,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    # (NSKY_BENCH_DEVICE / NSKY_DIST_BACKEND: the one-GPU test of this file's N > 1 path, tests/test_gpu_bench_two_ranks.py -- two ranks share
+    # cuda:0 over gloo; a driver run never sets them)
+    dev_index = int(os.environ.get("NSKY_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("NSKY_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # backend "nccl" == RCCL on ROCm
+        dist.init_process_group(backend, rank=rank, world_size=world)  # backend "nccl" == RCCL on ROCm
 
     from neusky_amd.engine import GraphedTrainStep, Optimizers, neusky_optimizers, train_iteration
     torch.manual_seed(1234 + rank)
@@ -415,7 +419,7 @@ def main():
         torch.cuda.synchronize()
         pipe.model.second_stream = True
         timer.uninstall()
-    t = torch.tensor([dt], device=device)
+    t = torch.tensor([dt], device=device if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -423,7 +427,7 @@ def main():
 
     # the same step with EXACT fp32 products everywhere (v_mfma_f32_32x32x2_f32, per-layer kernels): a few eager steps, rank 0
     exact = None
-    if rank == 0 and not args.no_exact_f32 and ops._POLICY != "f32":
+    if rank == 0 and world == 1 and not args.no_exact_f32 and ops._POLICY != "f32":  # (N = 1 only: a train iteration all-reduces, and the other ranks are done)
         policy = ops._POLICY
         ops.set_precision_policy("f32")
         try:
@@ -475,7 +479,7 @@ def main():
                        "launch": "HIP graph replay (1 graph/step + all-reduce + 5 Adam launches)" if use_graph else "eager (host launches every kernel)" + graph_note},
             "roofline": {**roof, "traffic": traffic,
                          "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r03_pmc_traffic.json)" + traffic_note,
-                         "kernel": dom["kernel"] + " = the kernel family with the largest total time in the three eager timing iterations",
+                         "kernel": dom["kernel"] + " = the kernel family with the largest total time in the three eager timing iterations (per launch: the median of the three)",
                          "peak_note": ("HBM3E ~8 TB/s; achieved = algorithmic bytes (inputs, saved activations and outputs once each) / launch time; "
                                        "the kernel's byte floor exceeds its flop floor at 833.3 TFLOP/s") if roof["bound"] == "hbm" else
                                       "fp16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-grade product = 833.3 TFLOP/s of algorithmic FLOPs",
