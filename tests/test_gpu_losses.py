@@ -147,3 +147,48 @@ def test_eval_branch_matches_the_reference_golden(golden_dir):
     ggpu = torch.autograd.grad(out[0] + 1.3 * out[5], [rgb, hdr])
     for a, b in zip(ggpu, gref):
         assert (a.cpu().double() - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+
+
+def test_one_launch_objective_equals_the_sum_of_the_entries():
+    DEV = "cuda:0"
+    """losses.total_loss forms the objective from the UNSCALED pieces in one launch each way (ops.TotalLossFn / nsky_weighted_total); the
+    dictionary entries stay differentiable for a trainer that sums the values (nerfstudio: functools.reduce(torch.add, loss_dict.values())).
+    Both must be the same number and give the same gradients; and the weighted-total kernel itself against torch on ragged segments."""
+    from neusky_amd import ops
+    from neusky_amd.engine import Optimizers, neusky_optimizers
+    from neusky_amd.model_components.losses import total_loss
+    from util_step import make_randoms, randomise, randoms_to, small_pipeline_config
+    # ---- the kernel: three segments, with and without coefficient vectors
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.randn(n, generator=g).to(DEV).requires_grad_(True) for n in (8, 1024, 3001)]
+    cs = [torch.randn(8, generator=g).to(DEV), None, torch.rand(3001, generator=g).to(DEV)]
+    sc = [1.0, 0.25 / 1024, -3.0]
+    metas = tuple((c is not None, s) for c, s in zip(cs, sc))
+    tens = [t for x, c in zip(xs, cs) for t in ((x, c) if c is not None else (x,))]
+    got = ops.TotalLossFn.apply(metas, *tens)
+    want = sum(((x.double() * c.double()).sum() if c is not None else x.double().sum()) * s for x, c, s in zip(xs, cs, sc))
+    assert abs(float(got) - float(want)) <= 1e-5 * max(abs(float(want)), 1.0)
+    (got * 2.0).backward()
+    for x, c, s in zip(xs, cs, sc):
+        ref = (c if c is not None else torch.ones_like(x)) * (2.0 * s)
+        assert torch.allclose(x.grad, ref, rtol=1e-6, atol=1e-7)
+    # ---- the step: objective and slab gradients, one-launch total against the summed entries
+    torch.manual_seed(0)
+    pipe = small_pipeline_config(R=64, num_prop=(24, 12), S=8, D=24).setup(device=DEV)
+    pipe.train()
+    randomise(pipe)
+    opt = Optimizers(neusky_optimizers(), pipe.get_param_groups())
+    rb, batch = pipe.datamanager.next_train(0)
+    rnd = randoms_to(make_randoms(pipe, 64), DEV)
+    slabs = []
+    for mode in ("total", "sum"):
+        opt.zero_grad_all()
+        _, ld, _ = pipe.get_train_loss_dict(1000, ray_bundle=rb, batch=batch, randoms=rnd)
+        assert getattr(ld, "parts", None), "the merged dictionary lost its unscaled pieces"
+        loss = total_loss(ld) if mode == "total" else sum(ld.values())
+        loss.backward()
+        opt.collect_grads()
+        slabs.append((float(loss), opt.flat_g.detach().clone()))
+    (la, ga), (lb, gb) = slabs
+    assert abs(la - lb) <= 2e-6 * max(abs(lb), 1.0), (la, lb)
+    assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()), float((ga - gb).abs().max())
