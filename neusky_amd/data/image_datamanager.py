@@ -54,6 +54,7 @@ class DeviceImageDataManager:
         self.sky_pixels = torch.nonzero(~self.masks[..., 1])          # 1 - fg
         assert self.static_pixels.shape[0] > 0, "no pixel with the static mask set"
         self.gen = torch.Generator(device=device).manual_seed(seed)
+        self._half_pools: Dict = {}
 
     @classmethod
     def from_dataset(cls, dataset, **kw) -> "DeviceImageDataManager":
@@ -112,11 +113,29 @@ class DeviceImageDataManager:
         pool = self.sky_pixels if self.sky_pixels.shape[0] > 0 else self.static_pixels
         return self.generate_rays(self._draw(pool, number_of_rays))
 
-    def get_eval_image_half_bundle(self, sample_region: str = "full_image", image_index: int = 0, num_rays: Optional[int] = None):
-        """rays of ONE image restricted to an image half and to the static mask (datamanager :288-333), for eval-latent fitting"""
+    def get_eval_image_half_bundle(self, sample_region: str = "full_image", image_index: Optional[int] = None, num_rays: Optional[int] = None):
+        """rays restricted to an image half and to the static mask, for eval-latent fitting: drawn over ALL stacked images (the
+        reference's eval pixel sampler works on its cached eval image batch, datamanager :288-305) or over one (`image_index`)"""
         n = num_rays or self.train_num_rays_per_batch
-        idx = self._draw(self.half_pixels(sample_region, image_index), n)
+        key = (sample_region, image_index)
+        pool = self._half_pools.get(key)
+        if pool is None:  # built once per (region, image): nonzero / boolean indexing never runs inside a replayed step
+            pool = self._half_pools[key] = self.half_pixels(sample_region, image_index)
+        idx = self._draw(pool, n)
         return self.generate_rays(idx), self.collate(idx)
+
+    def pixels_of_images(self, positions) -> torch.Tensor:
+        """static-mask pixels of the stacked images `positions` (a list of stack positions)"""
+        sel = torch.zeros(self.N, dtype=torch.bool, device=self.device)
+        sel[torch.as_tensor(list(positions), dtype=torch.long, device=self.device)] = True
+        return self.static_pixels[sel[self.static_pixels[:, 0]]]
+
+    def state_dict(self) -> Dict:
+        """what an exact resume needs: the generator's state (utils.checkpoints)"""
+        return {"gen": self.gen.get_state()}
+
+    def load_state_dict(self, state: Dict) -> None:
+        self.gen.set_state(state["gen"].cpu())
 
 
 # =====================================================================================================================
@@ -154,25 +173,48 @@ class NeuSkyDataManager:
     train_dataset / eval_dataset (len, scene_box, metadata), num_val / num_test, next_train, next_eval, next_eval_image,
     eval_dataloader, get_sky_ray_bundle, get_eval_image_half_bundle, get_param_groups."""
 
-    def __init__(self, config: NeuSkyDataManagerConfig, device="cuda:0", test_mode: str = "val", world_size: int = 1, local_rank: int = 0, **_):
+    def __init__(self, config: NeuSkyDataManagerConfig, device="cuda:0", test_mode: str = "val", world_size: int = 1, local_rank: int = 0,
+                 eval_latent_optimise_method: Optional[str] = "per_image", **_):
         from .dataparsers import NeRFOSRCityScapesDataParserConfig, NeuSkyDataset
         if config.train_num_images_to_sample_from != -1:
             raise NotImplementedError("train_num_images_to_sample_from: every image is resident on the device (images_on_gpu)")
         self.config, self.device, self.test_mode = config, device, test_mode
+        self.eval_latent_optimise_method = eval_latent_optimise_method or "per_image"  # passed by the pipeline (neusky_pipeline.py:129-135)
         pc = config.dataparser if config.dataparser is not None else NeRFOSRCityScapesDataParserConfig()
         if config.data is not None:
             pc.data = Path(config.data)
         self.dataparser = pc.setup()
-        eval_split = test_mode if test_mode in ("test", "val") else "val"
+        eval_split = "test" if test_mode in ("test", "inference") else "val"  # datamanager :97
         s = float(config.camera_res_scale_factor)
         self.train_dataset = NeuSkyDataset(self.dataparser.get_dataparser_outputs(split="train"), scale_factor=s, split="train")
         self.eval_dataset = NeuSkyDataset(self.dataparser.get_dataparser_outputs(split=eval_split), scale_factor=s, split=eval_split)
-        # every rank holds the whole scene and draws its own rays (ray-sharded data parallelism: the generator is seeded by the rank)
+        # every rank holds the whole scene and draws its own rays (ray-sharded data parallelism): the generators are seeded by the GLOBAL
+        # rank (two nodes' ranks with the same local rank must not draw the same batches)
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else local_rank
         self.train = DeviceImageDataManager.from_dataset(self.train_dataset, train_num_rays_per_batch=config.train_num_rays_per_batch,
-                                                         device=device, seed=local_rank)
+                                                         device=device, seed=rank)
         self.eval = DeviceImageDataManager.from_dataset(self.eval_dataset, train_num_rays_per_batch=config.eval_num_rays_per_batch,
-                                                        device=device, seed=100_003 + local_rank)
-        self.num_val = self.num_test = len(self.eval_dataset)
+                                                        device=device, seed=100_003 + rank)
+        md = self.eval_dataset.metadata
+        if self.eval_latent_optimise_method == "per_image":  # datamanager :114-119: one latent per image
+            self.num_test = len(self.eval_dataset) if eval_split == "test" else len(self.dataparser.get_dataparser_outputs(split="test").image_filenames)
+            self.num_val = len(self.eval_dataset)
+            self.indices_to_session = None
+        else:
+            # NeRF-OSR relighting benchmark (:120-122,183-233): one latent per capture SESSION; the latents are fitted on one held-out image
+            # per session and compared on the images that have an evaluation mask
+            if md.get("session_to_indices") is None:
+                raise ValueError(f"eval_latent_optimise_method={self.eval_latent_optimise_method!r} needs a dataparser with session metadata")
+            s2i = md["session_to_indices"]
+            self.indices_to_session = md["indices_to_session"]
+            self.num_test = self.num_val = len(s2i)
+            self.holdout_indices = [s2i[k][rel] for k, rel in zip(s2i.keys(), md["session_holdout_indices"])]
+            self.compare_indices = list(self.eval_dataset.test_eval_mask_dict.keys())
+            self._session_of = torch.tensor([self.indices_to_session[i] for i in range(len(self.eval_dataset))], dtype=torch.long, device=device)
+            self._session_pools = {"optimise": self.eval.pixels_of_images(self.holdout_indices),
+                                   "compare": self.eval.pixels_of_images(self.compare_indices or self.holdout_indices)}
+            self._compare_cursor = 0
 
     def get_param_groups(self) -> Dict:
         return {}
@@ -186,13 +228,41 @@ class NeuSkyDataManager:
     def next_eval(self, step: int) -> Tuple[RayBundle, Dict]:
         return self.eval.next_train(step)
 
-    def get_eval_image_half_bundle(self, sample_region: str = "full_image", image_index: int = 0, num_rays: Optional[int] = None):
+    def get_eval_image_half_bundle(self, sample_region: str = "full_image", image_index: Optional[int] = None, num_rays: Optional[int] = None):
+        """datamanager :288-305: rays of the eval images (all of them unless `image_index` names one) inside an image half and the
+        static mask; batch["indices"][:, 0] = the eval image = the row of the eval latent table the ray trains"""
         return self.eval.get_eval_image_half_bundle(sample_region, image_index, num_rays)
 
-    def next_eval_image(self, idx: int):
-        """-> (image_idx, camera ray bundle [H, W], batch {image [H,W,3], mask [H,W,4], image_idx})"""
+    def get_nerfosr_lighting_eval_bundle(self, stage: str):
+        """datamanager :307-330: rays of the held-out image of every session ("optimise") or of the images with an evaluation mask
+        ("compare"), static mask; the image index of every ray is replaced by its SESSION index (one RENI++ latent per session).
+        The reference generates these rays with its TRAIN ray generator (:321); the eval cameras are used here."""
+        assert stage in ("optimise", "compare")
+        if self.indices_to_session is None:
+            raise ValueError("get_nerfosr_lighting_eval_bundle: the datamanager was set up with eval_latent_optimise_method='per_image'")
         e = self.eval
-        i = int(idx) % e.N
+        idx = e._draw(self._session_pools[stage], e.train_num_rays_per_batch)
+        rb, batch = e.generate_rays(idx), e.collate(idx)
+        sess = self._session_of[batch["indices"][:, 0]]
+        batch["indices"][:, 0] = sess
+        rb.camera_indices = sess[:, None].contiguous()
+        return rb, batch
+
+    def state_dict(self) -> Dict:
+        return {"train": self.train.state_dict(), "eval": self.eval.state_dict()}
+
+    def load_state_dict(self, state: Dict) -> None:
+        self.train.load_state_dict(state["train"])
+        self.eval.load_state_dict(state["eval"])
+
+    def next_eval_image(self, idx: int):
+        """-> (image_idx, camera ray bundle [H, W], batch {image [H,W,3], mask [H,W,4], image_idx}); in the NeRF-OSR session modes
+        the images are the ones with an evaluation mask and image_idx is the SESSION of the image (:239-253)"""
+        e = self.eval
+        if self.indices_to_session is not None and self.compare_indices:
+            i = self.compare_indices[int(idx) % len(self.compare_indices)]
+        else:
+            i = int(idx) % e.N
         yy, xx = torch.meshgrid(torch.arange(e.H, device=e.device), torch.arange(e.W, device=e.device), indexing="ij")
         pix = torch.stack([torch.full_like(yy, i), yy, xx], -1).reshape(-1, 3)
         rb = e.generate_rays(pix)
@@ -200,6 +270,9 @@ class NeuSkyDataManager:
         bundle = RayBundle(origins=shape(rb.origins), directions=shape(rb.directions), pixel_area=shape(rb.pixel_area),
                            camera_indices=shape(rb.camera_indices), metadata={"directions_norm": shape(rb.metadata["directions_norm"])})
         image_idx = int(e.image_idx[i])
+        if self.indices_to_session is not None:
+            image_idx = int(self.indices_to_session[image_idx])
+            bundle.camera_indices = torch.full_like(bundle.camera_indices, image_idx)
         return image_idx, bundle, {"image": e.images[i], "mask": e.masks[i], "image_idx": image_idx}
 
     class _EvalLoader:

@@ -162,6 +162,14 @@ class SyntheticDataManager:
                  "indices": torch.stack([torch.full_like(y, image_idx), y, x], 1)}
         return rb, batch
 
+    def state_dict(self):
+        """exact resume (utils.checkpoints): the host generator and the eval cursors"""
+        return {"gen": self._gen.get_state(), "eval_cursor": getattr(self, "_eval_cursor", -1), "half_cursor": getattr(self, "_half_cursor", -1)}
+
+    def load_state_dict(self, state):
+        self._gen.set_state(state["gen"])
+        self._eval_cursor, self._half_cursor = int(state.get("eval_cursor", -1)), int(state.get("half_cursor", -1))
+
     def next_eval(self, step: int):
         self._eval_cursor = (getattr(self, "_eval_cursor", -1) + 1) % self.config.num_eval_images
         return self._eval_rays(self._eval_cursor, "full_image", self.config.eval_num_rays_per_batch, self._gen)

@@ -252,10 +252,15 @@ def _stream_buffers(key, nbytes, n_table, device):
     k = (key, int(nbytes), int(n_table), str(device))
     hit = _STREAM_BUFS.get(k)
     if hit is None:
+        # eviction: never wholesale and never a buffer a captured HIP graph may hold the address of (its pack kernel would write the
+        # stream into memory the allocator has handed to somebody else): only entries that were last touched OUTSIDE a capture, oldest first
         if len(_STREAM_BUFS) > 64:
-            _STREAM_BUFS.clear()
-        hit = _STREAM_BUFS[k] = (torch.zeros(int(nbytes), dtype=torch.uint8, device=device), torch.empty(int(n_table), device=device))
-    return hit
+            for old_k in [kk for kk, v in sorted(_STREAM_BUFS.items(), key=lambda kv: kv[1][2]) if not v[3]][:len(_STREAM_BUFS) - 64]:
+                del _STREAM_BUFS[old_k]
+        hit = _STREAM_BUFS[k] = [torch.zeros(int(nbytes), dtype=torch.uint8, device=device), torch.empty(int(n_table), device=device), 0, False]
+    hit[2] = _STEP_SEQ[0]
+    hit[3] = hit[3] or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
+    return hit[0], hit[1]
 
 
 def _order_after(hit_stream, hit_seq) -> None:

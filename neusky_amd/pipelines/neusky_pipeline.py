@@ -51,8 +51,8 @@ class NeuSkyPipeline(PipelineBase):
         nn.Module.__init__(self)  # not the nerfstudio base's constructor (neusky_amd/plugin.py)
         self.config = config
         self.test_mode = test_mode if config.test_mode is None else config.test_mode
-        self.datamanager = config.datamanager.setup(device=device, test_mode=self.test_mode, world_size=world_size,
-                                                    local_rank=local_rank)
+        self.datamanager = config.datamanager.setup(device=device, test_mode=self.test_mode, world_size=world_size, local_rank=local_rank,
+                                                    eval_latent_optimise_method=config.model.eval_latent_optimise_method)  # :129-135
         assert self.datamanager.train_dataset is not None, "Missing input dataset"
         self.register_buffer("num_train_data", torch.tensor(len(self.datamanager.train_dataset)))  # :146-148
         self.register_buffer("num_test_data", torch.tensor(self.datamanager.num_test))

@@ -109,11 +109,11 @@ def save_checkpoint(base_dir, step: int, pipeline, optimizers=None) -> str:
     path = checkpoint_path(base_dir, step)
     os.makedirs(os.path.dirname(path), exist_ok=True)
     from .utils import device_rng_state
-    dm_gen = getattr(getattr(pipeline, "datamanager", None), "_gen", None)
+    dm = getattr(pipeline, "datamanager", None)
     ckpt = {"step": int(step), "pipeline": {k: v.detach().cpu().clone() for k, v in pipeline.state_dict().items()},
             # what an exact resume needs besides parameters and Adam state: the call counters of the in-kernel generators, the
             # datamanager's host generator and the step of the last eval-latent fit (neusky_pipeline.py:202-210)
-            "rng": {"device": device_rng_state(), "datamanager": None if dm_gen is None else dm_gen.get_state(),
+            "rng": {"device": device_rng_state(), "datamanager": dm.state_dict() if hasattr(dm, "state_dict") else None,
                     "step_of_last_latent_optimisation": int(getattr(pipeline, "step_of_last_latent_optimisation", 0))},
             "optimizers": {} if optimizers is None else {k: {kk: (vv.cpu() if torch.is_tensor(vv) else vv) for kk, vv in st.items()}
                                                         for k, st in optimizers.state_dict().items()},
@@ -135,9 +135,9 @@ def load_checkpoint(path, pipeline, optimizers=None) -> int:
     if rng:
         from .utils import load_device_rng_state
         load_device_rng_state(rng.get("device", {}))
-        dm_gen = getattr(getattr(pipeline, "datamanager", None), "_gen", None)
-        if dm_gen is not None and rng.get("datamanager") is not None:
-            dm_gen.set_state(rng["datamanager"])
+        dm = getattr(pipeline, "datamanager", None)
+        if hasattr(dm, "load_state_dict") and rng.get("datamanager") is not None:
+            dm.load_state_dict(rng["datamanager"])  # every generator the datamanager draws rays with (train / eval / host)
         if hasattr(pipeline, "step_of_last_latent_optimisation"):
             pipeline.step_of_last_latent_optimisation = int(rng.get("step_of_last_latent_optimisation", 0))
     if hasattr(pipeline.model, "begin_step"):

@@ -41,12 +41,16 @@ def to_device_async(t: torch.Tensor, device) -> torch.Tensor:
     return t.contiguous().pin_memory().to(device, non_blocking=True)
 
 
-def device_rng_seed(stream_id: int = 0) -> int:
-    """seed of an in-kernel counter-based generator (csrc/samplers.hip): torch's seed, the rank (ranks that were seeded alike must not
-    draw the same rays) and a per-generator stream id"""
+def _rank() -> int:
     import torch.distributed as dist
-    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
-    return (torch.initial_seed() + 7919 * rank + 104729 * stream_id) & (2**63 - 1)
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def device_rng_seed(stream_id: int = 0, base: int = None) -> int:
+    """seed of an in-kernel counter-based generator (csrc/samplers.hip): torch's seed (or `base`, a seed restored from a checkpoint),
+    the rank (ranks that were seeded alike must not draw the same rays) and a per-generator stream id"""
+    b = torch.initial_seed() + 104729 * stream_id if base is None else int(base)
+    return (b + 7919 * _rank()) & (2**63 - 1)
 
 
 # ---- in-kernel generators: (seed, call counter on the device) held by the object that draws, listed here for checkpoints
@@ -62,9 +66,13 @@ def device_rng(owner, name: str, stream_id: int, device) -> tuple:
     sequence instead of redrawing step 0's."""
     attr = "_nsky_rng_" + name
     st = getattr(owner, attr, None)
-    if st is None or st[1].device != torch.device(device):
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:  # "cuda" and "cuda:0" name the same device: never re-create the state (and its counter)
+        dev = torch.device("cuda", torch.cuda.current_device())
+    if st is None or st[1].device != dev:
         pend = _RNG_PENDING.pop(name, None)
-        st = (device_rng_seed(stream_id) if pend is None else int(pend[0]), torch.zeros(1, dtype=torch.int64, device=device))
+        # a checkpoint holds the rank-free base of the seed: every rank re-derives its own (ranks never share a random sequence)
+        st = (device_rng_seed(stream_id) if pend is None else device_rng_seed(stream_id, base=pend[0]), torch.zeros(1, dtype=torch.int64, device=dev))
         if pend is not None:
             st[1].fill_(int(pend[1]))
         object.__setattr__(owner, attr, st)
@@ -77,17 +85,17 @@ def device_rng_state() -> dict:
     for name, ref in _RNG_OWNERS.items():
         o = ref()
         st = getattr(o, "_nsky_rng_" + name, None) if o is not None else None
-        if st is not None:
-            out[name] = (int(st[0]), int(st[1].item()))
+        if st is not None:  # (rank-free base of the seed, calls so far)
+            out[name] = ((int(st[0]) - 7919 * _rank()) & (2**63 - 1), int(st[1].item()))
     return out
 
 
 def load_device_rng_state(state: dict) -> None:
-    for name, (seed, count) in state.items():
+    for name, (base, count) in state.items():
         ref = _RNG_OWNERS.get(name)
         o = ref() if ref is not None else None
         st = getattr(o, "_nsky_rng_" + name, None) if o is not None else None
-        if st is not None:  # a live generator: same counter tensor (a captured graph reads it), checkpoint's seed and call count
-            object.__setattr__(o, "_nsky_rng_" + name, (int(seed), st[1].fill_(int(count))))
+        if st is not None:  # a live generator: same counter tensor (a captured graph reads it); the checkpoint's seed base + THIS rank
+            object.__setattr__(o, "_nsky_rng_" + name, (device_rng_seed(0, base=base), st[1].fill_(int(count))))
         else:
-            _RNG_PENDING[name] = (int(seed), int(count))
+            _RNG_PENDING[name] = (int(base), int(count))

@@ -130,3 +130,34 @@ def test_saved_state_loads_into_a_fresh_pipeline_and_renders_identically(tmp_pat
             outs.append(p_.model.get_outputs_for_camera_ray_bundle(mk(), camera_index=0, chunk=64, use_graph=False))
     for k in ("rgb", "depth", "normal", "albedo"):
         assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_device_rng_state_is_rank_free(monkeypatch):
+    """a checkpoint written by rank 0 must not hand every rank the same in-kernel seed: the saved value is the rank-free base, each rank
+    re-derives its own seed on load, and the call counter is what is restored"""
+    from neusky_amd.utils import utils as U
+
+    class Owner:
+        pass
+
+    monkeypatch.setattr(U, "_rank", lambda: 0)
+    o0 = Owner()
+    seed0, counter0 = U.device_rng(o0, "test_rank_free", 5, "cpu")
+    counter0.fill_(17)
+    saved = U.device_rng_state()["test_rank_free"]
+    assert saved == (seed0, 17)  # rank 0: base == seed
+    # rank 3 resumes from rank 0's file: a generator that already exists ...
+    monkeypatch.setattr(U, "_rank", lambda: 3)
+    o3 = Owner()
+    seed3, counter3 = U.device_rng(o3, "test_rank_free", 5, "cpu")
+    assert seed3 == seed0 + 3 * 7919
+    U.load_device_rng_state({"test_rank_free": saved})
+    s, c = U.device_rng(o3, "test_rank_free", 5, "cpu")
+    assert s == seed0 + 3 * 7919 and int(c) == 17 and c is counter3
+    # ... and one created after the load
+    U._RNG_OWNERS.pop("test_rank_free", None)
+    U.load_device_rng_state({"test_rank_free": saved})
+    o3b = Owner()
+    s, c = U.device_rng(o3b, "test_rank_free", 5, "cpu")
+    assert s == seed0 + 3 * 7919 and int(c) == 17
+    U._RNG_OWNERS.pop("test_rank_free", None)

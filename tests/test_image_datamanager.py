@@ -149,3 +149,66 @@ def test_pipeline_trains_on_the_parsed_nerfosr_fixture(tmp_path):
     assert rb.origins.is_cuda and batch["image"].shape == (32, 3)
     idx, cam_rb, full = pipe.datamanager.next_eval_image(0)
     assert cam_rb.origins.shape[:2] == full["image"].shape[:2]
+
+
+def _fixture_datamanager(tmp_path, device="cpu", test_mode="val", method="per_image", rays=256):
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import dataset_fixture as fx
+    from neusky_amd.data import dataparsers as dp
+    from neusky_amd.data.image_datamanager import NeuSkyDataManagerConfig
+    root = fx.build_nerfosr(str(tmp_path))
+    cfg = NeuSkyDataManagerConfig(
+        dataparser=dp.NeRFOSRCityScapesDataParserConfig(data=root, scene="site1", crop_to_equal_size=True, mask_vegetation=True,
+                                                        session_holdout_indices=[0, 0, 0], mask_out_of_view_frustum_objects=True),
+        train_num_rays_per_batch=64, eval_num_rays_per_batch=rays)
+    return cfg.setup(device=device, test_mode=test_mode, eval_latent_optimise_method=method)
+
+
+def test_eval_half_bundle_draws_from_every_eval_image(tmp_path):
+    """neusky_datamanager.py:288-305: the eval-latent fit samples the whole cached eval batch -- every eval image's latent row gets
+    rays (a default of image 0 left all other eval latents at their zero initialisation); num_val / num_test as :114-119"""
+    dm = _fixture_datamanager(tmp_path)
+    n_eval = len(dm.eval_dataset)
+    assert n_eval > 1 and dm.num_val == n_eval
+    assert dm.num_test == len(dm.dataparser.get_dataparser_outputs(split="test").image_filenames)
+    seen = set()
+    for _ in range(4):
+        rb, batch = dm.get_eval_image_half_bundle(sample_region="left_image_half")
+        assert (batch["indices"][:, 2] < dm.eval.W // 2).all() and batch["mask"][:, 0].all()
+        assert torch.equal(rb.camera_indices[:, 0], batch["indices"][:, 0])
+        seen |= set(batch["indices"][:, 0].tolist())
+    assert seen == set(range(n_eval)), seen
+    rb, batch = dm.get_eval_image_half_bundle(sample_region="full_image", image_index=1)
+    assert set(batch["indices"][:, 0].tolist()) == {1}
+
+
+def test_nerfosr_session_modes(tmp_path):
+    """neusky_datamanager.py:120-122,183-233,239-253,307-330: one latent per capture session; the optimise bundle comes from the held-out
+    image of each session, the compare bundle from the images with an evaluation mask, image indices are replaced by session indices"""
+    dm = _fixture_datamanager(tmp_path, test_mode="test", method="nerf_osr_holdout")
+    md = dm.eval_dataset.metadata
+    n_sessions = len(md["session_to_indices"])
+    assert dm.num_val == dm.num_test == n_sessions == 3
+    for stage, images in (("optimise", dm.holdout_indices), ("compare", dm.compare_indices)):
+        rb, batch = dm.get_nerfosr_lighting_eval_bundle(stage)
+        sess = batch["indices"][:, 0]
+        assert set(sess.tolist()) <= {md["indices_to_session"][i] for i in images} and torch.equal(rb.camera_indices[:, 0], sess)
+        assert batch["mask"][:, 0].all() and batch["image"].shape == (256, 3)
+    idx, cam_rb, full = dm.next_eval_image(0)
+    assert idx == md["indices_to_session"][dm.compare_indices[0]] and int(cam_rb.camera_indices.unique()) == idx
+    with pytest.raises(ValueError):
+        _fixture_datamanager(tmp_path, method="per_image").get_nerfosr_lighting_eval_bundle("optimise")
+
+
+def test_datamanager_generator_state_round_trip(tmp_path):
+    """exact resume (utils/checkpoints.py): the train / eval generators are part of the checkpoint"""
+    dm = _fixture_datamanager(tmp_path)
+    dm.next_train(0)
+    state = dm.state_dict()
+    a = dm.next_train(1)[1]["indices"].clone()
+    e = dm.next_eval(1)[1]["indices"].clone()
+    dm.next_train(2)
+    dm.load_state_dict(state)
+    assert torch.equal(dm.next_train(1)[1]["indices"], a) and torch.equal(dm.next_eval(1)[1]["indices"], e)
