@@ -21,7 +21,7 @@ def test_load_reference_state_dict_cpu():
         "_model.field.deviation_network.variance": torch.tensor([0.42]),
         "_model.train_illumination_latents": torch.rand(pipe.model.train_illumination_latents.shape, generator=g),
         "_model.visibility_threshold": torch.tensor(0.77),
-        "_model.proposal_networks.0.mlp_base.params": torch.zeros(10),
+        "_model.proposal_networks.0.mlp_base.unknown_blob": torch.zeros(10),
         "_model.visibility_field.field.ddf.net.0.linear.weight": torch.zeros(4),
         "datamanager.something": torch.zeros(1),
     }
@@ -41,7 +41,7 @@ def test_load_reference_state_dict_cpu():
     }
     state.update(extra)
     loaded, unmapped = load_reference_pipeline_state(pipe, state)
-    assert sorted(unmapped) == ["_model.proposal_networks.0.mlp_base.params", "_model.visibility_field.field.ddf.net.0.linear.weight"]
+    assert sorted(unmapped) == ["_model.proposal_networks.0.mlp_base.unknown_blob", "_model.visibility_field.field.ddf.net.0.linear.weight"]
     assert len(loaded) == 9 + len(extra)
     assert torch.equal(ddf.net[0].layer.weight.detach(), extra["_model.visibility_field.field.ddf.net.0.layer.weight"])
     assert torch.equal(ddf.mapping_network.network[2].bias.detach(), extra["_model.visibility_field.field.ddf.mapping_network.network.2.bias"])
@@ -161,3 +161,95 @@ def test_device_rng_state_is_rank_free(monkeypatch):
     s, c = U.device_rng(o3b, "test_rank_free", 5, "cpu")
     assert s == seed0 + 3 * 7919 and int(c) == 17
     U._RNG_OWNERS.pop("test_rank_free", None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tests/golden/ref_state_dict.npz: a state dict written by the REFERENCE's own modules (make_golden_checkpoint.py)
+def _ref_fixture_pipeline(device):
+    """the reduced NeuSky whose shapes the fixture was generated for (make_golden_checkpoint.py: DDF, FIELD)"""
+    cfg = small_pipeline_config(R=8, images=3)
+    d = cfg.visibility_field.ddf_field
+    d.hidden_features, d.hidden_layers, d.mapping_features, d.mapping_layers = 128, 2, 128, 2
+    f = cfg.model.sdf_field
+    f.hidden_dim, f.geo_feat_dim, f.hidden_dim_color = 64, 64, 64
+    torch.manual_seed(0)
+    return cfg.setup(device=device)
+
+
+def _ref_fixture(golden_dir):
+    import os
+
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "ref_state_dict.npz"))
+    state = {k: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith("_model.")}
+    rng = np.random.default_rng(20240704)  # fixture_inputs() of the generator
+    x = rng.uniform(-1.0, 1.0, (4096, 15)).astype(np.float32)
+    cond = (0.5 * rng.standard_normal((4096, 35))).astype(np.float32)
+    pts = rng.uniform(-0.8, 0.8, (512, 3)).astype(np.float32)
+    feat = (0.3 * rng.standard_normal((512, 64))).astype(np.float32)
+    return g, state, torch.from_numpy(x), torch.from_numpy(cond), torch.from_numpy(pts), torch.from_numpy(feat)
+
+
+def test_reference_generated_state_dict_maps_completely(golden_dir):
+    """every key the reference's DDFFiLMSiren / weight-normed colour + geometry stacks write lands on a parameter: nothing unmapped,
+    values identical, and the weight the kernels consume is torch's weight_norm product of the loaded (g, v)"""
+    from neusky_amd.utils.checkpoints import load_reference_pipeline_state
+    pipe = _ref_fixture_pipeline("cpu")
+    g, state, *_ = _ref_fixture(golden_dir)
+    loaded, unmapped = load_reference_pipeline_state(pipe, state)
+    assert unmapped == [] and sorted(loaded) == sorted(state)
+    ddf, f = pipe.model.visibility_field.field.ddf, pipe.model.field
+    own = dict(ddf.named_parameters())
+    for k, v in state.items():
+        if ".ddf." in k:
+            assert torch.equal(own[k.split(".ddf.")[1]].detach(), v.float()), k
+    assert torch.equal(f.clin0.weight_v.detach(), state["_model.field.clin0.weight_v"].float())
+    assert torch.allclose(f.glin1.weight().detach(), torch.from_numpy(g["expect.glin1_weight"]), rtol=1e-6, atol=1e-7)
+    assert abs(float(f.deviation_network.variance) - 0.3) < 1e-3
+
+
+def test_tcnn_fused_mlp_blob_decoding():
+    """tiny-cuda-nn's published FullyFusedMLP layout (UNPINNED: no tcnn source or CUDA-written checkpoint here): row-major [out, in]
+    fp16 matrices, widths padded to 16, no biases; NetworkWithInputEncoding stores [network | encoding]"""
+    from neusky_amd.utils.checkpoints import decode_tcnn_fused_mlp, load_reference_pipeline_state
+    pipe = small_pipeline_config(R=8, images=3).setup(device="cpu")
+    net = pipe.model.proposal_networks[0]
+    gen = torch.Generator().manual_seed(5)
+    w0 = torch.zeros(16, 16); w0[:, :10] = torch.randn(16, 10, generator=gen)
+    w1 = torch.zeros(16, 16); w1[0] = torch.randn(16, generator=gen)
+    table = (torch.rand(net.encoding.params.numel(), generator=gen) - 0.5) * 1e-2
+    blob = torch.cat([w0.reshape(-1), w1.reshape(-1), table]).half()
+    layers, used = decode_tcnn_fused_mlp(blob, 10, 16, 1, 1)
+    assert used == 512 and layers[0][0].shape == (16, 10) and layers[1][0].shape == (1, 16)
+    loaded, unmapped = load_reference_pipeline_state(pipe, {"_model.proposal_networks.0.mlp_base.params": blob})
+    assert loaded == ["_model.proposal_networks.0.mlp_base.params"] and unmapped == []
+    assert torch.equal(net.lin0.weight.detach(), w0[:, :10].half().float()) and torch.equal(net.lin1.weight.detach(), w1[:1].half().float())
+    assert float(net.lin0.bias.abs().max()) == 0.0 and torch.equal(net.encoding.params.detach(), table.half().float())
+    # the network blob alone, next to a separately stored table
+    loaded, _ = load_reference_pipeline_state(pipe, {"_model.proposal_networks.1.mlp_base.1.params": blob[:512]})
+    assert loaded and torch.equal(pipe.model.proposal_networks[1].lin0.weight.detach(), w0[:, :10].half().float())
+    with pytest.raises(ValueError):
+        load_reference_pipeline_state(pipe, {"_model.proposal_networks.0.mlp_base.params": blob[:100]})
+
+
+@pytest.mark.gpu
+def test_reference_state_dict_reproduces_reference_outputs_on_the_kernels(golden_dir):
+    """the reference's own modules wrote the weights AND the expected outputs; loaded through
+    load_reference_pipeline_state, the HIP chain kernels (4 096 rows: the fused FiLM-SIREN forward) and the colour layers reproduce them"""
+    from neusky_amd.utils.checkpoints import load_reference_pipeline_state
+    pipe = _ref_fixture_pipeline("cuda:0")
+    g, state, x, cond, pts, feat = _ref_fixture(golden_dir)
+    loaded, unmapped = load_reference_pipeline_state(pipe, state)
+    assert unmapped == [] and len(loaded) == len(state)
+    dev = "cuda:0"
+    ddf = pipe.model.visibility_field.field.ddf
+    pad4 = lambda t: torch.nn.functional.pad(t, (0, (-t.shape[1]) % 4)).contiguous().to(dev)  # noqa: E731
+    with torch.no_grad():
+        res = ddf(pad4(x), pad4(cond))
+        ref = torch.from_numpy(g["expect.ddf_raw"])
+        err = (res.cpu() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-4, err
+        rgb = pipe.model.field.get_colors(pts.to(dev), feat.to(dev))
+        ref_c = torch.from_numpy(g["expect.albedo"])
+        err_c = (rgb.cpu() - ref_c).abs().max().item()
+        assert err_c < 1e-4, err_c
