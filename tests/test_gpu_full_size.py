@@ -134,3 +134,148 @@ def test_full_size_chain_backward_rows_against_float64_autograd():
     dF = rows(dfp, 2 * n_film * H)
     assert rel(dF.t() @ rows(hs[-1]), p["ddf.map_wo"].grad) < 3e-4
     assert rel(dF.sum(0), p["ddf.map_bo"].grad) < 3e-4
+
+
+# per-tensor-family bars of tests/test_gpu_step.py (fractions of the tensor's largest |gradient|)
+def _family(k):
+    return ("ddf.table" if k == "ddf.table" else k.split("_")[0]) if k.startswith("ddf.") else k.split(".")[0].split("_")[0]
+
+
+def test_full_size_backward_oracle_slice(full_forward):
+    """The BACKWARD of the 1024 x 96 x 512 step against the float64 oracle: a probe objective on the rendered radiance of the 16
+    slice rays (random weights) is differentiated by the HIP path through the full-size launches (hemisphere composite, visibility,
+    the DDF chain backward and its weight-gradient launch over 263 456 rows, the fused field backward over 99 304 points, the owner
+    scatter into the hash tables, the illumination decoder's chain over 154 624 rows) and by torch autograd through the oracle's
+    evaluation of those 16 rays alone -- the probe involves no other ray, so the two gradients are the same mathematical object."""
+    from test_gpu_step import GRAD_BARS, _module_grads
+    from util_step import oracle_params, oracle_step_cfg
+    f = full_forward
+    pipe, rb, rnd, outs = f["pipe"], f["rb"], f["rnd"], f["outs"]
+    idx = torch.tensor([0, 1, 63, 64, 127, 255, 256, 300, 511, 512, 700, 767, 768, 900, 1022, 1023])
+    w = torch.randn(len(idx), 3, generator=torch.Generator().manual_seed(21), dtype=torch.float64)
+    for q in pipe.parameters():
+        q.grad = None
+    (outs["rgb"][idx.to(DEV)] * w.float().to(DEV)).sum().backward(retain_graph=True)
+    for q in pipe.parameters():  # (the radiance does not reach every parameter: the proposal networks train through their own loss)
+        if q.grad is None:
+            q.grad = torch.zeros_like(q)
+    got = _module_grads(pipe)
+    p = oracle_params(pipe)
+    light = pipe.model.illumination_sampler(rotation=rnd["light_rotation"]).double()
+    jit = [j[idx].double() for j in rnd["jitters"]]
+    with torch.enable_grad():
+        *_, rgb = O.neusky_forward_rays(p, oracle_step_cfg(pipe), rb.origins.cpu().double()[idx], rb.directions.cpu().double()[idx],
+                                        rb.camera_indices.cpu().reshape(-1)[idx], jit, light)
+        keys = ["train_latents", "train_scale", "visibility_threshold", "field.variance", "field.table", "ddf.table"] + \
+               [k for k in p if k.startswith(("ddf.map_", "ddf.film_", "ddf.out_", "field.glin", "field.clin"))]
+        ref = torch.autograd.grad((rgb * w).sum(), [p[k] for k in keys], allow_unused=True)
+        # the same probe through the oracle in float32 (the reference's own arithmetic): how ill-conditioned each gradient of THIS
+        # objective is -- a 16-ray probe leaves the cancelling sums of the DDF's mapping network and hash table far fewer terms
+        # than the batch objective the fixed bars were measured on
+        p32 = oracle_params(pipe, dtype=torch.float32)
+        *_, rgb32 = O.neusky_forward_rays(p32, oracle_step_cfg(pipe), rb.origins.cpu().float()[idx], rb.directions.cpu().float()[idx],
+                                          rb.camera_indices.cpu().reshape(-1)[idx], [j.float() for j in jit], light.float())
+        ref32 = torch.autograd.grad((rgb32 * w.float()).sum(), [p32[k] for k in keys], allow_unused=True)
+    rows, bad = [], []
+    for k, r, r32 in zip(keys, ref, ref32):
+        if r is None:
+            continue
+        a, b = got[k].detach().cpu().double().reshape(-1), r.reshape(-1)
+        scale = b.abs().max().item()
+        if scale == 0.0:
+            continue
+        err = (a - b).abs().max().item() / scale
+        gap32 = (r32.double().reshape(-1) - b).abs().max().item() / scale
+        bar = max(GRAD_BARS[_family(k)], 2.5 * gap32)  # never further from exact math than 2.5 x the reference's own fp32 evaluation
+        rows.append((k, err, gap32, bar))
+        if err > bar:
+            bad.append((k, err, gap32, bar))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/r04_full_size_backward_slice.txt", "w") as fh:
+        fh.write("1024x96x512 step, probe objective on 16 rays: max |grad - grad_f64| / max |grad_f64| per tensor: HIP, float32 oracle, bar\n")
+        for k, e, g32, bar in rows:
+            fh.write(f"{k:24s} {e:.3e}  {g32:.3e}  {bar:.1e}\n")
+    assert len(rows) >= 30 and not bad, bad
+
+
+def test_full_size_gradient_slab_default_policy_vs_exact_f32(full_forward):
+    """Every parameter gradient of the full-size training step under the default precision policy (fused chain / field kernels,
+    fp16-split products, streaming weight-gradient kernel, owner scatter) against the SAME step under NSKY_PRECISION=f32 -- a different
+    kernel set (per-layer exact-fp32 MFMA GEMMs, no fused chains) on the same batch and the same injected random draws -- per tensor,
+    with the per-family bars of the oracle comparison (two fp32 evaluations: each sits within its bar of float64)."""
+    from neusky_amd import ops
+    from test_gpu_step import GRAD_BARS, _module_grads
+    from util_step import randoms_to
+    f = full_forward
+    pipe, rb, batch, rnd = f["pipe"], f["rb"], f["batch"], f["rnd"]
+
+    def grads():
+        for q in pipe.parameters():
+            q.grad = None
+        pipe.model.begin_step()
+        _, ld, _ = pipe.get_train_loss_dict(10_000, ray_bundle=rb, batch=batch, randoms=randoms_to(rnd, DEV))
+        sum(ld.values()).backward()
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in _module_grads(pipe).items() if v is not None}, float(sum(ld.values()))
+
+    policy = ops._POLICY
+    assert policy != "f32"
+    g_def, l_def = grads()
+    ops.set_precision_policy("f32")
+    try:
+        g_f32, l_f32 = grads()
+    finally:
+        ops.set_precision_policy(policy)
+        pipe.model.begin_step()
+    assert abs(l_def - l_f32) < 2e-4 * max(abs(l_f32), 1e-3), (l_def, l_f32)
+    rows, bad = [], []
+    for k, b in g_f32.items():
+        if k.startswith("reni.") or k not in g_def:
+            continue
+        scale = b.abs().max().item()
+        if scale == 0.0:
+            continue
+        err = (g_def[k] - b).abs().max().item() / scale
+        rows.append((k, err))
+        if err > GRAD_BARS[_family(k)]:
+            bad.append((k, err, GRAD_BARS[_family(k)]))
+    with open("gpurun_out/r04_full_size_slab_vs_f32.txt", "w") as fh:
+        fh.write("1024x96x512 step: max |grad(default policy) - grad(f32 policy)| / max |grad(f32 policy)| per tensor\n")
+        for k, e in rows:
+            fh.write(f"{k:24s} {e:.3e}  (bar {GRAD_BARS[_family(k)]:.0e})\n")
+    assert len(rows) >= 40 and not bad, bad
+
+
+def test_full_size_render_frame_pixels_against_the_oracle():
+    """BASELINE configs[4] at its own size: ONE 1920 x 1080 frame through the chunked, graph-replayed render pass (512 directions,
+    256 DDF queries per ray, full-size networks and tables); 64 pixels spread over the frame (corners and chunk boundaries
+    included) through the float64 oracle's eval-mode render: radiance <= 1e-4 relative, and the whole frame finite"""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    from util_step import oracle_params, oracle_step_cfg, randomise
+    torch.manual_seed(0)
+    pipe = bench.build_pipeline(DEV, 1, 0)
+    randomise(pipe)
+    m = pipe.model
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(3)
+        m.eval_illumination_latents.copy_((torch.randn(m.eval_illumination_latents.shape, generator=g) * 0.3).to(DEV))
+        m.eval_scale.copy_((1 + 0.2 * torch.rand(m.eval_scale.shape, generator=g)).to(DEV))
+    pipe.eval()
+    H, W = 1080, 1920
+    rb, _, cp, d = bench.frame_1080p_rays(pipe, DEV)
+    out = m.get_outputs_for_camera_ray_bundle(rb, camera_index=0, chunk=4096, use_graph=True)
+    torch.cuda.synchronize()
+    assert out["rgb"].shape == (H, W, 3) and torch.isfinite(out["rgb"]).all()
+    gi = torch.Generator().manual_seed(17)
+    pix = torch.cat([torch.tensor([0, W - 1, (H - 1) * W, H * W - 1, 4095, 4096, 8191, 8192]), torch.randint(0, H * W, (56,), generator=gi)])
+    p = oracle_params(pipe)
+    ref = O.neusky_render({k: v.detach() for k, v in p.items()}, oracle_step_cfg(pipe), cp.double().expand(len(pix), 3).contiguous(),
+                          d.reshape(-1, 3)[pix].double(), m.eval_illumination_latents[0].detach().cpu().double(),
+                          m.eval_scale[0].detach().cpu().double(), m.illumination_sampler.directions.double().cpu(), None)
+    got = out["rgb"].reshape(-1, 3)[pix.to(DEV)].cpu().double()
+    rel = ((got - ref["rgb"]).abs().max() / ref["rgb"].abs().max()).item()
+    with open("gpurun_out/r04_render_1080p_pixels.txt", "w") as fh:
+        fh.write(f"1920x1080 frame, 64-pixel float64 oracle slice: rgb rel err {rel:.3e}\n")
+    assert rel < 1e-4, rel
