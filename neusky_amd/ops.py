@@ -19,12 +19,13 @@ from . import hip
 
 
 # Arithmetic of the dense contractions (operands and results are fp32 in memory either way; see include/neusky_hip.h).  Two policies:
-#   splith (default): every large contraction -- the FiLM-SIREN chains, the SDF / albedo field and all their weight gradients -- is
-#                    fp32-grade: fp16 hi + residual planes on power-of-two pre-scaled operands, three fp16 MFMAs per product (~2^-22).
-#                    The per-layer kernels that remain for SMALL row counts (< 4096 rows: tests, tiny batches) use the fp16 split
-#                    forward (2^11-scaled residual) and a 2-term bf16 split backward; proposal layers and N <= 64 heads: exact fp32 MFMA.
+#   splith (default): every large contraction -- the FiLM-SIREN chains, the sdf value chain, the SDF / albedo field and all their weight
+#                    gradients -- runs on the fused chain kernels at ANY row count: fp32-grade products from fp16 hi + residual planes on
+#                    power-of-two pre-scaled operands, three fp16 MFMAs per product (~2^-22).  Round 4 retired the row-count switches to
+#                    the per-layer kernels and with them the last 2-term bf16 (2^-16) backward products: what still runs per layer (shapes
+#                    the chain kernels do not take, narrow heads, proposal layers) uses the fp16 split forward and the EXACT fp32 MFMA backward.
 #   f32            : every product on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), per-layer kernels only: the measurement reference
-#                    (bench.py's `fp32_exact` line).
+#                    (bench.py's `fp32_exact` line; tests/test_gpu_full_size.py compares the two kernel sets).
 import os as _os
 
 _POLICIES = ("f32", "splith")
@@ -33,16 +34,15 @@ _POLICY = _os.environ.get("NSKY_PRECISION", "splith")
 if _POLICY not in _POLICIES:
     raise ValueError(f"NSKY_PRECISION={_POLICY!r}: expected one of {' | '.join(_POLICIES)}")
 FWD_PRECISION = _FWD.get(_POLICY, hip.PREC_F32)
-BWD_PRECISION = hip.PREC_F32 if _POLICY == "f32" else hip.PREC_BF16X2
+BWD_PRECISION = hip.PREC_F32  # per-layer backward GEMMs: exact fp32 MFMA under either policy
 
 
 def set_precision_policy(policy: str) -> None:
-    global FWD_PRECISION, BWD_PRECISION, _POLICY
+    global FWD_PRECISION, _POLICY
     if policy not in _POLICIES:
         raise ValueError(policy)
     _POLICY = policy
     FWD_PRECISION = _FWD.get(policy, hip.PREC_F32)
-    BWD_PRECISION = hip.PREC_F32 if policy == "f32" else hip.PREC_BF16X2
 
 
 def fgemm(A, W, Cout, M, N, K, **k):
@@ -128,7 +128,7 @@ def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None, acc
             dW, db = flat[:like.numel()].view_as(like), flat[nw:].view_as(bias_like)
         else:
             dW, db = zeros_like(like), None
-    if (BWD_PRECISION == hip.PREC_BF16X2 and a_native_nt == 0 and b_native_nt == 0 and a_scale_max is None and M >= WGRAD_STREAM_MIN_ROWS
+    if (_POLICY == "splith" and a_native_nt == 0 and b_native_nt == 0 and a_scale_max is None and M >= WGRAD_STREAM_MIN_ROWS
             and n_out >= 64 and k_in >= 64 and n_out % 4 == 0 and k_in % 4 == 0 and dZ.is_cuda and ld(dZ) % 4 == 0 and ld(X) % 4 == 0):
         # long reductions over row-major operands (the field's layers): the streaming kernel, dW and db in one pass
         prob = hip.wgrad_problem_rowmajor(dZ, n_out, X, k_in, M, dW, db, 0 if bias_rows is None else bias_rows)
@@ -301,8 +301,6 @@ def ld(t):
 
 def grad_input(dZ, W, M, k_in, n_red, out, **epi):
     """dX[M, k_in] = dZ[M, n_red] @ W[n_red, k_in]   (W stored [out, in] = [n_red, k_in])."""
-    if BWD_PRECISION == hip.PREC_BF16X2 and n_red % _PLANES_K_STEP == 0 and n_red >= _PLANES_MIN_K and k_in > 64 and M >= 4096:
-        return hip.gemm_planes(dZ, _planes(W, k_in, n_red, True, BWD_PRECISION), out, M, k_in, n_red, precision=BWD_PRECISION, **epi)
     return hip.gemm(dZ, W, out, M, k_in, n_red, a_kcontig=True, b_kcontig=False, precision=BWD_PRECISION, **epi)
 
 
@@ -433,7 +431,6 @@ class DenseFn(torch.autograd.Function):
 # =============================================================================================
 # FiLM-SIREN (DDF network, RENI-shaped illumination decoder)
 # =============================================================================================
-FUSED_FILM_MIN_ROWS = 4096  # below: a handful of workgroups each walking a ~0.2 ms serial chain; the per-layer kernels are as fast (measured at 1024 rows)
 _FILM_STREAMS: dict = {}
 
 
@@ -444,7 +441,7 @@ def forget_film_streams(wb) -> None:
 
 
 def _film_fused_ok(M, H, Hm, n_map, n_film, mw, fw, ow, x, cond) -> bool:
-    return (FWD_PRECISION == hip.PREC_F16X2 and M >= FUSED_FILM_MIN_ROWS and x.is_cuda and ld(x) <= 16
+    return (FWD_PRECISION == hip.PREC_F16X2 and x.is_cuda and ld(x) <= 16
             and hip.film_supported(H, Hm, n_map, n_film, mw[0].shape[1], fw[0].shape[1], ow.shape[0])
             and ld(x) >= fw[0].shape[1] and ld(cond) >= mw[0].shape[1])
 
@@ -850,7 +847,6 @@ class SDFAlbedoFn(torch.autograd.Function):
 # =============================================================================================
 # SDF + albedo field as chain kernels (csrc/field_chain.hip)
 # =============================================================================================
-FUSED_FIELD_MIN_POINTS = 1024  # 4096 stacked value + tangent rows: below, a handful of workgroups walk a serial chain
 _FIELD_STREAMS: dict = {}
 
 
@@ -868,7 +864,7 @@ def _field_pack(kind, weights, layers_fn):
 
 
 def field_fused_ok(ET, W0, W1, W2, Wc0, Wc1) -> bool:
-    return (FWD_PRECISION == hip.PREC_F16X2 and ET.is_cuda and ET.shape[0] // 4 >= FUSED_FIELD_MIN_POINTS and ld(ET) == W0.shape[1]
+    return (FWD_PRECISION == hip.PREC_F16X2 and ET.is_cuda and ET.shape[0] >= 4 and ld(ET) == W0.shape[1]
             and hip.field_supported(W0.shape[1], W0.shape[0], W2.shape[0] - 4, Wc1.shape[0], Wc0.shape[1]))
 
 
@@ -976,7 +972,6 @@ def field_apply(ET, *args):
     return SDFAlbedoFn.apply(ET, *args)
 
 
-FUSED_SDF_MIN_ROWS = 4096
 _SDF_STREAMS: dict = {}
 
 
@@ -1006,7 +1001,7 @@ class SDFValueFn(torch.autograd.Function):
         dev = E.device
         Hd, Kin = W0.shape
         GF = W2.shape[0] - 4
-        ctx.fused = (FWD_PRECISION == hip.PREC_F16X2 and M >= FUSED_SDF_MIN_ROWS and E.is_cuda and hip.sdf_supported(Kin, Hd)
+        ctx.fused = (FWD_PRECISION == hip.PREC_F16X2 and E.is_cuda and hip.sdf_supported(Kin, Hd)
                      and ld(E) >= Kin and ld(E) % 4 == 0)
         ctx.cfg = (M, Hd, Kin, GF, beta, train_weights)
         if ctx.fused:

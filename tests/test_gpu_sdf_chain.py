@@ -33,10 +33,11 @@ def _reference(E, ws, g_sdf):
     return sdf.detach(), grads
 
 
-def _run(E, ws, g_sdf, min_rows):
+def _run(E, ws, g_sdf, fused=True):
+    """fused=True: the default policy (the sdf value chain kernels at any row count); False: NSKY_PRECISION=f32, the per-layer exact-fp32 path"""
     from neusky_amd import ops
-    old = ops.FUSED_SDF_MIN_ROWS
-    ops.FUSED_SDF_MIN_ROWS = min_rows
+    policy = ops._POLICY
+    ops.set_precision_policy(policy if fused else "f32")
     try:
         ops.begin_step(DEV)
         Eg = E.clone().requires_grad_(True)
@@ -44,7 +45,7 @@ def _run(E, ws, g_sdf, min_rows):
         grads = torch.autograd.grad((sdf * g_sdf).sum(), [Eg] + list(ws))
         torch.cuda.synchronize()
     finally:
-        ops.FUSED_SDF_MIN_ROWS = old
+        ops.set_precision_policy(policy)
     return sdf.detach(), grads
 
 
@@ -55,7 +56,7 @@ def _close(got, want, rel, what):
     assert err <= bar, f"{what}: max err {err:.3e} > {bar:.3e}"
 
 
-@pytest.mark.parametrize("M", [4096, 5000, 33000])
+@pytest.mark.parametrize("M", [1, 77, 4096, 5000, 33000])
 def test_fused_sdf_chain_matches_float64(M):
     g = torch.Generator().manual_seed(M)
     E = (torch.randn(M, 72, generator=g) * 0.5).to(DEV)
@@ -63,7 +64,7 @@ def test_fused_sdf_chain_matches_float64(M):
     ws = _weights(seed=M)
     g_sdf = torch.randn(M, generator=g).to(DEV)
     want_sdf, want = _reference(E, ws, g_sdf)
-    sdf, got = _run(E, ws, g_sdf, 1024)
+    sdf, got = _run(E, ws, g_sdf)
     _close(sdf, want_sdf, 2e-6, "sdf")
     names = ["dE", "dW0", "db0", "dW1", "db1", "dW2", "db2"]
     for n, a, b in zip(names, got, want):
@@ -83,8 +84,8 @@ def test_fused_sdf_chain_matches_per_layer_path_large_pre_activations():
     E[:, 71] = 0.0
     ws = _weights(seed=9, scale=2.0)
     g_sdf = torch.randn(M, generator=g).to(DEV)
-    sdf_a, ga = _run(E, ws, g_sdf, 1024)
-    sdf_b, gb = _run(E, ws, g_sdf, 1 << 30)
+    sdf_a, ga = _run(E, ws, g_sdf)
+    sdf_b, gb = _run(E, ws, g_sdf, fused=False)
     want_sdf, want = _reference(E, ws, g_sdf)
     _close(sdf_a, want_sdf, 2e-6, "sdf fused")
     _close(sdf_b, want_sdf, 2e-6, "sdf per-layer")
