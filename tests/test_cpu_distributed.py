@@ -154,14 +154,36 @@ def _pipeline_worker(rank, world, port, out_q):
             gen = torch.Generator().manual_seed(31 * gi + pi)  # same base on both ranks
             base = torch.randn(p.shape, generator=gen)
             p.grad.copy_(base * (rank + 1))  # mean over ranks = 1.5 * base
+    def fill():
+        opt.zero_grad_all()
+        for gi, g in enumerate(opt.groups):
+            for pi, p in enumerate(g.params):
+                if (gi, pi) in skipped:
+                    continue
+                gen = torch.Generator().manual_seed(31 * gi + pi)
+                p.grad.copy_(torch.randn(p.shape, generator=gen) * (rank + 1))
+
+    def check():
+        ok = True
+        for gi, g in enumerate(opt.groups):
+            for pi, p in enumerate(g.params):
+                gen = torch.Generator().manual_seed(31 * gi + pi)
+                base = torch.randn(p.shape, generator=gen)
+                want = torch.zeros_like(base) if (gi, pi) in skipped else 1.5 * base
+                ok &= bool(torch.allclose(p.grad, want, atol=1e-6))
+        return ok
+
     opt.all_reduce_gradients()
-    reduce_ok = True
-    for gi, g in enumerate(opt.groups):
-        for pi, p in enumerate(g.params):
-            gen = torch.Generator().manual_seed(31 * gi + pi)
-            base = torch.randn(p.shape, generator=gen)
-            want = torch.zeros_like(base) if (gi, pi) in skipped else 1.5 * base
-            reduce_ok &= bool(torch.allclose(p.grad, want, atol=1e-6))
+    reduce_ok = check()
+    # the bucketed exchange: asynchronous all-reduces of the two slab ranges (DDF / scalar / latent groups first, then field + proposal),
+    # each group usable once ITS bucket has been waited for; same result as the single message
+    fill()
+    opt.all_reduce_gradients(bucketed=True)
+    buckets = [[g.name for g in gs] for gs, _ in opt._buckets()]
+    reduce_ok &= buckets == [["illumination_field", "visibility_sigmoid", "ddf_field"], ["proposal_networks", "fields"]] and len(opt._pending) == 2
+    for g in opt.groups:
+        opt._wait_bucket_of(g)
+    reduce_ok &= len(opt._pending) == 0 and check()
     state = torch.cat([t.detach().reshape(-1).float() for t in list(pipe.parameters()) + list(pipe.buffers())])
     out_q.put((rank, names, bool(layout_ok), bool(frozen_ok), bool(reduce_ok), len(skipped), float(state.double().sum()),
                float(state.double().abs().sum()), int(opt.flat_g.numel())))
@@ -190,3 +212,47 @@ def test_two_rank_pipeline_groups_slab_and_replicas():
         assert r[5] > 0
     assert r0[6] == r1[6] and r0[7] == r1[7], "replicas differ after the state broadcast (frozen parameters / buffers included)"
     assert r0[8] == r1[8]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the RCCL branch of the exchange (engine.Optimizers.all_reduce_gradients): no process group here, the collectives are recorded
+def test_nccl_branch_of_the_gradient_exchange(monkeypatch):
+    """with backend "nccl" the slab is all-reduced in place with ReduceOp.AVG -- once, or once per bucket asynchronously -- and the
+    optimizer step of a group waits for the bucket that holds it"""
+    import neusky_amd.engine as E
+    params = {k: [torch.nn.Parameter(torch.randn(n))] for k, n in (("proposal_networks", 8), ("fields", 12), ("illumination_field", 4),
+                                                                     ("visibility_sigmoid", 1), ("ddf_field", 16))}
+    opt = E.Optimizers(E.neusky_optimizers(), params, world_size=8)
+    calls, waited, stepped = [], [], []
+
+    class Work:
+        def __init__(self, i):
+            self.i = i
+
+        def wait(self):
+            waited.append(self.i)
+
+    def fake_all_reduce(t, op=None, async_op=False):
+        calls.append((t.data_ptr(), t.numel(), op, async_op))
+        return Work(len(calls) - 1) if async_op else None
+
+    monkeypatch.setattr(E.dist, "get_backend", lambda: "nccl")
+    monkeypatch.setattr(E.dist, "all_reduce", fake_all_reduce)
+    monkeypatch.setattr(E.hip, "adam_step", lambda p, g, *a: stepped.append((g.data_ptr(), list(waited))))
+    opt.all_reduce_gradients()
+    assert calls == [(opt.flat_g.data_ptr(), opt.flat_g.numel(), E.dist.ReduceOp.AVG, False)]
+    calls.clear()
+    opt.all_reduce_gradients(bucketed=True)
+    n_a = sum(g.numel for g in opt.groups if g.name in ("illumination_field", "visibility_sigmoid", "ddf_field"))
+    n_b = sum(g.numel for g in opt.groups if g.name in ("proposal_networks", "fields"))
+    ptr = {g.name: g.flat_g.data_ptr() for g in opt.groups}
+    assert calls == [(ptr["illumination_field"], n_a, E.dist.ReduceOp.AVG, True), (ptr["proposal_networks"], n_b, E.dist.ReduceOp.AVG, True)]
+    opt.optimizer_scheduler_step_all(10)
+    # Adam launches in bucket order; the first bucket's groups only waited for collective 0
+    assert [s[0] for s in stepped] == [ptr[k] for k in ("illumination_field", "visibility_sigmoid", "ddf_field", "proposal_networks", "fields")]
+    assert stepped[0][1] == [0] and stepped[2][1] == [0] and stepped[3][1] == [0, 1] and opt._pending == []
+    # a single process never touches the process group
+    calls.clear()
+    solo = E.Optimizers(E.neusky_optimizers(), {k: [torch.nn.Parameter(torch.randn(4))] for k in params}, world_size=1)
+    solo.all_reduce_gradients()
+    assert calls == []
