@@ -256,6 +256,48 @@ def envmap_decode_line(device):
             "hip_ms": gpu[len(gpu) // 2], "max_rel_diff_hip_vs_cpu": rel, "median_of": 10}
 
 
+def attention_decoder_line(device, steps=5):
+    """the SAME training step with the illumination decoder the reference configures (neusky_config.py:78-95: conditioning="Attention",
+    VN / SO2-about-z invariance, 8 heads x 6 layers, hidden 128) in place of the FiLM-SIREN decoder of the headline: this project's
+    restatement of the published RENI++ architecture (model_components/illumination.py:AttentionDecoder; ns_reni's source and weights
+    are absent from the reference tree: PARITY UNPINNED, own oracle oracle.reni_attention_decode).  Its query side runs as batched
+    library GEMMs + softmax / layer-norm launches, not on this package's chain kernels; eager launches, median of `steps` iterations."""
+    from neusky_amd.engine import Optimizers, neusky_optimizers, train_iteration
+    from neusky_amd.configs.neusky_config import synthetic_pipeline_config
+    from neusky_amd.utils.randomise import randomise
+    cfg = synthetic_pipeline_config()
+    cfg.model.num_neus_samples_per_ray = SAMPLES
+    cfg.model.num_proposal_samples_per_ray = tuple(PROPOSAL)
+    cfg.model.illumination_sampler.num_directions = DIRECTIONS
+    cfg.datamanager.train_num_rays_per_batch = RAYS
+    cfg.model.illumination_field.conditioning = "Attention"
+    torch.manual_seed(0)
+    pipe = cfg.setup(device=device, world_size=1, local_rank=0)
+    pipe.train()
+    randomise(pipe)
+    opt = Optimizers(neusky_optimizers(), pipe.get_param_groups())
+    batches = [pipe.datamanager.next_train(i) for i in range(3)]
+    for i in range(2):
+        train_iteration(pipe, opt, 3000 + i, ray_bundle=batches[i][0], batch=batches[i][1])
+    torch.cuda.synchronize()
+    ts = []
+    for i in range(steps):
+        t0 = time.perf_counter()
+        loss, _, _ = train_iteration(pipe, opt, 3002 + i, ray_bundle=batches[i % 3][0], batch=batches[i % 3][1])
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    ms = ts[len(ts) // 2]
+    out = {"workload": "full NeuSky train step as the headline, illumination decoder = RENI++ attention decoder (neusky_config.py:78-95): "
+                       "300 cameras x 512 directions + 1024 ray rows, 100 tokens, 8 heads x 6 layers, hidden 128",
+           "ms_per_step": ms, "rays_per_s": RAYS / (ms * 1e-3), "launch": "eager", "final_loss": float(loss),
+           "parity": "unpinned (decoder source and weights absent from the reference tree); HIP path vs oracle.reni_attention_decode: tests/test_illumination_attention.py",
+           "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9}
+    del pipe, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 def frame_1080p_rays(pipe, device, H=1080, W=1920):
     """the 1920 x 1080 pinhole frame of the render-pass configuration: camera 0 of the synthetic scene, focal 1100 px
     (-> the frame's ray bundle, a bundle factory for sub-frames, the camera position and the [H, W, 3] unit directions)"""
@@ -550,6 +592,7 @@ def main():
         }
         if world == 1 and not args.no_extra_configs:
             line["envmap_decode"] = envmap_decode_line(device)
+            line["attention_decoder"] = attention_decoder_line(device)
             line["forward_only"] = forward_only_line(pipe, device)
             line["render_1080p"] = render_1080p_line(pipe, device)
         if world == 1 and not args.no_cpu_baseline:

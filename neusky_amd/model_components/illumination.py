@@ -240,9 +240,9 @@ class AttentionDecoder(nn.Module):
       output:   log-HDR rgb = Wout LNf(q);   radiance = exp(.) * scale
 
     t_n is LINEAR in (d_x, d_y): t_n(d) = d_x A_n + d_y B_n + C_n with A, B, C functions of the latent only.  K and V of a camera are
-    therefore three [L, H] matrices each (per layer), shared by all of its directions: scores and values for the D directions of a
-    camera are dense products [D, 16] x [16, 3 L] and [D, 3 L] x [3 L, 16] per head -- the per-(camera, direction) token matrix
-    (U D L H = 2 G floats per layer at 300 cameras x 512 directions) is never formed.  The batched products run on the matrix cores
+    therefore three [L, H] matrices each (per layer), shared by all of its directions; the weights (d_x, d_y, 1) move to the query
+    side, so scores and values for the D directions of a camera are dense products [D, 48] x [48, L] and [D, L] x [L, 48] per head
+    -- the per-(camera, direction) token matrix (U D L H = 2 G floats per layer at 300 cameras x 512 directions) is never formed.  The batched products run on the matrix cores
     through the library GEMM (torch.bmm -> rocBLAS, exact fp32); this conditioning mode is outside the benchmarked step, which uses the
     FiLM-SIREN decoder on this package's own chain kernels."""
 
@@ -285,19 +285,23 @@ class AttentionDecoder(nn.Module):
         T3 = torch.cat([A, B, C], 1)  # [U, 3 L, H]
         coef = torch.stack([dirs[..., 0], dirs[..., 1], torch.ones_like(dirs[..., 0])], -1)  # [U, D, 3]
         q = self.query_embed(self.query_inputs(dirs))  # [U, D, H]
-        heads = lambda t, n: t.reshape(U, n, nh, dh).transpose(1, 2)  # noqa: E731  [U, nh, n, dh]
+        # t_n(d) = d_x A_n + d_y B_n + C_n makes every key / value a sum of three per-camera vectors weighted by (d_x, d_y, 1).  The
+        # weights move to the QUERY side: q . k_n(d) = [d_x q | d_y q | q] . [kA_n | kB_n | kC_n], a contraction over 3 dh = 48 per head,
+        # and sum_n p_n v_n(d) = d_x (p VA) + d_y (p VB) + (p VC): scores and values are ONE [D, 48] x [48, L] and ONE [D, L] x [L, 48]
+        # product per head and camera; neither the [U, nh, D, 3, L] score parts nor a [D, 3 L] probability matrix is ever formed.
+        L = self.L
+        parts = lambda t: t.reshape(U, 3, L, nh, dh).permute(0, 3, 2, 1, 4).reshape(U, nh, L, 3 * dh)  # noqa: E731  [U, nh, L, (part, dh)]
+        cx = coef.reshape(U, 1, D, 3, 1)
         for blk in self.layers:
-            K3, V3 = heads(blk.wk(T3), 3 * self.L), heads(blk.wv(T3), 3 * self.L)
+            K3, V3 = blk.wk(T3), blk.wv(T3)  # [U, 3 L, H]
             # the bias of K / V belongs to the constant part only: remove it from the d_x and d_y thirds
-            bk, bv = blk.wk.bias.reshape(1, nh, 1, dh), blk.wv.bias.reshape(1, nh, 1, dh)
-            mask = torch.cat([torch.ones(2 * self.L, device=T3.device), torch.zeros(self.L, device=T3.device)]).reshape(1, 1, -1, 1)
-            K3, V3 = K3 - bk * mask, V3 - bv * mask
-            Q = heads(blk.wq(blk.ln1(q)), D) * (dh ** -0.5)
-            S3 = torch.matmul(Q, K3.transpose(-1, -2)).reshape(U, nh, D, 3, self.L)  # q . (A_n, B_n, C_n parts of k_n)
-            S = (S3 * coef.reshape(U, 1, D, 3, 1)).sum(3)  # [U, nh, D, L]
-            P = torch.softmax(S, -1)
-            P3 = (P.unsqueeze(3) * coef.reshape(U, 1, D, 3, 1)).reshape(U, nh, D, 3 * self.L)
-            O = torch.matmul(P3, V3).transpose(1, 2).reshape(U, D, H)
+            mask = torch.cat([torch.ones(2 * L, device=T3.device), torch.zeros(L, device=T3.device)]).reshape(1, -1, 1)
+            Kt, Vt = parts(K3 - blk.wk.bias * mask), parts(V3 - blk.wv.bias * mask)
+            Q = (blk.wq(blk.ln1(q)) * (dh ** -0.5)).reshape(U, D, nh, 1, dh).transpose(1, 2)  # [U, nh, D, 1, dh]
+            Qt = (Q * cx).reshape(U, nh, D, 3 * dh)
+            P = torch.softmax(torch.matmul(Qt, Kt.transpose(-1, -2)), -1)  # [U, nh, D, L]
+            O3 = torch.matmul(P, Vt).reshape(U, nh, D, 3, dh)
+            O = (O3 * cx).sum(3).transpose(1, 2).reshape(U, D, H)
             q = q + blk.wo(O)
             q = q + blk.ff2(torch.relu(blk.ff1(blk.ln2(q))))
         return self.out(self.ln_f(q))
