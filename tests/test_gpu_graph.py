@@ -105,3 +105,59 @@ def test_proposal_anneal_follows_the_step_under_graph_replay():
         e = float(total_loss(ld))
         assert abs(e - seen[s][1]) <= 1e-5 * abs(e), (s, e, seen[s][1])
     assert abs(seen[5][1] - seen[2000][1]) > 1e-6 * abs(seen[5][1])  # the anneal really changes the step
+
+
+def test_icosphere_direction_set_trains_and_replays():
+    """the reference's own direction set (neusky_config.py:97-101 -> illumination_samplers.py:85-119: an icosphere; order 8 = 642
+    vertices here, the nearest to its num_directions = 512) instead of the default antipodal lattice: the set is centrally symmetric,
+    so exactly D / 2 = 321 directions lie in the upper hemisphere after any rotation -- static shapes, the graph path applies -- and the
+    step's radiance matches the float64 oracle on the same (rotated) set; a replayed graph reproduces the eager step"""
+    from neusky_amd.engine import GraphedTrainStep, Optimizers, neusky_optimizers
+    from neusky_amd.model_components.losses import total_loss
+    from oracle import neusky_oracle as O
+    from util_step import make_randoms, oracle_params, oracle_randoms, oracle_step_cfg, randoms_to
+    torch.manual_seed(0)
+    cfg = small_pipeline_config(R=32, num_prop=(32, 16), S=12, D=32, vmf=(2, 16), sky=16, images=5)
+    cfg.model.illumination_sampler.icosphere_order = 8
+    pipe = cfg.setup(device=DEV)
+    pipe.train()
+    randomise(pipe)
+    D = pipe.model.illumination_sampler.directions.shape[0]
+    assert D == 642
+    base = pipe.model.illumination_sampler.directions
+    assert (torch.cdist(base.double(), -base.double()).min(dim=1).values < 1e-5).all(), "the icosphere is centrally symmetric"
+    opt = Optimizers(neusky_optimizers(), pipe.get_param_groups())
+    rb, batch = pipe.datamanager.next_train(0)
+    R = 32
+    rnd_host = make_randoms(pipe, R)
+    rnd = randoms_to(rnd_host, DEV)
+    for k in ("light_rotation", "grid_perturb", "grid_dirs"):
+        rnd[k] = rnd[k].to(DEV)
+    step = 10_000
+    pipe.model.set_step(step)
+    opt.zero_grad_all()
+    outs, ld, _ = pipe.get_train_loss_dict(step, ray_bundle=rb, batch=batch, randoms=rnd)
+    assert outs["visibility_dict"]["visibility"].shape == (R, D)
+    assert outs["visibility_dict"]["expected_termination_dist"].numel() == R * (D // 2)
+    total_loss(ld).backward()
+    eager_ld = {k: float(v.detach()) for k, v in ld.items()}
+    eager_g = opt.flat_g.clone()
+    got = outs["rgb"].detach().cpu().double()
+    del outs, ld
+    p = oracle_params(pipe)
+    light = pipe.model.illumination_sampler(rotation=rnd_host["light_rotation"]).double()
+    ref_ld, ref = O.neusky_train_step(p, oracle_step_cfg(pipe), rb.origins.cpu().double(), rb.directions.cpu().double(),
+                                      rb.camera_indices.cpu().reshape(-1), batch["image"].cpu().double(), batch["mask"].cpu(),
+                                      oracle_randoms(rnd_host, light), light)
+    rel = ((got - ref["rgb"].detach()).abs().max() / ref["rgb"].detach().abs().max()).item()
+    assert rel < 1e-4, rel
+    for k, v in ref_ld.items():
+        assert abs(eager_ld[k] - float(v)) < 2e-4 * max(abs(float(v)), 1e-3), (k, eager_ld[k], float(v))
+    stepper = GraphedTrainStep(pipe, opt, rb, batch, warmup=2, start_step=step, randoms=rnd)
+    stepper.load(rb, batch, sky=rnd["sky_ray_bundle"])
+    pipe.model.set_step(step)
+    stepper.graph.replay()
+    torch.cuda.synchronize()
+    for k, v in stepper.loss_dict.items():
+        assert abs(float(v) - eager_ld[k]) <= 1e-6 * max(abs(eager_ld[k]), 1e-3), (k, float(v), eager_ld[k])
+    assert float((opt.flat_g - eager_g).abs().max()) <= 1e-5 * float(eager_g.abs().max())
