@@ -298,6 +298,37 @@ def attention_decoder_line(device, steps=5):
     return out
 
 
+def global_batch_line(device, rays=8192, steps=5):
+    """BASELINE configs[3]'s GLOBAL batch (8192 rays) as ONE GPU's batch (eager launches, median of `steps`): what the 288 GB of one
+    MI355X allow when no 8-GPU node is at hand -- 2.1 M DDF rows per step; fixed per-step costs (slab fills, Adam over the hash tables,
+    weight packing) and the last-round tails of the big launches are amortised over 8 x the rays.  Not the headline (that is 1024
+    rays per GPU, weak scaling); parity at this size: tests/test_gpu_full_size.py::test_global_batch_of_configs3_on_one_gpu_forward_slice."""
+    from neusky_amd.engine import Optimizers, neusky_optimizers, train_iteration
+    from neusky_amd.utils.randomise import randomise
+    torch.manual_seed(0)
+    torch.cuda.reset_peak_memory_stats()
+    pipe = build_pipeline(device, 1, 0, rays=rays)
+    randomise(pipe)
+    opt = Optimizers(neusky_optimizers(), pipe.get_param_groups())
+    batches = [pipe.datamanager.next_train(i) for i in range(3)]
+    for i in range(2):
+        train_iteration(pipe, opt, 3000 + i, ray_bundle=batches[i][0], batch=batches[i][1])
+    torch.cuda.synchronize()
+    ts = []
+    for i in range(steps):
+        t0 = time.perf_counter()
+        train_iteration(pipe, opt, 3002 + i, ray_bundle=batches[i % 3][0], batch=batches[i % 3][1])
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    ms = ts[len(ts) // 2]
+    out = {"workload": f"full NeuSky train step, {rays} rays x {SAMPLES} samples x {DIRECTIONS} directions on ONE GPU (the global batch of BASELINE configs[3])",
+           "ms_per_step": ms, "rays_per_s": rays / (ms * 1e-3), "launch": "eager", "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9}
+    del pipe, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 def frame_1080p_rays(pipe, device, H=1080, W=1920):
     """the 1920 x 1080 pinhole frame of the render-pass configuration: camera 0 of the synthetic scene, focal 1100 px
     (-> the frame's ray bundle, a bundle factory for sub-frames, the camera position and the [H, W, 3] unit directions)"""
@@ -593,6 +624,7 @@ def main():
         if world == 1 and not args.no_extra_configs:
             line["envmap_decode"] = envmap_decode_line(device)
             line["attention_decoder"] = attention_decoder_line(device)
+            line["global_batch_8192_one_gpu"] = global_batch_line(device)
             line["forward_only"] = forward_only_line(pipe, device)
             line["render_1080p"] = render_1080p_line(pipe, device)
         if world == 1 and not args.no_cpu_baseline:

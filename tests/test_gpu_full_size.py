@@ -279,3 +279,47 @@ def test_full_size_render_frame_pixels_against_the_oracle():
     with open("gpurun_out/r04_render_1080p_pixels.txt", "w") as fh:
         fh.write(f"1920x1080 frame, 64-pixel float64 oracle slice: rgb rel err {rel:.3e}\n")
     assert rel < 1e-4, rel
+
+
+def test_global_batch_of_configs3_on_one_gpu_forward_slice():
+    """BASELINE configs[3]'s GLOBAL batch (8192 rays x 96 samples x 512 directions) as ONE rank's batch: 2.1 M DDF rows, 0.79 M field
+    points, a [2.1 M, 2560] gradient matrix of 5.4 G elements in the backward (64-bit indexing everywhere), ~93 GB of the 288 GB: the
+    forward's radiance on 12 rays spread over the batch against the float64 oracle, and one full backward + optimizer step stays finite.
+    (The 8-GPU form shards these rays 1024 per rank: per-rank work = configs[2], exchange = one all-reduce of the gradient slab.)"""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    from neusky_amd.engine import Optimizers, neusky_optimizers
+    from neusky_amd.model_components.losses import total_loss
+    from util_step import make_randoms, oracle_params, oracle_step_cfg, randomise, randoms_to
+    torch.manual_seed(0)
+    R = 8192
+    pipe = bench.build_pipeline(DEV, 1, 0, rays=R)
+    randomise(pipe)
+    opt = Optimizers(neusky_optimizers(), pipe.get_param_groups())
+    rb, batch = pipe.datamanager.next_train(0)
+    rnd = make_randoms(pipe, R)
+    pipe.model.set_step(10_000)
+    opt.zero_grad_all()
+    outs, ld, _ = pipe.get_train_loss_dict(10_000, ray_bundle=rb, batch=batch, randoms=randoms_to(rnd, DEV))
+    assert outs["rgb"].shape == (R, 3) and torch.isfinite(outs["rgb"]).all()
+    idx = torch.tensor([0, 1, 1023, 1024, 2047, 3000, 4095, 4096, 6000, 7168, 8190, 8191])
+    p = oracle_params(pipe)
+    light = pipe.model.illumination_sampler(rotation=rnd["light_rotation"]).double()
+    jit = [j[idx].double() for j in rnd["jitters"]]
+    with torch.enable_grad():  # (the oracle takes its normals from torch.autograd.grad, as the reference does)
+        samp, *_, rgb = O.neusky_forward_rays(p, oracle_step_cfg(pipe), rb.origins.cpu().double()[idx], rb.directions.cpu().double()[idx],
+                                              rb.camera_indices.cpu().reshape(-1)[idx], jit, light)
+    rgb = rgb.detach()
+    for got, ref in zip(outs["pdf_inds_list"], samp["inds_list"]):
+        assert torch.equal(got.cpu().to(torch.int64)[idx], ref)
+    rel = ((outs["rgb"].detach().cpu().double()[idx] - rgb).abs().max() / rgb.abs().max()).item()
+    assert rel < 1e-4, rel
+    total_loss(ld).backward()
+    opt.collect_grads()
+    assert torch.isfinite(opt.flat_g).all() and float(opt.flat_g.abs().max()) > 0
+    opt.optimizer_scheduler_step_all(10_000)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(g.flat_p).all() for g in opt.groups)
+    with open("gpurun_out/r04_global_batch_8192.txt", "w") as fh:
+        fh.write(f"8192 rays x 96 x 512 on one MI355X: rgb rel err of a 12-ray float64 slice {rel:.3e}; peak memory {torch.cuda.max_memory_allocated() / 1e9:.1f} GB\n")
