@@ -1100,13 +1100,27 @@ __global__ __launch_bounds__(512, 2) void sdf_bwd_kernel(const SdfBwdArgs a) {
         const int r = 4 * gq + q;
         dv[r] = g * ww[q] * -expm1f(-beta * av[r]);
         m = fmaxf(m, fabsf(dv[r]));
-        if (a.dw2) {
-          float p = g * av[r];
-#pragma unroll
-          for (int off = 16; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);  // over the 32 rows of this lane half
-          if (c == 0) atomicAdd(dw2s + 32 * t + 8 * gq + 4 * h + q, p);
-        }
       }
+    }
+    if (a.dw2) {
+      // dw2[feature] += sum over the 32 rows of this lane half of g a1: a halving butterfly (at every step a lane keeps the half of
+      // its values its bit selects and adds the partner's: 8 + 4 + 2 + 1 + 1 = 16 exchanges instead of 16 x 5), after which lane
+      // (c, h) holds the row sum of accumulator register 8 c4 + 4 c3 + 2 c2 + c1 and the even lanes add theirs: one LDS atomic
+      float v8[8], v4[4], v2[2];
+      const bool b4 = (c & 16) != 0, b3 = (c & 8) != 0, b2 = (c & 4) != 0, b1 = (c & 2) != 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float lo = g * av[j], hi = g * av[8 + j];
+        v8[j] = (b4 ? hi : lo) + __shfl_xor(b4 ? lo : hi, 16, 64);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v4[j] = (b3 ? v8[4 + j] : v8[j]) + __shfl_xor(b3 ? v8[j] : v8[4 + j], 8, 64);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) v2[j] = (b2 ? v4[2 + j] : v4[j]) + __shfl_xor(b2 ? v4[j] : v4[2 + j], 4, 64);
+      float v1 = (b1 ? v2[1] : v2[0]) + __shfl_xor(b1 ? v2[0] : v2[1], 2, 64);
+      v1 += __shfl_xor(v1, 1, 64);
+      const int r = (b4 ? 8 : 0) + (b3 ? 4 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0);
+      if ((c & 1) == 0) atomicAdd(dw2s + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3), v1);
     }
     store_tile(dz1blk + t * 1024, lane, dv);
   }
