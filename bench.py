@@ -580,7 +580,7 @@ def main():
         peak = PEAK_BF16_MFMA_TFLOPS / 3.0
         for k in kernels:
             k["frac_of_833_tflops"] = k["achieved_tflops"] / peak
-        traffic, tsrc, traffic_note = None, os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"), ""
+        traffic, tsrc, traffic_note = None, os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"), ""
         dom = kernels[0]
         if os.path.exists(tsrc):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_bench.sh; not re-collected live)
             tj = json.load(open(tsrc))
@@ -589,7 +589,7 @@ def main():
             srcs = [os.path.join(ROOT, "neusky_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "neusky_amd", "csrc"))]
             if max(os.path.getmtime(f) for f in srcs) > os.path.getmtime(tsrc) + 60 and tj.get("kernel_sources_sha") != _sources_sha(srcs):
                 traffic_note = " (STALE: the kernel sources changed after the counters were collected)"
-                print("bench.py: warning: profiles/r03_pmc_traffic.json predates the kernel sources; re-run tools/pmc_bench.sh", file=sys.stderr)
+                print("bench.py: warning: profiles/r04_pmc_traffic.json predates the kernel sources; re-run tools/pmc_bench.sh", file=sys.stderr)
         roof = {"bound": "mfma", "achieved": dom["achieved_tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["achieved_tflops"] / peak}
         if "algorithmic_bytes_per_launch" in dom and dom["algorithmic_bytes_per_launch"] / (HBM_PEAK_GBS * 1e9) > dom["algorithmic_flops_per_launch"] / (peak * 1e12):
             roof = {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["achieved_GBs"] / HBM_PEAK_GBS}
@@ -609,7 +609,7 @@ def main():
                        "parallelism": f"ray-sharded dp{world}", "final_loss": final_loss,
                        "launch": "HIP graph replay (1 graph/step + all-reduce + 5 Adam launches)" if use_graph else "eager (host launches every kernel)" + graph_note},
             "roofline": {**roof, "traffic": traffic,
-                         "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r03_pmc_traffic.json)" + traffic_note,
+                         "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r04_pmc_traffic.json)" + traffic_note,
                          "kernel": dom["kernel"] + " = the kernel family with the largest total time in the three eager timing iterations (per launch: the median of the three)",
                          "peak_note": ("HBM3E ~8 TB/s; achieved = algorithmic bytes (inputs, saved activations and outputs once each) / launch time; "
                                        "the kernel's byte floor exceeds its flop floor at 833.3 TFLOP/s") if roof["bound"] == "hbm" else
