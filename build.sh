@@ -10,7 +10,10 @@ for f in $SRCS; do
   o="build/$(basename $f).o"
   OBJS="$OBJS $o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ include/neusky_hip.h -nt "$o" ] || [ neusky_amd/csrc/common.h -nt "$o" ] || [ neusky_amd/csrc/chain.h -nt "$o" ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$f" -o "$o" &
+    EXTRA=""
+    # attention.hip: scalar (SGPR) operands feed plain v_fmac; the SLP vectoriser's v_pk_fma_f32 needs them copied into VGPR pairs first
+    case "$f" in *attention.hip) EXTRA="-fno-slp-vectorize";; esac
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $EXTRA -c "$f" -o "$o" &
     pids="$pids $!"
   fi
 done

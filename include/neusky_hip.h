@@ -27,7 +27,7 @@ extern "C" {
 typedef void* nsky_stream_t; /* hipStream_t */
 
 const char* nsky_last_error(void);
-int nsky_abi_version(void); /* 11 (bumped when a struct layout or an entry point's signature changes) */
+int nsky_abi_version(void); /* 12 (bumped when a struct layout or an entry point's signature changes) */
 
 /* ------------------------------------------------------------------------------------------
  * Dense layer on the matrix cores: C[M,N] = epilogue( sum_k A(m,k) * B(n,k) + bias[n] )
@@ -625,6 +625,20 @@ int nsky_main_losses_bwd(const nsky_main_losses_desc* d, const float* wsum, cons
  * (neusky_model.py:1071-1072).  None of it is differentiated. */
 int nsky_train_metrics(const float* pred, const float* gt, const float* mask, int64_t n, float peak_sq, const float* variance, float* out,
                        nsky_stream_t stream);
+/* Attention core of the RENI++ transformer decoder -- the illumination model the reference configures (neusky/configs/neusky_config.py:78-95:
+ * conditioning="Attention", VN invariance, SO2 about z, 8 heads x 6 layers, hidden 128) and decodes at neusky/models/neusky_model.py:488-506,
+ * 535-549.  The `reni` package holding the decoder is absent from the reference tree: the arithmetic follows the published architecture as
+ * restated in oracle/neusky_oracle.py:reni_attention_decode (PARITY UNPINNED).  For every camera u, direction d and head h (head width 16):
+ *     q~ = scale * [d_x q | d_y q | q],   s_n = q~ . K~[u,h,n],   p = softmax_n(s),   o = d_x (p V~)[0:16] + d_y (p V~)[16:32] + (p V~)[32:48]
+ * with K~, V~ [U, n_heads, L, 48] the per-camera key / value parts (the token is linear in (d_x, d_y): three 16-wide parts per token, L <= 128),
+ * Q, O, dO, dQ [U, D, 16 n_heads] row-major, dirs [U, D, 3], row_max / row_sum [U, n_heads, D] (saved by the forward for the backward).
+ * Replaces the per-head `softmax(Q K^T) V` of the decoder's cross-attention (two batched matrix products, a softmax and their autograd nodes per
+ * layer); exact fp32 arithmetic.  _bwd returns dQ and the per-camera dK~, dV~ (summed over the camera's D rows); directions carry no gradient. */
+int nsky_attn_core_fwd(const float* Q, const float* dirs, const float* Kt, const float* Vt, int32_t U, int32_t D, int32_t L, int32_t n_heads,
+                       float scale, float* O, float* row_max, float* row_sum, nsky_stream_t stream);
+int nsky_attn_core_bwd(const float* Q, const float* dirs, const float* Kt, const float* Vt, const float* O, const float* row_max,
+                       const float* row_sum, const float* dO, int32_t U, int32_t D, int32_t L, int32_t n_heads, float scale, float* dQ,
+                       float* dKt, float* dVt, float* drow_scratch /* [U, n_heads, D] */, nsky_stream_t stream);
 /* The step's objective: total = sum over segments of scale_s * sum_i coef_s[i] x_s[i] (coef NULL: 1).  Replaces the dozen scalar
  * multiplies, sums and adds that scale and merge the loss dictionaries (nerfstudio scale_dict + functools.reduce(torch.add, ...),
  * neusky_pipeline.py:283-289; interlevel_loss' mean, neusky_model.py:987-988) by one launch each way.  One workgroup; bwd writes

@@ -52,7 +52,7 @@ class GemmDesc(C.Structure):
 
 _lib.nsky_last_error.restype = C.c_char_p
 _lib.nsky_abi_version.restype = C.c_int
-ABI_VERSION = 11  # the ctypes structures below mirror this version of include/neusky_hip.h
+ABI_VERSION = 12  # the ctypes structures below mirror this version of include/neusky_hip.h
 if _lib.nsky_abi_version() != ABI_VERSION:
     raise NeuSkyHipError(f"libneusky_hip.so has ABI version {_lib.nsky_abi_version()}, this package binds version {ABI_VERSION}: rebuild (build.sh)")
 
@@ -529,6 +529,32 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     n = p.numel()
     assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
     check(_adam(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, beta1, beta2, eps, step, grad_scale, stream_ptr()), "nsky_adam_step")
+
+
+# ------------------------------------------------------------------------------------------ attention core (RENI++ transformer decoder)
+_attn_fwd = _sig("nsky_attn_core_fwd", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_attn_bwd = _sig("nsky_attn_core_bwd", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                 C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+
+
+def attn_core_fwd(Q, dirs, Kt, Vt, scale, O, row_max, row_sum):
+    """Q [U,D,16 nh], dirs [U,D,3], Kt / Vt [U,nh,L,48] -> O [U,D,16 nh], row_max / row_sum [U,nh,D] (include/neusky_hip.h)"""
+    U, D, H = Q.shape
+    nh, L = Kt.shape[1], Kt.shape[2]
+    assert H == 16 * nh and Kt.shape[3] == 48 and all(t.is_contiguous() for t in (Q, dirs, Kt, Vt, O, row_max, row_sum))
+    check(_attn_fwd(ptr(Q), ptr(dirs), ptr(Kt), ptr(Vt), U, D, L, nh, float(scale), ptr(O), ptr(row_max), ptr(row_sum), stream_ptr()),
+          "nsky_attn_core_fwd")
+    return O
+
+
+def attn_core_bwd(Q, dirs, Kt, Vt, O, row_max, row_sum, dO, scale, dQ, dKt, dVt):
+    U, D, H = Q.shape
+    nh, L = Kt.shape[1], Kt.shape[2]
+    assert all(t.is_contiguous() for t in (Q, dirs, Kt, Vt, O, row_max, row_sum, dO, dQ, dKt, dVt))
+    drow = torch.empty_like(row_sum)  # D = dO . O per row and head: from the row kernel to the token kernel
+    check(_attn_bwd(ptr(Q), ptr(dirs), ptr(Kt), ptr(Vt), ptr(O), ptr(row_max), ptr(row_sum), ptr(dO), U, D, L, nh, float(scale),
+                    ptr(dQ), ptr(dKt), ptr(dVt), ptr(drow), stream_ptr()), "nsky_attn_core_bwd")
 
 
 # ------------------------------------------------------------------------------------------ fused loss terms

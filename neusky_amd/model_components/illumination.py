@@ -297,11 +297,16 @@ class AttentionDecoder(nn.Module):
             # the bias of K / V belongs to the constant part only: remove it from the d_x and d_y thirds
             mask = torch.cat([torch.ones(2 * L, device=T3.device), torch.zeros(L, device=T3.device)]).reshape(1, -1, 1)
             Kt, Vt = parts(K3 - blk.wk.bias * mask), parts(V3 - blk.wv.bias * mask)
-            Q = (blk.wq(blk.ln1(q)) * (dh ** -0.5)).reshape(U, D, nh, 1, dh).transpose(1, 2)  # [U, nh, D, 1, dh]
-            Qt = (Q * cx).reshape(U, nh, D, 3 * dh)
-            P = torch.softmax(torch.matmul(Qt, Kt.transpose(-1, -2)), -1)  # [U, nh, D, L]
-            O3 = torch.matmul(P, Vt).reshape(U, nh, D, 3, dh)
-            O = (O3 * cx).sum(3).transpose(1, 2).reshape(U, D, H)
+            Qp = blk.wq(blk.ln1(q))  # [U, D, H]
+            if Qp.is_cuda and dh == 16 and L <= 128 and D >= 32:
+                # the attention core as HIP kernels (csrc/attention.hip): no [U, nh, D, L] score / probability matrices in memory
+                O = ops.AttnCoreFn.apply(Qp, dirs, Kt, Vt, dh ** -0.5)
+            else:  # the same arithmetic as batched products (CPU; a handful of rows per camera: the rays' own rows)
+                Q = (Qp * (dh ** -0.5)).reshape(U, D, nh, 1, dh).transpose(1, 2)  # [U, nh, D, 1, dh]
+                Qt = (Q * cx).reshape(U, nh, D, 3 * dh)
+                P = torch.softmax(torch.matmul(Qt, Kt.transpose(-1, -2)), -1)  # [U, nh, D, L]
+                O3 = torch.matmul(P, Vt).reshape(U, nh, D, 3, dh)
+                O = (O3 * cx).sum(3).transpose(1, 2).reshape(U, D, H)
             q = q + blk.wo(O)
             q = q + blk.ff2(torch.relu(blk.ff1(blk.ln2(q))))
         return self.out(self.ln_f(q))

@@ -1647,3 +1647,33 @@ class DDFLossesFn(torch.autograd.Function):
         for k, i in enumerate(idx):
             res[i] = outs[k]
         return tuple(res)
+
+
+# =============================================================================================
+# attention core of the RENI++ transformer decoder (csrc/attention.hip)
+# =============================================================================================
+class AttnCoreFn(torch.autograd.Function):
+    """O[u, d] = per-head softmax_n(q~ . K~_n) V~ combined with (d_x, d_y, 1) -- model_components/illumination.py:AttentionDecoder.
+    Q [U, D, H] (H = 16 heads_n), dirs [U, D, 3] (no gradient), Kt / Vt [U, heads, L, 48] -> O [U, D, H].  Saves Q, O and two row
+    statistics per head (instead of the [U, heads, D, L] score / probability matrices of the batched-product form)."""
+
+    @staticmethod
+    def forward(ctx, Q, dirs, Kt, Vt, scale):
+        Q, dirs, Kt, Vt = Q.contiguous(), dirs.contiguous(), Kt.contiguous(), Vt.contiguous()
+        U, D, H = Q.shape
+        nh = Kt.shape[1]
+        O = torch.empty_like(Q)
+        rmax = torch.empty(U, nh, D, device=Q.device)
+        rsum = torch.empty(U, nh, D, device=Q.device)
+        hip.attn_core_fwd(Q, dirs, Kt, Vt, scale, O, rmax, rsum)
+        ctx.save_for_backward(Q, dirs, Kt, Vt, O, rmax, rsum)
+        ctx.scale = scale
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        Q, dirs, Kt, Vt, O, rmax, rsum = ctx.saved_tensors
+        dO = dO.contiguous()
+        dQ, dKt, dVt = torch.empty_like(Q), torch.empty_like(Kt), torch.empty_like(Vt)
+        hip.attn_core_bwd(Q, dirs, Kt, Vt, O, rmax, rsum, dO, ctx.scale, dQ, dKt, dVt)
+        return dQ, None, dKt, dVt, None

@@ -33,8 +33,8 @@ def _field(L=12, device="cpu", seed=0):
     return f
 
 
-def _check(device):
-    L, U, D = 12, 4, 9
+def _check(device, D=9):
+    L, U = 12, 4
     f = _field(L, device)
     g = torch.Generator().manual_seed(1)
     lat = (torch.randn(U, L, 3, generator=g) * 0.6).to(device).requires_grad_(True)
@@ -62,7 +62,45 @@ def test_attention_decoder_matches_the_oracle_cpu():
 
 @pytest.mark.gpu
 def test_attention_decoder_matches_the_oracle_gpu():
-    _check("cuda:0")
+    _check("cuda:0")          # a handful of directions per camera: the batched-product form
+
+
+@pytest.mark.gpu
+def test_attention_decoder_on_the_core_kernels():
+    """D = 70 directions per camera: the attention core runs on csrc/attention.hip (partial workgroups, partial row blocks).  Values
+    against the float64 oracle; latent gradients against the SAME decoder with the batched-product core on the same device (1e-5) --
+    against float64 only to 5e-3: among the 4 x 70 x 256 x 6 ReLU units of the feed-forward blocks a pre-activation of ~1e-8 takes the
+    other branch in float32 (measured: 7.4e-4 of the gradient maximum, identical for both cores and with every Linear / LayerNorm
+    evaluated in float64)."""
+    from neusky_amd import ops
+    dev, L, U, D = "cuda:0", 12, 4, 70
+    res = {}
+    kernel_apply = ops.AttnCoreFn.apply
+    try:
+        for mode in ("kernel", "products"):
+            if mode == "products":
+                ops.AttnCoreFn.apply = staticmethod(lambda Q, dirs, Kt, Vt, scale: _attn_core_reference(Q, dirs, Kt, Vt, scale))
+            f = _field(L, dev)
+            g = torch.Generator().manual_seed(1)
+            lat = (torch.randn(U, L, 3, generator=g) * 0.6).to(dev).requires_grad_(True)
+            dirs = torch.randn(D, 3, generator=g)
+            dirs = (dirs / dirs.norm(dim=-1, keepdim=True)).to(dev)
+            sc = (torch.rand(U, generator=g) + 0.5).to(dev)
+            got = f.forward_grid(dirs, lat, sc)
+            wts = torch.randn(U, D, 3, generator=g).to(dev)
+            (got * wts).sum().backward()
+            res[mode] = (got.detach().cpu().double(), lat.grad.cpu().double())
+    finally:
+        ops.AttnCoreFn.apply = kernel_apply
+    p = attn_params(f.network)
+    lat64 = lat.detach().cpu().double().requires_grad_(True)
+    ref = O.reni_attention_decode(lat64[:, None].expand(U, D, L, 3).reshape(-1, L, 3), dirs.cpu().double()[None].expand(U, D, 3).reshape(-1, 3),
+                                  sc.cpu().double()[:, None].expand(U, D).reshape(-1), p).reshape(U, D, 3)
+    (ref * wts.cpu().double()).sum().backward()
+    rel = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()  # noqa: E731
+    assert rel(res["kernel"][0], ref.detach()) < 2e-5
+    assert rel(res["kernel"][0], res["products"][0]) < 1e-5 and rel(res["kernel"][1], res["products"][1]) < 1e-5
+    assert rel(res["kernel"][1], lat64.grad) < 5e-3
 
 
 def test_so2_equivariance_about_z():
@@ -118,3 +156,42 @@ def test_train_step_with_the_attention_decoder():
         assert torch.isfinite(loss), ld
     assert not torch.equal(pipe.model.train_illumination_latents.detach(), lat0)
     assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in pipe.model.illumination_field.network.parameters())
+
+
+def _attn_core_reference(Q, dirs, Kt, Vt, scale):
+    """the batched-product form of the attention core (float64): q~ = scale [d_x q | d_y q | q], softmax(q~ K~^T) V~, combine"""
+    U, D, H = Q.shape
+    nh, L = Kt.shape[1], Kt.shape[2]
+    dh = H // nh
+    cx = torch.stack([dirs[..., 0], dirs[..., 1], torch.ones_like(dirs[..., 0])], -1).reshape(U, 1, D, 3, 1)
+    Qh = (Q * scale).reshape(U, D, nh, 1, dh).transpose(1, 2)
+    Qt = (Qh * cx).reshape(U, nh, D, 3 * dh)
+    P = torch.softmax(Qt @ Kt.transpose(-1, -2), -1)
+    O3 = (P @ Vt).reshape(U, nh, D, 3, dh)
+    return (O3 * cx).sum(3).transpose(1, 2).reshape(U, D, H)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("U,D,L,nh", [(3, 512, 100, 8), (2, 77, 36, 8), (5, 33, 128, 2), (1, 1, 4, 1), (4, 64, 12, 8), (4, 70, 12, 8)])
+def test_attention_core_kernels_match_float64(U, D, L, nh):
+    """nsky_attn_core_fwd / _bwd (csrc/attention.hip) against the float64 batched-product form and its autograd: output, dQ and the
+    per-camera dK~, dV~ (summed over the camera's rows); ragged D (partial workgroups, partial row blocks of the token kernel)"""
+    from neusky_amd import ops
+    g = torch.Generator().manual_seed(U * 1000 + D)
+    H = 16 * nh
+    Q = torch.randn(U, D, H, generator=g, dtype=torch.float64)
+    dirs = torch.nn.functional.normalize(torch.randn(U, D, 3, generator=g, dtype=torch.float64), dim=-1)
+    Kt = torch.randn(U, nh, L, 48, generator=g, dtype=torch.float64) * 0.7
+    Vt = torch.randn(U, nh, L, 48, generator=g, dtype=torch.float64)
+    dO = torch.randn(U, D, H, generator=g, dtype=torch.float64)
+    ref_in = [t.clone().requires_grad_(True) for t in (Q, Kt, Vt)]
+    ref = _attn_core_reference(ref_in[0], dirs, ref_in[1], ref_in[2], 0.25)
+    ref.backward(dO)
+    dev = "cuda:0"
+    got_in = [t.float().to(dev).requires_grad_(True) for t in (Q, Kt, Vt)]
+    got = ops.AttnCoreFn.apply(got_in[0], dirs.float().to(dev), got_in[1], got_in[2], 0.25)
+    got.backward(dO.float().to(dev))
+    rel = lambda a, b: (a.detach().cpu().double() - b).abs().max().item() / max(b.abs().max().item(), 1e-30)  # noqa: E731
+    assert rel(got, ref.detach()) < 5e-6
+    for name, a, b in zip(("dQ", "dK~", "dV~"), got_in, ref_in):
+        assert rel(a.grad, b.grad) < 2e-5, (name, rel(a.grad, b.grad))
