@@ -420,7 +420,9 @@ class DenseFn(torch.autograd.Function):
         dZ = dY.contiguous()
         if act == "relu":
             dZ = torch.ops.aten.threshold_backward(dZ, Y, 0.0)  # dY where Y > 0, one pass (no mask tensor)
-        dW, db = grad_weight(dZ, X, M, n_out, K, Wp, bp)
+        dW = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:  # (a frozen layer -- the RENI++ decoder -- takes no weight gradient)
+            dW, db = grad_weight(dZ, X, M, n_out, K, Wp, bp)
         dX = None
         if need_dx:
             dX = torch.empty(M, K, device=X.device)
