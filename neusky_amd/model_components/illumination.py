@@ -272,6 +272,18 @@ class AttentionDecoder(nn.Module):
         C = zz * E[:, 2] + r * E[:, 3] + e
         return A, B, C
 
+    @staticmethod
+    def _linear(x: torch.Tensor, lin: nn.Linear, act: str = "none") -> torch.Tensor:
+        """lin(x) (+ ReLU) over the last dimension: on the device and for long batches this package's dense-layer kernel (fp32-grade
+        fp16-split products, bias and activation in the epilogue; exact-fp32 input gradient), otherwise torch"""
+        K, N = lin.weight.shape[1], lin.weight.shape[0]
+        rows = x.numel() // K
+        if x.is_cuda and rows >= 4096 and K % 4 == 0 and N % 4 == 0 and N > 64:
+            y = ops.DenseFn.apply(x.reshape(rows, K).contiguous(), lin.weight, lin.bias, N, act, True)
+            return y.reshape(*x.shape[:-1], N)
+        y = torch.nn.functional.linear(x, lin.weight, lin.bias)
+        return torch.relu(y) if act == "relu" else y
+
     def query_inputs(self, dirs: torch.Tensor) -> torch.Tensor:
         x = torch.stack([torch.sqrt(dirs[..., 0] ** 2 + dirs[..., 1] ** 2 + 1e-20), dirs[..., 2]], -1)
         return torch.cat([x, nerf_encoding(x, 2, 2.0)], -1)
@@ -293,11 +305,11 @@ class AttentionDecoder(nn.Module):
         parts = lambda t: t.reshape(U, 3, L, nh, dh).permute(0, 3, 2, 1, 4).reshape(U, nh, L, 3 * dh)  # noqa: E731  [U, nh, L, (part, dh)]
         cx = coef.reshape(U, 1, D, 3, 1)
         for blk in self.layers:
-            K3, V3 = blk.wk(T3), blk.wv(T3)  # [U, 3 L, H]
+            K3, V3 = self._linear(T3, blk.wk), self._linear(T3, blk.wv)  # [U, 3 L, H]
             # the bias of K / V belongs to the constant part only: remove it from the d_x and d_y thirds
             mask = torch.cat([torch.ones(2 * L, device=T3.device), torch.zeros(L, device=T3.device)]).reshape(1, -1, 1)
             Kt, Vt = parts(K3 - blk.wk.bias * mask), parts(V3 - blk.wv.bias * mask)
-            Qp = blk.wq(blk.ln1(q))  # [U, D, H]
+            Qp = self._linear(blk.ln1(q), blk.wq)  # [U, D, H]
             if Qp.is_cuda and dh == 16 and L <= 128 and D >= 32:
                 # the attention core as HIP kernels (csrc/attention.hip): no [U, nh, D, L] score / probability matrices in memory
                 O = ops.AttnCoreFn.apply(Qp, dirs, Kt, Vt, dh ** -0.5)
@@ -307,8 +319,8 @@ class AttentionDecoder(nn.Module):
                 P = torch.softmax(torch.matmul(Qt, Kt.transpose(-1, -2)), -1)  # [U, nh, D, L]
                 O3 = torch.matmul(P, Vt).reshape(U, nh, D, 3, dh)
                 O = (O3 * cx).sum(3).transpose(1, 2).reshape(U, D, H)
-            q = q + blk.wo(O)
-            q = q + blk.ff2(torch.relu(blk.ff1(blk.ln2(q))))
+            q = q + self._linear(O, blk.wo)
+            q = q + self._linear(self._linear(blk.ln2(q), blk.ff1, "relu"), blk.ff2)
         return self.out(self.ln_f(q))
 
 
