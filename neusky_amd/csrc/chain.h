@@ -140,6 +140,22 @@ template <int N>
 __device__ __forceinline__ void frag_wait(f16x8& h, f16x8& l) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(h), "+v"(l) : "n"(N) : "memory");
 }
+// The LAST wait of a product and the hand-over of the landed fragments to the registers that carry them into the next product, as
+// ONE statement.  A tied ("+v") operand lets the register allocator satisfy the tie with a copy IN FRONT of the statement when the
+// value has to change registers anyway (here it does: three buffers rotate over KS k-steps, the carried pair must end where the
+// next product expects buffer 0), and a copy in front of the wait captures whatever the destination of the in-flight ds_read held:
+// the field kernels of round 3 were built that way (v_mov_b64 x 4, then s_waitcnt lgkmcnt(0)) and gave one wave a stale first
+// k-step of its next tile in about one launch of six (tools/isa_lint.py checks every kernel for the pattern).
+// Here the moves are the statement's own, behind the wait; sources and destinations are separate (early-clobber) operands.
+__device__ __forceinline__ void frag_settle(f16x8& ch, f16x8& cl, const f16x8& h, const f16x8& l) {
+  typedef unsigned long u64x2 __attribute__((ext_vector_type(2)));
+  const u64x2 sh = __builtin_bit_cast(u64x2, h), sl = __builtin_bit_cast(u64x2, l);
+  unsigned long h0, h1, l0, l1;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\tv_mov_b64 %0, %4\n\tv_mov_b64 %1, %5\n\tv_mov_b64 %2, %6\n\tv_mov_b64 %3, %7"
+               : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1) : "v"(sh[0]), "v"(sh[1]), "v"(sl[0]), "v"(sl[1]) : "memory");
+  ch = __builtin_bit_cast(f16x8, u64x2{h0, h1});
+  cl = __builtin_bit_cast(f16x8, u64x2{l0, l1});
+}
 
 template <int RG = RING_GROUPS>
 __device__ __forceinline__ uint32_t ws_addr(const WStream& w, int group, int slab) {
@@ -220,12 +236,10 @@ __device__ __forceinline__ void product(WStream& w, const f16x8 (&bh)[KS], const
     __builtin_amdgcn_sched_barrier(0);
     // fragments of k-step ks + 1 (slab KS = first slab of the next tile): only the pair requested above may still be in flight
     if (ks + 2 <= KS) frag_wait<2>(fh[(ks + 1) % 3], fl[(ks + 1) % 3]);
-    else frag_wait<0>(fh[(ks + 1) % 3], fl[(ks + 1) % 3]);
   }
-  // nothing is in flight here (the last wait was lgkmcnt(0)): no load crosses a loop back-edge or a branch join, where the
-  // compiler is free to insert register copies
-  w.ch = fh[KS % 3];
-  w.cl = fl[KS % 3];
+  // the last wait (lgkmcnt(0)) and the carry in one statement: nothing is in flight behind it, no load crosses a loop back-edge or
+  // a branch join
+  frag_settle(w.ch, w.cl, fh[KS % 3], fl[KS % 3]);
   w.g = g0 + NG;
 }
 
@@ -255,13 +269,11 @@ __device__ __forceinline__ void product_pair(WStream& w, const f16x8 (&bh)[4], c
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks % 3], bh[ks & 3], acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (ks + 2 <= KS) frag_wait<2>(fh[(ks + 1) % 3], fl[(ks + 1) % 3]);
-    else frag_wait<0>(fh[(ks + 1) % 3], fl[(ks + 1) % 3]);
   };
   request(1);
   step(0, a0); step(1, a0); step(2, a0); step(3, a0);
   step(4, a1); step(5, a1); step(6, a1); step(7, a1);
-  w.ch = fh[KS % 3];
-  w.cl = fl[KS % 3];
+  frag_settle(w.ch, w.cl, fh[KS % 3], fl[KS % 3]);
   w.g = g0 + 1;
 }
 
@@ -284,9 +296,7 @@ __device__ __forceinline__ void product_dyn(WStream& w, int ksn, const f16x8 (&b
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      frag_wait<0>(nh, nl);
-      ah = nh;
-      al = nl;
+      frag_settle(ah, al, nh, nl);
     }
   }
   w.ch = ah;

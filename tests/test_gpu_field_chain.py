@@ -233,3 +233,25 @@ def test_native_weighted_colsum_and_masked_bias():
     wantb = dZ.double()[0::4].sum(0)
     assert (dW.cpu().double() - wantW).abs().max() <= 3e-5 * wantW.abs().max()
     assert (db.cpu().double() - wantb).abs().max() <= 3e-5 * wantb.abs().max()
+
+
+def test_fused_field_is_bitwise_repeatable():
+    """The four field kernels have no atomics on their activation outputs: repeated launches on the same inputs must agree to the
+    bit.  Round 3's build did not (tools/isa_lint.py, chain.h frag_settle): one wave's tile of d(encode rows) came out wrong in
+    about one launch of six at this size, from weight fragments copied before their LDS read had landed."""
+    from neusky_amd import ops
+    N = 33001
+    g = torch.Generator().manual_seed(N)
+    ET = _inputs(N, N + 1)
+    ws = _weights(seed=N)
+    g_sdf, g_grad, g_alb = torch.randn(N, generator=g).to(DEV), torch.randn(N, 3, generator=g).to(DEV), torch.randn(N, 3, generator=g).to(DEV)
+    first = None
+    for it in range(40):
+        sdf, grad, alb, got = _run(ops.FieldChainFn, ET, ws, g_sdf, g_grad, g_alb)
+        cur = {"sdf": sdf, "grad": grad, "albedo": alb, "dET": got[0][:, :KIN - 1]}
+        if first is None:
+            first = {k: v.clone() for k, v in cur.items()}
+            continue
+        for k, v in cur.items():
+            bad = (v != first[k]).reshape(v.shape[0], -1).any(dim=1)
+            assert not bool(bad.any()), f"launch {it}: {k} differs from launch 0 in {int(bad.sum())} rows, first {torch.nonzero(bad).flatten()[:8].tolist()}"

@@ -196,3 +196,42 @@ def test_fused_backward_matches_float64_autograd(H, n_map, n_film, cond_dim, x_d
     w0 = ops.pad_weight(net.net[0].layer.weight)
     dW, db = ops.grad_weight(dzs[0], xp, M, H, xp.shape[1], w0, net.net[0].layer.bias, a_native_nt=H // 32)
     assert rel(dW[:, :x_dim].cpu().double(), p["ddf.film_w0"].grad) < 3e-4 and rel(db.cpu().double(), p["ddf.film_b0"].grad) < 3e-4
+
+
+@pytest.mark.parametrize("H,n_map,n_film,cond_dim,x_dim,out_dim", [(256, 5, 5, 35, 15, 1), (128, 5, 9, 300, 10, 3)])
+def test_fused_chain_is_bitwise_repeatable(H, n_map, n_film, cond_dim, x_dim, out_dim):
+    """no atomics on the activation outputs of the three chain kernels: repeated launches agree to the bit (the rule
+    tools/isa_lint.py checks statically; the mapping backward of round 3's build violated it)"""
+    from neusky_amd import hip
+    M = 66000 + 37
+    net = _net(H, n_map, n_film, cond_dim, x_dim, out_dim)
+    cond, x = _inputs(M, cond_dim, x_dim)
+    lins = net.mapping_network.linears()
+    desc = hip.film_net(cond_dim, x_dim, out_dim, [l.weight for l in lins[:-1]], [l.bias for l in lins[:-1]], lins[-1].weight, lins[-1].bias,
+                        [l.layer.weight for l in net.net], [l.layer.bias for l in net.net], net.final_layer.weight, net.final_layer.bias)
+    (s0, t0), (s1, t1), (s2, t2) = _pack(desc, 0), _pack(desc, 1), _pack(desc, 2)
+    Mp = hip.film_rows(M)
+    mk = lambda n, w=H: [torch.full((Mp, w), float("nan"), device=DEV) for _ in range(n)]  # noqa: E731
+    g = torch.Generator().manual_seed(5)
+    d_res = torch.zeros(M, 4); d_res[:, :out_dim] = torch.randn(M, out_dim, generator=g)
+    d_res, cond, x = d_res.to(DEV), cond.to(DEV), x.to(DEV)
+    first = None
+    for it in range(16):
+        hs, zs, ys, dzs, dpres = mk(n_map), mk(n_film), mk(n_film), mk(n_film), mk(n_map)
+        res = torch.empty(M, 4, device=DEV)
+        dfp = torch.full((Mp, 2 * n_film * H), float("nan"), device=DEV)
+        rowmax = torch.full((Mp,), float("nan"), device=DEV)
+        d_cond = torch.full((M, cond.shape[1]), float("nan"), device=DEV)
+        d_x = torch.full((M, x.shape[1]), float("nan"), device=DEV)
+        gmax = torch.zeros(n_film + 1 + n_map, device=DEV)
+        hip.film_chain_fwd(desc, s0, t0, cond, x, M, hs, zs, ys, res)
+        hip.film_chain_bwd_film(desc, s1, t1, M, d_res, hs[-1], zs, dzs, dfp, rowmax, gmax[:n_film + 1], d_x)
+        hip.film_chain_bwd_map(desc, s2, t2, M, dfp, rowmax, hs, dpres, d_cond, gmax[n_film + 1:])
+        torch.cuda.synchronize()
+        cur = {"res": res[:, :out_dim], "z_last": zs[-1][:M], "dz0": dzs[0][:M], "dfp": dfp[:M], "dpre0": dpres[0][:M], "d_cond": d_cond[:, :cond_dim], "d_x": d_x[:, :x_dim]}
+        if first is None:
+            first = {k: v.clone() for k, v in cur.items()}
+            continue
+        for k, v in cur.items():
+            bad = (v != first[k]).reshape(v.shape[0], -1).any(dim=1)
+            assert not bool(bad.any()), f"launch {it}: {k} differs from launch 0 in {int(bad.sum())} rows, first {torch.nonzero(bad).flatten()[:8].tolist()}"
