@@ -102,6 +102,245 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_core_fwd_kernel(const AttnAr
   a.rsum[st] = l;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The forward on the matrix cores (rows of a camera in blocks of 128: four waves x 32 rows; the VALU kernel above keeps the short
+// blocks: a ray's own row, D < 32).  Both products of a head run as fp32-grade fp16 hi + residual splits (3 x v_mfma_f32_32x32x16_f16
+// per product, the chain kernels' arithmetic), tokens on the M side:
+//     S^T[token, row] = K~[token, 48] q~^T[48, row]      4 token tiles x 3 k-steps        A = K~ fragments (LDS), B = q~ planes (registers)
+//     O~^T[dim, row]  = V~^T[dim, token] P^T[token, row]  2 dim tiles x 8 k-steps          A = V~^T fragments (LDS), B = the score
+//                                                                                          accumulators themselves, exponentiated:
+// the accumulator of a 32 x 32 tile holds, in lane (row c, half h) register 4 g + q, token 8 g + 4 h + q of row c -- eight consecutive
+// registers are exactly the eight k-slots a B fragment of the next product wants (k-slot (h, j) <-> token 8 (j / 4) + 4 h + j % 4 of
+// the k-step: the A fragments are packed with the same slot order), so the probabilities never leave the registers.  A row's maximum
+// and sum are register reductions plus one exchange with lane c + 32.  A head's fragments are packed by the whole workgroup from the
+// fp32 K~ / V~ (loaded one head ahead, into registers, under the previous head's products).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MF_WAVES = 4, MF_THREADS = 64 * MF_WAVES, MF_ROWS = 32 * MF_WAVES;
+constexpr int MF_KF = 4 * 3, MF_VF = 2 * 8;  // fragments (hi + lo pairs) of K~ and of V~^T per head
+
+__device__ __forceinline__ void split8h(const float (&x)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const _Float16 xh = (_Float16)x[j];
+    hi[j] = xh;
+    lo[j] = (_Float16)(x[j] - (float)xh);
+  }
+}
+
+// power-of-two scale s with m s in [2^14, 2^15) (the fp16 residual of every element within 2^-13 of the largest stays a normal
+// number: the matrix cores flush fp16 subnormals), inv = 1 / s
+__device__ __forceinline__ float pow2_scale(float m, float& inv) {
+  if (!(m > 0.0f) || !(m < 3.0e38f)) { inv = 1.0f; return 1.0f; }
+  int e;
+  (void)frexpf(m, &e);
+  e = max(-100, min(100, e));
+  inv = ldexpf(1.0f, e - 15);
+  return ldexpf(1.0f, 15 - e);
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+__global__ __launch_bounds__(MF_THREADS, 2) void attn_core_fwd_mfma_kernel(const AttnArgs a) {
+  __shared__ f16x8 sK[MF_KF * 2 * 64];  // 24 KB: [token tile][k-step][hi, lo][lane]
+  __shared__ f16x8 sV[MF_VF * 2 * 64];  // 32 KB: [dim tile][k-step][hi, lo][lane]
+  extern __shared__ __attribute__((aligned(16))) float sR[];  // [16 ceil(L / 16)][48] (<= 24 KB): a head's V~ rows as they are in memory (transposed on the way into sV)
+  __shared__ float sM[2][MF_WAVES][2];  // largest |K~|, |V~| of the head being packed, per wave (double-buffered by head parity)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h2 = lane >> 5;
+  const int u = blockIdx.y;
+  const int d = blockIdx.x * MF_ROWS + wave * 32 + c;
+  const bool live = d < a.D;
+  const long row = (long)u * a.D + (live ? d : a.D - 1);
+  const int H = a.nh * DH;
+  const float dx = a.dirs[row * 3], dy = a.dirs[row * 3 + 1];
+  const int n_tt = (a.L + 31) >> 5, n_ks = (a.L + 15) >> 4;  // token tiles / value k-steps that hold a token
+  const int nV4 = a.L * (E / 4);                             // float4 pieces of a head's V~ (<= 1536 = 6 per thread)
+  // packing roles: K~ item i = tid + 256 i (i < 3): fragment item / 64 = (token tile, k-step), piece lane item % 64; V~: float4 piece
+  // tid + 256 i (i < 6) of the head's rows.  Every load is unconditional, from a clamped address (a load inside a branch is waited for
+  // on the spot); what lies beyond the tokens is zeroed when it is packed.
+  float4 rk[3][2], rv[6];
+  auto fetch = [&](int h) {
+    const float* Ku = a.Kt + ((long)u * a.nh + h) * a.L * E;
+    const float4* Vu = reinterpret_cast<const float4*>(a.Vt + ((long)u * a.nh + h) * a.L * E);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int item = tid + MF_THREADS * i, f = item >> 6, l = item & 63;
+      const int token = 32 * (f / 3) + (l & 31), col = 16 * (f % 3) + 4 * (l >> 5);
+      const float* kp = Ku + min(token, a.L - 1) * E + col;
+      rk[i][0] = *reinterpret_cast<const float4*>(kp);
+      rk[i][1] = *reinterpret_cast<const float4*>(kp + 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rv[i] = Vu[min(tid + MF_THREADS * i, nV4 - 1)];
+  };
+  fetch(0);
+  for (int h = 0; h < a.nh; ++h) {
+    {  // largest magnitudes of this head's K~ and V~
+      float mk = 0.0f, mv = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int item = tid + MF_THREADS * i, f = item >> 6, l = item & 63;
+        if (32 * (f / 3) + (l & 31) >= a.L) rk[i][0] = rk[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        mk = fmaxf(fmaxf(mk, fmaxf(fmaxf(fabsf(rk[i][0].x), fabsf(rk[i][0].y)), fmaxf(fabsf(rk[i][0].z), fabsf(rk[i][0].w)))),
+                   fmaxf(fmaxf(fabsf(rk[i][1].x), fabsf(rk[i][1].y)), fmaxf(fabsf(rk[i][1].z), fabsf(rk[i][1].w))));
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) mv = fmaxf(mv, fmaxf(fmaxf(fabsf(rv[i].x), fabsf(rv[i].y)), fmaxf(fabsf(rv[i].z), fabsf(rv[i].w))));
+      mk = wave_max(mk); mv = wave_max(mv);
+      if (lane == 0) { sM[h & 1][wave][0] = mk; sM[h & 1][wave][1] = mv; }
+    }
+    __syncthreads();  // the previous head's fragments and rows are no longer read; the maxima are in place
+    float k_inv, v_inv;
+    const float k_s = pow2_scale(fmaxf(fmaxf(sM[h & 1][0][0], sM[h & 1][1][0]), fmaxf(sM[h & 1][2][0], sM[h & 1][3][0])), k_inv);
+    const float v_s = pow2_scale(fmaxf(fmaxf(sM[h & 1][0][1], sM[h & 1][1][1]), fmaxf(sM[h & 1][2][1], sM[h & 1][3][1])), v_inv);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int item = tid + MF_THREADS * i, f = item >> 6, l = item & 63;
+      const float x[8] = {rk[i][0].x * k_s, rk[i][0].y * k_s, rk[i][0].z * k_s, rk[i][0].w * k_s, rk[i][1].x * k_s, rk[i][1].y * k_s, rk[i][1].z * k_s, rk[i][1].w * k_s};
+      f16x8 hi, lo;
+      split8h(x, hi, lo);
+      sK[(2 * f) * 64 + l] = hi;
+      sK[(2 * f + 1) * 64 + l] = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int piece = tid + MF_THREADS * i;
+      if (piece < 16 * n_ks * (E / 4)) reinterpret_cast<float4*>(sR)[piece] = piece < nV4 ? make_float4(rv[i].x * v_s, rv[i].y * v_s, rv[i].z * v_s, rv[i].w * v_s) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    if (h + 1 < a.nh) fetch(h + 1);  // in flight under this head's products
+    // V~^T fragments: item = (dim tile, k-step) x lane (dim r, half hh): the eight tokens 16 ks + 8 (j / 4) + 4 hh + j % 4 of dim 32 dt + r
+    // (lanes along the dims: consecutive LDS banks)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int item = tid + MF_THREADS * i, f = item >> 6, l = item & 63;
+      const int dim = 32 * (f >> 3) + (l & 31), t0 = 16 * (f & 7) + 4 * (l >> 5);
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = (dim < E && (f & 7) < n_ks) ? sR[(t0 + 8 * (j >> 2) + (j & 3)) * E + dim] : 0.0f;
+      f16x8 hi, lo;
+      split8h(x, hi, lo);
+      sV[(2 * f) * 64 + l] = hi;
+      sV[(2 * f + 1) * 64 + l] = lo;
+    }
+    __syncthreads();
+    // ---- q~ planes: k-step p = part p of [d_x q | d_y q | q]; k-slot (h2, j) <-> feature 8 (j / 4) + 4 h2 + j % 4 of the head
+    f16x8 qh[3], ql[3];
+    float q_inv;
+    {
+      const float* qp = a.Q + row * (long)H + h * DH + 4 * h2;
+      const float4 qa = *reinterpret_cast<const float4*>(qp), qb = *reinterpret_cast<const float4*>(qp + 8);
+      const float q8[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+      float qm = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qm = fmaxf(qm, fabsf(q8[j]));
+      qm = fmaxf(qm, __shfl_xor(qm, 32, 64));
+      const float q_s = pow2_scale(qm, q_inv);  // |d_x|, |d_y| <= 1: the plain part is the largest
+      const float coef[3] = {dx * q_s, dy * q_s, q_s};
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          // d_x q is not exact in fp32: the ROUNDED product is what gets split.  Left to itself the compiler forms the high half from
+          // the rounded product (v_cvt) and the residual from the exact one (v_fma_mix), or the other way round: where the two
+          // roundings disagree (one element in 2^14) the pair is off by an fp16 ulp, 2^-11 of the element
+          x[j] = q8[j] * coef[p];
+          asm volatile("" : "+v"(x[j]));
+        }
+        split8h(x, qh[p], ql[p]);
+      }
+    }
+    // ---- scores (token tiles without a token are skipped: wave-uniform branches)
+    const float s_inv = k_inv * q_inv * a.scale;  // accumulator -> score
+    f32x16 s[4];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[tt][r] = 0.0f;
+      if (tt < n_tt) {
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          const f16x8 ah = sK[(2 * (tt * 3 + ks)) * 64 + lane], al = sK[(2 * (tt * 3 + ks) + 1) * 64 + lane];
+          s[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[ks], s[tt], 0, 0, 0);
+          s[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[ks], s[tt], 0, 0, 0);
+          s[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[ks], s[tt], 0, 0, 0);
+        }
+        // register 4 g + q: token 32 tt + 8 g + 4 h2 + q
+        if (32 * tt + 32 <= a.L) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s[tt][r] *= s_inv; m = fmaxf(m, s[tt][r]); }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            s[tt][r] = 32 * tt + 8 * (r >> 2) + 4 * h2 + (r & 3) < a.L ? s[tt][r] * s_inv : -3.0e38f;
+            m = fmaxf(m, s[tt][r]);
+          }
+        }
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float lsum = 0.0f;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+      if (tt < n_tt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __expf(s[tt][r] - m);  // (a masked score: exp(-3e38 - m) = 0)
+          lsum += p;
+          s[tt][r] = p * 16384.0f;  // p <= 1: the fp16 pair resolves 2^-24 of 2^14 p
+        }
+      }
+    lsum += __shfl_xor(lsum, 32, 64);
+    // ---- O~^T = V~^T P^T: the exponentiated accumulators are the B planes
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      if (ks < n_ks) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = s[ks >> 1][8 * (ks & 1) + j];
+        f16x8 ph, pl;
+        split8h(x, ph, pl);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const f16x8 ah = sV[(2 * (dt * 8 + ks)) * 64 + lane], al = sV[(2 * (dt * 8 + ks) + 1) * 64 + lane];
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pl, o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ph, o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ph, o[dt], 0, 0, 0);
+        }
+      }
+    // ---- combine the three parts: feature e = 8 g + 4 h2 + q (g = 0, 1) <- d_x O~[e] + d_y O~[16 + e] + O~[32 + e]
+    if (live) {
+      const float inv = v_inv / (16384.0f * lsum);
+      float* op = a.O + row * (long)H + h * DH + 4 * h2;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        float4 r;
+        r.x = (dx * o[0][4 * g] + dy * o[0][4 * (g + 2)] + o[1][4 * g]) * inv;
+        r.y = (dx * o[0][4 * g + 1] + dy * o[0][4 * (g + 2) + 1] + o[1][4 * g + 1]) * inv;
+        r.z = (dx * o[0][4 * g + 2] + dy * o[0][4 * (g + 2) + 2] + o[1][4 * g + 2]) * inv;
+        r.w = (dx * o[0][4 * g + 3] + dy * o[0][4 * (g + 2) + 3] + o[1][4 * g + 3]) * inv;
+        *reinterpret_cast<float4*>(op + 8 * g) = r;
+      }
+      if (h2 == 0) {
+        const long st = ((long)u * a.nh + h) * a.D + d;
+        a.rmax[st] = m;
+        a.rsum[st] = lsum;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(ATT_THREADS) void attn_core_bwd_rows_kernel(const AttnArgs a, const float* __restrict__ Kt, const float* __restrict__ Vt,
                                                                           float* __restrict__ drow) {
   const int tid = threadIdx.x, h = blockIdx.y, u = blockIdx.z;
@@ -263,7 +502,10 @@ extern "C" int nsky_attn_core_fwd(const float* Q, const float* dirs, const float
   AttnArgs a{};
   a.Q = Q; a.dirs = dirs; a.Kt = Kt; a.Vt = Vt; a.O = O; a.rmax = row_max; a.rsum = row_sum;
   a.U = U; a.D = D; a.L = L; a.nh = n_heads; a.scale = scale;
-  hipLaunchKernelGGL(attn_core_fwd_kernel, dim3(ceil_div(D, ATT_THREADS), n_heads, U), dim3(ATT_THREADS), 0, (hipStream_t)stream, a, Kt, Vt);
+  if (D >= 32)  // matrix-core form: 128-row blocks of a camera
+    hipLaunchKernelGGL(attn_core_fwd_mfma_kernel, dim3(ceil_div(D, MF_ROWS), U), dim3(MF_THREADS), (size_t)16 * ceil_div(L, 16) * E * sizeof(float), (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(attn_core_fwd_kernel, dim3(ceil_div(D, ATT_THREADS), n_heads, U), dim3(ATT_THREADS), 0, (hipStream_t)stream, a, Kt, Vt);
   NSKY_CHECK_LAUNCH("nsky_attn_core_fwd");
   return NSKY_OK;
 }
