@@ -341,6 +341,205 @@ __global__ __launch_bounds__(MF_THREADS, 2) void attn_core_fwd_mfma_kernel(const
   }
 }
 
+// The row side of the backward on the matrix cores, 256 rows of a camera per workgroup (eight waves x 32 rows):
+//     S^T  = K~ q~^T,   dP^T = V~ dO~^T          tokens on the M side, k = the 48 dims (dO~ = [d_x dO | d_y dO | dO])
+//     dS   = P (dP - D) with P = exp(S - max) / sum from the forward's row statistics, D = dO . O
+//     dq~^T = K~^T dS^T                           dims on the M side, k = tokens: dS goes from the accumulators into the B planes
+// A head needs K~ twice (token-major and dim-major fragments) and V~ token-major: 80 KB of fragments + the rows of K~ being transposed.
+constexpr int MB_WAVES = 8, MB_THREADS = 64 * MB_WAVES, MB_ROWS = 32 * MB_WAVES;
+
+__global__ __launch_bounds__(MB_THREADS, 1) void attn_core_bwd_rows_mfma_kernel(const AttnArgs a, float* __restrict__ drow) {
+  __shared__ f16x8 sKt[MF_KF * 2 * 64];  // 24 KB: K~ [token tile][k-step of dims][hi, lo][lane]
+  __shared__ f16x8 sVt[MF_KF * 2 * 64];  // 24 KB: V~, the same form
+  __shared__ f16x8 sKd[MF_VF * 2 * 64];  // 32 KB: K~^T [dim tile][k-step of tokens][hi, lo][lane]
+  extern __shared__ __attribute__((aligned(16))) float sR[];  // [16 ceil(L / 16)][48]: K~ rows on their way into sKd
+  __shared__ float sM[2][MB_WAVES][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h2 = lane >> 5;
+  const int u = blockIdx.y;
+  const int d = blockIdx.x * MB_ROWS + wave * 32 + c;
+  const bool live = d < a.D;
+  const long row = (long)u * a.D + (live ? d : a.D - 1);
+  const int H = a.nh * DH;
+  const float dx = a.dirs[row * 3], dy = a.dirs[row * 3 + 1];
+  const int n_tt = (a.L + 31) >> 5, n_ks = (a.L + 15) >> 4;
+  const int nK4 = a.L * (E / 4);
+  // token-major items (12 fragments x 64 lanes = 768): item tid, and item 512 + tid for the first four waves
+  float4 rk[2][2], rv[2][2], rr[3];
+  auto fetch = [&](int h) {
+    const float* Ku = a.Kt + ((long)u * a.nh + h) * a.L * E;
+    const float* Vu = a.Vt + ((long)u * a.nh + h) * a.L * E;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int item = min(tid + MB_THREADS * i, MF_KF * 64 - 1), f = item >> 6, l = item & 63;
+      const int token = 32 * (f / 3) + (l & 31), col = 16 * (f % 3) + 4 * (l >> 5);
+      const long off = (long)min(token, a.L - 1) * E + col;
+      rk[i][0] = *reinterpret_cast<const float4*>(Ku + off); rk[i][1] = *reinterpret_cast<const float4*>(Ku + off + 8);
+      rv[i][0] = *reinterpret_cast<const float4*>(Vu + off); rv[i][1] = *reinterpret_cast<const float4*>(Vu + off + 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rr[i] = reinterpret_cast<const float4*>(Ku)[min(tid + MB_THREADS * i, nK4 - 1)];
+  };
+  auto max4 = [](float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); };
+  fetch(0);
+  for (int h = 0; h < a.nh; ++h) {
+    {
+      float mk = 0.0f, mv = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int item = tid + MB_THREADS * i, f = min(item, MF_KF * 64 - 1) >> 6;
+        if (item >= MF_KF * 64 || 32 * (f / 3) + (item & 31) >= a.L) rk[i][0] = rk[i][1] = rv[i][0] = rv[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        mk = fmaxf(mk, fmaxf(max4(rk[i][0]), max4(rk[i][1])));
+        mv = fmaxf(mv, fmaxf(max4(rv[i][0]), max4(rv[i][1])));
+      }
+      mk = wave_max(mk); mv = wave_max(mv);
+      if (lane == 0) { sM[h & 1][wave][0] = mk; sM[h & 1][wave][1] = mv; }
+    }
+    __syncthreads();
+    float k_inv, v_inv, mk = 0.0f, mv = 0.0f;
+#pragma unroll
+    for (int w = 0; w < MB_WAVES; ++w) { mk = fmaxf(mk, sM[h & 1][w][0]); mv = fmaxf(mv, sM[h & 1][w][1]); }
+    const float k_s = pow2_scale(mk, k_inv), v_s = pow2_scale(mv, v_inv);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int item = tid + MB_THREADS * i, f = item >> 6, l = item & 63;
+      if (item < MF_KF * 64) {
+        const float xk[8] = {rk[i][0].x * k_s, rk[i][0].y * k_s, rk[i][0].z * k_s, rk[i][0].w * k_s, rk[i][1].x * k_s, rk[i][1].y * k_s, rk[i][1].z * k_s, rk[i][1].w * k_s};
+        const float xv[8] = {rv[i][0].x * v_s, rv[i][0].y * v_s, rv[i][0].z * v_s, rv[i][0].w * v_s, rv[i][1].x * v_s, rv[i][1].y * v_s, rv[i][1].z * v_s, rv[i][1].w * v_s};
+        f16x8 hi, lo;
+        split8h(xk, hi, lo);
+        sKt[(2 * f) * 64 + l] = hi; sKt[(2 * f + 1) * 64 + l] = lo;
+        split8h(xv, hi, lo);
+        sVt[(2 * f) * 64 + l] = hi; sVt[(2 * f + 1) * 64 + l] = lo;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int piece = tid + MB_THREADS * i;
+      if (piece < 16 * n_ks * (E / 4)) reinterpret_cast<float4*>(sR)[piece] = piece < nK4 ? make_float4(rr[i].x * k_s, rr[i].y * k_s, rr[i].z * k_s, rr[i].w * k_s) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    if (h + 1 < a.nh) fetch(h + 1);
+    // K~^T fragments: 16 x 64 = 1024 items, two per thread
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int item = tid + MB_THREADS * i, f = item >> 6, l = item & 63;
+      const int dim = 32 * (f >> 3) + (l & 31), t0 = 16 * (f & 7) + 4 * (l >> 5);
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = (dim < E && (f & 7) < n_ks) ? sR[(t0 + 8 * (j >> 2) + (j & 3)) * E + dim] : 0.0f;
+      f16x8 hi, lo;
+      split8h(x, hi, lo);
+      sKd[(2 * f) * 64 + l] = hi; sKd[(2 * f + 1) * 64 + l] = lo;
+    }
+    __syncthreads();
+    // ---- this row's operands: q~ and dO~ planes (k-slot (h2, j) <-> feature 8 (j / 4) + 4 h2 + j % 4), D = dO . O, the forward's statistics
+    f16x8 qh[3], ql[3], gh[3], gl[3];
+    float q_inv, g_inv, Drow;
+    {
+      const long ho = row * (long)H + h * DH + 4 * h2;
+      const float4 qa = *reinterpret_cast<const float4*>(a.Q + ho), qb = *reinterpret_cast<const float4*>(a.Q + ho + 8);
+      const float4 ga = *reinterpret_cast<const float4*>(a.dO + ho), gb = *reinterpret_cast<const float4*>(a.dO + ho + 8);
+      const float4 oa = *reinterpret_cast<const float4*>(a.O + ho), ob = *reinterpret_cast<const float4*>(a.O + ho + 8);
+      const float q8[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w}, g8[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+      Drow = (ga.x * oa.x + ga.y * oa.y + ga.z * oa.z + ga.w * oa.w) + (gb.x * ob.x + gb.y * ob.y + gb.z * ob.z + gb.w * ob.w);
+      Drow += __shfl_xor(Drow, 32, 64);
+      float qm = 0.0f, gm = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { qm = fmaxf(qm, fabsf(q8[j])); gm = fmaxf(gm, fabsf(g8[j])); }
+      qm = fmaxf(qm, __shfl_xor(qm, 32, 64)); gm = fmaxf(gm, __shfl_xor(gm, 32, 64));
+      const float q_s = pow2_scale(qm, q_inv), g_s = pow2_scale(gm, g_inv);
+      const float cq[3] = {dx * q_s, dy * q_s, q_s}, cg[3] = {dx * g_s, dy * g_s, g_s};
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        float x[8], y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {  // (the rounded products are what gets split: see the forward)
+          x[j] = q8[j] * cq[p]; y[j] = g8[j] * cg[p];
+          asm volatile("" : "+v"(x[j]), "+v"(y[j]));
+        }
+        split8h(x, qh[p], ql[p]);
+        split8h(y, gh[p], gl[p]);
+      }
+    }
+    const long st = ((long)u * a.nh + h) * a.D + (live ? d : a.D - 1);
+    const float m = a.rmax[st], l_inv = 1.0f / a.rsum[st];
+    const float s_inv = k_inv * q_inv * a.scale, dp_inv = v_inv * g_inv;
+    // ---- dS, tile by tile (register 4 g + q: token 32 tt + 8 g + 4 h2 + q)
+    f32x16 ds[4];
+    float dsm = 0.0f;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ds[tt][r] = 0.0f;
+      if (tt < n_tt) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          const f16x8 kh = sKt[(2 * (tt * 3 + ks)) * 64 + lane], kl = sKt[(2 * (tt * 3 + ks) + 1) * 64 + lane];
+          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
+          const f16x8 vh = sVt[(2 * (tt * 3 + ks)) * 64 + lane], vl = sVt[(2 * (tt * 3 + ks) + 1) * 64 + lane];
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, gl[ks], dp, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, gh[ks], dp, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, gh[ks], dp, 0, 0, 0);
+        }
+        const bool whole = 32 * tt + 32 <= a.L;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __expf(s[r] * s_inv - m) * l_inv;
+          float v = p * (dp[r] * dp_inv - Drow);
+          if (!whole) v = 32 * tt + 8 * (r >> 2) + 4 * h2 + (r & 3) < a.L ? v : 0.0f;
+          ds[tt][r] = v;
+          dsm = fmaxf(dsm, fabsf(v));
+        }
+      }
+    }
+    dsm = fmaxf(dsm, __shfl_xor(dsm, 32, 64));
+    float ds_inv;
+    const float ds_s = pow2_scale(dsm, ds_inv);
+    // ---- dq~^T = K~^T dS^T
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      if (ks < n_ks) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = ds[ks >> 1][8 * (ks & 1) + j] * ds_s;
+        f16x8 ph, pl;
+        split8h(x, ph, pl);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const f16x8 ah = sKd[(2 * (dt * 8 + ks)) * 64 + lane], al = sKd[(2 * (dt * 8 + ks) + 1) * 64 + lane];
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pl, o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ph, o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ph, o[dt], 0, 0, 0);
+        }
+      }
+    if (live) {
+      const float inv = k_inv * ds_inv * a.scale;
+      float* qp = a.dQ + row * (long)H + h * DH + 4 * h2;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        float4 r;
+        r.x = (dx * o[0][4 * g] + dy * o[0][4 * (g + 2)] + o[1][4 * g]) * inv;
+        r.y = (dx * o[0][4 * g + 1] + dy * o[0][4 * (g + 2) + 1] + o[1][4 * g + 1]) * inv;
+        r.z = (dx * o[0][4 * g + 2] + dy * o[0][4 * (g + 2) + 2] + o[1][4 * g + 2]) * inv;
+        r.w = (dx * o[0][4 * g + 3] + dy * o[0][4 * (g + 2) + 3] + o[1][4 * g + 3]) * inv;
+        *reinterpret_cast<float4*>(qp + 8 * g) = r;
+      }
+      if (h2 == 0) drow[st] = Drow;
+    }
+  }
+}
+
 __global__ __launch_bounds__(ATT_THREADS) void attn_core_bwd_rows_kernel(const AttnArgs a, const float* __restrict__ Kt, const float* __restrict__ Vt,
                                                                           float* __restrict__ drow) {
   const int tid = threadIdx.x, h = blockIdx.y, u = blockIdx.z;
@@ -522,7 +721,10 @@ extern "C" int nsky_attn_core_bwd(const float* Q, const float* dirs, const float
   a.U = U; a.D = D; a.L = L; a.nh = n_heads; a.scale = scale;
   // D = dO . O per row and head travels from the row kernel to the token kernel through the row_sum-shaped scratch behind dQ's last use:
   // it is stored in place of nothing the caller reads -- `drow` aliases no output: the caller passes it (see neusky_hip.h)
-  hipLaunchKernelGGL(attn_core_bwd_rows_kernel, dim3(ceil_div(D, ATT_THREADS), n_heads, U), dim3(ATT_THREADS), 0, (hipStream_t)stream, a, Kt, Vt, drow);
+  if (D >= 32)
+    hipLaunchKernelGGL(attn_core_bwd_rows_mfma_kernel, dim3(ceil_div(D, MB_ROWS), U), dim3(MB_THREADS), (size_t)16 * ceil_div(L, 16) * E * sizeof(float), (hipStream_t)stream, a, drow);
+  else
+    hipLaunchKernelGGL(attn_core_bwd_rows_kernel, dim3(ceil_div(D, ATT_THREADS), n_heads, U), dim3(ATT_THREADS), 0, (hipStream_t)stream, a, Kt, Vt, drow);
   NSKY_CHECK_LAUNCH("nsky_attn_core_bwd (rows)");
   // one workgroup per (camera, head) leaves most of the chip idle when there are few cameras: split the rows, reduce by atomics
   int splits = 1;
