@@ -27,7 +27,7 @@ extern "C" {
 typedef void* nsky_stream_t; /* hipStream_t */
 
 const char* nsky_last_error(void);
-int nsky_abi_version(void); /* 12 (bumped when a struct layout or an entry point's signature changes) */
+int nsky_abi_version(void); /* 13 (bumped when a struct layout or an entry point's signature changes) */
 
 /* ------------------------------------------------------------------------------------------
  * Dense layer on the matrix cores: C[M,N] = epilogue( sum_k A(m,k) * B(n,k) + bias[n] )
@@ -633,12 +633,14 @@ int nsky_train_metrics(const float* pred, const float* gt, const float* mask, in
  * with K~, V~ [U, n_heads, L, 48] the per-camera key / value parts (the token is linear in (d_x, d_y): three 16-wide parts per token, L <= 128),
  * Q, O, dO, dQ [U, D, 16 n_heads] row-major, dirs [U, D, 3], row_max / row_sum [U, n_heads, D] (saved by the forward for the backward).
  * Replaces the per-head `softmax(Q K^T) V` of the decoder's cross-attention (two batched matrix products, a softmax and their autograd nodes per
- * layer); exact fp32 arithmetic.  _bwd returns dQ and the per-camera dK~, dV~ (summed over the camera's D rows); directions carry no gradient. */
+ * layer).  Arithmetic: D >= 32 rows per camera: matrix cores, fp32-grade fp16 hi + residual products (the chain kernels' arithmetic); a camera's
+ * short blocks (a ray's own row): exact fp32 on the vector units.  _bwd returns dQ and the per-camera dK~, dV~ (summed over the camera's D rows); directions carry no gradient. */
 int nsky_attn_core_fwd(const float* Q, const float* dirs, const float* Kt, const float* Vt, int32_t U, int32_t D, int32_t L, int32_t n_heads,
                        float scale, float* O, float* row_max, float* row_sum, nsky_stream_t stream);
 int nsky_attn_core_bwd(const float* Q, const float* dirs, const float* Kt, const float* Vt, const float* O, const float* row_max,
                        const float* row_sum, const float* dO, int32_t U, int32_t D, int32_t L, int32_t n_heads, float scale, float* dQ,
-                       float* dKt, float* dVt, float* drow_scratch /* [U, n_heads, D] */, nsky_stream_t stream);
+                       float* dKt, float* dVt, float* drow_scratch /* U n_heads (D + 4) floats: D = dO . O per row and head, then the operand maxima of every (camera, head) */,
+                       nsky_stream_t stream);
 /* The step's objective: total = sum over segments of scale_s * sum_i coef_s[i] x_s[i] (coef NULL: 1).  Replaces the dozen scalar
  * multiplies, sums and adds that scale and merge the loss dictionaries (nerfstudio scale_dict + functools.reduce(torch.add, ...),
  * neusky_pipeline.py:283-289; interlevel_loss' mean, neusky_model.py:987-988) by one launch each way.  One workgroup; bwd writes

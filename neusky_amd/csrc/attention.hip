@@ -348,7 +348,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void attn_core_fwd_mfma_kernel(const
 // A head needs K~ twice (token-major and dim-major fragments) and V~ token-major: 80 KB of fragments + the rows of K~ being transposed.
 constexpr int MB_WAVES = 8, MB_THREADS = 64 * MB_WAVES, MB_ROWS = 32 * MB_WAVES;
 
-__global__ __launch_bounds__(MB_THREADS, 1) void attn_core_bwd_rows_mfma_kernel(const AttnArgs a, float* __restrict__ drow) {
+__device__ __forceinline__ void publish_absmax(float* slot, float v, int lane) {  // v >= 0: the bit patterns order like the values
+  v = wave_max(v);
+  if (lane == 0 && v > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(v));
+}
+
+__global__ __launch_bounds__(MB_THREADS, 1) void attn_core_bwd_rows_mfma_kernel(const AttnArgs a, float* __restrict__ drow, float* __restrict__ stat) {
   __shared__ f16x8 sKt[MF_KF * 2 * 64];  // 24 KB: K~ [token tile][k-step of dims][hi, lo][lane]
   __shared__ f16x8 sVt[MF_KF * 2 * 64];  // 24 KB: V~, the same form
   __shared__ f16x8 sKd[MF_VF * 2 * 64];  // 32 KB: K~^T [dim tile][k-step of tokens][hi, lo][lane]
@@ -448,6 +453,9 @@ __global__ __launch_bounds__(MB_THREADS, 1) void attn_core_bwd_rows_mfma_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) { qm = fmaxf(qm, fabsf(q8[j])); gm = fmaxf(gm, fabsf(g8[j])); }
       qm = fmaxf(qm, __shfl_xor(qm, 32, 64)); gm = fmaxf(gm, __shfl_xor(gm, 32, 64));
+      // largest |q|, |dO| (and below |dS|) of this (camera, head): the token kernel scales its operands with them
+      publish_absmax(stat + ((long)u * a.nh + h) * 4, live ? qm : 0.0f, lane);
+      publish_absmax(stat + ((long)u * a.nh + h) * 4 + 1, live ? gm : 0.0f, lane);
       const float q_s = pow2_scale(qm, q_inv), g_s = pow2_scale(gm, g_inv);
       const float cq[3] = {dx * q_s, dy * q_s, q_s}, cg[3] = {dx * g_s, dy * g_s, g_s};
 #pragma unroll
@@ -499,6 +507,7 @@ __global__ __launch_bounds__(MB_THREADS, 1) void attn_core_bwd_rows_mfma_kernel(
       }
     }
     dsm = fmaxf(dsm, __shfl_xor(dsm, 32, 64));
+    publish_absmax(stat + ((long)u * a.nh + h) * 4 + 2, live ? dsm : 0.0f, lane);
     float ds_inv;
     const float ds_s = pow2_scale(dsm, ds_inv);
     // ---- dq~^T = K~^T dS^T
@@ -536,6 +545,192 @@ __global__ __launch_bounds__(MB_THREADS, 1) void attn_core_bwd_rows_mfma_kernel(
         *reinterpret_cast<float4*>(qp + 8 * g) = r;
       }
       if (h2 == 0) drow[st] = Drow;
+    }
+  }
+}
+
+// The token side on the matrix cores: one workgroup per (camera, head), wave w owns the token tile 32 w .. 32 w + 31 and walks the
+// camera's rows 32 at a time.  Swapping the operands of the score product gives the TRANSPOSED accumulator for free (fragment layouts of
+// the two MFMA inputs are the same: lane = the outer index, eight k-slots in registers):
+//     S  = q~ K~^T,   dP = dO~ V~^T        A = the row tile's q~ / dO~ fragments (LDS), B = this wave's K~ / V~ fragments (registers):
+//                                          lane = token, register 4 g + q = row 8 g + 4 h2 + q
+//     dV~ += P^T dO~,   dK~ += dS^T q~     A = the accumulators themselves (lane = token, k-slots = rows), B = dO~ / q~ with the rows on k
+// The sums over the camera's rows stay in accumulators (2 x 2 tiles per wave): no atomics, no cross-lane reduction, a plain store at the
+// end.  Operand scales come from the row kernel's published maxima (uniform over the rows, as the accumulation requires).
+constexpr int MT_WAVES = 4, MT_THREADS = 64 * MT_WAVES;
+
+__global__ __launch_bounds__(MT_THREADS, 2) void attn_core_bwd_tokens_mfma_kernel(const AttnArgs a, const float* __restrict__ drow, const float* __restrict__ stat) {
+  __shared__ f16x8 sQA[3 * 2 * 64], sGA[3 * 2 * 64];  // q~ / dO~ of the row tile, rows on the lanes: [part][hi, lo][lane]        6 KB each
+  __shared__ f16x8 sQB[4 * 2 * 64], sGB[4 * 2 * 64];  // the same with the rows on k: [dim tile][16-row k-step][hi, lo][lane]     8 KB each
+  __shared__ __attribute__((aligned(16))) float sRawQ[32 * DH], sRawG[32 * DH];
+  __shared__ __attribute__((aligned(16))) float sDx[32], sDy[32], sMx[32], sLi[32], sDr[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, h2 = lane >> 5;
+  const int h = blockIdx.x, u = blockIdx.y;
+  const int H = a.nh * DH;
+  const int token = 32 * wave + n;
+  const bool has_tokens = 32 * wave < a.L;
+  const float* st4 = stat + ((long)u * a.nh + h) * 4;
+  float q_inv, g_inv, ds_inv;
+  const float q_s = pow2_scale(st4[0], q_inv), g_s = pow2_scale(st4[1], g_inv), ds_s = pow2_scale(st4[2], ds_inv);
+  // ---- this wave's K~ / V~ fragments (B operand: lane = token, k-slot (h2, j) <-> dim 16 p + 8 (j / 4) + 4 h2 + j % 4), scaled per wave
+  f16x8 kh[3], kl[3], vh[3], vl[3];
+  float k_inv, v_inv;
+  {
+    const long off = (((long)u * a.nh + h) * a.L + min(token, a.L - 1)) * E + 4 * h2;
+    float4 kr[3][2], vr[3][2];
+    float mk = 0.0f, mv = 0.0f;
+    auto max4 = [](float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); };
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      kr[p][0] = *reinterpret_cast<const float4*>(a.Kt + off + 16 * p); kr[p][1] = *reinterpret_cast<const float4*>(a.Kt + off + 16 * p + 8);
+      vr[p][0] = *reinterpret_cast<const float4*>(a.Vt + off + 16 * p); vr[p][1] = *reinterpret_cast<const float4*>(a.Vt + off + 16 * p + 8);
+      if (token >= a.L) kr[p][0] = kr[p][1] = vr[p][0] = vr[p][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      mk = fmaxf(mk, fmaxf(max4(kr[p][0]), max4(kr[p][1])));
+      mv = fmaxf(mv, fmaxf(max4(vr[p][0]), max4(vr[p][1])));
+    }
+    const float k_s = pow2_scale(wave_max(mk), k_inv), v_s = pow2_scale(wave_max(mv), v_inv);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const float xk[8] = {kr[p][0].x * k_s, kr[p][0].y * k_s, kr[p][0].z * k_s, kr[p][0].w * k_s, kr[p][1].x * k_s, kr[p][1].y * k_s, kr[p][1].z * k_s, kr[p][1].w * k_s};
+      const float xv[8] = {vr[p][0].x * v_s, vr[p][0].y * v_s, vr[p][0].z * v_s, vr[p][0].w * v_s, vr[p][1].x * v_s, vr[p][1].y * v_s, vr[p][1].z * v_s, vr[p][1].w * v_s};
+      split8h(xk, kh[p], kl[p]);
+      split8h(xv, vh[p], vl[p]);
+    }
+  }
+  const float s_inv = k_inv * q_inv * a.scale, dp_inv = v_inv * g_inv;
+  f32x16 accK[2], accV[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accK[dt][r] = 0.0f; accV[dt][r] = 0.0f; }
+  // staging roles: thread t < 128: float4 (t & 3) of row t >> 2 of Q; t >= 128: of dO; threads 0 .. 31 also the row's statistics
+  const int s_row = (tid & 127) >> 2, s_q4 = tid & 3;
+  const float* s_src = (tid < 128 ? a.Q : a.dO) + h * DH + 4 * s_q4;
+  float* s_dst = (tid < 128 ? sRawQ : sRawG) + s_row * DH + 4 * s_q4;
+  float4 raw;
+  float r_dx, r_dy, r_m, r_li, r_dr;
+  auto fetch = [&](int d0) {
+    const int d = d0 + s_row;
+    raw = *reinterpret_cast<const float4*>(s_src + ((long)u * a.D + min(d, a.D - 1)) * H);
+    if (d >= a.D) raw = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 32) {
+      const int dd = d0 + tid;
+      const long row = (long)u * a.D + min(dd, a.D - 1);
+      const long st = ((long)u * a.nh + h) * a.D + min(dd, a.D - 1);
+      r_dx = a.dirs[row * 3]; r_dy = a.dirs[row * 3 + 1]; r_m = a.rmax[st]; r_li = 1.0f / a.rsum[st]; r_dr = drow[st];
+      if (dd >= a.D) { r_li = 0.0f; r_dr = 0.0f; }  // a row beyond the camera's: p = 0, dS = 0
+    }
+  };
+  fetch(0);
+  for (int d0 = 0; d0 < a.D; d0 += 32) {
+    __syncthreads();  // the previous row tile's fragments and rows are no longer read
+    *reinterpret_cast<float4*>(s_dst) = raw;
+    if (tid < 32) { sDx[tid] = r_dx; sDy[tid] = r_dy; sMx[tid] = r_m; sLi[tid] = r_li; sDr[tid] = r_dr; }
+    __syncthreads();
+    if (d0 + 32 < a.D) fetch(d0 + 32);
+    // ---- fragments of the row tile: 14 x 64 lane-items (3 + 3 with the rows on the lanes, 4 + 4 with the rows on k), waves take them in turn
+    for (int f = wave; f < 14; f += MT_WAVES) {
+      const bool isq = f < 3 || (f >= 6 && f < 10);
+      const float* rawp = isq ? sRawQ : sRawG;
+      const float sc = isq ? q_s : g_s;
+      float x[8];
+      f16x8* dst;
+      if (f < 6) {  // rows on the lanes: lane (row n, half h2), part p: features 8 (j / 4) + 4 h2 + j % 4 of the row, times (d_x, d_y, 1)
+        const int p = f < 3 ? f : f - 3;
+        const float cf = (p == 0 ? sDx[n] : (p == 1 ? sDy[n] : 1.0f)) * sc;
+        const float4 v0 = *reinterpret_cast<const float4*>(rawp + n * DH + 4 * h2), v1 = *reinterpret_cast<const float4*>(rawp + n * DH + 8 + 4 * h2);
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = v[j] * cf;
+        dst = (f < 3 ? sQA : sGA) + (2 * p) * 64;
+      } else {  // rows on k: lane (dim n of tile dt, half h2), k-step kr: rows 16 kr + 8 (j / 4) + 4 h2 + j % 4
+        const int g = f < 10 ? f - 6 : f - 10, dt = g >> 1, kr = g & 1;
+        const int dim = 32 * dt + n, p = dim >> 4, e = dim & 15;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = 16 * kr + 8 * (j >> 2) + 4 * h2 + (j & 3);
+          const float cf = (p == 0 ? sDx[r] : (p == 1 ? sDy[r] : 1.0f)) * sc;
+          x[j] = dim < E ? rawp[r * DH + e] * cf : 0.0f;
+        }
+        dst = (f < 10 ? sQB : sGB) + (2 * g) * 64;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(x[j]));  // the rounded product is what gets split (see the forward)
+      f16x8 hi, lo;
+      split8h(x, hi, lo);
+      dst[lane] = hi;
+      dst[64 + lane] = lo;
+    }
+    __syncthreads();
+    if (has_tokens) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const f16x8 qh = sQA[(2 * p) * 64 + lane], ql = sQA[(2 * p + 1) * 64 + lane];
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh, kl[p], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql, kh[p], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh, kh[p], s, 0, 0, 0);
+        const f16x8 gh = sGA[(2 * p) * 64 + lane], gl = sGA[(2 * p + 1) * 64 + lane];
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, vl[p], dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, vh[p], dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, vh[p], dp, 0, 0, 0);
+      }
+      // register 4 g + q: row 8 g + 4 h2 + q of the tile; this lane's token
+      const float tok_live = token < a.L ? 1.0f : 0.0f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 m4 = *reinterpret_cast<const float4*>(sMx + 8 * g + 4 * h2), l4 = *reinterpret_cast<const float4*>(sLi + 8 * g + 4 * h2),
+                     d4 = *reinterpret_cast<const float4*>(sDr + 8 * g + 4 * h2);
+        const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float p = __expf(s[4 * g + q] * s_inv - mm[q]) * (ll[q] * tok_live);
+          dp[4 * g + q] = p * (dp[4 * g + q] * dp_inv - dd[q]) * ds_s;  // dS, scaled
+          s[4 * g + q] = p * 16384.0f;                                  // P, scaled
+        }
+      }
+#pragma unroll
+      for (int kr = 0; kr < 2; ++kr) {
+        float xp[8], xs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { xp[j] = s[8 * kr + j]; xs[j] = dp[8 * kr + j]; }
+        f16x8 ph, pl, dh_, dl_;
+        split8h(xp, ph, pl);
+        split8h(xs, dh_, dl_);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const f16x8 bh = sGB[(2 * (2 * dt + kr)) * 64 + lane], bl = sGB[(2 * (2 * dt + kr) + 1) * 64 + lane];
+          accV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, bl, accV[dt], 0, 0, 0);
+          accV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, bh, accV[dt], 0, 0, 0);
+          accV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, bh, accV[dt], 0, 0, 0);
+          const f16x8 ch = sQB[(2 * (2 * dt + kr)) * 64 + lane], cl = sQB[(2 * (2 * dt + kr) + 1) * 64 + lane];
+          accK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh_, cl, accK[dt], 0, 0, 0);
+          accK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dl_, ch, accK[dt], 0, 0, 0);
+          accK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh_, ch, accK[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- accumulator of dim tile dt: lane = dim 32 dt + n, register 4 g + q = token 32 wave + 8 g + 4 h2 + q
+  if (has_tokens) {
+    const float v_out = g_inv / 16384.0f, k_out = q_inv * ds_inv * a.scale;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int dim = 32 * dt + n;
+      if (dim < E) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int tk = 32 * wave + 8 * (r >> 2) + 4 * h2 + (r & 3);
+          if (tk < a.L) {
+            const long o = (((long)u * a.nh + h) * a.L + tk) * E + dim;
+            a.dKt[o] = accK[dt][r] * k_out;
+            a.dVt[o] = accV[dt][r] * v_out;
+          }
+        }
+      }
     }
   }
 }
@@ -721,10 +916,16 @@ extern "C" int nsky_attn_core_bwd(const float* Q, const float* dirs, const float
   a.U = U; a.D = D; a.L = L; a.nh = n_heads; a.scale = scale;
   // D = dO . O per row and head travels from the row kernel to the token kernel through the row_sum-shaped scratch behind dQ's last use:
   // it is stored in place of nothing the caller reads -- `drow` aliases no output: the caller passes it (see neusky_hip.h)
-  if (D >= 32)
-    hipLaunchKernelGGL(attn_core_bwd_rows_mfma_kernel, dim3(ceil_div(D, MB_ROWS), U), dim3(MB_THREADS), (size_t)16 * ceil_div(L, 16) * E * sizeof(float), (hipStream_t)stream, a, drow);
-  else
-    hipLaunchKernelGGL(attn_core_bwd_rows_kernel, dim3(ceil_div(D, ATT_THREADS), n_heads, U), dim3(ATT_THREADS), 0, (hipStream_t)stream, a, Kt, Vt, drow);
+  if (D >= 32) {  // matrix-core forms; the row kernel publishes the operand maxima of every (camera, head) behind the D = dO . O scratch
+    float* stat = drow + (size_t)U * n_heads * D;
+    (void)hipMemsetAsync(stat, 0, (size_t)U * n_heads * 4 * sizeof(float), (hipStream_t)stream);
+    hipLaunchKernelGGL(attn_core_bwd_rows_mfma_kernel, dim3(ceil_div(D, MB_ROWS), U), dim3(MB_THREADS), (size_t)16 * ceil_div(L, 16) * E * sizeof(float), (hipStream_t)stream, a, drow, stat);
+    NSKY_CHECK_LAUNCH("nsky_attn_core_bwd (rows)");
+    hipLaunchKernelGGL(attn_core_bwd_tokens_mfma_kernel, dim3(n_heads, U), dim3(MT_THREADS), 0, (hipStream_t)stream, a, (const float*)drow, (const float*)stat);
+    NSKY_CHECK_LAUNCH("nsky_attn_core_bwd (tokens)");
+    return NSKY_OK;
+  }
+  hipLaunchKernelGGL(attn_core_bwd_rows_kernel, dim3(ceil_div(D, ATT_THREADS), n_heads, U), dim3(ATT_THREADS), 0, (hipStream_t)stream, a, Kt, Vt, drow);
   NSKY_CHECK_LAUNCH("nsky_attn_core_bwd (rows)");
   // one workgroup per (camera, head) leaves most of the chip idle when there are few cameras: split the rows, reduce by atomics
   int splits = 1;

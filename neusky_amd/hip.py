@@ -52,7 +52,7 @@ class GemmDesc(C.Structure):
 
 _lib.nsky_last_error.restype = C.c_char_p
 _lib.nsky_abi_version.restype = C.c_int
-ABI_VERSION = 12  # the ctypes structures below mirror this version of include/neusky_hip.h
+ABI_VERSION = 13  # the ctypes structures below mirror this version of include/neusky_hip.h
 if _lib.nsky_abi_version() != ABI_VERSION:
     raise NeuSkyHipError(f"libneusky_hip.so has ABI version {_lib.nsky_abi_version()}, this package binds version {ABI_VERSION}: rebuild (build.sh)")
 
@@ -552,7 +552,8 @@ def attn_core_bwd(Q, dirs, Kt, Vt, O, row_max, row_sum, dO, scale, dQ, dKt, dVt)
     U, D, H = Q.shape
     nh, L = Kt.shape[1], Kt.shape[2]
     assert all(t.is_contiguous() for t in (Q, dirs, Kt, Vt, O, row_max, row_sum, dO, dQ, dKt, dVt))
-    drow = torch.empty_like(row_sum)  # D = dO . O per row and head: from the row kernel to the token kernel
+    # D = dO . O per row and head (from the row kernel to the token kernel), then four floats per (camera, head): the operand maxima
+    drow = torch.empty(U * nh * (D + 4), device=Q.device)
     check(_attn_bwd(ptr(Q), ptr(dirs), ptr(Kt), ptr(Vt), ptr(O), ptr(row_max), ptr(row_sum), ptr(dO), U, D, L, nh, float(scale),
                     ptr(dQ), ptr(dKt), ptr(dVt), ptr(drow), stream_ptr()), "nsky_attn_core_bwd")
 
