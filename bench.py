@@ -392,6 +392,14 @@ def render_1080p_line(pipe, device, chunk=4096):
     return res
 
 
+STEP_KERNEL_SOURCES_EXCLUDE = ("attention.hip",)  # kernels of the attention-decoder key only: not in the headline step the counters describe
+
+
+def step_kernel_sources():
+    csrc = os.path.join(ROOT, "neusky_amd", "csrc")
+    return [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f not in STEP_KERNEL_SOURCES_EXCLUDE]
+
+
 def _sources_sha(paths) -> str:
     import hashlib
     h = hashlib.sha256()
@@ -595,7 +603,7 @@ def main():
             tj = json.load(open(tsrc))
             traffic = tj.get("bytes_per_launch", {}).get(dom["kernel"].split(" ")[0])
             so = os.path.join(ROOT, "neusky_amd", "libneusky_hip.so")
-            srcs = [os.path.join(ROOT, "neusky_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "neusky_amd", "csrc"))]
+            srcs = step_kernel_sources()
             if max(os.path.getmtime(f) for f in srcs) > os.path.getmtime(tsrc) + 60 and tj.get("kernel_sources_sha") != _sources_sha(srcs):
                 traffic_note = " (STALE: the kernel sources changed after the counters were collected)"
                 print("bench.py: warning: profiles/r04_pmc_traffic.json predates the kernel sources; re-run tools/pmc_bench.sh", file=sys.stderr)

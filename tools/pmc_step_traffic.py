@@ -37,5 +37,5 @@ out = {"command": "tools/pmc_bench.sh: rocprofv3 --kernel-trace --pmc <FETCH_SIZ
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (for the source hash bench.py compares against: the counters describe THESE kernels)
 csrc = os.path.join(ROOT, "neusky_amd", "csrc")
-out["kernel_sources_sha"] = bench._sources_sha([os.path.join(csrc, f) for f in os.listdir(csrc)])
+out["kernel_sources_sha"] = bench._sources_sha(bench.step_kernel_sources())
 json.dump(out, open(os.path.join(ROOT, "profiles", out_name), "w"), indent=1)
