@@ -27,7 +27,7 @@ extern "C" {
 typedef void* nsky_stream_t; /* hipStream_t */
 
 const char* nsky_last_error(void);
-int nsky_abi_version(void); /* 13 (bumped when a struct layout or an entry point's signature changes) */
+int nsky_abi_version(void); /* 14 (bumped when a struct layout or an entry point's signature changes) */
 
 /* ------------------------------------------------------------------------------------------
  * Dense layer on the matrix cores: C[M,N] = epilogue( sum_k A(m,k) * B(n,k) + bias[n] )
@@ -641,6 +641,16 @@ int nsky_attn_core_bwd(const float* Q, const float* dirs, const float* Kt, const
                        const float* row_sum, const float* dO, int32_t U, int32_t D, int32_t L, int32_t n_heads, float scale, float* dQ,
                        float* dKt, float* dVt, float* drow_scratch /* U n_heads (D + 4) floats: D = dO . O per row and head, then the operand maxima of every (camera, head) */,
                        nsky_stream_t stream);
+/* The rays' own rows of the same decoder (the background radiance along a ray's own direction, neusky_model.py:535-549): a ray attends to
+ * the keys / values of ITS camera.  Q, O, dO, dQ [R, 16 n_heads], dirs [R, 3], row_max / row_sum [R, n_heads]; the rays sorted by camera:
+ * perm[i] = the ray at sorted position i, seg[u] .. seg[u + 1] the positions of camera u (seg [U + 1]).  _bwd ADDS the rays' part to
+ * dKt / dVt (which hold the grid rows' sums from nsky_attn_core_bwd, launched earlier on the same stream).  Exact fp32 on the vector units.
+ * Replaces decoding the rays as R one-direction cameras (which projects R x 3 L token rows per layer). */
+int nsky_attn_core_rays_fwd(const float* Q, const float* dirs, const int32_t* perm, const int32_t* seg, const float* Kt, const float* Vt, int32_t U,
+                            int32_t R, int32_t L, int32_t n_heads, float scale, float* O, float* row_max, float* row_sum, nsky_stream_t stream);
+int nsky_attn_core_rays_bwd(const float* Q, const float* dirs, const int32_t* perm, const int32_t* seg, const float* Kt, const float* Vt, const float* O,
+                            const float* row_max, const float* row_sum, const float* dO, int32_t U, int32_t R, int32_t L, int32_t n_heads, float scale,
+                            float* dQ, float* dKt, float* dVt, nsky_stream_t stream);
 /* The step's objective: total = sum over segments of scale_s * sum_i coef_s[i] x_s[i] (coef NULL: 1).  Replaces the dozen scalar
  * multiplies, sums and adds that scale and merge the loss dictionaries (nerfstudio scale_dict + functools.reduce(torch.add, ...),
  * neusky_pipeline.py:283-289; interlevel_loss' mean, neusky_model.py:987-988) by one launch each way.  One workgroup; bwd writes

@@ -879,6 +879,131 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_core_bwd_tokens_kernel(const
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The rays' own rows (neusky_model.py:535-549: the background radiance of a ray along its own direction): a ray is one more direction
+// of ITS camera.  The rows arrive sorted by camera (perm[i] = the ray at sorted position i, seg[u] .. seg[u + 1] = camera u's rays); one
+// workgroup per (camera, head) keeps K~_n (and, backward, V~_n and both gradients) of token n in thread n's registers -- the layout of
+// the token kernel above -- and walks the camera's handful of rays:
+//   forward : s_n by thread n, block maximum / sum through LDS, then thread e < 48 sums p_n V~[n][e] over the tokens (V~ read along e)
+//   backward: ds_n, dK~_n += ds_n q~, dV~_n += p_n dO~ in registers; dq~[e] = sum_n ds_n K~[n][e] by thread e; at the end the camera's
+//             dK~ / dV~ (already holding the grid rows' sums: same stream, earlier launch) take the rays' part by a plain read-add-write.
+struct RayArgs {
+  const float* Q; const float* dirs; const float* Kt; const float* Vt;   // Q [R, H], dirs [R, 3]
+  const int* perm; const int* seg;                                       // [R], [U + 1]
+  float* O; float* rmax; float* rsum;                                    // [R, H], [R, heads] x 2
+  const float* dO; float* dQ; float* dKt; float* dVt;
+  int U, R, L, nh;
+  float scale;
+};
+
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* red, int tid) {  // 128 threads = 2 waves
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(v, off, 64);
+    v = is_max ? fmaxf(v, o) : v + o;
+  }
+  __syncthreads();  // (red is free again)
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return is_max ? fmaxf(red[0], red[1]) : red[0] + red[1];
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(ATT_THREADS) void attn_rays_kernel(const RayArgs a) {
+  __shared__ float red[2];
+  __shared__ float sP[ATT_LMAX];   // p_n (forward) / ds_n (backward)
+  __shared__ float sO[E];          // the 48-wide sums before the (d_x, d_y, 1) combination
+  const int tid = threadIdx.x, h = blockIdx.x, u = blockIdx.y;
+  const int r_beg = a.seg[u], r_end = a.seg[u + 1];
+  if (r_beg == r_end) return;
+  const int n = tid;
+  const bool tok = n < a.L;
+  const int H = a.nh * DH;
+  const long kv0 = ((long)u * a.nh + h) * a.L * E;
+  const long kv = kv0 + (long)(tok ? n : 0) * E;
+  float Kn[E], Vn[BWD ? E : 1], dK[BWD ? E : 1], dV[BWD ? E : 1];
+#pragma unroll
+  for (int k = 0; k < E / 4; ++k) {
+    const float4 kk = reinterpret_cast<const float4*>(a.Kt + kv)[k];
+    Kn[4 * k] = kk.x; Kn[4 * k + 1] = kk.y; Kn[4 * k + 2] = kk.z; Kn[4 * k + 3] = kk.w;
+    if (BWD) {
+      const float4 vv = reinterpret_cast<const float4*>(a.Vt + kv)[k];
+      Vn[4 * k] = vv.x; Vn[4 * k + 1] = vv.y; Vn[4 * k + 2] = vv.z; Vn[4 * k + 3] = vv.w;
+      dK[4 * k] = dK[4 * k + 1] = dK[4 * k + 2] = dK[4 * k + 3] = 0.0f;
+      dV[4 * k] = dV[4 * k + 1] = dV[4 * k + 2] = dV[4 * k + 3] = 0.0f;
+    }
+  }
+  for (int i = r_beg; i < r_end; ++i) {
+    const int r = a.perm[i];                       // block-uniform
+    const float* qp = a.Q + (long)r * H + h * DH;
+    const float dx = a.dirs[(long)r * 3], dy = a.dirs[(long)r * 3 + 1];
+    float q[DH], g[BWD ? DH : 1];
+    float Drow = 0.0f;
+#pragma unroll
+    for (int j = 0; j < DH; ++j) {
+      q[j] = qp[j];
+      if (BWD) {
+        g[j] = a.dO[(long)r * H + h * DH + j];
+        Drow = fmaf(g[j], a.O[(long)r * H + h * DH + j], Drow);
+      }
+    }
+    float sA = 0.f, sB = 0.f, sC = 0.f;
+#pragma unroll
+    for (int j = 0; j < DH; ++j) { sA = fmaf(q[j], Kn[j], sA); sB = fmaf(q[j], Kn[DH + j], sB); sC = fmaf(q[j], Kn[2 * DH + j], sC); }
+    const float s = tok ? a.scale * fmaf(dx, sA, fmaf(dy, sB, sC)) : -3.0e38f;
+    const long st = (long)r * a.nh + h;
+    if (!BWD) {
+      const float m = block_reduce(s, true, red, tid);
+      const float p = tok ? __expf(s - m) : 0.0f;
+      const float l = block_reduce(p, false, red, tid);
+      if (tok) sP[n] = p;
+      __syncthreads();
+      if (tid < E) {  // thread e: sum over the tokens, V~ read along e
+        float acc = 0.0f;
+        for (int t2 = 0; t2 < a.L; ++t2) acc = fmaf(sP[t2], a.Vt[kv0 + (long)t2 * E + tid], acc);
+        sO[tid] = acc;
+      }
+      __syncthreads();
+      if (tid < DH) a.O[(long)r * H + h * DH + tid] = (dx * sO[tid] + dy * sO[DH + tid] + sO[2 * DH + tid]) / l;
+      if (tid == 0) { a.rmax[st] = m; a.rsum[st] = l; }
+    } else {
+      const float m = a.rmax[st], inv = 1.0f / a.rsum[st];
+      float pA = 0.f, pB = 0.f, pC = 0.f;
+#pragma unroll
+      for (int j = 0; j < DH; ++j) { pA = fmaf(g[j], Vn[j], pA); pB = fmaf(g[j], Vn[DH + j], pB); pC = fmaf(g[j], Vn[2 * DH + j], pC); }
+      const float p = tok ? __expf(s - m) * inv : 0.0f;
+      const float ds = p * (fmaf(dx, pA, fmaf(dy, pB, pC)) - Drow) * a.scale;
+      const float dsx = ds * dx, dsy = ds * dy, px = p * dx, py = p * dy;
+#pragma unroll
+      for (int j = 0; j < DH; ++j) {
+        dK[j] = fmaf(dsx, q[j], dK[j]); dK[DH + j] = fmaf(dsy, q[j], dK[DH + j]); dK[2 * DH + j] = fmaf(ds, q[j], dK[2 * DH + j]);
+        dV[j] = fmaf(px, g[j], dV[j]); dV[DH + j] = fmaf(py, g[j], dV[DH + j]); dV[2 * DH + j] = fmaf(p, g[j], dV[2 * DH + j]);
+      }
+      __syncthreads();  // (the previous ray's sP / sO are no longer read)
+      if (tok) sP[n] = ds;
+      __syncthreads();
+      if (tid < E) {
+        float acc = 0.0f;
+        for (int t2 = 0; t2 < a.L; ++t2) acc = fmaf(sP[t2], a.Kt[kv0 + (long)t2 * E + tid], acc);
+        sO[tid] = acc;
+      }
+      __syncthreads();
+      if (tid < DH) a.dQ[(long)r * H + h * DH + tid] = dx * sO[tid] + dy * sO[DH + tid] + sO[2 * DH + tid];  // (ds carries the scale)
+    }
+    __syncthreads();
+  }
+  if (BWD && tok) {
+#pragma unroll
+    for (int k = 0; k < E / 4; ++k) {
+      float4 x = reinterpret_cast<float4*>(a.dKt + kv)[k], y = reinterpret_cast<float4*>(a.dVt + kv)[k];
+      x.x += dK[4 * k]; x.y += dK[4 * k + 1]; x.z += dK[4 * k + 2]; x.w += dK[4 * k + 3];
+      y.x += dV[4 * k]; y.y += dV[4 * k + 1]; y.z += dV[4 * k + 2]; y.w += dV[4 * k + 3];
+      reinterpret_cast<float4*>(a.dKt + kv)[k] = x;
+      reinterpret_cast<float4*>(a.dVt + kv)[k] = y;
+    }
+  }
+}
+
 int check_attn(const char* who, int U, int D, int L, int nh, const void* const* ptrs, int np) {
   NSKY_CHECK_ARG(U >= 1 && D >= 1 && L >= 1 && L <= ATT_LMAX && L * E % 4 == 0 && nh >= 1 && nh <= 65535 && U <= 65535,
                  "%s: U %d, D %d, L %d (1..%d), heads %d", who, U, D, L, ATT_LMAX, nh);
@@ -936,5 +1061,34 @@ extern "C" int nsky_attn_core_bwd(const float* Q, const float* dirs, const float
   }
   hipLaunchKernelGGL(attn_core_bwd_tokens_kernel, dim3(n_heads, U, splits), dim3(ATT_THREADS), 0, (hipStream_t)stream, a, (const float*)drow, splits);
   NSKY_CHECK_LAUNCH("nsky_attn_core_bwd (tokens)");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_attn_core_rays_fwd(const float* Q, const float* dirs, const int32_t* perm, const int32_t* seg, const float* Kt, const float* Vt,
+                                       int32_t U, int32_t R, int32_t L, int32_t n_heads, float scale, float* O, float* row_max, float* row_sum,
+                                       nsky_stream_t stream) {
+  const void* ptrs[] = {Kt, Vt};
+  if (int rc = check_attn("nsky_attn_core_rays_fwd", U, 1, L, n_heads, ptrs, 2)) return rc;
+  NSKY_CHECK_ARG(Q && dirs && perm && seg && O && row_max && row_sum && R >= 1, "nsky_attn_core_rays_fwd: null operand / no rays");
+  RayArgs a{};
+  a.Q = Q; a.dirs = dirs; a.Kt = Kt; a.Vt = Vt; a.perm = perm; a.seg = seg; a.O = O; a.rmax = row_max; a.rsum = row_sum;
+  a.U = U; a.R = R; a.L = L; a.nh = n_heads; a.scale = scale;
+  hipLaunchKernelGGL(attn_rays_kernel<false>, dim3(n_heads, U), dim3(ATT_THREADS), 0, (hipStream_t)stream, a);
+  NSKY_CHECK_LAUNCH("nsky_attn_core_rays_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_attn_core_rays_bwd(const float* Q, const float* dirs, const int32_t* perm, const int32_t* seg, const float* Kt, const float* Vt,
+                                       const float* O, const float* row_max, const float* row_sum, const float* dO, int32_t U, int32_t R, int32_t L,
+                                       int32_t n_heads, float scale, float* dQ, float* dKt, float* dVt, nsky_stream_t stream) {
+  const void* ptrs[] = {Kt, Vt, dKt, dVt};
+  if (int rc = check_attn("nsky_attn_core_rays_bwd", U, 1, L, n_heads, ptrs, 4)) return rc;
+  NSKY_CHECK_ARG(Q && dirs && perm && seg && O && row_max && row_sum && dO && dQ && R >= 1, "nsky_attn_core_rays_bwd: null operand / no rays");
+  RayArgs a{};
+  a.Q = Q; a.dirs = dirs; a.Kt = Kt; a.Vt = Vt; a.perm = perm; a.seg = seg; a.O = const_cast<float*>(O); a.rmax = const_cast<float*>(row_max);
+  a.rsum = const_cast<float*>(row_sum); a.dO = dO; a.dQ = dQ; a.dKt = dKt; a.dVt = dVt;
+  a.U = U; a.R = R; a.L = L; a.nh = n_heads; a.scale = scale;
+  hipLaunchKernelGGL(attn_rays_kernel<true>, dim3(n_heads, U), dim3(ATT_THREADS), 0, (hipStream_t)stream, a);
+  NSKY_CHECK_LAUNCH("nsky_attn_core_rays_bwd");
   return NSKY_OK;
 }

@@ -52,7 +52,7 @@ class GemmDesc(C.Structure):
 
 _lib.nsky_last_error.restype = C.c_char_p
 _lib.nsky_abi_version.restype = C.c_int
-ABI_VERSION = 13  # the ctypes structures below mirror this version of include/neusky_hip.h
+ABI_VERSION = 14  # the ctypes structures below mirror this version of include/neusky_hip.h
 if _lib.nsky_abi_version() != ABI_VERSION:
     raise NeuSkyHipError(f"libneusky_hip.so has ABI version {_lib.nsky_abi_version()}, this package binds version {ABI_VERSION}: rebuild (build.sh)")
 
@@ -536,6 +536,30 @@ _attn_fwd = _sig("nsky_attn_core_fwd", C.c_void_p, C.c_void_p, C.c_void_p, C.c_v
                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 _attn_bwd = _sig("nsky_attn_core_bwd", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                  C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_attn_rays_fwd = _sig("nsky_attn_core_rays_fwd", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                      C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_attn_rays_bwd = _sig("nsky_attn_core_rays_bwd", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                      C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+
+
+def attn_core_rays_fwd(Q, dirs, perm, seg, Kt, Vt, scale, O, row_max, row_sum):
+    """the rays' rows, sorted by camera (perm [R] int32, seg [U + 1] int32): Q / O [R, 16 nh], dirs [R, 3], row_max / row_sum [R, nh]"""
+    R, H = Q.shape
+    U, nh, L = Kt.shape[0], Kt.shape[1], Kt.shape[2]
+    assert H == 16 * nh and perm.dtype == torch.int32 and seg.dtype == torch.int32 and seg.numel() == U + 1
+    assert all(t.is_contiguous() for t in (Q, dirs, perm, seg, Kt, Vt, O, row_max, row_sum))
+    check(_attn_rays_fwd(ptr(Q), ptr(dirs), ptr(perm), ptr(seg), ptr(Kt), ptr(Vt), U, R, L, nh, float(scale), ptr(O), ptr(row_max), ptr(row_sum),
+                         stream_ptr()), "nsky_attn_core_rays_fwd")
+    return O
+
+
+def attn_core_rays_bwd(Q, dirs, perm, seg, Kt, Vt, O, row_max, row_sum, dO, scale, dQ, dKt, dVt):
+    """adds the rays' part to dKt / dVt (call after attn_core_bwd on the same stream)"""
+    R, H = Q.shape
+    U, nh, L = Kt.shape[0], Kt.shape[1], Kt.shape[2]
+    assert all(t.is_contiguous() for t in (Q, dirs, perm, seg, Kt, Vt, O, row_max, row_sum, dO, dQ, dKt, dVt))
+    check(_attn_rays_bwd(ptr(Q), ptr(dirs), ptr(perm), ptr(seg), ptr(Kt), ptr(Vt), ptr(O), ptr(row_max), ptr(row_sum), ptr(dO), U, R, L, nh,
+                         float(scale), ptr(dQ), ptr(dKt), ptr(dVt), stream_ptr()), "nsky_attn_core_rays_bwd")
 
 
 def attn_core_fwd(Q, dirs, Kt, Vt, scale, O, row_max, row_sum):

@@ -288,40 +288,62 @@ class AttentionDecoder(nn.Module):
         x = torch.stack([torch.sqrt(dirs[..., 0] ** 2 + dirs[..., 1] ** 2 + 1e-20), dirs[..., 2]], -1)
         return torch.cat([x, nerf_encoding(x, 2, 2.0)], -1)
 
-    def forward(self, latents: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
-        """latents [U, L, 3], dirs [U, D, 3] (the directions each latent is decoded at) -> log-HDR rgb [U, D, 3]"""
+    def forward(self, latents: torch.Tensor, dirs: torch.Tensor, ray_dirs: Optional[torch.Tensor] = None,
+                ray_cam: Optional[torch.Tensor] = None):
+        """latents [U, L, 3], dirs [U, D, 3] (the directions each latent is decoded at) -> log-HDR rgb [U, D, 3].
+        With ray_dirs [R, 3] and ray_cam [R] (the latent each ray is decoded with): also the rays' rows, -> ([U, D, 3], [R, 3]).  A ray is
+        one more direction of ITS camera: its row rides behind the U D grid rows through every row-local layer (layer norms, Wq, Wo, the
+        feed-forward block) and attends to its camera's keys and values -- K~ / V~ are formed once per camera, not once per ray (decoding
+        the rays as R one-direction cameras projects R x 3 L token rows per layer: twice the grid's own row count at 1024 rays)."""
         U, D = dirs.shape[:2]
         H, nh = self.H, self.heads
         dh = H // nh
+        R = 0 if ray_dirs is None else ray_dirs.shape[0]
+        N = U * D
         A, B, C = self.token_coefficients(latents)
         T3 = torch.cat([A, B, C], 1)  # [U, 3 L, H]
-        coef = torch.stack([dirs[..., 0], dirs[..., 1], torch.ones_like(dirs[..., 0])], -1)  # [U, D, 3]
-        q = self.query_embed(self.query_inputs(dirs))  # [U, D, H]
+        all_dirs = dirs.reshape(N, 3) if R == 0 else torch.cat([dirs.reshape(N, 3), ray_dirs], 0)
+        q = self.query_embed(self.query_inputs(all_dirs))  # [N + R, H]
         # t_n(d) = d_x A_n + d_y B_n + C_n makes every key / value a sum of three per-camera vectors weighted by (d_x, d_y, 1).  The
         # weights move to the QUERY side: q . k_n(d) = [d_x q | d_y q | q] . [kA_n | kB_n | kC_n], a contraction over 3 dh = 48 per head,
         # and sum_n p_n v_n(d) = d_x (p VA) + d_y (p VB) + (p VC): scores and values are ONE [D, 48] x [48, L] and ONE [D, L] x [L, 48]
         # product per head and camera; neither the [U, nh, D, 3, L] score parts nor a [D, 3 L] probability matrix is ever formed.
         L = self.L
         parts = lambda t: t.reshape(U, 3, L, nh, dh).permute(0, 3, 2, 1, 4).reshape(U, nh, L, 3 * dh)  # noqa: E731  [U, nh, L, (part, dh)]
-        cx = coef.reshape(U, 1, D, 3, 1)
+        on_kernels = q.is_cuda and dh == 16 and L <= 128
+        ray_cam = None if R == 0 else ray_cam.reshape(-1)
+        ray_perm = ray_seg = None
+        if R and on_kernels and D >= 32:  # the rays sorted by camera, for the per-camera ray kernels (device ops: graph-capturable)
+            cam_sorted, ray_perm = torch.sort(ray_cam)
+            ray_seg = torch.searchsorted(cam_sorted, torch.arange(U + 1, device=q.device)).to(torch.int32)
+            ray_perm = ray_perm.to(torch.int32)
+
+        def core(Qp, dd, Kt, Vt):  # batched-product form: Qp [X, Y, H], dd [X, Y, 3], Kt / Vt [X, nh, L, 48] -> [X, Y, H]
+            X, Y = Qp.shape[:2]
+            cx = torch.stack([dd[..., 0], dd[..., 1], torch.ones_like(dd[..., 0])], -1).reshape(X, 1, Y, 3, 1)
+            Q = (Qp * (dh ** -0.5)).reshape(X, Y, nh, 1, dh).transpose(1, 2)  # [X, nh, Y, 1, dh]
+            Qt = (Q * cx).reshape(X, nh, Y, 3 * dh)
+            P = torch.softmax(torch.matmul(Qt, Kt.transpose(-1, -2)), -1)  # [X, nh, Y, L]
+            O3 = torch.matmul(P, Vt).reshape(X, nh, Y, 3, dh)
+            return (O3 * cx).sum(3).transpose(1, 2).reshape(X, Y, H)
+
         for blk in self.layers:
             K3, V3 = self._linear(T3, blk.wk), self._linear(T3, blk.wv)  # [U, 3 L, H]
             # the bias of K / V belongs to the constant part only: remove it from the d_x and d_y thirds
             mask = torch.cat([torch.ones(2 * L, device=T3.device), torch.zeros(L, device=T3.device)]).reshape(1, -1, 1)
             Kt, Vt = parts(K3 - blk.wk.bias * mask), parts(V3 - blk.wv.bias * mask)
-            Qp = self._linear(blk.ln1(q), blk.wq)  # [U, D, H]
-            if Qp.is_cuda and dh == 16 and L <= 128 and D >= 32:
+            Qp = self._linear(blk.ln1(q), blk.wq)  # [N + R, H]
+            if on_kernels and D >= 32:
                 # the attention core as HIP kernels (csrc/attention.hip): no [U, nh, D, L] score / probability matrices in memory
-                O = ops.AttnCoreFn.apply(Qp, dirs, Kt, Vt, dh ** -0.5)
-            else:  # the same arithmetic as batched products (CPU; a handful of rows per camera: the rays' own rows)
-                Q = (Qp * (dh ** -0.5)).reshape(U, D, nh, 1, dh).transpose(1, 2)  # [U, nh, D, 1, dh]
-                Qt = (Q * cx).reshape(U, nh, D, 3 * dh)
-                P = torch.softmax(torch.matmul(Qt, Kt.transpose(-1, -2)), -1)  # [U, nh, D, L]
-                O3 = torch.matmul(P, Vt).reshape(U, nh, D, 3, dh)
-                O = (O3 * cx).sum(3).transpose(1, 2).reshape(U, D, H)
+                O = ops.AttnCoreFn.apply(Qp, dirs, Kt, Vt, dh ** -0.5, ray_dirs, ray_perm, ray_seg)
+            else:  # the same arithmetic as batched products (CPU; short direction lists)
+                O = core(Qp[:N].reshape(U, D, H), dirs, Kt, Vt).reshape(N, H)
+                if R:
+                    O = torch.cat([O, core(Qp[N:].reshape(R, 1, H), ray_dirs[:, None, :], Kt[ray_cam], Vt[ray_cam]).reshape(R, H)], 0)
             q = q + self._linear(O, blk.wo)
             q = q + self._linear(self._linear(blk.ln2(q), blk.ff1, "relu"), blk.ff2)
-        return self.out(self.ln_f(q))
+        out = self.out(self.ln_f(q))
+        return out.reshape(U, D, 3) if R == 0 else (out[:N].reshape(U, D, 3), out[N:])
 
 
 class RENIField(nn.Module):
@@ -384,8 +406,9 @@ class RENIField(nn.Module):
         """forward_grid(directions, latent_codes, scale) and forward(ray_directions, latent_codes[ray_latent], scale[ray_latent]) from
         ONE pass of the decoder: the rays' rows ride behind the U D grid rows (-> [U,D,3], [R,3])"""
         U, D = latent_codes.shape[0], directions.shape[0]
-        if self.attention:
-            return self.forward_grid(directions, latent_codes, scale), self.forward(ray_directions, latent_codes[ray_latent.reshape(-1)], scale[ray_latent.reshape(-1)])
+        if self.attention:  # the rays as extra directions of their cameras: one pass, keys / values once per camera
+            grid, rays = self.network(latent_codes, directions[None].expand(U, D, 3), ray_directions, ray_latent)
+            return torch.exp(grid) * scale[:, None, None], torch.exp(rays) * scale[ray_latent.reshape(-1)][:, None]
         cond, x = ops.RENIGridInputsFn.apply(latent_codes, directions, ray_directions, ray_latent)
         raw = self.network(x, cond, train_weights=not self.config.fixed_decoder, padded_output=True)
         return ops.RENIOutputFn.apply(raw, scale, ray_latent, U, D)  # exp + the per-image scale of both row sets

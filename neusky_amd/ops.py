@@ -1656,26 +1656,41 @@ class DDFLossesFn(torch.autograd.Function):
 # =============================================================================================
 class AttnCoreFn(torch.autograd.Function):
     """O[u, d] = per-head softmax_n(q~ . K~_n) V~ combined with (d_x, d_y, 1) -- model_components/illumination.py:AttentionDecoder.
-    Q [U, D, H] (H = 16 heads_n), dirs [U, D, 3] (no gradient), Kt / Vt [U, heads, L, 48] -> O [U, D, H].  Saves Q, O and two row
-    statistics per head (instead of the [U, heads, D, L] score / probability matrices of the batched-product form)."""
+    Q [U D (+ R), H] (H = 16 heads_n; rows u D + d, then the R ray rows), dirs [U, D, 3] (no gradient), Kt / Vt [U, heads, L, 48]
+    -> O like Q.  ray_dirs [R, 3], ray_perm [R], ray_seg [U + 1] (int32: the rays sorted by camera, hip.attn_core_rays_fwd): a ray's
+    row attends to the keys / values of its camera.  Saves Q, O and two row statistics per head (instead of the [U, heads, D, L] score /
+    probability matrices of the batched-product form)."""
 
     @staticmethod
-    def forward(ctx, Q, dirs, Kt, Vt, scale):
+    def forward(ctx, Q, dirs, Kt, Vt, scale, ray_dirs=None, ray_perm=None, ray_seg=None):
         Q, dirs, Kt, Vt = Q.contiguous(), dirs.contiguous(), Kt.contiguous(), Vt.contiguous()
-        U, D, H = Q.shape
-        nh = Kt.shape[1]
+        U, D = dirs.shape[:2]
+        H, nh, N = Q.shape[-1], Kt.shape[1], U * D
+        R = 0 if ray_dirs is None else ray_dirs.shape[0]
+        ctx.shape = Q.shape
+        Q = Q.reshape(N + R, H)
         O = torch.empty_like(Q)
-        rmax = torch.empty(U, nh, D, device=Q.device)
-        rsum = torch.empty(U, nh, D, device=Q.device)
-        hip.attn_core_fwd(Q, dirs, Kt, Vt, scale, O, rmax, rsum)
-        ctx.save_for_backward(Q, dirs, Kt, Vt, O, rmax, rsum)
+        rmax = torch.empty(nh * (N + R), device=Q.device)
+        rsum = torch.empty(nh * (N + R), device=Q.device)
+        hip.attn_core_fwd(Q[:N].view(U, D, H), dirs, Kt, Vt, scale, O[:N].view(U, D, H), rmax[:nh * N].view(U, nh, D), rsum[:nh * N].view(U, nh, D))
+        if R:
+            ray_dirs = ray_dirs.contiguous()
+            hip.attn_core_rays_fwd(Q[N:], ray_dirs, ray_perm, ray_seg, Kt, Vt, scale, O[N:], rmax[nh * N:].view(R, nh), rsum[nh * N:].view(R, nh))
+        ctx.save_for_backward(Q, dirs, Kt, Vt, O, rmax, rsum, ray_dirs, ray_perm, ray_seg)
         ctx.scale = scale
-        return O
+        return O.view(ctx.shape)
 
     @staticmethod
     def backward(ctx, dO):
-        Q, dirs, Kt, Vt, O, rmax, rsum = ctx.saved_tensors
-        dO = dO.contiguous()
+        Q, dirs, Kt, Vt, O, rmax, rsum, ray_dirs, ray_perm, ray_seg = ctx.saved_tensors
+        U, D = dirs.shape[:2]
+        H, nh, N = Q.shape[-1], Kt.shape[1], U * D
+        R = Q.shape[0] - N
+        dO = dO.contiguous().reshape(N + R, H)
         dQ, dKt, dVt = torch.empty_like(Q), torch.empty_like(Kt), torch.empty_like(Vt)
-        hip.attn_core_bwd(Q, dirs, Kt, Vt, O, rmax, rsum, dO, ctx.scale, dQ, dKt, dVt)
-        return dQ, None, dKt, dVt, None
+        hip.attn_core_bwd(Q[:N].view(U, D, H), dirs, Kt, Vt, O[:N].view(U, D, H), rmax[:nh * N].view(U, nh, D), rsum[:nh * N].view(U, nh, D),
+                          dO[:N].view(U, D, H), ctx.scale, dQ[:N].view(U, D, H), dKt, dVt)
+        if R:  # adds the rays' part to dKt / dVt (same stream, behind the grid rows' kernels)
+            hip.attn_core_rays_bwd(Q[N:], ray_dirs, ray_perm, ray_seg, Kt, Vt, O[N:], rmax[nh * N:].view(R, nh), rsum[nh * N:].view(R, nh), dO[N:],
+                                   ctx.scale, dQ[N:], dKt, dVt)
+        return dQ.view(ctx.shape), None, dKt, dVt, None, None, None, None

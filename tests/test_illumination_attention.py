@@ -79,7 +79,8 @@ def test_attention_decoder_on_the_core_kernels():
     try:
         for mode in ("kernel", "products"):
             if mode == "products":
-                ops.AttnCoreFn.apply = staticmethod(lambda Q, dirs, Kt, Vt, scale: _attn_core_reference(Q, dirs, Kt, Vt, scale))
+                ops.AttnCoreFn.apply = staticmethod(lambda Q, dirs, Kt, Vt, scale, rd=None, rp=None, rs=None: _attn_core_reference(
+                    Q.reshape(*dirs.shape[:2], -1), dirs, Kt, Vt, scale).reshape(Q.shape))
             f = _field(L, dev)
             g = torch.Generator().manual_seed(1)
             lat = (torch.randn(U, L, 3, generator=g) * 0.6).to(dev).requires_grad_(True)
@@ -101,6 +102,43 @@ def test_attention_decoder_on_the_core_kernels():
     assert rel(res["kernel"][0], ref.detach()) < 2e-5
     assert rel(res["kernel"][0], res["products"][0]) < 1e-5 and rel(res["kernel"][1], res["products"][1]) < 1e-5
     assert rel(res["kernel"][1], lat64.grad) < 5e-3
+
+
+def _grid_and_rays(dev, D):
+    """forward_grid_and_rays (the rays as extra directions of their cameras: keys / values once per camera) against the two separate
+    decodes it replaces -- forward_grid, and forward on the per-ray gathered latents -- values and latent / scale gradients"""
+    L, U, R = 12, 5, 37
+    f = _field(L, dev)
+    g = torch.Generator().manual_seed(11)
+    lat0 = (torch.randn(U, L, 3, generator=g) * 0.6).to(dev)
+    sc0 = (torch.rand(U, generator=g) + 0.5).to(dev)
+    dirs = torch.nn.functional.normalize(torch.randn(D, 3, generator=g), dim=-1).to(dev)
+    rdirs = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(dev)
+    cam = torch.randint(0, U, (R,), generator=g).to(dev)
+    cam[:3] = 2  # several rays of one camera; camera 4 may have none
+    wg, wr = torch.randn(U, D, 3, generator=g).to(dev), torch.randn(R, 3, generator=g).to(dev)
+    res = []
+    for mode in ("joint", "separate"):
+        lat, sc = lat0.clone().requires_grad_(True), sc0.clone().requires_grad_(True)
+        if mode == "joint":
+            cols, bg = f.forward_grid_and_rays(dirs, lat, sc, rdirs, cam)
+        else:
+            cols, bg = f.forward_grid(dirs, lat, sc), f(rdirs, lat[cam], sc[cam])
+        ((cols * wg).sum() + (bg * wr).sum()).backward()
+        res.append((cols.detach(), bg.detach(), lat.grad.clone(), sc.grad.clone()))
+    rel = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()  # noqa: E731
+    for name, a, b in zip(("grid", "rays", "d latents", "d scale"), res[0], res[1]):
+        assert rel(a, b) < 2e-5, (name, rel(a, b))
+
+
+def test_rays_ride_with_their_cameras_cpu():
+    _grid_and_rays("cpu", 9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [9, 70])
+def test_rays_ride_with_their_cameras_gpu(D):
+    _grid_and_rays("cuda:0", D)  # D = 70: the grid rows on the matrix-core kernels, the rays' rows on the short-block kernels
 
 
 def test_so2_equivariance_about_z():
