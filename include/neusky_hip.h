@@ -651,6 +651,14 @@ int nsky_attn_core_rays_fwd(const float* Q, const float* dirs, const int32_t* pe
 int nsky_attn_core_rays_bwd(const float* Q, const float* dirs, const int32_t* perm, const int32_t* seg, const float* Kt, const float* Vt, const float* O,
                             const float* row_max, const float* row_sum, const float* dO, int32_t U, int32_t R, int32_t L, int32_t n_heads, float scale,
                             float* dQ, float* dKt, float* dVt, nsky_stream_t stream);
+/* Residual add + layer norm of the decoder's row stream ([M, W] row-major, W = 64, 128, 256 or 512): s = x + r (r NULL: s = x, not stored),
+ * y = LayerNorm(s) gamma + beta (biased variance, eps inside the root: torch.nn.LayerNorm), stats [M, 2] = (mean, rstd) of every row.
+ * _bwd, for frozen gamma / beta (the RENI++ decoder is fixed, neusky_config.py:87): ds = d LayerNorm / d s (dy) + ds_in (ds_in NULL: none) --
+ * the gradient of x and of r alike.  Replace torch's add + native_layer_norm (+ their backward nodes) of every decoder block. */
+int nsky_add_layer_norm_fwd(const float* x, const float* r, const float* gamma, const float* beta, int64_t M, int32_t W, float eps, float* s, float* y,
+                            float* stats, nsky_stream_t stream);
+int nsky_add_layer_norm_bwd(const float* s, const float* stats, const float* gamma, const float* dy, const float* ds_in, int64_t M, int32_t W, float* ds,
+                            nsky_stream_t stream);
 /* The step's objective: total = sum over segments of scale_s * sum_i coef_s[i] x_s[i] (coef NULL: 1).  Replaces the dozen scalar
  * multiplies, sums and adds that scale and merge the loss dictionaries (nerfstudio scale_dict + functools.reduce(torch.add, ...),
  * neusky_pipeline.py:283-289; interlevel_loss' mean, neusky_model.py:987-988) by one launch each way.  One workgroup; bwd writes

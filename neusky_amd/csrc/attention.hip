@@ -1004,6 +1004,116 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_rays_kernel(const RayArgs a)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Residual add + layer norm of the decoder's row-local stream, one wave per row (width W = 64 V, V = 1, 2, 4 or 8 consecutive features per
+// lane): s = x + r (stored when r is given), y = (s - mean) rstd gamma + beta, the row's (mean, rstd) saved.  Backward, for frozen
+// gamma / beta: ds = rstd (g - mean(g) - xhat mean(g xhat)) + ds_in, g = dy gamma -- the gradient of both x and r.
+struct LnArgs {
+  const float* x; const float* r; const float* gamma; const float* beta;
+  float* s; float* y; float* stats;            // stats [M, 2]
+  const float* dy; const float* ds_in; float* ds;
+  long M; float eps;
+};
+
+template <int V>
+__device__ __forceinline__ void ln_load(const float* p, float (&v)[V]) {
+  if (V == 1) v[0] = p[0];
+  if (V == 2) { const float2 a = *reinterpret_cast<const float2*>(p); v[0] = a.x; v[V > 1 ? 1 : 0] = a.y; }
+  if (V >= 4) {
+#pragma unroll
+    for (int i = 0; i < V / 4; ++i) {
+      const float4 a = reinterpret_cast<const float4*>(p)[i];
+      v[4 * i] = a.x; v[V > 1 ? 4 * i + 1 : 0] = a.y; v[V > 2 ? 4 * i + 2 : 0] = a.z; v[V > 3 ? 4 * i + 3 : 0] = a.w;
+    }
+  }
+}
+template <int V>
+__device__ __forceinline__ void ln_store(float* p, const float (&v)[V]) {
+  if (V == 1) p[0] = v[0];
+  if (V == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[V > 1 ? 1 : 0]);
+  if (V >= 4) {
+#pragma unroll
+    for (int i = 0; i < V / 4; ++i) reinterpret_cast<float4*>(p)[i] = make_float4(v[4 * i], v[V > 1 ? 4 * i + 1 : 0], v[V > 2 ? 4 * i + 2 : 0], v[V > 3 ? 4 * i + 3 : 0]);
+  }
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <int V, bool BWD>
+__global__ __launch_bounds__(256) void add_layer_norm_kernel(const LnArgs a) {
+  constexpr int W = 64 * V;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.M) return;
+  const long off = row * W + lane * V;
+  float gm[V];
+  ln_load<V>(a.gamma + lane * V, gm);
+  if (!BWD) {
+    float v[V], bt[V];
+    ln_load<V>(a.x + off, v);
+    if (a.r) {
+      float r[V];
+      ln_load<V>(a.r + off, r);
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] += r[j];
+      ln_store<V>(a.s + off, v);
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) sum += v[j];
+    const float mean = wave_sum(sum) * (1.0f / W);
+    float sq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) sq = fmaf(v[j] - mean, v[j] - mean, sq);
+    const float rstd = rsqrtf(wave_sum(sq) * (1.0f / W) + a.eps);
+    ln_load<V>(a.beta + lane * V, bt);
+#pragma unroll
+    for (int j = 0; j < V; ++j) v[j] = fmaf((v[j] - mean) * rstd, gm[j], bt[j]);
+    ln_store<V>(a.y + off, v);
+    if (lane == 0) { a.stats[2 * row] = mean; a.stats[2 * row + 1] = rstd; }
+  } else {
+    float s[V], g[V];
+    ln_load<V>(a.x + off, s);      // the saved sum s = x + r
+    ln_load<V>(a.dy + off, g);
+    const float mean = a.stats[2 * row], rstd = a.stats[2 * row + 1];
+    float c1 = 0.0f, c2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      g[j] *= gm[j];
+      s[j] = (s[j] - mean) * rstd;
+      c1 += g[j];
+      c2 = fmaf(g[j], s[j], c2);
+    }
+    c1 = wave_sum(c1) * (1.0f / W);
+    c2 = wave_sum(c2) * (1.0f / W);
+#pragma unroll
+    for (int j = 0; j < V; ++j) g[j] = rstd * (g[j] - c1 - s[j] * c2);
+    if (a.ds_in) {
+      float u[V];
+      ln_load<V>(a.ds_in + off, u);
+#pragma unroll
+      for (int j = 0; j < V; ++j) g[j] += u[j];
+    }
+    ln_store<V>(a.ds + off, g);
+  }
+}
+
+template <bool BWD>
+int launch_add_ln(const LnArgs& a, int W, hipStream_t stream) {
+  const dim3 grid((unsigned)((a.M + 3) / 4));
+  switch (W) {
+    case 64: hipLaunchKernelGGL((add_layer_norm_kernel<1, BWD>), grid, dim3(256), 0, stream, a); break;
+    case 128: hipLaunchKernelGGL((add_layer_norm_kernel<2, BWD>), grid, dim3(256), 0, stream, a); break;
+    case 256: hipLaunchKernelGGL((add_layer_norm_kernel<4, BWD>), grid, dim3(256), 0, stream, a); break;
+    case 512: hipLaunchKernelGGL((add_layer_norm_kernel<8, BWD>), grid, dim3(256), 0, stream, a); break;
+    default: return NSKY_ERR_ARG;
+  }
+  return NSKY_OK;
+}
+
 int check_attn(const char* who, int U, int D, int L, int nh, const void* const* ptrs, int np) {
   NSKY_CHECK_ARG(U >= 1 && D >= 1 && L >= 1 && L <= ATT_LMAX && L * E % 4 == 0 && nh >= 1 && nh <= 65535 && U <= 65535,
                  "%s: U %d, D %d, L %d (1..%d), heads %d", who, U, D, L, ATT_LMAX, nh);
@@ -1090,5 +1200,28 @@ extern "C" int nsky_attn_core_rays_bwd(const float* Q, const float* dirs, const 
   a.U = U; a.R = R; a.L = L; a.nh = n_heads; a.scale = scale;
   hipLaunchKernelGGL(attn_rays_kernel<true>, dim3(n_heads, U), dim3(ATT_THREADS), 0, (hipStream_t)stream, a);
   NSKY_CHECK_LAUNCH("nsky_attn_core_rays_bwd");
+  return NSKY_OK;
+}
+
+#define NSKY_AL16(p) (((uintptr_t)(p) % 16) == 0)
+extern "C" int nsky_add_layer_norm_fwd(const float* x, const float* r, const float* gamma, const float* beta, int64_t M, int32_t W, float eps, float* s,
+                                       float* y, float* stats, nsky_stream_t stream) {
+  NSKY_CHECK_ARG(x && gamma && beta && y && stats && M >= 1 && (r == nullptr || s != nullptr), "nsky_add_layer_norm_fwd: null operand / empty batch");
+  NSKY_CHECK_ARG(NSKY_AL16(x) && NSKY_AL16(y) && (!r || (NSKY_AL16(r) && NSKY_AL16(s))) && NSKY_AL16(gamma) && NSKY_AL16(beta), "nsky_add_layer_norm_fwd: alignment");
+  LnArgs a{};
+  a.x = x; a.r = r; a.gamma = gamma; a.beta = beta; a.s = s; a.y = y; a.stats = stats; a.M = M; a.eps = eps;
+  NSKY_CHECK_ARG(launch_add_ln<false>(a, W, (hipStream_t)stream) == NSKY_OK, "nsky_add_layer_norm_fwd: width %d (64, 128, 256 or 512)", W);
+  NSKY_CHECK_LAUNCH("nsky_add_layer_norm_fwd");
+  return NSKY_OK;
+}
+
+extern "C" int nsky_add_layer_norm_bwd(const float* s, const float* stats, const float* gamma, const float* dy, const float* ds_in, int64_t M, int32_t W,
+                                       float* ds, nsky_stream_t stream) {
+  NSKY_CHECK_ARG(s && stats && gamma && dy && ds && M >= 1, "nsky_add_layer_norm_bwd: null operand / empty batch");
+  NSKY_CHECK_ARG(NSKY_AL16(s) && NSKY_AL16(dy) && NSKY_AL16(ds) && (!ds_in || NSKY_AL16(ds_in)) && NSKY_AL16(gamma), "nsky_add_layer_norm_bwd: alignment");
+  LnArgs a{};
+  a.x = s; a.stats = const_cast<float*>(stats); a.gamma = gamma; a.dy = dy; a.ds_in = ds_in; a.ds = ds; a.M = M;
+  NSKY_CHECK_ARG(launch_add_ln<true>(a, W, (hipStream_t)stream) == NSKY_OK, "nsky_add_layer_norm_bwd: width %d (64, 128, 256 or 512)", W);
+  NSKY_CHECK_LAUNCH("nsky_add_layer_norm_bwd");
   return NSKY_OK;
 }

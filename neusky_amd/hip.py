@@ -536,6 +536,24 @@ _attn_fwd = _sig("nsky_attn_core_fwd", C.c_void_p, C.c_void_p, C.c_void_p, C.c_v
                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 _attn_bwd = _sig("nsky_attn_core_bwd", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                  C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_add_ln_fwd = _sig("nsky_add_layer_norm_fwd", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_void_p)
+_add_ln_bwd = _sig("nsky_add_layer_norm_bwd", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p)
+
+
+def add_layer_norm_fwd(x, r, gamma, beta, eps, s, y, stats):
+    """s = x + r (r None: s = x, not stored), y = LayerNorm(s), stats [M, 2] = (mean, rstd); x, r, s, y [M, W] contiguous"""
+    M, W = x.shape
+    assert all(t is None or t.is_contiguous() for t in (x, r, gamma, beta, s, y, stats))
+    check(_add_ln_fwd(ptr(x), ptr(r), ptr(gamma), ptr(beta), M, W, float(eps), ptr(s), ptr(y), ptr(stats), stream_ptr()), "nsky_add_layer_norm_fwd")
+
+
+def add_layer_norm_bwd(s, stats, gamma, dy, ds_in, ds):
+    M, W = s.shape
+    assert all(t is None or t.is_contiguous() for t in (s, stats, gamma, dy, ds_in, ds))
+    check(_add_ln_bwd(ptr(s), ptr(stats), ptr(gamma), ptr(dy), ptr(ds_in), M, W, ptr(ds), stream_ptr()), "nsky_add_layer_norm_bwd")
+
+
 _attn_rays_fwd = _sig("nsky_attn_core_rays_fwd", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                       C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 _attn_rays_bwd = _sig("nsky_attn_core_rays_bwd", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

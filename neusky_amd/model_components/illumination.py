@@ -327,12 +327,14 @@ class AttentionDecoder(nn.Module):
             O3 = torch.matmul(P, Vt).reshape(X, nh, Y, 3, dh)
             return (O3 * cx).sum(3).transpose(1, 2).reshape(X, Y, H)
 
+        resid = None  # the block's pending residual: added inside the next layer norm's pass (ops.add_layer_norm)
         for blk in self.layers:
             K3, V3 = self._linear(T3, blk.wk), self._linear(T3, blk.wv)  # [U, 3 L, H]
             # the bias of K / V belongs to the constant part only: remove it from the d_x and d_y thirds
             mask = torch.cat([torch.ones(2 * L, device=T3.device), torch.zeros(L, device=T3.device)]).reshape(1, -1, 1)
             Kt, Vt = parts(K3 - blk.wk.bias * mask), parts(V3 - blk.wv.bias * mask)
-            Qp = self._linear(blk.ln1(q), blk.wq)  # [N + R, H]
+            q, n1 = ops.add_layer_norm(q, resid, blk.ln1)
+            Qp = self._linear(n1, blk.wq)  # [N + R, H]
             if on_kernels and D >= 32:
                 # the attention core as HIP kernels (csrc/attention.hip): no [U, nh, D, L] score / probability matrices in memory
                 O = ops.AttnCoreFn.apply(Qp, dirs, Kt, Vt, dh ** -0.5, ray_dirs, ray_perm, ray_seg)
@@ -340,9 +342,9 @@ class AttentionDecoder(nn.Module):
                 O = core(Qp[:N].reshape(U, D, H), dirs, Kt, Vt).reshape(N, H)
                 if R:
                     O = torch.cat([O, core(Qp[N:].reshape(R, 1, H), ray_dirs[:, None, :], Kt[ray_cam], Vt[ray_cam]).reshape(R, H)], 0)
-            q = q + self._linear(O, blk.wo)
-            q = q + self._linear(self._linear(blk.ln2(q), blk.ff1, "relu"), blk.ff2)
-        out = self.out(self.ln_f(q))
+            q, n2 = ops.add_layer_norm(q, self._linear(O, blk.wo), blk.ln2)
+            resid = self._linear(self._linear(n2, blk.ff1, "relu"), blk.ff2)
+        out = self.out(ops.add_layer_norm(q, resid, self.ln_f)[1])
         return out.reshape(U, D, 3) if R == 0 else (out[:N].reshape(U, D, 3), out[N:])
 
 

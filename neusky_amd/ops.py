@@ -1654,6 +1654,42 @@ class DDFLossesFn(torch.autograd.Function):
 # =============================================================================================
 # attention core of the RENI++ transformer decoder (csrc/attention.hip)
 # =============================================================================================
+class AddLayerNormFn(torch.autograd.Function):
+    """(s, y) = (x + r, LayerNorm(x + r)) of a [M, W] row stream in one pass (csrc/attention.hip: add_layer_norm_kernel); r None: s is x.
+    gamma / beta are taken as constants (the frozen RENI++ decoder): callers with trainable norms use torch."""
+
+    @staticmethod
+    def forward(ctx, x, r, gamma, beta, eps):
+        x = x.contiguous()
+        M, W = x.shape
+        y, stats = torch.empty_like(x), torch.empty(M, 2, device=x.device)
+        s = x if r is None else torch.empty_like(x)
+        hip.add_layer_norm_fwd(x, None if r is None else r.contiguous(), gamma, beta, eps, None if r is None else s, y, stats)
+        ctx.save_for_backward(s, stats, gamma)
+        ctx.has_r = r is not None
+        ctx.set_materialize_grads(False)  # (an unused s -- the last norm of the stack -- hands None to backward, not a zero matrix)
+        return s, y
+
+    @staticmethod
+    def backward(ctx, ds_in, dy):
+        s, stats, gamma = ctx.saved_tensors
+        if dy is None:  # only the sum was used
+            return ds_in, (ds_in if ctx.has_r else None), None, None, None
+        ds = torch.empty_like(s)
+        hip.add_layer_norm_bwd(s, stats, gamma, dy.contiguous(), None if ds_in is None else ds_in.contiguous(), ds)
+        return ds, (ds if ctx.has_r else None), None, None, None
+
+
+def add_layer_norm(x, r, ln):
+    """(x + r, ln(x + r)) for a torch.nn.LayerNorm `ln` over the last dimension; r may be None"""
+    W = x.shape[-1]
+    if x.is_cuda and W in (64, 128, 256, 512) and not ln.weight.requires_grad and not ln.bias.requires_grad and x.numel() // W >= 256:
+        s, y = AddLayerNormFn.apply(x.reshape(-1, W), None if r is None else r.reshape(-1, W), ln.weight, ln.bias, ln.eps)
+        return s.view(x.shape), y.view(x.shape)
+    s = x if r is None else x + r
+    return s, ln(s)
+
+
 class AttnCoreFn(torch.autograd.Function):
     """O[u, d] = per-head softmax_n(q~ . K~_n) V~ combined with (d_x, d_y, 1) -- model_components/illumination.py:AttentionDecoder.
     Q [U D (+ R), H] (H = 16 heads_n; rows u D + d, then the R ray rows), dirs [U, D, 3] (no gradient), Kt / Vt [U, heads, L, 48]

@@ -141,6 +141,35 @@ def test_rays_ride_with_their_cameras_gpu(D):
     _grid_and_rays("cuda:0", D)  # D = 70: the grid rows on the matrix-core kernels, the rays' rows on the short-block kernels
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,W,with_r", [(1001, 128, True), (1001, 128, False), (300, 64, True), (517, 256, True), (259, 512, True)])
+def test_add_layer_norm_kernels_match_float64(M, W, with_r):
+    """nsky_add_layer_norm_fwd / _bwd against torch in float64: sum, normalised rows, and the gradient of x and r with both outputs used"""
+    from neusky_amd import ops
+    g = torch.Generator().manual_seed(M + W)
+    x, r = torch.randn(M, W, generator=g, dtype=torch.float64) * 2 + 0.3, torch.randn(M, W, generator=g, dtype=torch.float64)
+    ln = torch.nn.LayerNorm(W).double()
+    with torch.no_grad():
+        ln.weight.add_(torch.randn(W, generator=g, dtype=torch.float64) * 0.2); ln.bias.add_(torch.randn(W, generator=g, dtype=torch.float64) * 0.2)
+    ws, wy = torch.randn(M, W, generator=g, dtype=torch.float64), torch.randn(M, W, generator=g, dtype=torch.float64)
+    x64, r64 = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    s64 = x64 + r64 if with_r else x64 * 1.0
+    ((s64 * ws).sum() + (ln(s64) * wy).sum()).backward()
+    dev = "cuda:0"
+    lnf = torch.nn.LayerNorm(W).to(dev)
+    lnf.load_state_dict({k: v.float() for k, v in ln.state_dict().items()})
+    for p_ in lnf.parameters():
+        p_.requires_grad_(False)
+    xf, rf = x.float().to(dev).requires_grad_(True), r.float().to(dev).requires_grad_(True)
+    s, y = ops.add_layer_norm(xf, rf if with_r else None, lnf)
+    ((s * ws.float().to(dev)).sum() + (y * wy.float().to(dev)).sum()).backward()
+    rel = lambda a, b: ((a.detach().cpu().double() - b).abs().max() / b.abs().max()).item()  # noqa: E731
+    assert rel(s, s64.detach()) < 1e-6 and rel(y, ln(s64).detach()) < 2e-6
+    assert rel(xf.grad, x64.grad) < 3e-6
+    if with_r:
+        assert rel(rf.grad, r64.grad) < 3e-6
+
+
 def test_so2_equivariance_about_z():
     """rotating latents and directions together about z leaves the decoded radiance unchanged (RENI++'s defining property for
     equivariance="SO2", axis_of_invariance="z"); a rotation about another axis does not"""
