@@ -298,7 +298,8 @@ def attention_decoder_line(device, steps=5):
     ms = ts[len(ts) // 2]
     out = {"workload": "full NeuSky train step as the headline, illumination decoder = RENI++ attention decoder (neusky_config.py:78-95): "
                        "300 cameras x 512 directions + 1024 ray rows, 100 tokens, 8 heads x 6 layers, hidden 128; attention core on "
-                       "csrc/attention.hip, linear layers on this package's dense-layer kernels, layer norms / residuals torch",
+                       "csrc/attention.hip (matrix-core forms for the camera grids, per-camera ray kernels for the rays' own rows), residual add + layer norm "
+                       "fused (same file), linear layers on this package's dense-layer kernels",
            "ms_per_step": ms, "rays_per_s": RAYS / (ms * 1e-3), "launch": launch, "final_loss": float(loss),
            "parity": "unpinned (decoder source and weights absent from the reference tree); HIP path vs oracle.reni_attention_decode: tests/test_illumination_attention.py",
            "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9}
