@@ -284,6 +284,12 @@ class AttentionDecoder(nn.Module):
         y = torch.nn.functional.linear(x, lin.weight, lin.bias)
         return torch.relu(y) if act == "relu" else y
 
+    def _feed_forward(self, x: torch.Tensor, blk) -> torch.Tensor:
+        frozen = not any(p.requires_grad for p in (blk.ff1.weight, blk.ff1.bias, blk.ff2.weight, blk.ff2.bias))
+        if x.is_cuda and frozen and x.dim() == 2 and x.shape[0] >= 4096 and x.shape[1] % 4 == 0:
+            return ops.FrozenFeedForwardFn.apply(x, blk.ff1.weight, blk.ff1.bias, blk.ff2.weight, blk.ff2.bias)
+        return self._linear(self._linear(x, blk.ff1, "relu"), blk.ff2)
+
     def query_inputs(self, dirs: torch.Tensor) -> torch.Tensor:
         x = torch.stack([torch.sqrt(dirs[..., 0] ** 2 + dirs[..., 1] ** 2 + 1e-20), dirs[..., 2]], -1)
         return torch.cat([x, nerf_encoding(x, 2, 2.0)], -1)
@@ -343,7 +349,7 @@ class AttentionDecoder(nn.Module):
                 if R:
                     O = torch.cat([O, core(Qp[N:].reshape(R, 1, H), ray_dirs[:, None, :], Kt[ray_cam], Vt[ray_cam]).reshape(R, H)], 0)
             q, n2 = ops.add_layer_norm(q, self._linear(O, blk.wo), blk.ln2)
-            resid = self._linear(self._linear(n2, blk.ff1, "relu"), blk.ff2)
+            resid = self._feed_forward(n2, blk)
         out = self.out(ops.add_layer_norm(q, resid, self.ln_f)[1])
         return out.reshape(U, D, 3) if R == 0 else (out[:N].reshape(U, D, 3), out[N:])
 

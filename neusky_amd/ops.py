@@ -1654,6 +1654,33 @@ class DDFLossesFn(torch.autograd.Function):
 # =============================================================================================
 # attention core of the RENI++ transformer decoder (csrc/attention.hip)
 # =============================================================================================
+class FrozenFeedForwardFn(torch.autograd.Function):
+    """y = W2 relu(W1 x + b1) + b2 with constant weights (the frozen RENI++ decoder's feed-forward block) as ONE autograd node: the ReLU
+    mask is applied in the epilogue of the second layer's input-gradient product (EPI_BWD_RELU on the saved hidden rows), so no
+    threshold pass over the [M, hidden] gradient exists.  x [M, K] contiguous, K and the widths multiples of 4."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2):
+        x = x.contiguous()
+        M = x.shape[0]
+        h = torch.empty(M, W1.shape[0], device=x.device)
+        fgemm(x, W1, h, M, W1.shape[0], W1.shape[1], bias=b1, epi=hip.EPI_RELU)
+        y = torch.empty(M, W2.shape[0], device=x.device)
+        fgemm(h, W2, y, M, W2.shape[0], W2.shape[1], bias=b2)
+        ctx.save_for_backward(h, W1, W2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, W1, W2 = ctx.saved_tensors
+        M = h.shape[0]
+        dz = torch.empty_like(h)
+        grad_input(dy.contiguous(), W2, M, W2.shape[1], W2.shape[0], dz, epi=hip.EPI_BWD_RELU, aux0=h)
+        dx = torch.empty(M, W1.shape[1], device=h.device)
+        grad_input(dz, W1, M, W1.shape[1], W1.shape[0], dx)
+        return dx, None, None, None, None
+
+
 class AddLayerNormFn(torch.autograd.Function):
     """(s, y) = (x + r, LayerNorm(x + r)) of a [M, W] row stream in one pass (csrc/attention.hip: add_layer_norm_kernel); r None: s is x.
     gamma / beta are taken as constants (the frozen RENI++ decoder): callers with trainable norms use torch."""

@@ -262,3 +262,28 @@ def test_attention_core_kernels_match_float64(U, D, L, nh):
     assert rel(got, ref.detach()) < 5e-6
     for name, a, b in zip(("dQ", "dK~", "dV~"), got_in, ref_in):
         assert rel(a.grad, b.grad) < 2e-5, (name, rel(a.grad, b.grad))
+
+
+@pytest.mark.gpu
+def test_frozen_feed_forward_node_matches_two_dense_layers():
+    """ops.FrozenFeedForwardFn (ReLU mask in the second layer's input-gradient epilogue) against the two-layer composition it replaces"""
+    from neusky_amd import ops
+    dev, M = "cuda:0", 5000
+    g = torch.Generator().manual_seed(2)
+    ff1, ff2 = torch.nn.Linear(128, 256).to(dev), torch.nn.Linear(256, 128).to(dev)
+    for p_ in list(ff1.parameters()) + list(ff2.parameters()):
+        p_.requires_grad_(False)
+    x0 = torch.randn(M, 128, generator=g).to(dev)
+    w = torch.randn(M, 128, generator=g).to(dev)
+    outs = []
+    for mode in ("node", "layers"):
+        x = x0.clone().requires_grad_(True)
+        if mode == "node":
+            y = ops.FrozenFeedForwardFn.apply(x, ff1.weight, ff1.bias, ff2.weight, ff2.bias)
+        else:
+            y = ops.DenseFn.apply(ops.DenseFn.apply(x, ff1.weight, ff1.bias, 256, "relu", True), ff2.weight, ff2.bias, 128, "none", True)
+        (y * w).sum().backward()
+        outs.append((y.detach(), x.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and (outs[0][1] - outs[1][1]).abs().max().item() <= 1e-6 * outs[1][1].abs().max().item()
+    ref = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(x0.double(), ff1.weight.double(), ff1.bias.double())), ff2.weight.double(), ff2.bias.double())
+    assert ((outs[0][0].double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
