@@ -452,7 +452,8 @@ __global__ void visibility_rays_kernel(const float* __restrict__ origins, const 
   const float y[3] = {-sp[0], -sp[1], -sp[2]};
   float xl[3] = {-y[1], y[0], 0.0f};  // cross(up=(0,0,1), y)
   const float xn = sqrtf(xl[0] * xl[0] + xl[1] * xl[1] + xl[2] * xl[2]);
-  xl[0] /= xn; xl[1] /= xn; xl[2] /= xn;
+  if (xn > 0.0f) { xl[0] /= xn; xl[1] /= xn; xl[2] /= xn; }
+  else { xl[0] = 1.0f; xl[1] = 0.0f; xl[2] = 0.0f; }  // sphere hit ON the pole (0 / 0 in the reference): any unit vector across the axis
   float zl[3] = {y[1] * xl[2] - y[2] * xl[1], y[2] * xl[0] - y[0] * xl[2], y[0] * xl[1] - y[1] * xl[0]};  // cross(y, x)
   const float zn = sqrtf(zl[0] * zl[0] + zl[1] * zl[1] + zl[2] * zl[2]);
   zl[0] /= zn; zl[1] /= zn; zl[2] /= zn;

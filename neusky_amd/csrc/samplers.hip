@@ -32,7 +32,10 @@ struct Philox {
   }
 };
 
-__device__ __forceinline__ float u01(uint32_t w) { return ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // in (0, 1)
+// uniform in (0, 1), both ends excluded IN FLOAT: 23 bits + 1/2 is exact in fp32 (24 bits + 1/2 rounds the top value up to 1.0, which as
+// cos(phi) = 2 u - 1 = 1 puts a multi-view point exactly on the pole, where the local frame of ddf_model.py:158-181 divides 0 by 0: one NaN
+// per ~10 k training steps)
+__device__ __forceinline__ float u01(uint32_t w) { return ((float)(w >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 
 __global__ void advance_counter_kernel(uint64_t* counter) { *counter += 1; }
 
@@ -104,7 +107,8 @@ __device__ __forceinline__ void local_frame(const float pos[3], float x[3], floa
   y[0] = -pos[0]; y[1] = -pos[1]; y[2] = -pos[2];
   x[0] = -y[1]; x[1] = y[0]; x[2] = 0.0f;  // cross(up = (0, 0, 1), y)
   const float xn = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-  x[0] /= xn; x[1] /= xn; x[2] /= xn;
+  if (xn > 0.0f) { x[0] /= xn; x[1] /= xn; x[2] /= xn; }
+  else { x[0] = 1.0f; x[1] = 0.0f; x[2] = 0.0f; }  // a position ON the pole (the reference divides 0 by 0 there): any unit vector across the axis
   z[0] = y[1] * x[2] - y[2] * x[1]; z[1] = y[2] * x[0] - y[0] * x[2]; z[2] = y[0] * x[1] - y[1] * x[0];  // cross(y, x)
   const float zn = sqrtf(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);
   z[0] /= zn; z[1] /= zn; z[2] /= zn;

@@ -270,3 +270,35 @@ def test_proposal_mlp_matches_torch(P, in_dim, ldf):
     for a, b, n in zip(ps, q, ("dW0", "db0", "dW1", "db1")):
         tol = (2e-5 + 1e-9 * P) * max(1.0, float(b.grad.abs().max()))  # (fp32 sums of P terms, order not fixed)
         assert torch.allclose(a.grad.cpu().double(), b.grad, atol=tol), (n, float((a.grad.cpu().double() - b.grad).abs().max()))
+
+
+def test_fit_rows_are_finite_on_the_pole_and_drawn_points_stay_off_it():
+    """get_localised_transforms (ddf_model.py:158-181) divides 0 by 0 for a position on the z axis.  A multi-view point handed in exactly
+    on the pole gives finite encoded rows (any unit vector across the axis completes the frame), and the kernel's own draws never land
+    there: cos(phi) = 2 u - 1 with u strictly inside (0, 1) in float (round 4: u = 1.0 came out once in 2^24 draws -- a NaN in a
+    3000-step training run)."""
+    from neusky_amd import hip
+    N = 4096
+    g = torch.Generator().manual_seed(0)
+    pos = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).to(DEV)
+    dirs = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).to(DEV)
+    term = (torch.rand(N, generator=g) * 0.5 + 0.2).to(DEV).reshape(N, 1).contiguous()
+    mv = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    mv[:7] = torch.tensor([0.0, 0.0, 1.0])
+    mv[7:9] = torch.tensor([0.0, 0.0, -1.0])
+    mv = mv.to(DEV).contiguous()
+    q_pos, xrow = torch.full((2 * N, 3), float("nan"), device=DEV), torch.full((2 * N, 16), float("nan"), device=DEV)
+    mv_out = torch.empty(N, 3, device=DEV)
+    hip.ddf_fit_rows_fwd(pos, dirs, term.reshape(N), mv, 0, None, None, None, 1.0, True, 3.0, False, q_pos, xrow, mv_out, None, None)
+    torch.cuda.synchronize()
+    assert torch.isfinite(q_pos).all() and torch.isfinite(xrow[:, :15]).all()
+    d_loc = xrow[N:N + 9, :3]
+    assert ((d_loc.norm(dim=-1) - 1).abs() < 1e-5).all()  # a rotation of a unit direction
+    # drawn points: |z| < 1 strictly, over 2^22 draws
+    counter = torch.zeros(1, dtype=torch.int64, device=DEV)
+    worst = 0.0
+    for _ in range(1024):
+        hip.ddf_fit_rows_fwd(pos, dirs, term.reshape(N), None, 1234, counter, None, None, 1.0, True, 3.0, False, q_pos, xrow, mv_out, None, None)
+        worst = max(worst, float(mv_out[:, 2].abs().max()))
+        assert torch.isfinite(xrow[:, :15]).all()
+    assert worst < 1.0, worst
