@@ -68,7 +68,9 @@ class DDFModel(ModelBase):
         up[:, 2] = 1.0
         y = -positions
         x = torch.linalg.cross(up, y, dim=-1)
-        x = x / x.norm(dim=-1, keepdim=True)
+        xn = x.norm(dim=-1, keepdim=True)
+        # a position ON the z axis: 0 / 0 in the reference; any unit vector across the axis completes the frame (as csrc/samplers.hip does)
+        x = torch.where(xn > 0, x / xn.clamp_min(1e-38), torch.tensor([1.0, 0.0, 0.0], dtype=x.dtype, device=x.device).expand_as(x))
         z = torch.linalg.cross(y, x, dim=-1)
         z = z / z.norm(dim=-1, keepdim=True)
         return torch.stack((x, y, z), dim=-1)
