@@ -27,7 +27,7 @@ extern "C" {
 typedef void* nsky_stream_t; /* hipStream_t */
 
 const char* nsky_last_error(void);
-int nsky_abi_version(void); /* 14 (bumped when a struct layout or an entry point's signature changes) */
+int nsky_abi_version(void); /* 15 (bumped when a struct layout or an entry point's signature changes) */
 
 /* ------------------------------------------------------------------------------------------
  * Dense layer on the matrix cores: C[M,N] = epilogue( sum_k A(m,k) * B(n,k) + bias[n] )
@@ -220,6 +220,10 @@ typedef struct {
    * tiles beyond are walked but their outputs dropped); bias_row_mod = 4: db sums the rows with row % 4 == 0 only (quad-native
    * matrices of the SDF field, nsky_field_geo_bwd: row 4 n + j is row-set j of point n and only the value rows carry a bias). */
   int32_t bias_row_mod;
+  /* tile-native operands only: device scalar holding max |X| (may be null: the constant b_scale applies).  Operands that carry input
+   * tangents -- the quad-native encode rows and hidden activations of the SDF field -- have no a-priori bound (a hash level of resolution
+   * 2048 with table differences of order one has d feature / d x in the thousands): nsky_field_geo_fwd publishes their maxima. */
+  const float* b_scale_max;
 } nsky_wgrad_problem;
 int nsky_wgrad_native_batch(const nsky_wgrad_problem* problems, int32_t n_problems, int32_t rows, nsky_stream_t stream);
 
@@ -257,9 +261,11 @@ typedef struct nsky_field_net {
 /* QUAD-NATIVE matrices: tile-native [ceil32(4 N), width] whose row 4 n + j is row-set j of point n (j = 0: value, j = 1..3: d/dx_k).
  * ET: the stacked encode matrix [4 N, ldE] of nsky_encode_fwd (row j N + n).  Outputs: sdf [N], grad [N, 3] (d sdf / dx), a0q / a1q
  * (the two hidden layers' outputs, quad-native, width 256), Eq (optional; quad-native copy of the encode rows, width 128, for the first
- * layer's weight gradient), a1max [N] (optional: largest |a1| of each value row, the colour path's operand scale). */
+ * layer's weight gradient), a1max [N] (optional: largest |a1| of each value row, the colour path's operand scale), qmax [2] (optional; the
+ * caller zero-fills it: max |Eq| and max |a0q| over value and tangent rows, the b_scale_max of the first two layers' weight gradients). */
 int nsky_field_geo_fwd(const nsky_field_net* net, const void* stream_buf, const float* scales, int32_t total_groups, const float* ET,
-                       int32_t ldE, int32_t N, float* a0q, float* a1q, float* Eq, float* a1max, float* sdf, float* grad, nsky_stream_t stream);
+                       int32_t ldE, int32_t N, float* a0q, float* a1q, float* Eq, float* a1max, float* sdf, float* grad, float* qmax,
+                       nsky_stream_t stream);
 /* feat = W2f a1 + b2f; albedo = sigmoid(Wc2 relu(Wc1 relu(Wc0 [feat | x PE] + bc0) + bc1) + bc2) -> alb [N, 4] (3 used).  Saves (tile-
  * native, rows = points): a1v [ceil32(N), 256] (optional: value rows of a1), feat [ceil32(N), 256] and xpe [ceil32(N), 128] (columns 0..255
  * and 256..303 of the colour net's input; xpe's columns 48.. are not written), c0, c1 [ceil32(N), 256]. */

@@ -163,6 +163,7 @@ struct GeoFwdArgs {
   float* Eq;                  // quad-native [ceil32(4 N), 128] copy of the encode rows (optional)
   float* a1max;               // [N] largest |a1| of the value row (optional)
   float* sdf; float* grad;    // [N], [N, 3]
+  float* qmax;                // [2] (optional, caller zero-fills): max |Eq|, max |a0q| over value and tangent rows alike
 };
 
 // Epilogue of one 32-feature tile of a forward-mode softplus layer in the quad layout.  acc: this column's accumulator; inv: its
@@ -247,6 +248,7 @@ __device__ __forceinline__ void geo_fwd_tile(const GeoFwdArgs& a, WStream& ws, c
           stg4(eb + t * 1024 + g * 256, q);
         }
     }
+    if (a.qmax) publish_max(a.qmax, m, live, true, lane);
     const float s = row_scale(m, e_inv);
 #pragma unroll
     for (int ks = 0; ks < KS0; ++ks) {
@@ -269,6 +271,7 @@ __device__ __forceinline__ void geo_fwd_tile(const GeoFwdArgs& a, WStream& ws, c
   f16x8 ah[KS], al[KS];
   float a_inv = 1.0f;
   if (ACTIVE) {
+    if (a.qmax) publish_max(a.qmax + 1, m, live, true, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's a0 stores have left before it reads them back
     a_inv = planes_from_tiles<NT>(a0blk, lane, m, ah, al);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -980,7 +983,7 @@ extern "C" int nsky_chain_pack(const nsky_chain_layer* layers, int32_t n_layers,
 #define NSKY_AL16(p) (((uintptr_t)(p) % 16) == 0)
 
 extern "C" int nsky_field_geo_fwd(const nsky_field_net* net, const void* stream_buf, const float* scales, int32_t total_groups, const float* ET,
-                                  int32_t ldE, int32_t N, float* a0q, float* a1q, float* Eq, float* a1max, float* sdf, float* grad,
+                                  int32_t ldE, int32_t N, float* a0q, float* a1q, float* Eq, float* a1max, float* sdf, float* grad, float* qmax,
                                   nsky_stream_t stream) {
   if (int rc = check_field_net(net, "nsky_field_geo_fwd")) return rc;
   NSKY_CHECK_ARG(stream_buf && scales && ET && a0q && a1q && sdf && grad && N > 0 && net->b0 && net->b1 && net->w_sdf, "nsky_field_geo_fwd: null operand / empty batch");
@@ -990,7 +993,7 @@ extern "C" int nsky_field_geo_fwd(const nsky_field_net* net, const void* stream_
   NSKY_CHECK_ARG(total_groups == NT * groups_of(net->in_dim) + NT * groups_of(H), "nsky_field_geo_fwd: stream of %d groups does not hold W0, W1", total_groups);
   GeoFwdArgs a;
   a.net = *net; a.stream = (const unsigned char*)stream_buf; a.scales = scales; a.total_groups = total_groups; a.ET = ET; a.ldE = ldE; a.N = N;
-  a.n_tiles = ceil_div(N, 8); a.a0q = a0q; a.a1q = a1q; a.Eq = Eq; a.a1max = a1max; a.sdf = sdf; a.grad = grad;
+  a.n_tiles = ceil_div(N, 8); a.a0q = a0q; a.a1q = a1q; a.Eq = Eq; a.a1max = a1max; a.sdf = sdf; a.grad = grad; a.qmax = qmax;
   const dim3 grid(persistent_grid(a.n_tiles));
   hipLaunchKernelGGL((field_geo_fwd_kernel<5>), grid, dim3(THREADS), 0, (hipStream_t)stream, a);
   NSKY_CHECK_LAUNCH("nsky_field_geo_fwd");

@@ -40,6 +40,7 @@ struct WgradProblem {
   float* db;        // [32 nnt_a] or null
   const float* a_scale_max;  // device scalar: largest |dZ| (null: dZ is taken as it is)
   float b_scale;    // power of two applied to X
+  const float* b_scale_max;  // device scalar: largest |X| (null: the constant b_scale) -- operands that carry input tangents have no bound
   int nnt_a, nnt_b, ldw;   // tiles of 32 features each operand is walked in (row-major: ceil(width / 32) rounded up to the block)
   int tile0;        // first output block of this problem in the launch's block list
   int lda, ldb;     // row-major operands: leading dimensions (floats)
@@ -104,7 +105,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void wgrad_nati
 
   float a_inv = 1.0f;
   const float a_scale = P.a_scale_max ? pow2_scale(*P.a_scale_max, a_inv) : 1.0f;
-  const float b_scale = P.b_scale;
+  float b_unused;
+  const float b_scale = P.b_scale_max ? pow2_scale(*P.b_scale_max, b_unused) : P.b_scale;
 
   // ---- staging: this wave's block of each operand.  Native: lane = (row c, half hh), unit u = features 8 u + 4 hh .. + 3 of row c.
   // Row-major: lane = (row 8 u + lane / 8 of the block, features 4 (lane % 8) .. + 3 of the tile)
@@ -152,7 +154,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void wgrad_nati
     float v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      v[i] = live ? raw[uu][i] * s : 0.0f;
+      // (clamped to the fp16 range: an operand beyond its scale's reach saturates instead of turning the whole gradient into NaN)
+      v[i] = live ? __builtin_amdgcn_fmed3f(raw[uu][i] * s, -65504.0f, 65504.0f) : 0.0f;
       if (op == 0) bias[u][i] += bias_on ? v[i] : 0.0f;
     }
     unsigned char* img;
@@ -337,6 +340,7 @@ extern "C" int nsky_wgrad_native_batch(const nsky_wgrad_problem* problems, int32
     const nsky_wgrad_problem& q = problems[i];
     WgradProblem& P = a.p[i];
     P.A = q.dZ; P.B = q.X; P.dW = q.dW; P.db = q.db; P.a_scale_max = q.a_scale_max; P.b_scale = rm ? 1.0f : q.b_scale;
+    P.b_scale_max = rm ? nullptr : q.b_scale_max;
     P.nnt_a = rm ? ceil_div(q.width_a, 32 * NT) * NT : q.nnt_a;
     P.nnt_b = rm ? ceil_div(q.width_b, 32 * NT) * NT : q.nnt_b;
     P.ldw = q.ldw; P.tile0 = tiles;

@@ -52,7 +52,7 @@ class GemmDesc(C.Structure):
 
 _lib.nsky_last_error.restype = C.c_char_p
 _lib.nsky_abi_version.restype = C.c_int
-ABI_VERSION = 14  # the ctypes structures below mirror this version of include/neusky_hip.h
+ABI_VERSION = 15  # the ctypes structures below mirror this version of include/neusky_hip.h
 if _lib.nsky_abi_version() != ABI_VERSION:
     raise NeuSkyHipError(f"libneusky_hip.so has ABI version {_lib.nsky_abi_version()}, this package binds version {ABI_VERSION}: rebuild (build.sh)")
 
@@ -700,28 +700,30 @@ class WgradProblem(C.Structure):
     _fields_ = [("dZ", C.c_void_p), ("nnt_a", C.c_int32), ("X", C.c_void_p), ("nnt_b", C.c_int32), ("dW", C.c_void_p), ("ldw", C.c_int32),
                 ("db", C.c_void_p), ("a_scale_max", C.c_void_p), ("b_scale", C.c_float),
                 ("lda", C.c_int32), ("ldb", C.c_int32), ("width_a", C.c_int32), ("width_b", C.c_int32), ("bias_rows", C.c_int32),
-                ("bias_row_mod", C.c_int32)]
+                ("bias_row_mod", C.c_int32), ("b_scale_max", C.c_void_p)]
 
 
 WGRAD_MAX_PROBLEMS = 16
 _wgrad_native_batch = _sig("nsky_wgrad_native_batch", C.POINTER(WgradProblem), C.c_int32, C.c_int32, C.c_void_p)
 
 
-def wgrad_problem(dZ, nnt_a, X, nnt_b, rows, dW, db=None, a_scale_max=None, b_scale=64.0, width_a=0, width_b=0, bias_row_mod=0) -> WgradProblem:
+def wgrad_problem(dZ, nnt_a, X, nnt_b, rows, dW, db=None, a_scale_max=None, b_scale=64.0, width_a=0, width_b=0, bias_row_mod=0,
+                  b_scale_max=None) -> WgradProblem:
     """width_a / width_b: features of dZ / X that exist when fewer than the tiles walked (dW is then [width_a, width_b]);
-    bias_row_mod = 4: db sums the value rows (row % 4 == 0) of a quad-native dZ only"""
+    bias_row_mod = 4: db sums the value rows (row % 4 == 0) of a quad-native dZ only; b_scale_max: device scalar max |X| (replaces the
+    constant b_scale: operands that carry input tangents have no a-priori bound)"""
     wa, wb = width_a or 32 * nnt_a, width_b or 32 * nnt_b
     assert dW.stride(1) == 1 and dW.shape[0] >= wa and dW.shape[1] >= wb
     assert dZ.numel() >= film_rows(rows) * 32 * nnt_a and X.numel() >= film_rows(rows) * 32 * nnt_b
     return WgradProblem(ptr(dZ), nnt_a, ptr(X), nnt_b, ptr(dW), ld(dW), ptr(db), ptr(a_scale_max), float(b_scale), 0, 0, int(width_a), int(width_b), 0,
-                        int(bias_row_mod))
+                        int(bias_row_mod), ptr(b_scale_max))
 
 
 def wgrad_problem_rowmajor(dZ, n_out, X, k_in, rows, dW, db=None, bias_rows=0) -> WgradProblem:
     """dW[n_out, k_in] += dZ[:rows, :n_out]^T X[:rows, :k_in] over ROW-MAJOR operands (2-term bf16 products); see include/neusky_hip.h"""
     assert dW.stride(1) == 1 and dW.shape[0] >= n_out and dW.shape[1] >= k_in and n_out % 4 == 0 and k_in % 4 == 0
     assert dZ.shape[0] >= rows and X.shape[0] >= rows and ld(dZ) >= n_out and ld(X) >= k_in
-    return WgradProblem(ptr(dZ), 0, ptr(X), 0, ptr(dW), ld(dW), ptr(db), None, 1.0, ld(dZ), ld(X), n_out, k_in, int(bias_rows))
+    return WgradProblem(ptr(dZ), 0, ptr(X), 0, ptr(dW), ld(dW), ptr(db), None, 1.0, ld(dZ), ld(X), n_out, k_in, int(bias_rows), 0, None)
 
 
 def wgrad_native_batch(problems, rows):
@@ -961,7 +963,7 @@ class FieldNet(C.Structure):
 _chain_layout = _sig("nsky_chain_stream_layout", C.POINTER(ChainLayer), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32))
 _chain_pack = _sig("nsky_chain_pack", C.POINTER(ChainLayer), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p)
 _field_geo_fwd = _sig("nsky_field_geo_fwd", C.POINTER(FieldNet), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
-                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 _field_col_fwd = _sig("nsky_field_colour_fwd", C.POINTER(FieldNet), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 _field_col_bwd = _sig("nsky_field_colour_bwd", C.POINTER(FieldNet), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -1003,10 +1005,11 @@ def field_net(in_dim, npe, beta, b0, b1, w_sdf, b_sdf, b2f=None, bc0=None, bc1=N
                     bc0=ptr(bc0), bc1=ptr(bc1), wc2=ptr(wc2), ldc2=0 if wc2 is None else ld(wc2), bc2=ptr(bc2))
 
 
-def field_geo_fwd(net: FieldNet, pack, ET, N, a0q, a1q, Eq, a1max, sdf, grad):
+def field_geo_fwd(net: FieldNet, pack, ET, N, a0q, a1q, Eq, a1max, sdf, grad, qmax=None):
+    """qmax [2] (zero-filled by the caller): max |Eq|, max |a0q| -- the b_scale_max of the first two layers' weight gradients"""
     stream, scales, groups = pack
     check(_field_geo_fwd(C.byref(net), ptr(stream), ptr(scales), groups, ptr(ET), ld(ET), N, ptr(a0q), ptr(a1q), ptr(Eq), ptr(a1max), ptr(sdf),
-                         ptr(grad), stream_ptr()), "nsky_field_geo_fwd")
+                         ptr(grad), ptr(qmax), stream_ptr()), "nsky_field_geo_fwd")
 
 
 def field_colour_fwd(net: FieldNet, pack, ET, N, a1q, a1max, a1v, feat, xpe, c0, c1, alb):

@@ -421,6 +421,19 @@ class RENIField(nn.Module):
         raw = self.network(x, cond, train_weights=not self.config.fixed_decoder, padded_output=True)
         return ops.RENIOutputFn.apply(raw, scale, ray_latent, U, D)  # exp + the per-image scale of both row sets
 
+    def forward_camera(self, directions: torch.Tensor, latent: torch.Tensor, scale: Optional[torch.Tensor] = None,
+                       rotation: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """B directions against ONE latent code: directions [B, 3], latent [L, 3], scale a scalar tensor -> [B, 3].  The same numbers as
+        forward(directions, latent expanded to [B, L, 3], ...); the attention decoder forms the camera's keys / values once instead of
+        once per direction (a render chunk is 4096 rays of one camera)."""
+        if rotation is not None:
+            directions = directions @ rotation.transpose(-1, -2)
+        if self.attention:
+            out = torch.exp(self.network(latent[None], directions[None])[0])
+            return out * scale if scale is not None else out
+        B = directions.shape[0]
+        return self.forward(directions, latent[None].expand(B, -1, -1), None if scale is None else scale.expand(B))
+
     def forward(self, directions: torch.Tensor, latent_codes: torch.Tensor, scale: Optional[torch.Tensor] = None,
                 rotation: Optional[torch.Tensor] = None) -> torch.Tensor:
         """directions [B,3], latent_codes [B,L,3], scale [B] -> HDR radiance [B,3] (already unnormalised)."""

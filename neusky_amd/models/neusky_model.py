@@ -264,7 +264,7 @@ class NeuSkyFactoModel(ModelBase):
             dirs, cols, sel, cam, rot_f = frame
             self._upper_sel = sel
             R = camera_indices.shape[0]
-            bg = self.illumination_field(ray_directions, latents[cam][None].expand(R, -1, -1), scales[cam].expand(R), rot_f)
+            bg = self.illumination_field.forward_camera(ray_directions, latents[cam], scales[cam], rot_f)
             return dirs, cols, torch.zeros(R, dtype=torch.int32, device=dirs.device), bg
         if not self.training and self.config.fix_test_illumination_directions:
             dirs, sel = self.illumination_sampler.on_device(self.device, apply_random_rotation=False)  # :451-454
@@ -839,7 +839,7 @@ class NeuSkyFactoModel(ModelBase):
         if rotation is None:
             cols = self.illumination_field.forward_grid(dirs, latents[cam][None], scales[cam][None])
         else:
-            cols = self.illumination_field(dirs, latents[cam][None].expand(D, -1, -1), scales[cam].expand(D), rotation)[None]
+            cols = self.illumination_field.forward_camera(dirs, latents[cam], scales[cam], rotation)[None]
         # static per-model buffers: a chunk graph captured for one frame stays valid for the next (animation frames
         # only change the camera / rotation, render_animation.py:196-207)
         st = getattr(self, "_frame_static", None)

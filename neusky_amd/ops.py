@@ -892,7 +892,10 @@ class FieldChainFn(torch.autograd.Function):
         a1max = torch.empty(N, device=dev)
         sdf, grad = torch.empty(N, device=dev), torch.empty(N, 3, device=dev)
         pk = _field_pack("geo_fwd", (W0, W1), lambda: [hip.chain_layer(W0, 256, Kin), hip.chain_layer(W1, 256, 256)])
-        hip.field_geo_fwd(net, pk, ET, N, a0q, a1q, Eq, a1max, sdf, grad)
+        # largest |Eq|, |a0q| (tangent rows included): the operand scales of the first two layers' weight gradients
+        qmax = zeros(2, device=dev) if save else None
+        hip.field_geo_fwd(net, pk, ET, N, a0q, a1q, Eq, a1max, sdf, grad, qmax)
+        ctx.qmax = qmax
         if want_albedo:
             a1v = torch.empty(Mp, 256, device=dev) if save else None
             feat, c0, c1 = torch.empty(Mp, 256, device=dev), torch.empty(Mp, 256, device=dev), torch.empty(Mp, 256, device=dev)
@@ -948,8 +951,9 @@ class FieldChainFn(torch.autograd.Function):
         dW1, db1, f_1 = shared_grad(W1, b1)
         dW0, db0, f_0 = shared_grad(W0, b0)
         R4 = 4 * N
-        hip.wgrad_native_batch([hip.wgrad_problem(d1q, 8, a0q, 8, R4, dW1, db1, gmax[4:5], 8.0, bias_row_mod=4)], R4)
-        hip.wgrad_native_batch([hip.wgrad_problem(d0q, 8, Eq, 4, R4, dW0, db0, gmax[5:6], 64.0, width_b=Kin, bias_row_mod=4)], R4)
+        qmax = ctx.qmax
+        hip.wgrad_native_batch([hip.wgrad_problem(d1q, 8, a0q, 8, R4, dW1, db1, gmax[4:5], 8.0, bias_row_mod=4, b_scale_max=qmax[1:2])], R4)
+        hip.wgrad_native_batch([hip.wgrad_problem(d0q, 8, Eq, 4, R4, dW0, db0, gmax[5:6], 64.0, width_b=Kin, bias_row_mod=4, b_scale_max=qmax[0:1])], R4)
         hip.native_weighted_colsum(a1q, 8, R4, dW2[GF], db2[GF:GF + 1], g_sdf=g_sdf, g_grad=g_grad)
         k = lambda first, t: t if first else None  # noqa: E731  later nodes of the pass added in place
         if not colour:

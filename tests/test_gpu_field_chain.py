@@ -255,3 +255,23 @@ def test_fused_field_is_bitwise_repeatable():
         for k, v in cur.items():
             bad = (v != first[k]).reshape(v.shape[0], -1).any(dim=1)
             assert not bool(bad.any()), f"launch {it}: {k} differs from launch 0 in {int(bad.sum())} rows, first {torch.nonzero(bad).flatten()[:8].tolist()}"
+
+
+def test_fused_field_weight_gradients_with_steep_encode_tangents():
+    """Late in training the finest hash levels are steep: d feature / d x reaches the thousands (a table difference of order one times a
+    resolution of 2048).  The tangent rows of the encode matrix and of the hidden activations are operands of the first two layers'
+    weight gradients; with a FIXED pre-scale of 64 their fp16 split overflowed (a 27 000-step run of the bench workload: NaN in
+    d glin0 while every output and every other gradient was finite).  Operand scales now follow the published maxima."""
+    from neusky_amd import ops
+    N = 5003
+    g = torch.Generator().manual_seed(N)
+    ET = _inputs(N, N + 1)
+    ET[N:] *= 4000.0 / float(ET[N:].abs().max())  # tangent rows up to 4000
+    ws = _weights(seed=N, scale=0.05)  # (small first-layer weights keep the pre-activations in range)
+    g_sdf, g_grad, g_alb = torch.randn(N, generator=g).to(DEV), torch.randn(N, 3, generator=g).to(DEV), torch.randn(N, 3, generator=g).to(DEV)
+    want_sdf, want_grad, want_alb, want = _reference(ET, ws, g_sdf, g_grad, g_alb, _gpu_relu_masks(ET, ws))
+    sdf, grad, alb, got = _run(ops.FieldChainFn, ET, ws, g_sdf, g_grad, g_alb)
+    for n, a, b in zip(NAMES, got, want):
+        assert torch.isfinite(a).all(), n
+        e, s = _err(_crop(n, a), _crop(n, b))
+        assert e <= 1e-4 * s, f"{n}: max err {e:.3e} of {s:.3e}"

@@ -287,3 +287,26 @@ def test_frozen_feed_forward_node_matches_two_dense_layers():
     assert torch.equal(outs[0][0], outs[1][0]) and (outs[0][1] - outs[1][1]).abs().max().item() <= 1e-6 * outs[1][1].abs().max().item()
     ref = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(x0.double(), ff1.weight.double(), ff1.bias.double())), ff2.weight.double(), ff2.bias.double())
     assert ((outs[0][0].double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
+
+
+def _one_camera(dev, B):
+    f = _field(12, dev)
+    g = torch.Generator().manual_seed(5)
+    lat = (torch.randn(12, 3, generator=g) * 0.6).to(dev)
+    dirs = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1).to(dev)
+    sc = torch.tensor(1.3, device=dev)
+    c, s = math.cos(0.7), math.sin(0.7)
+    rot = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]], device=dev)
+    for r in (None, rot):
+        a = f.forward_camera(dirs, lat, sc, r)
+        b = f(dirs, lat[None].expand(B, -1, -1), sc.expand(B), r)
+        assert ((a - b).abs().max() / b.abs().max()).item() < 2e-5
+
+
+def test_one_camera_decode_equals_the_per_direction_decode_cpu():
+    _one_camera("cpu", 17)
+
+
+@pytest.mark.gpu
+def test_one_camera_decode_equals_the_per_direction_decode_gpu():
+    _one_camera("cuda:0", 300)  # the render chunk's form: one camera, its rays as the direction list (matrix-core kernels)
