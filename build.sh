@@ -20,3 +20,9 @@ done
 for p in $pids; do wait $p; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o neusky_amd/libneusky_hip.so $OBJS
 echo "built neusky_amd/libneusky_hip.so"
+# the waitcnt rule on the final ISA of every kernel (tools/isa_lint.py: no instruction touches the destination of a load that no
+# s_waitcnt covers -- hidden loads are invisible to the compiler's own bookkeeping): a violation fails the build
+lint_rc=0
+lint_out=$(python3 tools/isa_lint.py $OBJS) || lint_rc=$?
+echo "$lint_out" | tail -3
+exit $lint_rc
