@@ -107,6 +107,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void wgrad_nati
   const float a_scale = P.a_scale_max ? pow2_scale(*P.a_scale_max, a_inv) : 1.0f;
   float b_unused;
   const float b_scale = P.b_scale_max ? pow2_scale(*P.b_scale_max, b_unused) : P.b_scale;
+  const bool clamp_b = P.b_scale_max == nullptr;
 
   // ---- staging: this wave's block of each operand.  Native: lane = (row c, half hh), unit u = features 8 u + 4 hh .. + 3 of row c.
   // Row-major: lane = (row 8 u + lane / 8 of the block, features 4 (lane % 8) .. + 3 of the tile)
@@ -154,8 +155,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : 2) void wgrad_nati
     float v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      // (clamped to the fp16 range: an operand beyond its scale's reach saturates instead of turning the whole gradient into NaN)
-      v[i] = live ? __builtin_amdgcn_fmed3f(raw[uu][i] * s, -65504.0f, 65504.0f) : 0.0f;
+      v[i] = live ? raw[uu][i] * s : 0.0f;
+      // an X operand under a CONSTANT scale is clamped to the fp16 range: beyond the scale's reach it saturates instead of turning the
+      // whole gradient into NaN (operands scaled by their own maximum stay below 2^15)
+      if (op == 1 && clamp_b) v[i] = __builtin_amdgcn_fmed3f(v[i], -65504.0f, 65504.0f);
       if (op == 0) bias[u][i] += bias_on ? v[i] : 0.0f;
     }
     unsigned char* img;
