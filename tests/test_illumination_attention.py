@@ -310,3 +310,35 @@ def test_one_camera_decode_equals_the_per_direction_decode_cpu():
 @pytest.mark.gpu
 def test_one_camera_decode_equals_the_per_direction_decode_gpu():
     _one_camera("cuda:0", 300)  # the render chunk's form: one camera, its rays as the direction list (matrix-core kernels)
+
+
+@pytest.mark.gpu
+def test_attention_decoder_at_the_bench_size_against_the_oracle():
+    """The decode of the bench key `attention_decoder` at its own size -- 300 cameras x 512 directions + 1024 ray rows, 100 tokens, the
+    matrix-core attention kernels with their real grids, the per-camera ray kernels on a real ray-to-camera distribution, fused
+    add + layer norm, the feed-forward node -- against the float64 oracle on 40 (camera, direction) pairs and 24 rays spread over
+    the batch, and the latent gradient of a loss on exactly those rows."""
+    dev, U, D, L, R = "cuda:0", 300, 512, 100, 1024
+    f = _field(L, dev)
+    g = torch.Generator().manual_seed(9)
+    lat = (torch.randn(U, L, 3, generator=g) * 0.6).to(dev).requires_grad_(True)
+    dirs = torch.nn.functional.normalize(torch.randn(D, 3, generator=g), dim=-1).to(dev)
+    sc = (torch.rand(U, generator=g) + 0.5).to(dev)
+    rdirs = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(dev)
+    cam = torch.randint(0, U, (R,), generator=g).to(dev)
+    cols, bg = f.forward_grid_and_rays(dirs, lat, sc, rdirs, cam)
+    assert cols.shape == (U, D, 3) and bg.shape == (R, 3) and torch.isfinite(cols).all() and torch.isfinite(bg).all()
+    pu = torch.cat([torch.tensor([0, 0, 299, 299, 150]), torch.randint(0, U, (35,), generator=g)])
+    pd = torch.cat([torch.tensor([0, 511, 0, 511, 255]), torch.randint(0, D, (35,), generator=g)])
+    pr = torch.cat([torch.tensor([0, R - 1]), torch.randint(0, R, (22,), generator=g)])
+    wc, wb = torch.randn(40, 3, generator=g), torch.randn(24, 3, generator=g)
+    ((cols[pu.to(dev), pd.to(dev)] * wc.to(dev)).sum() + (bg[pr.to(dev)] * wb.to(dev)).sum()).backward()
+    p = attn_params(f.network)
+    lat64 = lat.detach().cpu().double().requires_grad_(True)
+    camc = cam.cpu()
+    ref_c = O.reni_attention_decode(lat64[pu], dirs.cpu().double()[pd], sc.cpu().double()[pu], p)
+    ref_b = O.reni_attention_decode(lat64[camc[pr]], rdirs.cpu().double()[pr], sc.cpu().double()[camc[pr]], p)
+    ((ref_c * wc.double()).sum() + (ref_b * wb.double()).sum()).backward()
+    rel = lambda a, b: ((a.detach().cpu().double() - b.detach()).abs().max() / b.detach().abs().max()).item()  # noqa: E731
+    assert rel(cols[pu.to(dev), pd.to(dev)], ref_c) < 2e-5 and rel(bg[pr.to(dev)], ref_b) < 2e-5
+    assert rel(lat.grad, lat64.grad) < 2e-3  # (ReLU units of the feed-forward blocks near zero: see test_attention_decoder_on_the_core_kernels)
