@@ -562,8 +562,9 @@ constexpr int MT_WAVES = 4, MT_THREADS = 64 * MT_WAVES;
 __global__ __launch_bounds__(MT_THREADS, 2) void attn_core_bwd_tokens_mfma_kernel(const AttnArgs a, const float* __restrict__ drow, const float* __restrict__ stat) {
   __shared__ f16x8 sQA[3 * 2 * 64], sGA[3 * 2 * 64];  // q~ / dO~ of the row tile, rows on the lanes: [part][hi, lo][lane]        6 KB each
   __shared__ f16x8 sQB[4 * 2 * 64], sGB[4 * 2 * 64];  // the same with the rows on k: [dim tile][16-row k-step][hi, lo][lane]     8 KB each
-  __shared__ __attribute__((aligned(16))) float sRawQ[32 * DH], sRawG[32 * DH];
-  __shared__ __attribute__((aligned(16))) float sDx[32], sDy[32], sMx[32], sLi[32], sDr[32];
+  // the row tile's q / dO rows and statistics, double-buffered: tile i + 1 is stored while tile i is being multiplied
+  __shared__ __attribute__((aligned(16))) float sRawQ[2][32 * DH], sRawG[2][32 * DH];
+  __shared__ __attribute__((aligned(16))) float sDx[2][32], sDy[2][32], sMx[2][32], sLi[2][32], sDr[2][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, h2 = lane >> 5;
   const int h = blockIdx.x, u = blockIdx.y;
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void attn_core_bwd_tokens_mfma_kerne
   // staging roles: thread t < 128: float4 (t & 3) of row t >> 2 of Q; t >= 128: of dO; threads 0 .. 31 also the row's statistics
   const int s_row = (tid & 127) >> 2, s_q4 = tid & 3;
   const float* s_src = (tid < 128 ? a.Q : a.dO) + h * DH + 4 * s_q4;
-  float* s_dst = (tid < 128 ? sRawQ : sRawG) + s_row * DH + 4 * s_q4;
+  const int s_off = s_row * DH + 4 * s_q4;
   float4 raw;
   float r_dx, r_dy, r_m, r_li, r_dr;
   auto fetch = [&](int d0) {
@@ -622,23 +623,25 @@ __global__ __launch_bounds__(MT_THREADS, 2) void attn_core_bwd_tokens_mfma_kerne
       if (dd >= a.D) { r_li = 0.0f; r_dr = 0.0f; }  // a row beyond the camera's: p = 0, dS = 0
     }
   };
+  auto stash = [&](int b) {  // the fetched row tile into buffer b
+    *reinterpret_cast<float4*>((tid < 128 ? sRawQ[b] : sRawG[b]) + s_off) = raw;
+    if (tid < 32) { sDx[b][tid] = r_dx; sDy[b][tid] = r_dy; sMx[b][tid] = r_m; sLi[b][tid] = r_li; sDr[b][tid] = r_dr; }
+  };
   fetch(0);
-  for (int d0 = 0; d0 < a.D; d0 += 32) {
-    __syncthreads();  // the previous row tile's fragments and rows are no longer read
-    *reinterpret_cast<float4*>(s_dst) = raw;
-    if (tid < 32) { sDx[tid] = r_dx; sDy[tid] = r_dy; sMx[tid] = r_m; sLi[tid] = r_li; sDr[tid] = r_dr; }
-    __syncthreads();
-    if (d0 + 32 < a.D) fetch(d0 + 32);
+  stash(0);
+  if (32 < a.D) fetch(32);
+  for (int d0 = 0, b = 0; d0 < a.D; d0 += 32, b ^= 1) {
+    __syncthreads();  // the previous row tile's fragments are no longer read; buffer b is complete
     // ---- fragments of the row tile: 14 x 64 lane-items (3 + 3 with the rows on the lanes, 4 + 4 with the rows on k), waves take them in turn
     for (int f = wave; f < 14; f += MT_WAVES) {
       const bool isq = f < 3 || (f >= 6 && f < 10);
-      const float* rawp = isq ? sRawQ : sRawG;
+      const float* rawp = isq ? sRawQ[b] : sRawG[b];
       const float sc = isq ? q_s : g_s;
       float x[8];
       f16x8* dst;
       if (f < 6) {  // rows on the lanes: lane (row n, half h2), part p: features 8 (j / 4) + 4 h2 + j % 4 of the row, times (d_x, d_y, 1)
         const int p = f < 3 ? f : f - 3;
-        const float cf = (p == 0 ? sDx[n] : (p == 1 ? sDy[n] : 1.0f)) * sc;
+        const float cf = (p == 0 ? sDx[b][n] : (p == 1 ? sDy[b][n] : 1.0f)) * sc;
         const float4 v0 = *reinterpret_cast<const float4*>(rawp + n * DH + 4 * h2), v1 = *reinterpret_cast<const float4*>(rawp + n * DH + 8 + 4 * h2);
         const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void attn_core_bwd_tokens_mfma_kerne
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int r = 16 * kr + 8 * (j >> 2) + 4 * h2 + (j & 3);
-          const float cf = (p == 0 ? sDx[r] : (p == 1 ? sDy[r] : 1.0f)) * sc;
+          const float cf = (p == 0 ? sDx[b][r] : (p == 1 ? sDy[b][r] : 1.0f)) * sc;
           x[j] = dim < E ? rawp[r * DH + e] * cf : 0.0f;
         }
         dst = (f < 10 ? sQB : sGB) + (2 * g) * 64;
@@ -662,7 +665,11 @@ __global__ __launch_bounds__(MT_THREADS, 2) void attn_core_bwd_tokens_mfma_kerne
       dst[lane] = hi;
       dst[64 + lane] = lo;
     }
-    __syncthreads();
+    __syncthreads();  // the fragments are in place; nobody reads buffer b ^ 1 any more (its tile was packed an iteration ago)
+    if (d0 + 32 < a.D) {
+      stash(b ^ 1);
+      if (d0 + 64 < a.D) fetch(d0 + 64);
+    }
     if (has_tokens) {
       f32x16 s, dp;
 #pragma unroll
@@ -682,8 +689,8 @@ __global__ __launch_bounds__(MT_THREADS, 2) void attn_core_bwd_tokens_mfma_kerne
       const float tok_live = token < a.L ? 1.0f : 0.0f;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 m4 = *reinterpret_cast<const float4*>(sMx + 8 * g + 4 * h2), l4 = *reinterpret_cast<const float4*>(sLi + 8 * g + 4 * h2),
-                     d4 = *reinterpret_cast<const float4*>(sDr + 8 * g + 4 * h2);
+        const float4 m4 = *reinterpret_cast<const float4*>(sMx[b] + 8 * g + 4 * h2), l4 = *reinterpret_cast<const float4*>(sLi[b] + 8 * g + 4 * h2),
+                     d4 = *reinterpret_cast<const float4*>(sDr[b] + 8 * g + 4 * h2);
         const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
