@@ -207,39 +207,52 @@ __device__ __forceinline__ void product_skip(WStream& w) {
 }
 
 // acc += W_tile X over KS k-steps, B planes in registers.  One wave per SIMD issues in order, so everything that is not an
-// MFMA is placed in the shadow of one: the LDS requests of k-step ks + 2 (and a group transition: barrier + 4 DMA pieces) right
+// MFMA is placed in the shadow of one: the LDS requests of k-step ks + NB - 1 (and a group transition: barrier + 4 DMA pieces) right
 // behind the first MFMA of k-step ks, the counted wait for the fragments of ks + 1 behind the third.
-template <int KS, int PW = 4, bool WRAP = false, int RG = RING_GROUPS>
+// NB fragment buffers rotate: reads run NB - 1 k-steps ahead of the MFMAs (NB = 4 where a wave has the registers: the last wait of a
+// product, for slab 0 of the next tile, then has had 9 MFMAs to be satisfied instead of 6).
+template <int KS, int PW = 4, bool WRAP = false, int RG = RING_GROUPS, int NB = 3>
 __device__ __forceinline__ void product(WStream& w, const f16x8 (&bh)[KS], const f16x8 (&bl)[KS], f32x16& acc) {
   constexpr int NG = (KS + GSLABS - 1) / GSLABS;  // groups of this tile; slab index KS stands for slab 0 of the next tile
-  f16x8 fh[3], fl[3];
+  constexpr int AHEAD = NB - 1;
+  f16x8 fh[NB], fl[NB];
   fh[0] = w.ch;
   fl[0] = w.cl;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { fh[1][j] = fh[2][j] = fl[1][j] = fl[2][j] = (_Float16)0.0f; }
+  for (int b = 1; b < NB; ++b)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { fh[b][j] = (_Float16)0.0f; fl[b][j] = (_Float16)0.0f; }
   const int g0 = w.g;
   auto request = [&](int s) {  // s static
-    if (s < KS) frag_read(fh[s % 3], fl[s % 3], ws_addr<RG>(w, g0 + s / GSLABS, s % GSLABS));
-    else frag_read(fh[s % 3], fl[s % 3], ws_addr<RG>(w, g0 + NG, 0));
+    if (s < KS) frag_read(fh[s % NB], fl[s % NB], ws_addr<RG>(w, g0 + s / GSLABS, s % GSLABS));
+    else frag_read(fh[s % NB], fl[s % NB], ws_addr<RG>(w, g0 + NG, 0));
   };
-  request(1);
+#pragma unroll
+  for (int s = 1; s < AHEAD; ++s)
+    if (s <= KS) request(s);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks % 3], bl[ks], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks % NB], bl[ks], acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (ks + 2 <= KS) request(ks + 2);  // into the buffer of k-step ks - 1, whose MFMAs have been issued
+    if (ks + AHEAD <= KS) request(ks + AHEAD);  // into the buffer of k-step ks - 1, whose MFMAs have been issued
     if ((ks & (GSLABS - 1)) == GSLABS - 1 || ks == KS - 1) ws_transition<PW, WRAP, RG>(w, g0 + ks / GSLABS);
     __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks % 3], bh[ks], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks % 3], bh[ks], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks % NB], bh[ks], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks % NB], bh[ks], acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    // fragments of k-step ks + 1 (slab KS = first slab of the next tile): only the pair requested above may still be in flight
-    if (ks + 2 <= KS) frag_wait<2>(fh[(ks + 1) % 3], fl[(ks + 1) % 3]);
+    // fragments of k-step ks + 1 (slab KS = first slab of the next tile): the younger pairs (slabs ks + 2 .. min(ks + AHEAD, KS)) may
+    // still be in flight
+    static_assert(AHEAD == 2 || AHEAD == 3, "two or three k-steps of read-ahead");
+    if (ks < KS - 1) {  // (ks is a constant after unrolling: one of the two waits survives)
+      if (AHEAD == 3 && ks + 3 <= KS) frag_wait<4>(fh[(ks + 1) % NB], fl[(ks + 1) % NB]);
+      else frag_wait<2>(fh[(ks + 1) % NB], fl[(ks + 1) % NB]);
+    }
   }
   // the last wait (lgkmcnt(0)) and the carry in one statement: nothing is in flight behind it, no load crosses a loop back-edge or
-  // a branch join
-  frag_settle(w.ch, w.cl, fh[KS % 3], fl[KS % 3]);
+  // a branch join.  (Even when the carried slab sits in buffer 0 -- NB = 4, KS a multiple of 4 -- the register allocator does not
+  // keep buffer 0 in the carry's registers and would copy in front of a tied wait: tools/isa_lint.py caught exactly that.)
+  frag_settle(w.ch, w.cl, fh[KS % NB], fl[KS % NB]);
   w.g = g0 + NG;
 }
 

@@ -24,6 +24,10 @@
 
 namespace {
 
+// fragment buffers of the four-wave forward kernel's products (chain.h product<.., NB>): it has the registers for a fourth pair (LDS reads
+// three k-steps ahead instead of two), measured same-box at 2.515-2.540 ms against 2.503-2.532 with three: the kernel does not wait on LDS
+constexpr int FWD_FRAG_BUFFERS = 3;
+
 
 // ---------------------------------------------------------------------------------------------------------------------
 // stream layout.  Forward order (tile = 32 output features x K):
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-      product<KS>(ws, hh, hl, acc);
+      product<KS, 4, false, RING_GROUPS, FWD_FRAG_BUFFERS>(ws, hh, hl, acc);
       const float inv = h_inv * sl[tile++];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -338,14 +342,14 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
       f32x16 aF, aP, aZ;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { aF[r] = 0.0f; aP[r] = 0.0f; aZ[r] = 0.0f; }
-      product<KS>(ws, hh, hl, aF);
-      product<KS>(ws, hh, hl, aP);
+      product<KS, 4, false, RING_GROUPS, FWD_FRAG_BUFFERS>(ws, hh, hl, aF);
+      product<KS, 4, false, RING_GROUPS, FWD_FRAG_BUFFERS>(ws, hh, hl, aP);
       float z_unscale;
       if (i == 0) {
         product<1>(ws, xh, xl, aZ);
         z_unscale = x_inv;
       } else {
-        product<KS>(ws, yh, yl, aZ);
+        product<KS, 4, false, RING_GROUPS, FWD_FRAG_BUFFERS>(ws, yh, yl, aZ);
         z_unscale = 1.0f / Y_SCALE;
       }
       const float iF = h_inv * sl[tile], iP = h_inv * sl[tile + 1], iZ = z_unscale * sl[tile + 2];
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    product<KS>(ws, yh, yl, acc);
+    product<KS, 4, false, RING_GROUPS, FWD_FRAG_BUFFERS>(ws, yh, yl, acc);
     const float inv = sl[tile] / Y_SCALE;
     const float* bO = bias_film + n_film * H;
     if (live && h == 0)
