@@ -920,9 +920,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_rays_kernel(const RayArgs a)
   __shared__ float red[2];
   __shared__ float sP[ATT_LMAX];   // p_n (forward) / ds_n (backward)
   __shared__ float sO[E];          // the 48-wide sums before the (d_x, d_y, 1) combination
+  // blockIdx.z: the 32-ray slice of the camera's rays this workgroup walks (a batch drawn from ONE image -- the eval-latent fit -- puts
+  // all its rays on one camera: its slices run side by side; a camera with up to 32 rays has one workgroup and the rest leave at once)
   const int tid = threadIdx.x, h = blockIdx.x, u = blockIdx.y;
-  const int r_beg = a.seg[u], r_end = a.seg[u + 1];
-  if (r_beg == r_end) return;
+  const int seg_beg = a.seg[u], seg_end = a.seg[u + 1];
+  if (seg_beg + 32 * (int)blockIdx.z >= seg_end) return;
+  const bool shared_camera = seg_end - seg_beg > 32;  // several workgroups add into this camera's dK~ / dV~: atomics
   const int n = tid;
   const bool tok = n < a.L;
   const int H = a.nh * DH;
@@ -940,7 +943,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_rays_kernel(const RayArgs a)
       dV[4 * k] = dV[4 * k + 1] = dV[4 * k + 2] = dV[4 * k + 3] = 0.0f;
     }
   }
-  for (int i = r_beg; i < r_end; ++i) {
+  for (int s0 = seg_beg + 32 * blockIdx.z; s0 < seg_end; s0 += 32 * gridDim.z)  // (slices z, z + Z, ..: more than 32 Z rays on one camera)
+  for (int i = s0; i < min(seg_end, s0 + 32); ++i) {
     const int r = a.perm[i];                       // block-uniform
     const float* qp = a.Q + (long)r * H + h * DH;
     const float dx = a.dirs[(long)r * 3], dy = a.dirs[(long)r * 3 + 1];
@@ -999,7 +1003,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_rays_kernel(const RayArgs a)
     }
     __syncthreads();
   }
-  if (BWD && tok) {
+  if (BWD && tok && shared_camera) {
+#pragma unroll
+    for (int k = 0; k < E; ++k) { atomicAdd(a.dKt + kv + k, dK[k]); atomicAdd(a.dVt + kv + k, dV[k]); }
+  } else if (BWD && tok) {
 #pragma unroll
     for (int k = 0; k < E / 4; ++k) {
       float4 x = reinterpret_cast<float4*>(a.dKt + kv)[k], y = reinterpret_cast<float4*>(a.dVt + kv)[k];
@@ -1190,7 +1197,7 @@ extern "C" int nsky_attn_core_rays_fwd(const float* Q, const float* dirs, const 
   RayArgs a{};
   a.Q = Q; a.dirs = dirs; a.Kt = Kt; a.Vt = Vt; a.perm = perm; a.seg = seg; a.O = O; a.rmax = row_max; a.rsum = row_sum;
   a.U = U; a.R = R; a.L = L; a.nh = n_heads; a.scale = scale;
-  hipLaunchKernelGGL(attn_rays_kernel<false>, dim3(n_heads, U), dim3(ATT_THREADS), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(attn_rays_kernel<false>, dim3(n_heads, U, min(32, ceil_div(R, 32))), dim3(ATT_THREADS), 0, (hipStream_t)stream, a);
   NSKY_CHECK_LAUNCH("nsky_attn_core_rays_fwd");
   return NSKY_OK;
 }
@@ -1205,7 +1212,7 @@ extern "C" int nsky_attn_core_rays_bwd(const float* Q, const float* dirs, const 
   a.Q = Q; a.dirs = dirs; a.Kt = Kt; a.Vt = Vt; a.perm = perm; a.seg = seg; a.O = const_cast<float*>(O); a.rmax = const_cast<float*>(row_max);
   a.rsum = const_cast<float*>(row_sum); a.dO = dO; a.dQ = dQ; a.dKt = dKt; a.dVt = dVt;
   a.U = U; a.R = R; a.L = L; a.nh = n_heads; a.scale = scale;
-  hipLaunchKernelGGL(attn_rays_kernel<true>, dim3(n_heads, U), dim3(ATT_THREADS), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(attn_rays_kernel<true>, dim3(n_heads, U, min(32, ceil_div(R, 32))), dim3(ATT_THREADS), 0, (hipStream_t)stream, a);
   NSKY_CHECK_LAUNCH("nsky_attn_core_rays_bwd");
   return NSKY_OK;
 }

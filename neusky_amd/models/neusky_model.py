@@ -274,7 +274,7 @@ class NeuSkyFactoModel(ModelBase):
             dirs, sel = self.illumination_sampler.on_device(self.device)  # :456-458, drawn on the device
         self._upper_sel = sel  # upper-hemisphere subset (:1650-1657): static size D/2 for the antipodal direction set
         D = dirs.shape[0]
-        if self.training and latents.shape[0] <= max(1024, camera_indices.shape[0]):
+        if (self.training or self.fitting_eval_latents) and latents.shape[0] <= max(1024, camera_indices.shape[0]):
             # every camera of the active latent set is decoded (U = num_train_data, or num_eval_data while the eval latents
             # are being fitted: static shape, no torch.unique host sync, hipGraph-safe); rows of cameras absent from the
             # batch are never read by the renderer and receive zero gradient
@@ -797,8 +797,14 @@ class NeuSkyFactoModel(ModelBase):
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    gloss = iteration(srb, sbatch, None, srnd)
+                try:
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                        gloss = iteration(srb, sbatch, None, srnd)
+                except RuntimeError as exc:  # a host-dependent op inside the iteration: run the fit with host launches instead
+                    import warnings
+                    warnings.warn(f"fit_latent_codes_for_eval: HIP graph capture refused ({str(exc)[:100]}); running eagerly")
+                    torch.cuda.synchronize()
+                    graph = None
             for it in range(steps):
                 rb, batch, rot = (rb0, batch0, rot0) if it == 0 else next_bundle(it)
                 if graph is not None:

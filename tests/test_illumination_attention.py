@@ -104,10 +104,10 @@ def test_attention_decoder_on_the_core_kernels():
     assert rel(res["kernel"][1], lat64.grad) < 5e-3
 
 
-def _grid_and_rays(dev, D):
+def _grid_and_rays(dev, D, R=37, one_camera=False):
     """forward_grid_and_rays (the rays as extra directions of their cameras: keys / values once per camera) against the two separate
     decodes it replaces -- forward_grid, and forward on the per-ray gathered latents -- values and latent / scale gradients"""
-    L, U, R = 12, 5, 37
+    L, U = 12, 5
     f = _field(L, dev)
     g = torch.Generator().manual_seed(11)
     lat0 = (torch.randn(U, L, 3, generator=g) * 0.6).to(dev)
@@ -116,6 +116,8 @@ def _grid_and_rays(dev, D):
     rdirs = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(dev)
     cam = torch.randint(0, U, (R,), generator=g).to(dev)
     cam[:3] = 2  # several rays of one camera; camera 4 may have none
+    if one_camera:  # a batch drawn from one image (the eval-latent fit): the camera's rays are walked by several workgroups
+        cam[:] = 3
     wg, wr = torch.randn(U, D, 3, generator=g).to(dev), torch.randn(R, 3, generator=g).to(dev)
     res = []
     for mode in ("joint", "separate"):
@@ -136,9 +138,10 @@ def test_rays_ride_with_their_cameras_cpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("D", [9, 70])
-def test_rays_ride_with_their_cameras_gpu(D):
-    _grid_and_rays("cuda:0", D)  # D = 70: the grid rows on the matrix-core kernels, the rays' rows on the short-block kernels
+@pytest.mark.parametrize("D,R,one_camera", [(9, 37, False), (70, 37, False), (70, 150, True), (70, 1100, True)])
+def test_rays_ride_with_their_cameras_gpu(D, R, one_camera):
+    # D = 70: the grid rows on the matrix-core kernels, the rays' rows on the per-camera ray kernels (one camera: 32-ray slices, atomics)
+    _grid_and_rays("cuda:0", D, R, one_camera)
 
 
 @pytest.mark.gpu
