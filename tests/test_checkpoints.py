@@ -253,3 +253,45 @@ def test_reference_state_dict_reproduces_reference_outputs_on_the_kernels(golden
         ref_c = torch.from_numpy(g["expect.albedo"])
         err_c = (rgb.cpu() - ref_c).abs().max().item()
         assert err_c < 1e-4, err_c
+
+
+@pytest.mark.gpu
+def test_resumed_training_continues_exactly(tmp_path):
+    """Twelve training steps in one go against six, a checkpoint, a FRESH pipeline (other initial weights, other RNG states) resumed
+    from it, and six more: the losses of steps 6..11 agree (1e-5; mostly to the bit).  Needs everything a step draws from: parameters, Adam state, the
+    datamanager's generators, the in-kernel generators' call counters and torch's device generator (the proposal sampler's jitter is a
+    torch.rand: round 4 found that one missing -- 1.6 % off at the first resumed step)."""
+    import gc
+    from util_step import randomise, small_pipeline_config
+    from neusky_amd.engine import Optimizers, neusky_optimizers, train_iteration
+    from neusky_amd.utils.checkpoints import load_checkpoint, save_checkpoint
+    from neusky_amd.utils import utils as U
+    dev = "cuda:0"
+    gc.collect()
+    U._RNG_OWNERS.clear(); U._RNG_PENDING.clear()  # (what earlier tests of this process registered / left pending by generator name)
+
+    def make(seed):
+        torch.manual_seed(seed)
+        pipe = small_pipeline_config(R=64, D=32, images=6).setup(device=dev)
+        pipe.train()
+        return pipe, Optimizers(neusky_optimizers(), pipe.get_param_groups())
+
+    pipe, opt = make(0)
+    randomise(pipe)
+    losses, path = [], None
+    for i in range(12):
+        rb, b = pipe.datamanager.next_train(i)
+        losses.append(float(train_iteration(pipe, opt, i, ray_bundle=rb, batch=b)[0]))
+        if i == 5:
+            path = save_checkpoint(tmp_path, 6, pipe, opt)
+    del pipe, opt, rb, b  # (the in-kernel generators are registered per process by name: the first pipeline has to be gone)
+    gc.collect()
+    pipe2, opt2 = make(123)
+    assert load_checkpoint(path, pipe2, opt2) == 6
+    resumed = []
+    for i in range(6, 12):
+        rb, b = pipe2.datamanager.next_train(i)
+        resumed.append(float(train_iteration(pipe2, opt2, i, ray_bundle=rb, batch=b)[0]))
+    # (float atomics -- the table-gradient scatter, split-K weight gradients -- add in a different order from launch to launch: the
+    # two runs may part in the last bits after a few steps; a missing piece of state shows as 1e-2)
+    assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(losses[6:], resumed)), (losses[6:], resumed)
