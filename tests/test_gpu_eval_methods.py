@@ -9,9 +9,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def test_eval_methods_run_and_keep_their_contracts():
+@pytest.mark.parametrize("conditioning", ["FiLM", "Attention"])
+def test_eval_methods_run_and_keep_their_contracts(conditioning):
     torch.manual_seed(0)
     cfg = small_pipeline_config(R=64, num_prop=(32, 16), S=12, D=32, images=4)
+    cfg.model.illumination_field.conditioning = conditioning  # (Attention: the decoder neusky_config.py:78-95 configures)
     cfg.model.eval_latent_optimizer = {"lr": 1e-1, "eps": 1e-15, "lr_final": 1e-7, "max_steps": 4}
     cfg.datamanager.eval_num_rays_per_batch = 64
     cfg.datamanager.eval_image_height, cfg.datamanager.eval_image_width = 12, 16
