@@ -30,6 +30,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
 RAYS, SAMPLES, DIRECTIONS, PROPOSAL = 1024, 96, 512, (256, 96)
+STEP_ALGORITHMIC_TFLOP = 2.3  # BASELINE.md section 4 / SURVEY 8(d): forward 762 GFLOP, forward + backward ~ 3 x
+PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"  # rocprofv3 --pmc passes of this round's kernels (tools/pmc_bench.sh + tools/pmc_step_traffic.py)
 
 
 def build_pipeline(device, world_size, local_rank, rays=RAYS, samples=SAMPLES, directions=DIRECTIONS, proposal=PROPOSAL):
@@ -66,7 +68,9 @@ class KernelTimer:
     def install(self):
         from neusky_amd import hip
         self._orig = {n: getattr(hip, n) for n in ("gemm", "gemm_planes", "film_chain_fwd", "film_chain_bwd_film", "film_chain_bwd_map",
-                                                   "wgrad_native_batch", "field_geo_fwd", "field_colour_fwd", "field_colour_bwd", "field_geo_bwd")}
+                                                   "wgrad_native_batch", "field_geo_fwd", "field_colour_fwd", "field_colour_bwd", "field_geo_bwd",
+                                                   "encode_fwd", "encode_bwd", "sdf_chain_fwd", "sdf_chain_bwd", "native_weighted_colsum",
+                                                   "adam_step")}
         o, t = self._orig, self
 
         def gemm(A, B, Cout, M, N, K, **kw):
@@ -116,8 +120,8 @@ class KernelTimer:
                     if p_ not in seen:
                         seen.add(p_)
                         by += 4.0 * rows * w
-            kind = "row-major, bf16 x2" if problems[0].lda > 0 else "tile-native, fp16 split"
-            return t._timed(f"wgrad_native_kernel ({kind}, {rows} rows)", o["wgrad_native_batch"], fl, fl, problems, rows, nbytes=by)
+            # ONE family for every launch of the kernel (DDF chain, illumination chain, field layers, sdf probe), as rocprof counts it
+            return t._timed("wgrad_native_kernel", o["wgrad_native_batch"], fl, fl, problems, rows, nbytes=by)
 
         # fused SDF / albedo field (csrc/field_chain.hip): products of the layers they replace; bytes = inputs, saves and outputs once each
         def geo_fwd(net, pack, ET, N, a0q, a1q, Eq, *a, **kw):
@@ -140,6 +144,38 @@ class KernelTimer:
             by = 4.0 * 4 * N * (256 * 4 + 72) + 4.0 * N * (4 + (256 + 40 if da1v is not None else 0))
             return t._timed("field_geo_bwd_kernel", o["field_geo_bwd"], fl, fl, net, pack, N, g_sdf, g_grad, da1v, *a, nbytes=by, **kw)
 
+        # HBM-shaped families (no contraction): algorithmic bytes only
+        def enc_fwd(geom, table, x, mode, include_x, pe_freqs, pe_max_exp, Y, T=None):
+            P = x.shape[0]
+            by = P * (12.0 + geom.n_levels * 8 * 2 * 4 + 4.0 * Y.shape[1] * (4 if T is not None else 1))
+            return t._timed("encode_fwd_kernel", o["encode_fwd"], 0.0, 0.0, geom, table, x, mode, include_x, pe_freqs, pe_max_exp, Y, T, nbytes=by)
+
+        def enc_bwd(geom, table, x, mode, include_x, pe_freqs, pe_max_exp, dY, dT, dtable, dx=None, **kw):
+            P = x.shape[0]
+            # the gradient rows in, one read-modify-write of 8 corners x 2 floats per level and point (1 024 B / point each way)
+            by = P * (12.0 + 4.0 * dY.shape[1] * (4 if dT is not None else 1) + (geom.n_levels * 8 * 2 * 4 * 2 if dtable is not None else 0))
+            return t._timed("encode_bwd (owner scatter + bitmaps + pack)", o["encode_bwd"], 0.0, 0.0, geom, table, x, mode, include_x, pe_freqs,
+                            pe_max_exp, dY, dT, dtable, dx, nbytes=by, **kw)
+
+        def sdf_fwd(net, stream, table, E, M, a0, a1, sdf):
+            fl = 2.0 * M * (net.in_dim * 256 + 256 * 256 + 256)
+            by = 4.0 * M * (E.shape[1] + (512 if a0 is not None else 0) + 1)
+            return t._timed("sdf_fwd_kernel", o["sdf_chain_fwd"], fl, fl, net, stream, table, E, M, a0, a1, sdf, nbytes=by)
+
+        def sdf_bwd(net, stream, table, M, g_sdf, a0, a1, dz1, dz0, dE, *a, **kw):
+            fl = 2.0 * M * (256 * 256 + net.in_dim * 256 + 256)
+            by = 4.0 * M * (1 + 512 + 512 + (dE.shape[1] if dE is not None else 0))
+            return t._timed("sdf_bwd_kernel", o["sdf_chain_bwd"], fl, fl, net, stream, table, M, g_sdf, a0, a1, dz1, dz0, dE, *a, nbytes=by, **kw)
+
+        def colsum(X, nt, rows, out, *a, **kw):
+            return t._timed("native_weighted_colsum_kernel", o["native_weighted_colsum"], 0.0, 0.0, X, nt, rows, out, *a,
+                            nbytes=4.0 * rows * (32 * nt + 4), **kw)
+
+        def adam(p, g, m, v, *a, **kw):
+            return t._timed("adam_kernel", o["adam_step"], 0.0, 0.0, p, g, m, v, *a, nbytes=28.0 * p.numel(), **kw)  # p, m, v read + written, g read
+
+        hip.encode_fwd, hip.encode_bwd, hip.sdf_chain_fwd, hip.sdf_chain_bwd, hip.native_weighted_colsum, hip.adam_step = (
+            enc_fwd, enc_bwd, sdf_fwd, sdf_bwd, colsum, adam)
         hip.gemm, hip.gemm_planes, hip.film_chain_fwd, hip.film_chain_bwd_film, hip.film_chain_bwd_map = gemm, gemm_planes, fwd, bwd_film, bwd_map
         hip.wgrad_native_batch = wgrad
         hip.field_geo_fwd, hip.field_colour_fwd, hip.field_colour_bwd, hip.field_geo_bwd = geo_fwd, col_fwd, col_bwd, geo_bwd
@@ -473,7 +509,7 @@ def cpu_baseline(seconds_budget=25.0):
                       f"{DIRECTIONS} directions + 16 DDF-fit + 8 sky rays; Adam excluded; {dt:.2f} s/step"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -482,22 +518,125 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured HIP graph")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the three extra eager steps under the exact-fp32 policy")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the forward-only (configs[1]) and 1080p render (configs[4]) lines")
-    args = ap.parse_args()
+    ap.add_argument("--no-spawn", action="store_true",
+                    help="N = 1 only: run the rank in THIS process, without a process group (for rocprofv3 -- python3 bench.py ...: the "
+                         "profiler's library initialises the GPU in the process it preloads into, which then must not start ranks)")
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+
+def spawn_ranks(args, argv) -> int:
+    """`python3 bench.py --gpus N` without an external launcher: THIS process touches no GPU (importing torch does not initialise HIP;
+    nothing below calls into torch.cuda) and starts one child process per rank -- the same file with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set, which is what `python -m torch.distributed.run` does and what the reference's launcher does per GPU
+    (nerfstudio's train.py spawns one process per device around neusky_pipeline.py:198-200).  Children are started with subprocess (fork +
+    exec in the child: this process is never replaced), rank 0's stdout is relayed (its ONE JSON line), the other ranks' stdout goes to
+    stderr; the exit code is non-zero if any rank's is, and a failing rank takes the others down (by PID) instead of leaving them in a
+    collective that can never complete."""
+    import socket
+    import subprocess
+    import threading
+    n = args.gpus
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   NSKY_BENCH_LAUNCHER="self-spawned")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this host driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, cwd=os.getcwd(),
+                                      stdout=subprocess.PIPE, text=True))
+    outs = [[] for _ in procs]
+
+    def pump(i):
+        for line in procs[i].stdout:
+            outs[i].append(line)
+            if i != 0:
+                sys.stderr.write(f"[rank {i}] {line}")
+
+    threads = [threading.Thread(target=pump, args=(i,), daemon=True) for i in range(n)]
+    for t in threads:
+        t.start()
+    rc = 0
+    live = set(range(n))
+    while live:
+        time.sleep(0.2)
+        for i in sorted(live):
+            code = procs[i].poll()
+            if code is None:
+                continue
+            live.discard(i)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write(f"bench.py: rank {i} exited with code {code}; stopping the other ranks\n")
+                for j in sorted(live):
+                    procs[j].terminate()  # exact PIDs this process started
+    for t in threads:
+        t.join(timeout=10)
+    sys.stdout.write("".join(outs[0]))
+    sys.stdout.flush()
+    return rc
+
+
+def rccl_selfcheck(opt, pipe, world, rank, device, backend):
+    """the collectives of the N > 1 step really executed on this process group before the timed region, at every N (N = 1 included: a
+    one-rank RCCL communicator): broadcast of the replicated state (neusky_pipeline.py:198-199), an all-reduce with a known answer, and
+    the gradient slab's all-reduce (mean) timed -- the message of engine.Optimizers.all_reduce_gradients."""
+    res = {"backend": backend, "ranks": dist.get_world_size()}
+    on_dev = backend == "nccl"
+    x = torch.full((1024,), float(rank + 1), device=device if on_dev else "cpu")
+    dist.all_reduce(x, op=dist.ReduceOp.SUM)
+    res["all_reduce_known_answer"] = bool((x == world * (world + 1) / 2).all().item())
+    res["tensors_broadcast"] = pipe.grad_sync.broadcast_parameters() if hasattr(pipe, "grad_sync") and pipe.grad_sync is not None else 0
+    if on_dev:
+        slab = opt.flat_g
+        slab.zero_()
+        for _ in range(2):
+            dist.all_reduce(slab, op=dist.ReduceOp.AVG)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(slab, op=dist.ReduceOp.AVG)
+        torch.cuda.synchronize()
+        res["gradient_slab_bytes"] = slab.numel() * 4
+        res["gradient_slab_all_reduce_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+        res["slab_stays_zero"] = bool((slab == 0).all().item())
+    return res
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # torch.distributed.run, or a child of spawn_ranks
+    if not launched and not args.no_spawn:
+        # before ANY GPU call: this process only starts the ranks and relays rank 0's line
+        raise SystemExit(spawn_ranks(args, argv))
+    if args.no_spawn and args.gpus > 1:
+        raise SystemExit("--no-spawn is the in-process N = 1 form (profilers); N > 1 starts one process per GPU")
+
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
+    if launched and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    launcher = os.environ.get("NSKY_BENCH_LAUNCHER", "external (torch.distributed.run)") if launched else "in-process (--no-spawn)"
     # (NSKY_BENCH_DEVICE / NSKY_DIST_BACKEND: the one-GPU test of this file's N > 1 path, tests/test_gpu_bench_two_ranks.py -- two ranks share
     # cuda:0 over gloo; a driver run never sets them)
     dev_index = int(os.environ.get("NSKY_BENCH_DEVICE", local_rank))
     backend = os.environ.get("NSKY_DIST_BACKEND", "nccl")
     torch.cuda.set_device(dev_index)
     device = f"cuda:{dev_index}"
-    if world > 1:
+    pg_note = None
+    if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend, rank=rank, world_size=world)  # backend "nccl" == RCCL on ROCm
+        try:
+            dist.init_process_group(backend, rank=rank, world_size=world)  # backend "nccl" == RCCL on ROCm
+        except Exception as exc:  # noqa: BLE001
+            if world > 1:
+                raise
+            pg_note = f"one-rank process group refused: {type(exc).__name__}: {str(exc)[:160]}"  # N = 1 needs no collective: say so, go on
 
     from neusky_amd.engine import GraphedTrainStep, Optimizers, neusky_optimizers, train_iteration
     torch.manual_seed(1234 + rank)
@@ -507,6 +646,13 @@ def main():
     if world > 1:
         pipe.grad_sync.broadcast_parameters()
     opt = Optimizers(neusky_optimizers(), pipe.get_param_groups(), world_size=world)
+    selfcheck = None
+    if launched and dist.is_initialized():
+        from neusky_amd.distributed import broadcast_module_state
+        selfcheck = rccl_selfcheck(opt, pipe, world, rank, device, backend)
+        if world == 1:  # (the pipeline only broadcasts at N > 1: here the one-rank broadcast is part of the check)
+            selfcheck["tensors_broadcast"] = broadcast_module_state(pipe, 0)
+        assert selfcheck["all_reduce_known_answer"], "the process group's all-reduce returned a wrong sum"
 
     # synthetic batches resident in HBM before the timed region
     batches = [pipe.datamanager.next_train(i) for i in range(args.steps + args.warmup)]
@@ -598,19 +744,42 @@ def main():
         peak = PEAK_BF16_MFMA_TFLOPS / 3.0
         for k in kernels:
             k["frac_of_833_tflops"] = k["achieved_tflops"] / peak
-        traffic, tsrc, traffic_note = None, os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"), ""
+        # a family's share of the step = its launches of ONE iteration (the timing iterations are three repeats of the same step)
+        iters = 3
+        for k in kernels:
+            k["ms_per_step"] = k["total_ms"] / iters
+            k["frac_of_8000_GBs"] = k["achieved_GBs"] / HBM_PEAK_GBS if "achieved_GBs" in k else None
+        traffic, whole_step_gb, tsrc = None, None, os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
+        traffic_src = {"file": "profiles/" + PMC_TRAFFIC_FILE, "collected": "committed rocprofv3 --pmc passes (tools/pmc_bench.sh), not this run"}
         dom = kernels[0]
-        if os.path.exists(tsrc):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_bench.sh; not re-collected live)
-            tj = json.load(open(tsrc))
+        tj = json.load(open(tsrc)) if os.path.exists(tsrc) else None
+        if tj is not None:  # HBM bytes per launch from the committed rocprofv3 --pmc passes; the check that they describe THESE kernels is a field
             traffic = tj.get("bytes_per_launch", {}).get(dom["kernel"].split(" ")[0])
-            so = os.path.join(ROOT, "neusky_amd", "libneusky_hip.so")
-            srcs = step_kernel_sources()
-            if max(os.path.getmtime(f) for f in srcs) > os.path.getmtime(tsrc) + 60 and tj.get("kernel_sources_sha") != _sources_sha(srcs):
-                traffic_note = " (STALE: the kernel sources changed after the counters were collected)"
-                print("bench.py: warning: profiles/r04_pmc_traffic.json predates the kernel sources; re-run tools/pmc_bench.sh", file=sys.stderr)
+            whole_step_gb = tj.get("whole_step_GB")
+            sha = _sources_sha(step_kernel_sources())
+            traffic_src.update({"kernel_sources_sha": sha, "counters_kernel_sources_sha": tj.get("kernel_sources_sha"),
+                                "describes_these_kernels": tj.get("kernel_sources_sha") == sha})
+            for k in kernels:
+                k["pmc_bytes_per_launch"] = tj.get("bytes_per_launch", {}).get(k["kernel"].split(" ")[0])
+
+        def bound_of(k):
+            hb = k.get("algorithmic_bytes_per_launch")
+            if hb is not None and hb / (HBM_PEAK_GBS * 1e9) > k["algorithmic_flops_per_launch"] / (peak * 1e12):
+                return "hbm"
+            return "mfma"
+
         roof = {"bound": "mfma", "achieved": dom["achieved_tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["achieved_tflops"] / peak}
-        if "algorithmic_bytes_per_launch" in dom and dom["algorithmic_bytes_per_launch"] / (HBM_PEAK_GBS * 1e9) > dom["algorithmic_flops_per_launch"] / (peak * 1e12):
+        if bound_of(dom) == "hbm":
             roof = {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["achieved_GBs"] / HBM_PEAK_GBS}
+        top3 = [{"kernel": k["kernel"], "ms_per_step": k["ms_per_step"], "launches_per_step": k["launches"] / iters, "bound": bound_of(k),
+                 "mfma_frac_of_833_tflops": k["frac_of_833_tflops"], "hbm_frac_of_8000_GBs": k["frac_of_8000_GBs"],
+                 "pmc_bytes_per_launch": k.get("pmc_bytes_per_launch")} for k in kernels[:3]]
+        ms_step = 1e3 * dt / args.steps
+        step_roof = {"algorithmic_tflop": STEP_ALGORITHMIC_TFLOP, "tf_s": STEP_ALGORITHMIC_TFLOP / (ms_step * 1e-3),
+                     "frac_of_833": STEP_ALGORITHMIC_TFLOP / (ms_step * 1e-3) / peak,
+                     "GB": whole_step_gb, "tb_s": None if whole_step_gb is None else whole_step_gb / ms_step,
+                     "frac_of_8": None if whole_step_gb is None else whole_step_gb / ms_step / (HBM_PEAK_GBS * 1e-3),
+                     "note": "algorithmic FLOPs of one step (BASELINE.md section 4: forward 762 G x 3) and the whole step's counter traffic, both over ms_per_step"}
         fwd = "fp16 hi + residual split, 3 x v_mfma_f32_32x32x16_f16 per product on power-of-two pre-scaled operands, one fp32 accumulator (~2^-22): FiLM-SIREN chains and the SDF / albedo field alike"
         bwd = ("the same fp16 split on per-row / per-matrix pre-scaled gradients (fp32-grade) for the FiLM-SIREN chains, the SDF / albedo field and all their weight gradients; "
                "proposal layers and all N <= 64 heads: exact fp32 MFMA")
@@ -624,11 +793,13 @@ def main():
                                    "(RENI-shaped: latent 100x3; the reference's configured Attention decoder is absent from its tree), "
                                    "hash L16 F2 T2^19 x2, 256-wide MLPs; fwd + losses + bwd + all-reduce + 5 Adam groups",
                        "rays_per_gpu": RAYS, "samples_per_ray": SAMPLES, "illumination_directions": DIRECTIONS,
-                       "parallelism": f"ray-sharded dp{world}", "final_loss": final_loss,
+                       "parallelism": f"ray-sharded dp{world}", "final_loss": final_loss, "launcher": launcher,
                        "launch": "HIP graph replay (1 graph/step + all-reduce + 5 Adam launches)" if use_graph else "eager (host launches every kernel)" + graph_note},
             "roofline": {**roof, "traffic": traffic,
-                         "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r04_pmc_traffic.json)" + traffic_note,
-                         "kernel": dom["kernel"] + " = the kernel family with the largest total time in the three eager timing iterations (per launch: the median of the three)",
+                         "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
+                         "kernel": dom["kernel"] + " = the kernel family with the largest total time per step in the three eager timing iterations "
+                                                   "(every launch of every family timed; per launch: the median of the three)",
+                         "top3": top3, "step": step_roof,
                          "peak_note": ("HBM3E ~8 TB/s; achieved = algorithmic bytes (inputs, saved activations and outputs once each) / launch time; "
                                        "the kernel's byte floor exceeds its flop floor at 833.3 TFLOP/s") if roof["bound"] == "hbm" else
                                       "fp16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-grade product = 833.3 TFLOP/s of algorithmic FLOPs",
@@ -638,6 +809,11 @@ def main():
                          "executed_flops_per_launch": dom["executed_flops_per_launch"]},
             "kernels": kernels[:8],
             "fp32_exact": exact,
+            # the process group the step's gradient exchange runs on (0 ranks: --no-spawn, no group) and its collectives exercised
+            # before the timed region (rccl_selfcheck)
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0,
+            "dist_backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if dist.is_initialized() else None,
+            "rccl_selfcheck": selfcheck if selfcheck is not None else pg_note,
         }
         if world == 1 and not args.no_extra_configs:
             line["envmap_decode"] = envmap_decode_line(device)
@@ -648,7 +824,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

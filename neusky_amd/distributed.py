@@ -10,8 +10,6 @@ so a single bucket after backward is used rather than overlapped buckets (SURVEY
 """
 from __future__ import annotations
 
-from typing import List
-
 import torch
 import torch.distributed as dist
 
@@ -41,46 +39,16 @@ def _broadcast(t: torch.Tensor, src: int) -> None:
         dist.broadcast(t, src=src)
 
 
-class GradientAllReduce:
-    """Per-parameter form of the gradient all-reduce (any list of parameters, gradients wherever autograd put them).  The
-    training engine does not use it: `engine.Optimizers` keeps all gradients in one slab and all-reduces that in place
-    (`Optimizers.all_reduce_gradients`).  The staging buffer here is therefore allocated on first use only."""
+class ReplicaSync:
+    """What is left of the DDP wrapper once the gradients live in `engine.Optimizers`' slab (which all-reduces itself,
+    `Optimizers.all_reduce_gradients`): the initial state broadcast and the barrier of neusky_pipeline.py:198-200."""
 
-    def __init__(self, params: List[torch.nn.Parameter], world_size: int, module: torch.nn.Module = None):
-        self.params = list(params)
-        self.world_size = world_size
+    def __init__(self, module: torch.nn.Module, world_size: int):
         self.module = module
-        self.numel = sum(p.numel() for p in self.params)
-        self.flat = None
+        self.world_size = world_size
 
-    def broadcast_parameters(self, src: int = 0) -> None:
-        if self.module is not None:
-            broadcast_module_state(self.module, src)
-            return
-        for p in self.params:
-            _broadcast(p.data, src)
+    def broadcast_parameters(self, src: int = 0) -> int:
+        return broadcast_module_state(self.module, src)
 
     def barrier(self) -> None:
         dist.barrier()
-
-    def all_reduce(self) -> None:
-        if self.flat is None:
-            self.flat = torch.zeros(self.numel, device=self.params[0].device, dtype=torch.float32)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(self.world_size)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                p.grad = self.flat[off:off + n].view_as(p).clone()
-            else:
-                p.grad.copy_(self.flat[off:off + n].view_as(p))
-            off += n

@@ -3,7 +3,7 @@
 `get_train_loss_dict` (:241-291), `generate_ddf_samples` (:493-515), `_setup_visibility_field` (:446-491).
 
 Multi-GPU: one process per GPU; parameters are replicated and the flat gradient is all-reduced (mean) over
-RCCL once per step (`neusky_amd.distributed.GradientAllReduce`).  The reference wraps the model in DDP and
+RCCL once per step (`neusky_amd.engine.Optimizers.all_reduce_gradients`, on the slab every group's gradients live in).  The reference wraps the model in DDP and
 then dereferences `.visibility_field` on the wrapper (:249-250, :278), which does not work (SURVEY.md F6);
 here the model is never wrapped, so the same call sites work at any world size.
 """
@@ -75,8 +75,8 @@ class NeuSkyPipeline(PipelineBase):
         self.max_eval_num = max(int(self.num_val_data if self.test_mode == "val" else self.num_test_data), 1)
         self.grad_sync = None
         if world_size > 1:
-            from ..distributed import GradientAllReduce
-            self.grad_sync = GradientAllReduce([p for p in self.parameters() if p.requires_grad], world_size, module=self)
+            from ..distributed import ReplicaSync
+            self.grad_sync = ReplicaSync(self, world_size)
             self.grad_sync.broadcast_parameters()  # identical replicas (all parameters, frozen ones too, and buffers), then the :200 barrier
             self.grad_sync.barrier()
 
@@ -161,11 +161,6 @@ class NeuSkyPipeline(PipelineBase):
             loss_dict = merge_loss_dicts(loss_dict, vis_loss)
             metrics_dict = {**metrics_dict, **vis_metrics}
         return model_outputs, loss_dict, metrics_dict
-
-    def sync_gradients(self) -> None:
-        """all-reduce (mean) of every trainable gradient; no-op on one GPU"""
-        if self.grad_sync is not None:
-            self.grad_sync.all_reduce()
 
     # ------------------------------------------------------------------ evaluation (neusky_pipeline.py:204-444)
     def _optimise_evaluation_latents(self, step) -> None:

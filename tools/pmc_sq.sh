@@ -2,7 +2,7 @@
 # SQ counters of the chain kernels (matrix-pipe busy cycles, vector/matrix co-execution, wait buckets): tools/pmc_sq.sh <tag> [program args...]
 # one pass per counter set (8 SQ slots), counters only with --kernel-trace.  Output: gpurun_out/sq_<tag>_<n>/ + gpurun_out/sq_<tag>.txt
 TAG=${1:-x}; shift
-PROG=${@:-bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-exact-f32 --no-extra-configs}
+PROG=${@:-bench.py --no-spawn --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-exact-f32 --no-extra-configs}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z_0-9]*" | sort -u > $R/gpurun_out/sq_counters_avail.txt

@@ -3,7 +3,7 @@ iteration = 4 iterations): 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; FETCH_SIZE
 import csv, glob, os, re, sys, collections, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 iters = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0
-out_name = sys.argv[2] if len(sys.argv) > 2 else "r04_pmc_traffic.json"
+out_name = sys.argv[2] if len(sys.argv) > 2 else "r05_pmc_traffic.json"
 tot = collections.defaultdict(lambda: [0.0, 0.0, 0])
 for c, idx in (("FETCH_SIZE", 0), ("WRITE_SIZE", 1)):
     files = glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_bench_{c}", "**", "*counter_collection.csv"), recursive=True)
