@@ -30,11 +30,18 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0) -> int:
 
 
 def _broadcast(t: torch.Tensor, src: int) -> None:
-    """RCCL broadcasts device tensors in place; under gloo (two ranks sharing one GPU in tests) a device tensor goes through the host"""
-    if t.is_cuda and dist.get_backend() != "nccl":
+    """RCCL broadcasts device tensors in place; a tensor on the other side of the backend is staged: a device tensor through the host
+    under gloo (two ranks sharing one GPU in tests), a host tensor (the pipeline's `num_*_data` buffers, host-resident latents) through
+    the current device under RCCL -- which has no CPU backend ("No backend type associated with device type cpu")."""
+    backend = dist.get_backend()
+    if t.is_cuda and backend != "nccl":
         host = t.cpu()
         dist.broadcast(host, src=src)
         t.copy_(host)
+    elif not t.is_cuda and backend == "nccl":
+        dev = t.to(torch.device("cuda", torch.cuda.current_device()))
+        dist.broadcast(dev, src=src)
+        t.copy_(dev)
     else:
         dist.broadcast(t, src=src)
 
