@@ -616,6 +616,12 @@ def main():
     if args.no_spawn and args.gpus > 1:
         raise SystemExit("--no-spawn is the in-process N = 1 form (profilers); N > 1 starts one process per GPU")
 
+    # ONE JSON line on stdout: libraries that print to file descriptor 1 (RCCL's version banner at the first collective) go to stderr;
+    # the line itself is written to the saved descriptor
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
     rank = int(os.environ.get("RANK", "0")) if launched else 0
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
@@ -823,7 +829,8 @@ def main():
             line["render_1080p"] = render_1080p_line(pipe, device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line))
+        line_out.write(json.dumps(line) + "\n")
+        line_out.flush()
     if dist.is_initialized():
         dist.destroy_process_group()
 

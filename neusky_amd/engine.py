@@ -113,6 +113,10 @@ class Optimizers:
             off += g.numel
         self._views = [(p, p.grad) for g in self.groups for p in g.params]
         self._backward_seen = False
+        # The ONE host seam of this class: a slab in host memory exists only in the world-size-2 `gloo` tests of the exchange logic
+        # (tests/test_cpu_distributed.py: layout, buckets, zero-fill semantics, mean) -- there gradients are accumulated by autograd
+        # into the slab views and nothing is gathered or stepped; every training path has the slab in HBM.
+        self._host_slab = self.flat_g.device.type == "cpu"
 
     def zero_grad_all(self) -> None:
         """zero the gradient slab.  Between this call and collect_grads() the .grad of a parameter that no kernel accumulates into the
@@ -122,7 +126,7 @@ class Optimizers:
         # Parameters whose gradient no kernel writes into the slab itself (everything behind weight norm / padding / plain torch
         # ops) start the backward with an undefined .grad: autograd's AccumulateGrad then keeps the incoming tensor instead of
         # launching one add kernel per parameter, and collect_grads() moves all of them into the slab with one launch.
-        if self._backward_seen and self.flat_g.is_cuda:
+        if self._backward_seen and not self._host_slab:
             for p, _ in self._views:
                 if not getattr(p, "_nsky_sunk", False):
                     p.grad = None
@@ -197,7 +201,7 @@ class Optimizers:
                 self._pending = [(gs, dist.all_reduce(view, op=dist.ReduceOp.AVG, async_op=True)) for gs, view in self._buckets()]
             else:
                 dist.all_reduce(self.flat_g, op=dist.ReduceOp.AVG)
-        elif self.flat_g.is_cuda:  # gloo with device gradients (two ranks sharing one GPU in tests): staged through the host
+        elif not self._host_slab:  # gloo with device gradients (two ranks sharing one GPU in tests): staged through the host
             host = self.flat_g.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
             self.flat_g.copy_(host.div_(self.world_size))
@@ -300,7 +304,7 @@ class GraphedTrainStep:
         pairs += [(batch["image"], self.batch["image"]), (batch["mask"], self.batch["mask"])]
         if sky is not None:
             pairs += [(sky.origins, self.sky.origins), (sky.directions, self.sky.directions)]
-        if all(s.is_cuda and s.is_contiguous() and d.is_contiguous() and s.dtype == d.dtype and s.shape == d.shape for s, d in pairs):
+        if all(s.device == d.device and s.is_contiguous() and d.is_contiguous() and s.dtype == d.dtype and s.shape == d.shape for s, d in pairs):
             hip.copy_segments(pairs)
         else:
             for s, d in pairs:

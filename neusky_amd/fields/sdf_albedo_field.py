@@ -288,7 +288,7 @@ class SDFAlbedoField(FieldBase):
         sdf, grad, albedo = self.field_values(x, want_albedo)
         extra = None
         if extra_points is not None:
-            if sdf.is_cuda and sdf.requires_grad:
+            if sdf.requires_grad:
                 sdf, e_sdf = ops.SplitRowsFn.apply(sdf, n_main)
                 grad, e_grad = ops.SplitRowsFn.apply(grad, n_main)
                 albedo = ops.SplitRowsFn.apply(albedo, n_main)[0] if albedo.requires_grad else albedo[:n_main]
@@ -299,7 +299,7 @@ class SDFAlbedoField(FieldBase):
         outputs = {
             NeuSkyFieldHeadNames.ALBEDO: albedo.view(R, S, 3),
             FieldHeadNames.SDF: sdf.view(R, S, 1),
-            FieldHeadNames.NORMALS: (ops.NormalizeFn.apply(grad) if grad.is_cuda else F.normalize(grad, p=2, dim=-1)).view(R, S, 3),
+            FieldHeadNames.NORMALS: ops.NormalizeFn.apply(grad).view(R, S, 3),
             FieldHeadNames.GRADIENT: grad.view(R, S, 3),
         }
         if return_alphas:

@@ -74,7 +74,13 @@ def stream_ptr() -> int:
 
 
 def ptr(t):
-    return None if t is None else t.data_ptr()
+    """device address of a tensor handed to the C ABI.  A host tensor is an error: there is no CPU path behind these entry points."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NeuSkyHipError(f"host tensor {tuple(t.shape)} handed to a HIP entry point: the product path runs on the device only "
+                             "(the CPU restatement is oracle/, test infrastructure)")
+    return t.data_ptr()
 
 
 def ld(t):

@@ -101,6 +101,6 @@ class VMFDDFSampler:
                          metadata={"directions_norm": st["norm"]})
 
     def __call__(self, generator=None) -> RayBundle:
-        if generator is None and str(self.device) != "cpu":
+        if generator is None:  # (a caller-supplied host generator = the reference's own host draw, ddf_sampler.py:249-286)
             return self.generate_ddf_samples_device(self.config.num_samples_on_sphere, self.config.num_rays_per_sample)
         return self.generate_ddf_samples(self.config.num_samples_on_sphere, self.config.num_rays_per_sample, generator=generator)

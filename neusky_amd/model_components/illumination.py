@@ -157,7 +157,7 @@ class IcosahedronSampler:
         base = self._dev_cache[key]
         rot = self.config.apply_random_rotation if apply_random_rotation is None else apply_random_rotation
         D = base.shape[0]
-        if base.is_cuda and (rotation is not None or rot) and not self.config.remove_lower_hemisphere and D % 2 == 0 and D <= 1024 \
+        if (rotation is not None or rot) and not self.config.remove_lower_hemisphere and D % 2 == 0 and D <= 1024 \
                 and (rotation is None or rotation.dim() == 2):
             # one kernel: rotation (drawn in the kernel, or the caller's), rotated set and its upper half (csrc/samplers.hip)
             from .. import hip
@@ -274,19 +274,21 @@ class AttentionDecoder(nn.Module):
 
     @staticmethod
     def _linear(x: torch.Tensor, lin: nn.Linear, act: str = "none") -> torch.Tensor:
-        """lin(x) (+ ReLU) over the last dimension: on the device and for long batches this package's dense-layer kernel (fp32-grade
-        fp16-split products, bias and activation in the epilogue; exact-fp32 input gradient), otherwise torch"""
+        """lin(x) (+ ReLU) over the last dimension on this package's dense-layer kernels at any row count (fp32-grade fp16-split
+        products, bias and activation in the epilogue; exact-fp32 input gradient); widths that are not multiples of 4 (the 10-wide query
+        input, the 3-wide head) are zero padded"""
         K, N = lin.weight.shape[1], lin.weight.shape[0]
         rows = x.numel() // K
-        if x.is_cuda and rows >= 4096 and K % 4 == 0 and N % 4 == 0 and N > 64:
-            y = ops.DenseFn.apply(x.reshape(rows, K).contiguous(), lin.weight, lin.bias, N, act, True)
-            return y.reshape(*x.shape[:-1], N)
-        y = torch.nn.functional.linear(x, lin.weight, lin.bias)
-        return torch.relu(y) if act == "relu" else y
+        Wp, bp = ops.pad_weight(lin.weight), ops.pad_bias(lin.bias)
+        x2 = x.reshape(rows, K)
+        if Wp.shape[1] != K:
+            x2 = torch.nn.functional.pad(x2, (0, Wp.shape[1] - K))
+        y = ops.DenseFn.apply(x2.contiguous(), Wp, bp, N, act, True)
+        return y[:, :N].reshape(*x.shape[:-1], N)
 
     def _feed_forward(self, x: torch.Tensor, blk) -> torch.Tensor:
         frozen = not any(p.requires_grad for p in (blk.ff1.weight, blk.ff1.bias, blk.ff2.weight, blk.ff2.bias))
-        if x.is_cuda and frozen and x.dim() == 2 and x.shape[0] >= 4096 and x.shape[1] % 4 == 0:
+        if frozen and x.dim() == 2 and x.shape[1] % 4 == 0:
             return ops.FrozenFeedForwardFn.apply(x, blk.ff1.weight, blk.ff1.bias, blk.ff2.weight, blk.ff2.bias)
         return self._linear(self._linear(x, blk.ff1, "relu"), blk.ff2)
 
@@ -316,22 +318,14 @@ class AttentionDecoder(nn.Module):
         # product per head and camera; neither the [U, nh, D, 3, L] score parts nor a [D, 3 L] probability matrix is ever formed.
         L = self.L
         parts = lambda t: t.reshape(U, 3, L, nh, dh).permute(0, 3, 2, 1, 4).reshape(U, nh, L, 3 * dh)  # noqa: E731  [U, nh, L, (part, dh)]
-        on_kernels = q.is_cuda and dh == 16 and L <= 128
+        if dh != 16 or L > 128:
+            raise NotImplementedError(f"attention core kernels (csrc/attention.hip): heads of 16 and at most 128 tokens, got {dh} / {L}")
         ray_cam = None if R == 0 else ray_cam.reshape(-1)
         ray_perm = ray_seg = None
-        if R and on_kernels and D >= 32:  # the rays sorted by camera, for the per-camera ray kernels (device ops: graph-capturable)
+        if R:  # the rays sorted by camera, for the per-camera ray kernels (device ops: graph-capturable)
             cam_sorted, ray_perm = torch.sort(ray_cam)
             ray_seg = torch.searchsorted(cam_sorted, torch.arange(U + 1, device=q.device)).to(torch.int32)
             ray_perm = ray_perm.to(torch.int32)
-
-        def core(Qp, dd, Kt, Vt):  # batched-product form: Qp [X, Y, H], dd [X, Y, 3], Kt / Vt [X, nh, L, 48] -> [X, Y, H]
-            X, Y = Qp.shape[:2]
-            cx = torch.stack([dd[..., 0], dd[..., 1], torch.ones_like(dd[..., 0])], -1).reshape(X, 1, Y, 3, 1)
-            Q = (Qp * (dh ** -0.5)).reshape(X, Y, nh, 1, dh).transpose(1, 2)  # [X, nh, Y, 1, dh]
-            Qt = (Q * cx).reshape(X, nh, Y, 3 * dh)
-            P = torch.softmax(torch.matmul(Qt, Kt.transpose(-1, -2)), -1)  # [X, nh, Y, L]
-            O3 = torch.matmul(P, Vt).reshape(X, nh, Y, 3, dh)
-            return (O3 * cx).sum(3).transpose(1, 2).reshape(X, Y, H)
 
         resid = None  # the block's pending residual: added inside the next layer norm's pass (ops.add_layer_norm)
         for blk in self.layers:
@@ -341,13 +335,9 @@ class AttentionDecoder(nn.Module):
             Kt, Vt = parts(K3 - blk.wk.bias * mask), parts(V3 - blk.wv.bias * mask)
             q, n1 = ops.add_layer_norm(q, resid, blk.ln1)
             Qp = self._linear(n1, blk.wq)  # [N + R, H]
-            if on_kernels and D >= 32:
-                # the attention core as HIP kernels (csrc/attention.hip): no [U, nh, D, L] score / probability matrices in memory
-                O = ops.AttnCoreFn.apply(Qp, dirs, Kt, Vt, dh ** -0.5, ray_dirs, ray_perm, ray_seg)
-            else:  # the same arithmetic as batched products (CPU; short direction lists)
-                O = core(Qp[:N].reshape(U, D, H), dirs, Kt, Vt).reshape(N, H)
-                if R:
-                    O = torch.cat([O, core(Qp[N:].reshape(R, 1, H), ray_dirs[:, None, :], Kt[ray_cam], Vt[ray_cam]).reshape(R, H)], 0)
+            # the attention core as HIP kernels (csrc/attention.hip: matrix-core forms from 32 directions per camera on, vector-unit forms
+            # below): no [U, nh, D, L] score / probability matrices in memory
+            O = ops.AttnCoreFn.apply(Qp, dirs, Kt, Vt, dh ** -0.5, ray_dirs, ray_perm, ray_seg)
             q, n2 = ops.add_layer_norm(q, self._linear(O, blk.wo), blk.ln2)
             resid = self._feed_forward(n2, blk)
         out = self.out(ops.add_layer_norm(q, resid, self.ln_f)[1])
@@ -397,16 +387,9 @@ class RENIField(nn.Module):
         if self.attention:
             out = torch.exp(self.network(latent_codes, directions[None].expand(U, D, 3)))
             return out * scale[:, None, None] if scale is not None else out
-        if latent_codes.is_cuda:  # both input matrices from one kernel (no [U D, 3 L] stack / pad copies)
-            cond, x = ops.RENIGridInputsFn.apply(latent_codes, directions)
-            out = torch.exp(self.network(x, cond, train_weights=not self.config.fixed_decoder)).reshape(U, D, 3)
-            return out * scale[:, None, None] if scale is not None else out
-        zxy, zz = latent_codes[..., :2], latent_codes[..., 2]
-        dxy, dz = directions[:, :2], directions[:, 2]
-        dot = torch.einsum("uln,dn->udl", zxy, dxy)
-        cond = torch.stack([zxy.norm(dim=-1)[:, None, :].expand(U, D, L), zz[:, None, :].expand(U, D, L), dot], -1).reshape(U * D, 3 * L)
-        x = torch.stack([dxy.norm(dim=-1), dz], -1)[None].expand(U, D, 2).reshape(U * D, 2)
-        out = self._decode(cond, x).reshape(U, D, 3)
+        # both input matrices from one kernel (no [U D, 3 L] stack / pad copies)
+        cond, x = ops.RENIGridInputsFn.apply(latent_codes, directions)
+        out = torch.exp(self.network(x, cond, train_weights=not self.config.fixed_decoder)).reshape(U, D, 3)
         return out * scale[:, None, None] if scale is not None else out
 
     def forward_grid_and_rays(self, directions: torch.Tensor, latent_codes: torch.Tensor, scale: torch.Tensor,

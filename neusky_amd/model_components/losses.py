@@ -28,13 +28,6 @@ def monosdf_normal_loss(normal_pred: torch.Tensor, normal_gt: torch.Tensor) -> t
     return torch.abs(normal_pred - normal_gt).sum(dim=-1).mean() + (1.0 - (normal_pred * normal_gt).sum(-1)).mean()
 
 
-def _outer(t0_starts, t0_ends, t1_starts, t1_ends, y1):
-    cy1 = torch.cat([torch.zeros_like(y1[..., :1]), torch.cumsum(y1, dim=-1)], dim=-1)
-    idx_lo = torch.clamp(torch.searchsorted(t1_starts.contiguous(), t0_starts.contiguous(), side="right") - 1, 0, y1.shape[-1] - 1)
-    idx_hi = torch.clamp(torch.searchsorted(t1_ends.contiguous(), t0_ends.contiguous(), side="right"), 0, y1.shape[-1] - 1)
-    return torch.take_along_dim(cy1[..., 1:], idx_hi, dim=-1) - torch.take_along_dim(cy1[..., :-1], idx_lo, dim=-1)
-
-
 def interlevel_per_ray(weights_list: Sequence[torch.Tensor], sbins_list: Sequence[torch.Tensor]):
     """per-ray interlevel sums of every proposal level ([R] each): interlevel_loss = sum of all of them / numel(final weights)"""
     from .. import ops
@@ -44,15 +37,9 @@ def interlevel_per_ray(weights_list: Sequence[torch.Tensor], sbins_list: Sequenc
 
 def interlevel_loss(weights_list: Sequence[torch.Tensor], sbins_list: Sequence[torch.Tensor]) -> torch.Tensor:
     """nerfstudio interlevel_loss (called neusky_model.py:987-988); weights [R,n], spacing bins [R,n+1]."""
-    c, w = sbins_list[-1].detach(), weights_list[-1].detach()
-    loss = 0.0
-    if w.is_cuda:  # one launch per proposal level each way (ops.InterlevelFn) instead of ~45 small torch kernels
-        per_ray = interlevel_per_ray(weights_list, sbins_list)
-        return (per_ray[0] if len(per_ray) == 1 else torch.cat(per_ray)).sum() * (1.0 / w.numel())
-    for sb, wp in zip(sbins_list[:-1], weights_list[:-1]):
-        w_outer = _outer(c[..., :-1], c[..., 1:], sb[..., :-1], sb[..., 1:], wp)
-        loss = loss + torch.mean(torch.clip(w - w_outer, min=0) ** 2 / (w + 1e-7))
-    return loss
+    # one launch per proposal level each way (ops.InterlevelFn)
+    per_ray = interlevel_per_ray(weights_list, sbins_list)
+    return (per_ray[0] if len(per_ray) == 1 else torch.cat(per_ray)).sum() * (1.0 / weights_list[-1].numel())
 
 
 class LossDict(dict):
@@ -72,20 +59,20 @@ def total_loss(loss_dict: Dict[str, torch.Tensor]) -> torch.Tensor:
     if t is not None:
         return t
     parts = getattr(loss_dict, "parts", None)
-    if parts and len(parts) <= 8 and all(p[0].is_cuda for p in parts):
-        from .. import ops
-        metas, tensors = [], []
-        for x, c, sc in parts:
-            metas.append((c is not None, float(sc)))
-            tensors.append(x)
-            if c is not None:
-                tensors.append(c)
-        loss_dict.total = ops.TotalLossFn.apply(tuple(metas), *tensors)
-        return loss_dict.total
     if parts:
-        t = sum(((x * c).sum() if c is not None else x.sum()) * sc for x, c, sc in parts)
-        loss_dict.total = t
-        return t
+        from .. import ops
+        total = None
+        for i in range(0, len(parts), 8):  # (one launch takes up to eight pieces: both models' terms and the interlevel sums are five)
+            metas, tensors = [], []
+            for x, c, sc in parts[i:i + 8]:
+                metas.append((c is not None, float(sc)))
+                tensors.append(x)
+                if c is not None:
+                    tensors.append(c)
+            t = ops.TotalLossFn.apply(tuple(metas), *tensors)
+            total = t if total is None else total + t
+        loss_dict.total = total
+        return total
     return sum(loss_dict.values())
 
 

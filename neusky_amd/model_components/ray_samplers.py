@@ -50,7 +50,7 @@ class HashMLPDensityField(nn.Module):
         """positions [R,n,3] -> pre-activation of the density head, [R*n, 4] (column 0; columns 1-3 are padding)"""
         x = positions.reshape(-1, 3).detach()
         feat = ops.HashEncodeFn.apply(x, self.encoding.table, self.geom, self.mode, False, 0, 0.0, False, False)
-        if feat.is_cuda and hip.proposal_mlp_supported(self.lin0.in_features, self.lin0.out_features) and self.lin1.out_features == 1:
+        if hip.proposal_mlp_supported(self.lin0.in_features, self.lin0.out_features) and self.lin1.out_features == 1:
             # both layers in registers, one kernel each way (csrc/proposal.hip) -> [R*n, 1]
             return ops.ProposalMLPFn.apply(feat, self.lin0.weight, self.lin0.bias, self.lin1.weight, self.lin1.bias)
         w0, b0, w1, b1 = self._padded()
@@ -78,19 +78,6 @@ def weights_from_density(density: torch.Tensor, deltas: torch.Tensor) -> torch.T
     return torch.nan_to_num(alphas * T)
 
 
-def uniform_bins(nears: torch.Tensor, fars: torch.Tensor, num_samples: int, jitter: Optional[torch.Tensor]):
-    """UniformSampler(single_jitter=True): spacing bins [R,n+1] in [0,1] and euclidean bins."""
-    bins = torch.linspace(0.0, 1.0, num_samples + 1, device=nears.device)[None]
-    if jitter is not None:
-        centers = (bins[..., 1:] + bins[..., :-1]) / 2.0
-        upper = torch.cat([centers, bins[..., -1:]], -1)
-        lower = torch.cat([bins[..., :1], centers], -1)
-        bins = lower + (upper - lower) * jitter
-    else:
-        bins = bins.expand(nears.shape[0], -1)
-    return bins.contiguous(), (bins * fars + (1 - bins) * nears).contiguous()
-
-
 class ProposalNetworkSampler(nn.Module):
     def __init__(self, num_nerf_samples_per_ray: int = 48, num_proposal_samples_per_ray: Tuple[int, ...] = (256, 96),
                  num_proposal_network_iterations: int = 2, histogram_padding: float = 0.01):
@@ -109,7 +96,7 @@ class ProposalNetworkSampler(nn.Module):
         captured fill would bake the capture-time value into every replay and overwrite what the caller set before the
         replay (GraphedTrainStep.step writes it eagerly, then replays)."""
         self._anneal = anneal
-        if self._anneal_t.is_cuda and torch.cuda.is_current_stream_capturing():
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             return
         self._anneal_t.fill_(anneal)
 

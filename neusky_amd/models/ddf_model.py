@@ -185,14 +185,11 @@ class DDFModel(ModelBase):
     def get_metrics_dict(self, outputs, batch) -> Dict[str, torch.Tensor]:
         """ddf_model.py:381-405 (depth PSNR over [0, ddf_radius])"""
         exp_d = outputs["expected_termination_dist"].detach()
-        mask = batch["mask"].to(exp_d.device)
+        mask = batch["mask"].to(exp_d.device, torch.float32)
         gt = batch["termination_dist"].to(exp_d.device).detach()
-        if exp_d.is_cuda and mask.dtype == torch.float32 and mask.numel() == exp_d.numel() and gt.numel() == exp_d.numel():
-            from .. import hip
-            return {"depth_psnr": hip.train_metrics(exp_d.contiguous(), gt.contiguous(), mask.contiguous(), self.ddf_radius**2)[0]}
-        pred = exp_d.unsqueeze(1) * mask
-        mse = F.mse_loss(pred, gt * mask)
-        return {"depth_psnr": 10 * torch.log10(self.ddf_radius**2 / mse)}
+        assert mask.numel() == exp_d.numel() and gt.numel() == exp_d.numel(), (mask.shape, gt.shape, exp_d.shape)
+        from .. import hip
+        return {"depth_psnr": hip.train_metrics(exp_d.contiguous(), gt.contiguous(), mask.contiguous(), self.ddf_radius**2)[0]}
 
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, torch.Tensor]:
         """ddf_model.py:407-493"""

@@ -235,7 +235,7 @@ class NeuSkyFactoModel(ModelBase):
         cam = ray_bundle.camera_indices.reshape(R, 1, 1).expand(R, S, 1) if ray_bundle.camera_indices is not None else None
         # starts and ends as two CONTIGUOUS [R, S] matrices from one launch: as column slices of the bins every consumer kernel
         # (NeuS weights, the per-ray reductions, twice each per step) first copied them
-        se = torch.stack((ebins[:, :-1], ebins[:, 1:])) if ebins.is_cuda else (ebins[:, :-1], ebins[:, 1:])
+        se = torch.stack((ebins[:, :-1], ebins[:, 1:]))
         rs = RaySamples(frustums=Frustums(origins=o, directions=d, starts=se[0][..., None], ends=se[1][..., None],
                                           pixel_area=None),
                         camera_indices=cam, deltas=(se[1] - se[0])[..., None],
@@ -279,10 +279,10 @@ class NeuSkyFactoModel(ModelBase):
             # are being fitted: static shape, no torch.unique host sync, hipGraph-safe); rows of cameras absent from the
             # batch are never read by the renderer and receive zero gradient
             inverse = camera_indices
-            if rotation is None and dirs.is_cuda:  # the rays' own background rows (:535-549) ride in the same decoder pass
+            if rotation is None:  # the rays' own background rows (:535-549) ride in the same decoder pass
                 cols, bg = self.illumination_field.forward_grid_and_rays(dirs, latents, scales, ray_directions, camera_indices)
                 return dirs, cols, inverse.to(torch.int32), bg
-            cols = self.illumination_field.forward_grid(dirs, latents, scales) if rotation is None else None
+            cols = None
             unique = torch.arange(latents.shape[0], device=dirs.device)
         else:
             unique, inverse = torch.unique(camera_indices, return_inverse=True)  # :461-463
@@ -307,7 +307,7 @@ class NeuSkyFactoModel(ModelBase):
         before the DDF-fit ground-truth pass, whose sampler geometry is a run of ~180 small launches that leave the chip
         idle, so the decode's dense layers fill it."""
         cam = ray_bundle.camera_indices.reshape(-1)
-        if not (self.training and cam.is_cuda and self.second_stream):
+        if not (self.training and self.second_stream):
             return
         main = torch.cuda.current_stream()
         side = self._illumination_stream()
@@ -327,11 +327,7 @@ class NeuSkyFactoModel(ModelBase):
 
     def render_depth(self, weights: torch.Tensor, ray_samples: RaySamples) -> torch.Tensor:
         """nerfstudio DepthRenderer('expected') (neusky_model.py:591): weights [R,S,1] -> [R,1]"""
-        if weights.is_cuda:
-            return self.ray_reductions(weights, ray_samples)[0]
-        steps = (ray_samples.frustums.starts + ray_samples.frustums.ends) / 2
-        depth = torch.sum(weights * steps, dim=-2) / (torch.sum(weights, -2) + 1e-10)
-        return torch.clip(depth, steps.min(), steps.max())
+        return self.ray_reductions(weights, ray_samples)[0]
 
     @staticmethod
     def ray_reductions(weights: torch.Tensor, ray_samples: RaySamples, normals: Optional[torch.Tensor] = None,
@@ -424,7 +420,7 @@ class NeuSkyFactoModel(ModelBase):
         # The illumination decode (big dense layers, nothing but the camera indices as input) runs on a second HIP stream
         # beside the proposal sampler + field pass (hundreds of small launches): a fork/join that the HIP graph keeps as
         # two parallel branches, forward and backward (autograd replays each node on its forward stream).
-        fork = self.training and cam.is_cuda and self.second_stream
+        fork = self.training and self.second_stream
         pending = getattr(self, "_illumination_pending", None)
         self._illumination_pending = None
         if fork and pending is not None:  # started by start_illumination (the pipeline, before the DDF-fit ground truth pass)
@@ -455,13 +451,11 @@ class NeuSkyFactoModel(ModelBase):
             "pdf_inds_list": inds_list, "illumination_directions": dirs, "hdr_illumination_colours": cam_colours,
             "cam_of_ray": cam_of_ray, "hdr_background_colours": hdr_bg,
         }
+        # :591, :595 and get_outputs' :812-813 in one pass
+        p2p_dist, accumulation, out["normal"], out["albedo_on_white"] = self.ray_reductions(
+            weights, ray_samples, field_outputs[FieldHeadNames.NORMALS], field_outputs[NeuSkyFieldHeadNames.ALBEDO])
+        out.update(p2p_dist=p2p_dist, accumulation=accumulation)
         if self.config.use_visibility:
-            if weights.is_cuda:  # :591, :595 and get_outputs' :812-813 in one pass
-                p2p_dist, accumulation, out["normal"], out["albedo_on_white"] = self.ray_reductions(
-                    weights, ray_samples, field_outputs[FieldHeadNames.NORMALS], field_outputs[NeuSkyFieldHeadNames.ALBEDO])
-            else:
-                p2p_dist = self.render_depth(weights, ray_samples)  # :591
-                accumulation = weights.sum(dim=-2)  # :595
             depth = p2p_dist / ray_bundle.metadata["directions_norm"]  # :593
             p2p_vis = p2p_dist.detach() if self.config.sdf_to_visibility_stop_gradients in ["depth", "both"] else p2p_dist
             if p2p_vis.requires_grad:
@@ -469,7 +463,7 @@ class NeuSkyFactoModel(ModelBase):
             out["visibility_dict"] = self.compute_visibility_compact(ray_bundle.origins, ray_bundle.directions, p2p_vis, dirs,
                                                              self.visibility_threshold, self.sigmoid_scale,
                                                              sel=getattr(self, "_upper_sel", None))
-            out.update(p2p_dist=p2p_dist, depth=depth, accumulation=accumulation)
+            out["depth"] = depth
         if probe is not None:
             # (sic) the reference hands `deltas=gap` ([3]) to get_alpha, which broadcasts [P,1]*[3] -> three alphas
             # per point, one per axis gap (equal for the cubic scene box) (:715-724, :732).  The probe points rode through the field
@@ -518,16 +512,9 @@ class NeuSkyFactoModel(ModelBase):
             light_directions=so["illumination_directions"], cam_colours=so["hdr_illumination_colours"],
             cam_of_ray=so["cam_of_ray"], visibility=visibility, background_illumination=so["hdr_background_colours"],
             weights=weights)  # :797-805
-        accumulation = so.get("accumulation", weights.sum(dim=-2))
-        p2p_dist = so.get("p2p_dist")
-        if p2p_dist is None:
-            p2p_dist = self.render_depth(weights, ray_samples)
+        accumulation, p2p_dist = so["accumulation"], so["p2p_dist"]
         depth = p2p_dist / ray_bundle.metadata["directions_norm"]
-        if "normal" in so and "albedo_on_white" in so:
-            normal, albedo = so["normal"], so["albedo_on_white"]
-        else:
-            normal = torch.sum(weights * fo[FieldHeadNames.NORMALS], dim=-2)  # :812 (SemanticRenderer-style)
-            albedo = torch.sum(weights * fo[NeuSkyFieldHeadNames.ALBEDO], dim=-2) + (1.0 - weights.sum(dim=-2))  # :813, white bg
+        normal, albedo = so["normal"], so["albedo_on_white"]  # :812-813 (white background), from the same reduction pass
         outputs: Dict[str, Any] = {
             "rgb": rgb, "albedo": albedo, "accumulation": accumulation, "depth": depth, "p2p_dist": p2p_dist, "normal": normal,
             "weights": weights, "hdr_background_colours": so["hdr_background_colours"],
@@ -590,34 +577,23 @@ class NeuSkyFactoModel(ModelBase):
         if train_branch and li["interlevel_loss"]:
             c_il = float(coefs.get("interlevel_loss", 1.0))
             wl, sl_ = outputs["weights_list"], outputs["sbins_list"]
-            if terms.is_cuda:
-                per_ray = interlevel_per_ray(wl, sl_)
-                inv_n = c_il / wl[-1].numel()
-                ld["interlevel_loss"] = (per_ray[0] if len(per_ray) == 1 else torch.cat(per_ray)).sum() * inv_n  # :987-988
-                ld.parts += [(pr, None, inv_n) for pr in per_ray]
-            else:
-                il = interlevel_loss(wl, sl_) * c_il
-                ld["interlevel_loss"] = il
-                ld.parts, ld.total = None, scaled.sum() + il
+            per_ray = interlevel_per_ray(wl, sl_)
+            inv_n = c_il / wl[-1].numel()
+            ld["interlevel_loss"] = (per_ray[0] if len(per_ray) == 1 else torch.cat(per_ray)).sum() * inv_n  # :987-988
+            ld.parts += [(pr, None, inv_n) for pr in per_ray]
         return ld
 
     def get_metrics_dict(self, outputs, batch) -> Dict[str, Any]:
         """neusky_model.py:1064-1077"""
-        image = batch["image"].to(self.device)
+        image = batch["image"].to(self.device, torch.float32)
         rgb = outputs["rgb"].detach()
-        if rgb.is_cuda and rgb.dtype == torch.float32 and image.dtype == torch.float32 and rgb.shape == image.shape:
-            # psnr, s_val and 1 / s_val from one launch (hip.train_metrics) instead of nine
-            v = self.field.deviation_network.variance.detach() if self.training else None
-            mv = hip.train_metrics(rgb.contiguous(), image.contiguous(), None, 1.0, v)
-            m: Dict[str, Any] = {"psnr": mv[0]}
-            if self.training:
-                m["s_val"], m["inv_s"] = mv[1:2], mv[2:3]
-        else:
-            mse = F.mse_loss(rgb, image)
-            m = {"psnr": -10.0 * torch.log10(mse)}
-            if self.training:
-                m["s_val"] = self.field.deviation_network.get_variance().detach()
-                m["inv_s"] = 1.0 / m["s_val"]
+        assert rgb.shape == image.shape, (rgb.shape, image.shape)
+        # psnr, s_val and 1 / s_val from one launch (hip.train_metrics)
+        v = self.field.deviation_network.variance.detach() if self.training else None
+        mv = hip.train_metrics(rgb.contiguous(), image.contiguous(), None, 1.0, v)
+        m: Dict[str, Any] = {"psnr": mv[0]}
+        if self.training:
+            m["s_val"], m["inv_s"] = mv[1:2], mv[2:3]
         if self.training:
             if self.config.visibility_threshold == "learnable" and self.visibility_field is not None:
                 m["visibility_threshold"] = self.visibility_threshold.detach()
@@ -686,16 +662,9 @@ class NeuSkyFactoModel(ModelBase):
         ray_samples, _, _, _, _ = self._sample(ray_bundle, sub)
         fo = self.field(ray_samples, return_alphas=True, want_albedo=False)  # depth / mask / normals only (:1337-1367)
         weights = fo["weights"]
-        if weights.is_cuda:
-            p2p, accumulations, normals, _ = self.ray_reductions(
-                weights, ray_samples, fo[FieldHeadNames.NORMALS], None,
-                max_clamp=2 * self.visibility_field.ddf_radius if self.visibility_field is not None else 0.0)
-        else:
-            accumulations = weights.sum(dim=-2).reshape(-1, 1)
-            p2p = self.render_depth(weights, ray_samples).reshape(-1, 1)
-            if self.visibility_field is not None:
-                p2p = torch.clamp(p2p, max=2 * self.visibility_field.ddf_radius)
-            normals = torch.sum(weights * fo[FieldHeadNames.NORMALS], dim=-2).reshape(-1, 3)
+        p2p, accumulations, normals, _ = self.ray_reductions(
+            weights, ray_samples, fo[FieldHeadNames.NORMALS], None,
+            max_clamp=2 * self.visibility_field.ddf_radius if self.visibility_field is not None else 0.0)
         mask = (accumulations > mask_threshold).float()
         if log_depth:  # :1354-1355
             p2p = torch.log(p2p + 1e-6)
@@ -779,7 +748,7 @@ class NeuSkyFactoModel(ModelBase):
         try:
             rb0, batch0, rot0 = next_bundle(0)
             if use_graph is None:
-                use_graph = rb0.origins.is_cuda and randoms_per_step is None and method != "nerf_osr_envmap"
+                use_graph = randoms_per_step is None and method != "nerf_osr_envmap"
             graph = None
             if use_graph:
                 c = lambda t: t.detach().clone()  # noqa: E731

@@ -26,18 +26,17 @@ from . import hip
 #                    the chain kernels do not take, narrow heads, proposal layers) uses the fp16 split forward and the EXACT fp32 MFMA backward.
 #   f32            : every product on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), per-layer kernels only: the measurement reference
 #                    (bench.py's `fp32_exact` line; tests/test_gpu_full_size.py compares the two kernel sets).
-import os as _os
-
 _POLICIES = ("f32", "splith")
 _FWD = {"splith": hip.PREC_F16X2}
-_POLICY = _os.environ.get("NSKY_PRECISION", "splith")
-if _POLICY not in _POLICIES:
-    raise ValueError(f"NSKY_PRECISION={_POLICY!r}: expected one of {' | '.join(_POLICIES)}")
+_POLICY = "splith"  # the product runs ONE policy; no environment variable or config key selects another
 FWD_PRECISION = _FWD.get(_POLICY, hip.PREC_F32)
 BWD_PRECISION = hip.PREC_F32  # per-layer backward GEMMs: exact fp32 MFMA under either policy
 
 
 def set_precision_policy(policy: str) -> None:
+    """MEASUREMENT / TEST HOOK ONLY (bench.py's `fp32_exact` leg, tests/test_gpu_full_size.py, tests/test_gpu_sdf_chain.py): "f32" sends
+    every product to the exact-fp32 MFMA on the per-layer kernels -- the independent kernel set the fused chains are compared with.
+    Nothing in neusky_amd/ calls it."""
     global FWD_PRECISION, _POLICY
     if policy not in _POLICIES:
         raise ValueError(policy)
@@ -129,7 +128,7 @@ def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None, acc
         else:
             dW, db = zeros_like(like), None
     if (_POLICY == "splith" and a_native_nt == 0 and b_native_nt == 0 and a_scale_max is None and M >= WGRAD_STREAM_MIN_ROWS
-            and n_out >= 64 and k_in >= 64 and n_out % 4 == 0 and k_in % 4 == 0 and dZ.is_cuda and ld(dZ) % 4 == 0 and ld(X) % 4 == 0):
+            and n_out >= 64 and k_in >= 64 and n_out % 4 == 0 and k_in % 4 == 0 and ld(dZ) % 4 == 0 and ld(X) % 4 == 0):
         # long reductions over row-major operands (the field's layers): the streaming kernel, dW and db in one pass
         prob = hip.wgrad_problem_rowmajor(dZ, n_out, X, k_in, M, dW, db, 0 if bias_rows is None else bias_rows)
         if batch is not None:
@@ -166,7 +165,7 @@ _SHARED_GRADS: dict = {}
 def shared_grad(like, bias_like):
     """-> (dW, db, first)"""
     # per stream: nodes replayed on different streams are ordered only along autograd's edges, so they do not share a buffer
-    sid = torch.cuda.current_stream().cuda_stream if like.is_cuda else 0
+    sid = torch.cuda.current_stream().cuda_stream
     key = (like.data_ptr(), tuple(like.shape), 0 if bias_like is None else bias_like.data_ptr(), sid)
     hit = _SHARED_GRADS.get(key)
     if hit is not None:
@@ -443,7 +442,7 @@ def forget_film_streams(wb) -> None:
 
 
 def _film_fused_ok(M, H, Hm, n_map, n_film, mw, fw, ow, x, cond) -> bool:
-    return (FWD_PRECISION == hip.PREC_F16X2 and x.is_cuda and ld(x) <= 16
+    return (FWD_PRECISION == hip.PREC_F16X2 and ld(x) <= 16
             and hip.film_supported(H, Hm, n_map, n_film, mw[0].shape[1], fw[0].shape[1], ow.shape[0])
             and ld(x) >= fw[0].shape[1] and ld(cond) >= mw[0].shape[1])
 
@@ -870,7 +869,7 @@ def _field_pack(kind, weights, layers_fn):
 
 
 def field_fused_ok(ET, W0, W1, W2, Wc0, Wc1) -> bool:
-    return (FWD_PRECISION == hip.PREC_F16X2 and ET.is_cuda and ET.shape[0] >= 4 and ld(ET) == W0.shape[1]
+    return (FWD_PRECISION == hip.PREC_F16X2 and ET.shape[0] >= 4 and ld(ET) == W0.shape[1]
             and hip.field_supported(W0.shape[1], W0.shape[0], W2.shape[0] - 4, Wc1.shape[0], Wc0.shape[1]))
 
 
@@ -1011,7 +1010,7 @@ class SDFValueFn(torch.autograd.Function):
         dev = E.device
         Hd, Kin = W0.shape
         GF = W2.shape[0] - 4
-        ctx.fused = (FWD_PRECISION == hip.PREC_F16X2 and E.is_cuda and hip.sdf_supported(Kin, Hd)
+        ctx.fused = (FWD_PRECISION == hip.PREC_F16X2 and hip.sdf_supported(Kin, Hd)
                      and ld(E) >= Kin and ld(E) % 4 == 0)
         ctx.cfg = (M, Hd, Kin, GF, beta, train_weights)
         if ctx.fused:
@@ -1718,11 +1717,10 @@ class AddLayerNormFn(torch.autograd.Function):
 def add_layer_norm(x, r, ln):
     """(x + r, ln(x + r)) for a torch.nn.LayerNorm `ln` over the last dimension; r may be None"""
     W = x.shape[-1]
-    if x.is_cuda and W in (64, 128, 256, 512) and not ln.weight.requires_grad and not ln.bias.requires_grad and x.numel() // W >= 256:
-        s, y = AddLayerNormFn.apply(x.reshape(-1, W), None if r is None else r.reshape(-1, W), ln.weight, ln.bias, ln.eps)
-        return s.view(x.shape), y.view(x.shape)
-    s = x if r is None else x + r
-    return s, ln(s)
+    if W not in (64, 128, 256, 512) or ln.weight.requires_grad or ln.bias.requires_grad:
+        raise NotImplementedError("add_layer_norm (csrc/attention.hip): frozen norms over 64 / 128 / 256 / 512 features (the RENI++ decoder's)")
+    s, y = AddLayerNormFn.apply(x.reshape(-1, W), None if r is None else r.reshape(-1, W), ln.weight, ln.bias, ln.eps)
+    return s.view(x.shape), y.view(x.shape)
 
 
 class AttnCoreFn(torch.autograd.Function):

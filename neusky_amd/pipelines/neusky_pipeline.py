@@ -239,8 +239,7 @@ class NeuSkyPipeline(PipelineBase):
                 if self.config.least_squares_global_scale:
                     outputs["rgb"] = self.global_scale(outputs["rgb"], batch["image"])
                 metrics_dict, _ = self.model.get_image_metrics_and_images(outputs, batch)
-                if outputs["rgb"].is_cuda:
-                    torch.cuda.synchronize()
+                torch.cuda.synchronize()
                 assert "num_rays_per_sec" not in metrics_dict
                 metrics_dict["num_rays_per_sec"] = num_rays / (time() - inner_start)
                 assert "fps" not in metrics_dict

@@ -56,10 +56,6 @@ def _check(device, D=9):
     assert (pp.reshape(U, D, 3) - got.detach()).abs().max() < 2e-5 * got.detach().abs().max()
 
 
-def test_attention_decoder_matches_the_oracle_cpu():
-    _check("cpu")
-
-
 @pytest.mark.gpu
 def test_attention_decoder_matches_the_oracle_gpu():
     _check("cuda:0")          # a handful of directions per camera: the batched-product form
@@ -133,10 +129,6 @@ def _grid_and_rays(dev, D, R=37, one_camera=False):
         assert rel(a, b) < 2e-5, (name, rel(a, b))
 
 
-def test_rays_ride_with_their_cameras_cpu():
-    _grid_and_rays("cpu", 9)
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("D,R,one_camera", [(9, 37, False), (70, 37, False), (70, 150, True), (70, 1100, True)])
 def test_rays_ride_with_their_cameras_gpu(D, R, one_camera):
@@ -173,22 +165,25 @@ def test_add_layer_norm_kernels_match_float64(M, W, with_r):
         assert rel(rf.grad, r64.grad) < 3e-6
 
 
+@pytest.mark.gpu
 def test_so2_equivariance_about_z():
     """rotating latents and directions together about z leaves the decoded radiance unchanged (RENI++'s defining property for
     equivariance="SO2", axis_of_invariance="z"); a rotation about another axis does not"""
-    f = _field(10)
+    dev = "cuda:0"
+    f = _field(10, dev)
     g = torch.Generator().manual_seed(3)
-    lat = torch.randn(3, 10, 3, generator=g) * 0.5
+    lat = (torch.randn(3, 10, 3, generator=g) * 0.5).to(dev)
     dirs = torch.randn(17, 3, generator=g)
-    dirs = dirs / dirs.norm(dim=-1, keepdim=True)
-    sc = torch.ones(3)
+    dirs = (dirs / dirs.norm(dim=-1, keepdim=True)).to(dev)
+    sc = torch.ones(3, device=dev)
     base = f.forward_grid(dirs, lat, sc)
     for a in (0.3, 2.1, -1.7):
-        R = torch.tensor([[math.cos(a), -math.sin(a), 0.0], [math.sin(a), math.cos(a), 0.0], [0.0, 0.0, 1.0]])
-        assert (f.forward_grid(dirs @ R.T, lat @ R.T, sc) - base).abs().max() < 1e-5 * base.abs().max()
-    Rx = torch.tensor([[1.0, 0.0, 0.0], [0.0, math.cos(0.5), -math.sin(0.5)], [0.0, math.sin(0.5), math.cos(0.5)]])
-    assert (f.forward_grid(dirs @ Rx.T, lat @ Rx.T, sc) - base).abs().max() > 1e-3 * base.abs().max()
+        R = torch.tensor([[math.cos(a), -math.sin(a), 0.0], [math.sin(a), math.cos(a), 0.0], [0.0, 0.0, 1.0]], device=dev)
+        assert (f.forward_grid((dirs @ R.T).contiguous(), (lat @ R.T).contiguous(), sc) - base).abs().max() < 1e-5 * base.abs().max()
+    Rx = torch.tensor([[1.0, 0.0, 0.0], [0.0, math.cos(0.5), -math.sin(0.5)], [0.0, math.sin(0.5), math.cos(0.5)]], device=dev)
+    assert (f.forward_grid((dirs @ Rx.T).contiguous(), (lat @ Rx.T).contiguous(), sc) - base).abs().max() > 1e-3 * base.abs().max()
     # and the oracle has the same property
+    lat, dirs = lat.cpu(), dirs.cpu()
     p = attn_params(f.network)
     B = 5
     l64, d64 = lat[0][None].expand(B, 10, 3).double(), dirs[:B].double()
@@ -306,13 +301,10 @@ def _one_camera(dev, B):
         assert ((a - b).abs().max() / b.abs().max()).item() < 2e-5
 
 
-def test_one_camera_decode_equals_the_per_direction_decode_cpu():
-    _one_camera("cpu", 17)
-
-
 @pytest.mark.gpu
-def test_one_camera_decode_equals_the_per_direction_decode_gpu():
-    _one_camera("cuda:0", 300)  # the render chunk's form: one camera, its rays as the direction list (matrix-core kernels)
+@pytest.mark.parametrize("D", [17, 300])  # short direction lists: the vector-unit kernels; the render chunk's form: the matrix-core kernels
+def test_one_camera_decode_equals_the_per_direction_decode_gpu(D):
+    _one_camera("cuda:0", D)
 
 
 @pytest.mark.gpu

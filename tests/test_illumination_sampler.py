@@ -4,6 +4,7 @@ properties the reference relies on: vertex count 10 nu^2 + 2, unit norm, central
 under any rotation), near-uniform spacing, the z > 0 filter and the rotation being a rigid motion."""
 import math
 
+import pytest
 import torch
 
 from neusky_amd.model_components.illumination import (IcosahedronSamplerConfig, antipodal_sphere, icosphere_vertices,
@@ -42,14 +43,23 @@ def test_sampler_options():
     d = full(rotation=R)
     assert d.shape == (492, 3)
     assert float((d.double() @ d.double().T - full.directions.double() @ full.directions.double().T).abs().max()) < 1e-5  # Gram matrix kept
-    dirs, sel = full.on_device("cpu", rotation=R)
-    assert sel.numel() == 246 and bool((dirs[sel.long(), 2] > 0).all())
-    rest = torch.ones(492, dtype=torch.bool); rest[sel.long()] = False
-    assert bool((dirs[rest, 2] <= 0).all())
     # filter after the rotation (illumination_samplers.py:113-118): data-dependent size on the host path
     cut = IcosahedronSamplerConfig(icosphere_order=4, apply_random_rotation=True, remove_lower_hemisphere=True).setup()
     d = cut(rotation=R)
     assert bool((d[:, 2] > 0).all()) and 70 <= d.shape[0] <= 81
+
+
+@pytest.mark.gpu
+def test_rotated_set_on_the_device_has_exactly_half_above_the_horizon():
+    """the rotated set and its upper half from ONE kernel (csrc/samplers.hip: illumination_directions_kernel)"""
+    full = IcosahedronSamplerConfig(icosphere_order=7, apply_random_rotation=True).setup()
+    R = random_rotation(torch.Generator().manual_seed(3))
+    dirs, sel = full.on_device("cuda:0", rotation=R)
+    dirs, sel = dirs.cpu(), sel.cpu()
+    assert (dirs - full(rotation=R)).abs().max() < 1e-6
+    assert sel.numel() == 246 and bool((dirs[sel.long(), 2] > 0).all())
+    rest = torch.ones(492, dtype=torch.bool); rest[sel.long()] = False
+    assert bool((dirs[rest, 2] <= 0).all())
 
 
 def test_fixed_icosphere_uses_strict_upper_hemisphere():
