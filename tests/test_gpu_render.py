@@ -234,8 +234,7 @@ def test_ray_setup_kernels_match_oracle():
 
 
 def test_interlevel_kernel_matches_torch_formulation():
-    """nsky_interlevel_fwd/bwd == nerfstudio interlevel_loss (the torch formulation kept in model_components/losses.py for
-    host tensors) for the two proposal levels (256 and 96 bins against 96 final samples), value and gradient."""
+    """nsky_interlevel_fwd/bwd == nerfstudio interlevel_loss (the oracle's torch formulation, oracle.interlevel_loss / _outer) for the two proposal levels (256 and 96 bins against 96 final samples), value and gradient."""
     from neusky_amd import ops
     from neusky_amd.model_components import losses as L
     dev = "cuda:0"
@@ -254,7 +253,7 @@ def test_interlevel_kernel_matches_torch_formulation():
         sb = bins(n)
         wp = (torch.rand(R, n, device=dev) * 0.02)
         wp64 = wp.double().requires_grad_(True)
-        w_outer = L._outer(c[..., :-1].double(), c[..., 1:].double(), sb[..., :-1].double(), sb[..., 1:].double(), wp64)
+        w_outer = O._outer(c[..., :-1].double(), c[..., 1:].double(), sb[..., :-1].double(), sb[..., 1:].double(), wp64)
         ref = torch.mean(torch.clip(w.double() - w_outer, min=0) ** 2 / (w.double() + 1e-7))
         ref.backward()
         assert float(ref) > 0
