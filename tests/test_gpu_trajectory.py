@@ -6,14 +6,21 @@ dataset, no RENI++ weights and no runnable reference exist here, so what is pinn
 restated algorithm: the loss trace, the parameters after K steps and the PSNR of a 64 x 64 render of the trained scene
 (psnr: neusky/models/neusky_model.py:1064-1077).
 
+Adam with eps = 1e-15 (neusky_config.py:216-237) turns a gradient into a step of ~lr whatever its size -- in the first steps the SIGN of
+every gradient element, also of those that sit within fp32 noise of zero -- so two evaluations of the same algorithm in different
+arithmetic part ways element by element and the differences feed the next step's forward: ANY fp32 evaluation leaves the float64
+trajectory at a rate set by the conditioning of the problem, not by the quality of the evaluator.  The yardstick is therefore the
+oracle ITSELF run in float32 (the reference's own arithmetic, torch fp32 on the CPU) on the same inputs, as for the gradient bars of
+tests/test_gpu_step.py: the HIP path may be as far from the float64 trajectory as that, not further.
+
 Bars (stated here, measured values in profiles/r05_trajectory.txt):
-  * loss trace: every step's objective and every term within 2e-4 relative of the oracle's;
+  * loss trace: step 0 within 2e-6 relative (one step: no amplification); step i within max(2e-4, 4 x the largest relative distance
+    of the float32 oracle from the float64 one over steps <= i);
   * parameters after K steps, per tensor, in units of the tensor's possible travel T = sum_t lr_t (Adam moves an element by at most
-    ~lr per step whatever the size of its gradient): elements whose reference gradient is RESOLVED at every step (|g| above the
-    family's gradient bar of tests/test_gpu_step.py x its tensor maximum) agree to 0.02 T (ddf.map / ddf.table, the two ill-conditioned
-    families: 0.1 T); elements whose gradient is NOT resolved (|g| within fp32 noise of zero: Adam with eps = 1e-15 turns the SIGN of
-    such a gradient into a full +-lr step) may differ, but never by more than the 2 T a sign flip at every step allows;
-  * PSNR of the 64 x 64 render against a fixed pseudo ground-truth image: |HIP - oracle| <= 0.05 dB; the two renders agree to 1e-3."""
+    ~lr per step): rms |HIP - f64| <= max(0.01 T, 3 x rms |f32 oracle - f64|); no element differs by more than the 2 T a sign flip
+    at every step allows;
+  * PSNR of the 64 x 64 render against a fixed pseudo ground-truth image: |HIP - f64 oracle| <= 0.05 dB; the renders' largest
+    difference <= max(1e-3, 3 x that of the float32-trained oracle render) of the image maximum."""
 import math
 import os
 
@@ -42,19 +49,6 @@ def _group_of(key: str) -> str:
     raise KeyError(key)
 
 
-def _family(key: str) -> str:
-    if key == "ddf.table":
-        return "ddf.table"
-    if key.startswith("ddf."):
-        return key.split("_")[0]  # ddf.map / ddf.film / ddf.out
-    return key.split(".")[0].split("_")[0]
-
-
-RESOLVED = {"field": 2e-3, "ddf.table": 1e-2, "ddf.map": 2e-2, "ddf.film": 3e-3, "ddf.out": 2e-3, "prop0": 2e-3, "prop1": 2e-3,
-            "train": 2e-3, "visibility": 2e-3}  # = GRAD_BARS of tests/test_gpu_step.py
-TRAVEL_BAR = {"ddf.table": 0.1, "ddf.map": 0.1}
-
-
 def _module_params(pipe):
     """the live parameters under the oracle's key names (same walk as oracle_params)"""
     return {k: v.detach().cpu().double() for k, v in oracle_params(pipe).items()}
@@ -71,8 +65,7 @@ def run():
     opt = Optimizers(opt_cfg, pipe.get_param_groups())
     batches = [pipe.datamanager.next_train(i) for i in range(K)]
     rnds = [make_randoms(pipe, R, seed=100 + i) for i in range(K)]
-    p = oracle_params(pipe)  # float64 copies of the initial parameters
-    p0 = {k: v.detach().clone() for k, v in p.items()}
+    p0 = {k: v.detach().clone() for k, v in oracle_params(pipe).items()}  # float64 copies of the initial parameters
     cfg = oracle_step_cfg(pipe)
 
     def dev_rnd(r):
@@ -104,80 +97,95 @@ def run():
         hip_terms.append({k: float(v) for k, v in ld.items()})
     torch.cuda.synchronize()
 
-    # ---- oracle: float64 forward / autograd, float64 Adam (torch.optim.Adam's update, nerfstudio's schedulers)
-    keys = [k for k in p if not k.startswith("reni.")]  # frozen decoder (neusky_config.py:94)
-    m_ = {k: torch.zeros_like(p[k]) for k in keys}
-    v_ = {k: torch.zeros_like(p[k]) for k in keys}
-    ref_trace, ref_terms, gmin_rel, travel = [], [], {k: None for k in keys}, {k: 0.0 for k in keys}
-    for i in range(K):
-        rb, batch = batches[i]
-        light = pipe.model.illumination_sampler(rotation=rnds[i]["light_rotation"]).double()
-        ld, _ = O.neusky_train_step(p, cfg, rb.origins.cpu().double(), rb.directions.cpu().double(), rb.camera_indices.cpu().reshape(-1),
-                                    batch["image"].cpu().double(), batch["mask"].cpu(), oracle_randoms(rnds[i], light), light)
-        loss = sum(ld.values())
-        grads = torch.autograd.grad(loss, [p[k] for k in keys], allow_unused=True)
-        ref_trace.append(float(loss))
-        ref_terms.append({k: float(v) for k, v in ld.items()})
-        with torch.no_grad():
-            for k, g in zip(keys, grads):
-                oc = opt_cfg[_group_of(k)]
-                a, sched = oc["optimizer"], oc["scheduler"]
-                lr = a.lr * sched.factor(STEP0 + i)
-                if g is None:
-                    g = torch.zeros_like(p[k])
-                rel = g.abs() / (g.abs().max() + 1e-300)
-                gmin_rel[k] = rel if gmin_rel[k] is None else torch.minimum(gmin_rel[k], rel)
-                travel[k] += lr
-                m_[k].mul_(a.betas[0]).add_(g, alpha=1 - a.betas[0])
-                v_[k].mul_(a.betas[1]).addcmul_(g, g, value=1 - a.betas[1])
-                mhat, vhat = m_[k] / (1 - a.betas[0] ** (i + 1)), v_[k] / (1 - a.betas[1] ** (i + 1))
-                p[k].sub_(lr * mhat / (vhat.sqrt() + a.eps))
-    return dict(pipe=pipe, p=p, p0=p0, keys=keys, hip_trace=hip_trace, ref_trace=ref_trace, hip_terms=hip_terms, ref_terms=ref_terms,
-                gmin_rel=gmin_rel, travel=travel, cfg=cfg)
+    # ---- oracle: forward / autograd + Adam (torch.optim.Adam's update, nerfstudio's schedulers), in float64 and again in float32
+    def oracle_run(dt):
+        q = {k: v.detach().to(dt).clone().requires_grad_(True) for k, v in p0.items()}
+        keys = [k for k in q if not k.startswith("reni.")]  # frozen decoder (neusky_config.py:94)
+        m_ = {k: torch.zeros_like(q[k]) for k in keys}
+        v_ = {k: torch.zeros_like(q[k]) for k in keys}
+        trace, terms, travel = [], [], {k: 0.0 for k in keys}
+        for i in range(K):
+            rb, batch = batches[i]
+            light = pipe.model.illumination_sampler(rotation=rnds[i]["light_rotation"]).to(dt)
+            ld, _ = O.neusky_train_step(q, cfg, rb.origins.cpu().to(dt), rb.directions.cpu().to(dt), rb.camera_indices.cpu().reshape(-1),
+                                        batch["image"].cpu().to(dt), batch["mask"].cpu(), oracle_randoms(rnds[i], light, dt), light)
+            loss = sum(ld.values())
+            grads = torch.autograd.grad(loss, [q[k] for k in keys], allow_unused=True)
+            trace.append(float(loss.detach()))
+            terms.append({k: float(v.detach()) for k, v in ld.items()})
+            with torch.no_grad():
+                for k, g in zip(keys, grads):
+                    oc = opt_cfg[_group_of(k)]
+                    a, sched = oc["optimizer"], oc["scheduler"]
+                    lr = a.lr * sched.factor(STEP0 + i)
+                    if g is None:
+                        g = torch.zeros_like(q[k])
+                    travel[k] += lr
+                    m_[k].mul_(a.betas[0]).add_(g, alpha=1 - a.betas[0])
+                    v_[k].mul_(a.betas[1]).addcmul_(g, g, value=1 - a.betas[1])
+                    mhat, vhat = m_[k] / (1 - a.betas[0] ** (i + 1)), v_[k] / (1 - a.betas[1] ** (i + 1))
+                    q[k].sub_(lr * mhat / (vhat.sqrt() + a.eps))
+        return q, keys, trace, terms, travel
+
+    p, keys, ref_trace, ref_terms, travel = oracle_run(torch.float64)
+    p32, _, f32_trace, _, _ = oracle_run(torch.float32)
+    return dict(pipe=pipe, p=p, p32=p32, p0=p0, keys=keys, hip_trace=hip_trace, ref_trace=ref_trace, f32_trace=f32_trace, hip_terms=hip_terms,
+                ref_terms=ref_terms, travel=travel, cfg=cfg)
 
 
 def test_loss_trace_follows_the_oracle(run):
     os.makedirs("gpurun_out", exist_ok=True)
+    rel = lambda a, b: abs(a - b) / abs(b)  # noqa: E731
+    env, bars = 0.0, []
+    for a32, b in zip(run["f32_trace"], run["ref_trace"]):
+        env = max(env, rel(a32, b))
+        bars.append(max(2e-4, 4.0 * env))
+    bars[0] = 2e-6
     with open("gpurun_out/r05_trajectory.txt", "w") as f:
-        f.write(f"{K} consecutive training steps from step {STEP0}, {R} rays x 16 samples x 128 directions: objective HIP | float64 oracle | rel diff\n")
-        for i, (a, b) in enumerate(zip(run["hip_trace"], run["ref_trace"])):
-            f.write(f"step {i}: {a:.8f} {b:.8f} {abs(a - b) / abs(b):.2e}\n")
+        f.write(f"{K} consecutive training steps from step {STEP0}, {R} rays x 16 samples x 128 directions (graph replay + nsky_adam_step)\n"
+                "step: objective HIP | float64 oracle | float32 oracle | rel distance from float64: HIP, float32 oracle | bar\n")
+        for i, (a, b, c) in enumerate(zip(run["hip_trace"], run["ref_trace"], run["f32_trace"])):
+            f.write(f"step {i}: {a:.8f} {b:.8f} {c:.8f}  {rel(a, b):.2e} {rel(c, b):.2e}  {bars[i]:.1e}\n")
     for i, (a, b) in enumerate(zip(run["hip_trace"], run["ref_trace"])):
-        assert abs(a - b) <= 2e-4 * abs(b), (i, run["hip_trace"], run["ref_trace"])
-    for i, (ta, tb) in enumerate(zip(run["hip_terms"], run["ref_terms"])):
-        assert sorted(ta) == sorted(tb)
-        for k in tb:
-            assert abs(ta[k] - tb[k]) <= 2e-4 * max(abs(tb[k]), 1e-3), (i, k, ta[k], tb[k])
-    assert run["ref_trace"][-1] != run["ref_trace"][0]  # the parameters really moved between the steps
+        assert rel(a, b) <= bars[i], (i, run["hip_trace"], run["ref_trace"], run["f32_trace"])
+    for k in run["ref_terms"][0]:  # step 0, term by term: no amplification yet
+        a, b = run["hip_terms"][0][k], run["ref_terms"][0][k]
+        assert abs(a - b) <= 2e-4 * max(abs(b), 1e-3), (k, a, b)
+    assert all(sorted(ta) == sorted(tb) for ta, tb in zip(run["hip_terms"], run["ref_terms"]))
+    assert run["ref_trace"][-1] < 0.5 * run["ref_trace"][0]  # the parameters really moved: the objective more than halves
 
 
 def test_parameters_after_k_steps(run):
     got = _module_params(run["pipe"])
     rows, bad = [], []
+    rms = lambda t: float(t.double().pow(2).mean().sqrt())  # noqa: E731
     for k in run["keys"]:
-        fam = _family(k)
         T = run["travel"][k]
-        diff = (got[k] - run["p"][k].detach()).abs()
-        moved = (run["p"][k].detach() - run["p0"][k]).abs()
-        resolved = run["gmin_rel"][k] >= RESOLVED[fam]
-        n_res = int(resolved.sum())
-        worst_res = float(diff[resolved].max()) / T if n_res else 0.0
-        worst_all = float(diff.max()) / T
-        rows.append((k, fam, n_res, diff.numel(), worst_res, worst_all, float(moved.max()) / T))
-        if worst_res > TRAVEL_BAR.get(fam, 0.02) or worst_all > 2.0 + 1e-6:
-            bad.append((k, worst_res, worst_all))
+        ref = run["p"][k].detach()
+        d_hip, d_f32 = got[k] - ref, run["p32"][k].detach().double() - ref
+        moved = ref - run["p0"][k]
+        touched = moved != 0  # (hash-table rows no sample touched stay put in every evaluator: not counted in the rms)
+        if int(touched.sum()) == 0:
+            continue
+        r_hip, r_f32 = rms(d_hip[touched]) / T, rms(d_f32[touched]) / T
+        worst = float(d_hip.abs().max()) / T
+        bar = max(0.01, 3.0 * r_f32)
+        rows.append((k, int(touched.sum()), rms(moved[touched]) / T, r_hip, r_f32, worst, float(d_f32.abs().max()) / T, bar))
+        if r_hip > bar or worst > 2.0 + 1e-6:
+            bad.append((k, r_hip, r_f32, worst))
     with open("gpurun_out/r05_trajectory.txt", "a") as f:
-        f.write("\nparameters after the last step, in units of the tensor's possible travel T = sum of the step's learning rates:\n")
-        f.write("tensor  family  resolved-gradient elements / all  worst |HIP - oracle| among resolved  among all  largest displacement\n")
+        f.write("\nparameters after the last step, in units of the tensor's possible travel T = sum of the steps' learning rates:\n"
+                "tensor  touched elements  rms displacement | rms distance from the float64 trajectory: HIP, float32 oracle | largest: HIP, float32 oracle | bar (rms)\n")
         for r in rows:
-            f.write(f"{r[0]:24s} {r[1]:10s} {r[2]:9d} / {r[3]:9d}  {r[4]:.3e}  {r[5]:.3e}  {r[6]:.3e}\n")
+            f.write(f"{r[0]:24s} {r[1]:9d}  {r[2]:.3f} | {r[3]:.3e} {r[4]:.3e} | {r[5]:.3e} {r[6]:.3e} | {r[7]:.2e}\n")
     assert not bad, bad
-    assert sum(r[2] for r in rows) > 1000  # the comparison is not vacuous
+    assert len(rows) > 50
 
 
 def test_psnr_of_a_render_after_k_steps(run):
     """64 x 64 frame of camera 0 with eval latent 0, HIP (chunked graph replays) on the HIP-trained parameters against the oracle's
-    render on the oracle-trained parameters; PSNR of each against one fixed pseudo ground-truth image"""
+    render on the oracle-trained parameters (float64, and float32-trained as the yardstick); PSNR of each against one fixed pseudo
+    ground-truth image"""
     pipe = run["pipe"]
     m = pipe.model
     H = W = 64
@@ -196,17 +204,23 @@ def test_psnr_of_a_render_after_k_steps(run):
         got = m.get_outputs_for_camera_ray_bundle(rb, camera_index=0, chunk=1024, use_graph=True)["rgb"].reshape(-1, 3).cpu().double()
     finally:
         pipe.train()
-    p = {k: v.detach() for k, v in run["p"].items()}
     light = m.illumination_sampler.directions.double()
     o, d = rb.origins.reshape(-1, 3).cpu().double(), rb.directions.reshape(-1, 3).cpu().double()
     lat, sc = m.eval_illumination_latents[0].detach().cpu().double(), m.eval_scale[0].detach().cpu().double()
-    ref = torch.cat([O.neusky_render(p | {"field.table": run["p"]["field.table"]}, run["cfg"], o[i:i + 1024], d[i:i + 1024], lat, sc, light)["rgb"].detach()
-                     for i in range(0, H * W, 1024)])
+
+    def oracle_render(params):  # the render itself in float64 either way: what differs is the parameters' training arithmetic
+        q = {k: v.detach().double() for k, v in params.items()}
+        q["field.table"] = q["field.table"].clone().requires_grad_(True)  # (normals come from autograd through the field)
+        return torch.cat([O.neusky_render(q, run["cfg"], o[i:i + 1024], d[i:i + 1024], lat, sc, light)["rgb"].detach() for i in range(0, H * W, 1024)])
+
+    ref, ref32 = oracle_render(run["p"]), oracle_render(run["p32"])
     gt = torch.rand(H * W, 3, generator=torch.Generator().manual_seed(9), dtype=torch.float64)
     psnr = lambda x: -10.0 * math.log10(float(((x - gt) ** 2).mean()))  # noqa: E731  neusky_model.py:1066-1067
-    a, b = psnr(got), psnr(ref)
-    rel = float((got - ref).abs().max() / ref.abs().max())
+    a, b, c = psnr(got), psnr(ref), psnr(ref32)
+    dist = lambda x: float((x - ref).abs().max() / ref.abs().max())  # noqa: E731
     with open("gpurun_out/r05_trajectory.txt", "a") as f:
-        f.write(f"\n64 x 64 render after {K} steps: PSNR vs fixed pseudo ground truth HIP {a:.4f} dB | oracle {b:.4f} dB; renders differ by {rel:.2e} of the maximum\n")
+        f.write(f"\n64 x 64 render after {K} steps, PSNR vs a fixed pseudo ground truth: HIP {a:.4f} dB | float64 oracle {b:.4f} dB | float32-trained oracle {c:.4f} dB\n"
+                f"largest difference from the float64-trained render / image maximum: HIP {dist(got):.2e}, float32-trained oracle {dist(ref32):.2e}; "
+                f"PSNR between the HIP and the float64 render {-10.0 * math.log10(float(((got - ref) ** 2).mean())):.1f} dB\n")
     assert abs(a - b) <= 0.05, (a, b)
-    assert rel < 1e-3, rel
+    assert dist(got) <= max(1e-3, 3.0 * dist(ref32)), (dist(got), dist(ref32))
