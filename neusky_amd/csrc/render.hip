@@ -612,7 +612,10 @@ __global__ __launch_bounds__(256) void density_weights_bwd_kernel(const float* _
 //   lo = clamp(searchsorted_right(starts, c_s) - 1, 0, n-1),  hi = clamp(searchsorted_right(ends, c_{s+1}), 0, n-1),
 // and the per-ray sum of max(w_s - w_outer, 0)^2 / (w_s + 1e-7).  One wave per ray; the proposal bins and the prefix
 // sums of wp live in LDS.  Backward: d wp_j = sum over the s whose [lo, hi] contains j of  -2 g max(.)/(w_s + 1e-7),
-// scattered as a difference array and prefix-summed.
+// scattered as a difference array and prefix-summed.  A bin no active interval covers has a gradient of EXACTLY zero in the reference's
+// autograd; the float prefix sum of +g / -g pairs leaves a residue of ~1e-9 g there, and Adam with eps = 1e-15 turns any nonzero
+// gradient into a step of ~lr (a trajectory test found hash-table rows moving that the oracle never touches): an integer difference
+// array of the coverage count decides which bins receive a gradient at all.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int upper_bound_f(const float* a, int n, float v) {  // first index with a[idx] > v
   int lo = 0, hi = n;
@@ -628,16 +631,17 @@ __global__ __launch_bounds__(256) void interlevel_kernel(const float* __restrict
                                                          const float* __restrict__ sb, const float* __restrict__ wp,
                                                          const float* __restrict__ g_ray, int R, int S, int n,
                                                          float* __restrict__ per_ray, float* __restrict__ d_wp) {
-  extern __shared__ float sm[];  // per wave: bins[n+1], cy[n+1] (exclusive prefix sums), diff[n+1]
+  extern __shared__ float sm[];  // per wave: bins[n+1], cy[n+1] (exclusive prefix sums), diff[n+1], cover[n+1] (int)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = blockIdx.x * 4 + wave;
   if (r >= R) return;
-  float* bins = sm + wave * 3 * (n + 1);
+  float* bins = sm + wave * 4 * (n + 1);
   float* cy = bins + (n + 1);
   float* diff = cy + (n + 1);
+  int* cover = reinterpret_cast<int*>(diff + (n + 1));
   for (int i = lane; i <= n; i += 64) {
     bins[i] = sb[(long)r * (n + 1) + i];
-    if (BWD) diff[i] = 0.0f;
+    if (BWD) { diff[i] = 0.0f; cover[i] = 0; }
   }
   if (lane == 0) {  // sequential prefix sums (n <= 256), the order torch.cumsum uses on one row
     float acc = 0.0f;
@@ -664,6 +668,8 @@ __global__ __launch_bounds__(256) void interlevel_kernel(const float* __restrict
       const float gj = -2.0f * g * dlt / (ws + 1e-7f);
       atomicAdd(diff + lo, gj);
       atomicAdd(diff + hi + 1, -gj);
+      atomicAdd(cover + lo, 1);
+      atomicAdd(cover + hi + 1, -1);
     }
   }
   if (!BWD) {
@@ -675,9 +681,11 @@ __global__ __launch_bounds__(256) void interlevel_kernel(const float* __restrict
   __threadfence_block();
   if (lane == 0) {
     float acc = 0.0f;
+    int cnt = 0;
     for (int i = 0; i < n; ++i) {
       acc += diff[i];
-      d_wp[(long)r * n + i] = acc;
+      cnt += cover[i];
+      d_wp[(long)r * n + i] = cnt > 0 ? acc : 0.0f;
     }
   }
 }
@@ -980,7 +988,7 @@ extern "C" int nsky_interlevel_fwd(const float* c, const float* w, const float* 
                                    float* per_ray, nsky_stream_t stream) {
   if (R == 0) return NSKY_OK;
   NSKY_CHECK_ARG(c && w && sb && wp && per_ray && R > 0 && S > 0 && n > 0 && n <= 4096, "nsky_interlevel_fwd: bad argument");
-  const size_t smem = 4 * 3 * (size_t)(n + 1) * sizeof(float);
+  const size_t smem = 4 * 4 * (size_t)(n + 1) * sizeof(float);
   hipLaunchKernelGGL((interlevel_kernel<false>), dim3(ceil_div(R, 4)), dim3(256), smem, (hipStream_t)stream, c, w, sb, wp, nullptr, R,
                      S, n, per_ray, nullptr);
   NSKY_CHECK_LAUNCH("nsky_interlevel_fwd");
@@ -991,7 +999,7 @@ extern "C" int nsky_interlevel_bwd(const float* c, const float* w, const float* 
                                    int32_t R, int32_t S, int32_t n, float* d_wp, nsky_stream_t stream) {
   if (R == 0) return NSKY_OK;
   NSKY_CHECK_ARG(c && w && sb && wp && d_per_ray && d_wp && R > 0 && S > 0 && n > 0 && n <= 4096, "nsky_interlevel_bwd: bad argument");
-  const size_t smem = 4 * 3 * (size_t)(n + 1) * sizeof(float);
+  const size_t smem = 4 * 4 * (size_t)(n + 1) * sizeof(float);
   hipLaunchKernelGGL((interlevel_kernel<true>), dim3(ceil_div(R, 4)), dim3(256), smem, (hipStream_t)stream, c, w, sb, wp, d_per_ray, R,
                      S, n, nullptr, d_wp);
   NSKY_CHECK_LAUNCH("nsky_interlevel_bwd");
