@@ -239,9 +239,36 @@ def forward_only_line(pipe, device):
         enc_t = _timed_ms(lambda: hip.encode_fwd(geom, table, x, field.grid_mode, True, 6, 5.0, Y, T))
     nbytes = P * (12 + geom.n_levels * 8 * 2 * 4 + 4 * ldy * 4)
     return {"workload": "SDF+albedo forward only, 1024 rays x 96 samples, hash L=16 F=2 (BASELINE configs[1])", "ms": whole,
-            "rays_per_s": RAYS / whole * 1e3, "points_per_s": P / whole * 1e3,
+            "rays_per_s": RAYS / whole * 1e3, "points_per_s": P / whole * 1e3, "cpu_baseline": forward_only_cpu(pipe),
             "encode_fwd": {"ms": enc_t, "algorithmic_bytes": nbytes, "achieved_GBs": nbytes / enc_t / 1e6, "peak_GBs": HBM_PEAK_GBS,
                            "frac": nbytes / enc_t / 1e6 / HBM_PEAK_GBS, "bound": "hbm (the 48.8 MB table is Infinity-Cache resident)"}}
+
+
+def forward_only_cpu(pipe, rays=64):
+    """the CPU leg of configs[1] (SURVEY 8(d) / BASELINE.md section 5): the oracle's field pass (hash encode -> geometry net with the
+    autograd normal -> colour net -> NeuS alpha, torch-CPU fp32, all host cores) on a bounded sample of the same workload: `rays` rays x
+    96 samples with the full-size tables and networks; median of 5"""
+    from oracle import neusky_oracle as O
+    from util_step import oracle_params, oracle_step_cfg
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    p = oracle_params(pipe, dtype=torch.float32)
+    cfg = oracle_step_cfg(pipe)
+    g = torch.Generator().manual_seed(0)
+    o = (torch.rand(rays, 3, generator=g) * 2 - 1) * 0.3
+    d = torch.nn.functional.normalize(torch.randn(rays, 3, generator=g), dim=-1)
+    eb = torch.linspace(0.05, 1.5, SAMPLES + 1)[None].expand(rays, -1).contiguous()
+
+    def once():
+        t0 = time.perf_counter()
+        O.field_pass(p, cfg, o, d, eb)
+        return time.perf_counter() - t0
+
+    once()
+    ts = sorted(once() for _ in range(5))
+    dt = ts[2]
+    return {"value": rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"median of 5 field passes (oracle.field_pass, torch-CPU fp32) of {rays} rays x {SAMPLES} samples, full-size hash table and networks; {dt * 1e3:.0f} ms/pass"}
 
 
 def envmap_decode_line(device):
@@ -671,6 +698,7 @@ def main():
     import neusky_amd.ops as ops
     from neusky_amd import hip as _hip
     timer = KernelTimer()
+    _async_wgrad = ops.ASYNC_WGRAD
     use_graph = not args.no_graph
     skies = [pipe.datamanager.get_sky_ray_bundle(pipe.config.num_sky_rays) for _ in range(args.steps + args.warmup)]
     graph_note = ""
@@ -696,10 +724,12 @@ def main():
         # one extra EAGER iteration of the same step (same kernels, shapes and stream) right after the timed region
         timer.install()
         pipe.model.second_stream = False  # one stream: every timed kernel has the chip to itself
+        ops.ASYNC_WGRAD = False           # (the weight-gradient launches too: in line, not beside the next nodes' kernels)
         for it in range(3):  # (three launches per kernel: a single launch's event time varies by 10 % from run to run)
             train_iteration(pipe, opt, 3000 + it, ray_bundle=batches[-1][0], batch=batches[-1][1])
         torch.cuda.synchronize()
         pipe.model.second_stream = True
+        ops.ASYNC_WGRAD = _async_wgrad
         timer.uninstall()
     else:
         for i in range(args.warmup):
@@ -714,10 +744,12 @@ def main():
         dt = time.perf_counter() - t0
         timer.install()
         pipe.model.second_stream = False
+        ops.ASYNC_WGRAD = False
         for it in range(3):
             train_iteration(pipe, opt, 3000 + it, ray_bundle=batches[-1][0], batch=batches[-1][1])
         torch.cuda.synchronize()
         pipe.model.second_stream = True
+        ops.ASYNC_WGRAD = _async_wgrad
         timer.uninstall()
     t = torch.tensor([dt], device=device if backend == "nccl" else "cpu")
     if world > 1:

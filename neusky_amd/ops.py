@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -71,6 +73,7 @@ class _PadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        join_weight_gradients()  # (g may be a weight-gradient accumulator of the side stream)
         o = ctx.orig
         return (g[:o[0], :o[1]] if len(o) == 2 else g[:o[0]]), None, None
 
@@ -178,6 +181,49 @@ def shared_grad(like, bias_like):
     db = flat[nw:].view_as(bias_like) if bias_like is not None else None
     _SHARED_GRADS[key] = (like, dW, db)
     return dW, db, True
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Weight gradients off the critical path.  The weight gradients of a chain (the streaming kernel: 2 ms for the DDF network) feed nothing
+# in the backward pass -- they land in the optimizer slab (`sink` parameters) or in accumulators only the weight-norm / padding nodes at
+# the very end of the pass read -- while the input gradients the same node returns are what the next nodes wait for (the hash-table
+# scatter, an LDS-atomic kernel that leaves the matrix pipes and most of the HBM bandwidth idle).  So a backward node may launch its
+# weight-gradient kernels on a SIDE stream: forked behind the node's own kernels, joined where their results are first read
+# (join_weight_gradients: the weight-norm / padding backward nodes, and a callback at the end of the backward pass).  Operands are
+# pinned to the side stream (record_stream) so the allocator does not hand their memory to a later kernel of the main stream.
+ASYNC_WGRAD = os.environ.get("NSKY_ASYNC_WGRAD", "1") != "0"  # (lab switch for same-box A/B runs; arithmetic is identical either way)
+_WGRAD_SIDE: dict = {}     # device index -> side stream
+_WGRAD_PENDING: list = []  # side streams with unjoined work of THIS backward pass
+
+
+def async_weight_gradients(launch, operands) -> None:
+    """run `launch()` (weight-gradient kernels only: nothing the caller returns may depend on them) on the side stream"""
+    if not ASYNC_WGRAD:
+        launch()
+        return
+    main = torch.cuda.current_stream()
+    side = _WGRAD_SIDE.get(main.device_index)
+    if side is None:
+        side = _WGRAD_SIDE[main.device_index] = torch.cuda.Stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        launch()
+    for t in operands:
+        if t is not None:
+            t.record_stream(side)
+    if not _WGRAD_PENDING:
+        torch.autograd.Variable._execution_engine.queue_callback(join_weight_gradients)
+    if side not in _WGRAD_PENDING:
+        _WGRAD_PENDING.append(side)
+
+
+def join_weight_gradients() -> None:
+    """the current stream waits for every weight-gradient launch made so far in this backward pass"""
+    if _WGRAD_PENDING:
+        cur = torch.cuda.current_stream()
+        for side in _WGRAD_PENDING:
+            cur.wait_stream(side)
+        _WGRAD_PENDING.clear()
 
 
 def grad_bias(dZ, M, n_out, like):
@@ -322,6 +368,7 @@ class WeightNormFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
+        join_weight_gradients()  # d_out is a weight-gradient accumulator the side stream may still be adding to
         v, g, inv, row_map, inverse_col = ctx.saved_tensors
         dv, dg = torch.empty_like(v), torch.empty_like(g)
         hip.weight_norm_bwd(d_out.contiguous(), v, g, inv, row_map, inverse_col, dv, dg)
@@ -603,17 +650,23 @@ class FilmSirenFn(torch.autograd.Function):
                 else:
                     grad_weight(dZ, X, M, n_out, k_in, like, bias_like, acc=acc(iw), a_native_nt=a_nt, b_native_nt=b_nt, a_scale_max=smax)
 
-            wgrad(d_res, ys[-1], ow.shape[0], H, ow, ob, o + 2 * n_film, 0, nt, None)
-            for i in range(n_film - 1, 0, -1):
-                wgrad(dzs[i], ys[i - 1], H, H, fw[i], fb[i], o + 2 * i, nt, nt, gmax[i:i + 1])
-            wgrad(dzs[0], x, H, fw[0].shape[1], fw[0], fb[0], o, nt, 0, None)
-            wgrad(dfp, hs[-1], 2 * n_film * H, Hm, mwo, mbo, 2 * n_map, 2 * n_film * nt, ntm, gmax[n_film:n_film + 1], 8.0)
-            for l in range(n_map - 1, 0, -1):
-                wgrad(dpres[l], hs[l - 1], Hm, Hm, mw[l], mb[l], 2 * l, ntm, ntm, gmax[n_film + 1 + l:n_film + 2 + l], 8.0)
-            k0 = mw[0].shape[1]
-            wgrad(dpres[0], cond, Hm, k0, mw[0], mb[0], 0, ntm, 0, gmax[n_film + 1:n_film + 2] if k0 > 64 else None)
-            if native:
-                hip.wgrad_native_batch(native, M)
+            def launch():
+                wgrad(d_res, ys[-1], ow.shape[0], H, ow, ob, o + 2 * n_film, 0, nt, None)
+                for i in range(n_film - 1, 0, -1):
+                    wgrad(dzs[i], ys[i - 1], H, H, fw[i], fb[i], o + 2 * i, nt, nt, gmax[i:i + 1])
+                wgrad(dzs[0], x, H, fw[0].shape[1], fw[0], fb[0], o, nt, 0, None)
+                wgrad(dfp, hs[-1], 2 * n_film * H, Hm, mwo, mbo, 2 * n_map, 2 * n_film * nt, ntm, gmax[n_film:n_film + 1], 8.0)
+                for l in range(n_map - 1, 0, -1):
+                    wgrad(dpres[l], hs[l - 1], Hm, Hm, mw[l], mb[l], 2 * l, ntm, ntm, gmax[n_film + 1 + l:n_film + 2 + l], 8.0)
+                k0 = mw[0].shape[1]
+                wgrad(dpres[0], cond, Hm, k0, mw[0], mb[0], 0, ntm, 0, gmax[n_film + 1:n_film + 2] if k0 > 64 else None)
+                if native:
+                    hip.wgrad_native_batch(native, M)
+
+            if all(sunk):  # every gradient lands in the optimizer slab: nothing this node returns depends on the launches
+                async_weight_gradients(launch, [d_res, x, cond, dfp, gmax, *ys, *hs, *dzs, *dpres])
+            else:
+                launch()
         return (d_x, d_cond, None, None, None, None, *[None if sunk[i] else g for i, g in enumerate(grads)])
 
     @staticmethod
