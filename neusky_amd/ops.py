@@ -1008,20 +1008,30 @@ class FieldChainFn(torch.autograd.Function):
         dW0, db0, f_0 = shared_grad(W0, b0)
         R4 = 4 * N
         qmax = ctx.qmax
-        hip.wgrad_native_batch([hip.wgrad_problem(d1q, 8, a0q, 8, R4, dW1, db1, gmax[4:5], 8.0, bias_row_mod=4, b_scale_max=qmax[1:2])], R4)
-        hip.wgrad_native_batch([hip.wgrad_problem(d0q, 8, Eq, 4, R4, dW0, db0, gmax[5:6], 64.0, width_b=Kin, bias_row_mod=4, b_scale_max=qmax[0:1])], R4)
-        hip.native_weighted_colsum(a1q, 8, R4, dW2[GF], db2[GF:GF + 1], g_sdf=g_sdf, g_grad=g_grad)
+        # (the accumulators are read by the weight-norm nodes at the end of the pass, which join the side stream: async_weight_gradients)
+
+        def launch_geo():
+            hip.wgrad_native_batch([hip.wgrad_problem(d1q, 8, a0q, 8, R4, dW1, db1, gmax[4:5], 8.0, bias_row_mod=4, b_scale_max=qmax[1:2])], R4)
+            hip.wgrad_native_batch([hip.wgrad_problem(d0q, 8, Eq, 4, R4, dW0, db0, gmax[5:6], 64.0, width_b=Kin, bias_row_mod=4, b_scale_max=qmax[0:1])], R4)
+            hip.native_weighted_colsum(a1q, 8, R4, dW2[GF], db2[GF:GF + 1], g_sdf=g_sdf, g_grad=g_grad)
+
         k = lambda first, t: t if first else None  # noqa: E731  later nodes of the pass added in place
         if not colour:
+            async_weight_gradients(launch_geo, [d1q, a0q, d0q, Eq, a1q, g_sdf, g_grad, gmax, qmax])
             return (dET, k(f_0, dW0), k(f_0, db0), k(f_1, dW1), k(f_1, db1), k(f_2, dW2), k(f_2, db2), *none6, None, None)
         dWc2, dbc2, f_c2 = shared_grad(Wc2, bc2)
         dWc1, dbc1, f_c1 = shared_grad(Wc1, bc1)
         dWc0, dbc0, f_c0 = shared_grad(Wc0, bc0)
-        hip.wgrad_native_batch([hip.wgrad_problem(dfeat, 8, a1v, 8, N, dW2[:GF], db2[:GF], gmax[2:3], 8.0),
-                                hip.wgrad_problem(dpc1, 8, c0, 8, N, dWc1, dbc1, gmax[0:1], 8.0),
-                                hip.wgrad_problem(dpc0, 8, feat, 8, N, dWc0[:, :GF], dbc0, gmax[1:2], 8.0)], N)
-        hip.wgrad_native_batch([hip.wgrad_problem(dpc0, 8, xpe, 4, N, dWc0[:, GF:], None, gmax[1:2], 64.0, width_b=Wc0.shape[1] - GF)], N)
-        hip.native_weighted_colsum(c1, 8, N, dWc2, dbc2, w4=dpc2, n_out=3)
+
+        def launch_all():
+            launch_geo()
+            hip.wgrad_native_batch([hip.wgrad_problem(dfeat, 8, a1v, 8, N, dW2[:GF], db2[:GF], gmax[2:3], 8.0),
+                                    hip.wgrad_problem(dpc1, 8, c0, 8, N, dWc1, dbc1, gmax[0:1], 8.0),
+                                    hip.wgrad_problem(dpc0, 8, feat, 8, N, dWc0[:, :GF], dbc0, gmax[1:2], 8.0)], N)
+            hip.wgrad_native_batch([hip.wgrad_problem(dpc0, 8, xpe, 4, N, dWc0[:, GF:], None, gmax[1:2], 64.0, width_b=Wc0.shape[1] - GF)], N)
+            hip.native_weighted_colsum(c1, 8, N, dWc2, dbc2, w4=dpc2, n_out=3)
+
+        async_weight_gradients(launch_all, [d1q, a0q, d0q, Eq, a1q, g_sdf, g_grad, gmax, qmax, dfeat, a1v, dpc1, c0, dpc0, feat, xpe, c1, dpc2])
         return (dET, k(f_0, dW0), k(f_0, db0), k(f_1, dW1), k(f_1, db1), k(f_2, dW2), k(f_2, db2), k(f_c0, dWc0), k(f_c0, dbc0),
                 k(f_c1, dWc1), k(f_c1, dbc1), k(f_c2, dWc2), k(f_c2, dbc2), None, None)
 
@@ -1109,9 +1119,13 @@ class SDFValueFn(torch.autograd.Function):
                           dW2[GF] if train_w else None, db2[GF:GF + 1] if train_w else None, gmax)
         if train_w:
             nt = Hd // 32
-            # softplus outputs are unbounded in principle: 2^3 keeps |a| up to 8000 inside fp16's range (as for the mapping network)
-            hip.wgrad_native_batch([hip.wgrad_problem(dZ1, nt, A0, nt, M, dW1, db1, gmax[0:1], 8.0)], M)
-            grad_weight(dZ0, E, M, Hd, Kin, W0, b0, acc=(dW0, db0), a_native_nt=nt, b_native_nt=0, a_scale_max=gmax[1:2])
+
+            def launch():
+                # softplus outputs are unbounded in principle: 2^3 keeps |a| up to 8000 inside fp16's range (as for the mapping network)
+                hip.wgrad_native_batch([hip.wgrad_problem(dZ1, nt, A0, nt, M, dW1, db1, gmax[0:1], 8.0)], M)
+                grad_weight(dZ0, E, M, Hd, Kin, W0, b0, acc=(dW0, db0), a_native_nt=nt, b_native_nt=0, a_scale_max=gmax[1:2])
+
+            async_weight_gradients(launch, [dZ1, A0, dZ0, E, gmax])
             if not f2: dW2 = db2 = None
             if not f1: dW1 = db1 = None
             if not f0: dW0 = db0 = None
