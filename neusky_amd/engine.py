@@ -15,7 +15,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 
-from . import hip
+from . import hip, ops
 from .model_components.losses import total_loss
 
 
@@ -93,6 +93,7 @@ class _Group:
             p.data = self.flat_p[off:off + k].view_as(p)
             p.grad = self.flat_g[off:off + k].view_as(p)
             p._nsky_grad_sink = True  # custom backward passes may accumulate into p.grad directly (zeroed by zero_grad_all)
+            ops.register_grad_sink(p)
             off += (k + 3) // 4 * 4
         if isinstance(self.sched, ExponentialDecaySchedulerConfig):
             self.sched.lr_init = self.opt.lr

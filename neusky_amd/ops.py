@@ -163,6 +163,27 @@ def grad_weight(dZ, X, M, n_out, k_in, like, bias_like=None, bias_rows=None, acc
 # (dW, db) pair and returns it, the later ones add into it in place (split-K atomics / beta = 1) and return None -- autograd
 # runs the weight's producer only after all of them, so it sees the finished sum without 2 x 15 separate zero fills and adds.
 _SHARED_GRADS: dict = {}
+# A bias that is an optimizer-slab parameter (engine._Group.bind registers it: register_grad_sink) accumulates straight into its slab view
+# and the nodes return None for it: no AccumulateGrad node ever touches the accumulator (which, while _SHARED_GRADS still refers to it,
+# AccumulateGrad would CLONE on the main stream -- under a captured graph in front of the side stream's last adds: found as two wrong bias
+# gradients under graph replay when the weight gradients first moved to the side stream).
+_GRAD_SINKS: dict = {}   # data_ptr of a slab parameter -> the parameter
+_SUNK_BIAS: set = set()  # data_ptrs of the slab views handed out as bias accumulators in this backward pass
+
+
+def register_grad_sink(p) -> None:
+    _GRAD_SINKS[p.data_ptr()] = p
+
+
+def _end_of_pass() -> None:
+    _SHARED_GRADS.clear()
+    _SUNK_BIAS.clear()
+
+
+def first_only(first, t):
+    """what a node returns to autograd for a shared accumulator: the tensor from the node that allocated it, None from the later ones
+    (they added in place) and None for a bias that accumulates in its own slab view"""
+    return t if (first and t is not None and t.data_ptr() not in _SUNK_BIAS) else None
 
 
 def shared_grad(like, bias_like):
@@ -174,11 +195,20 @@ def shared_grad(like, bias_like):
     if hit is not None:
         return hit[1], hit[2], False
     if not _SHARED_GRADS:  # first shared accumulator of this backward pass: forget them all when the pass ends
-        torch.autograd.Variable._execution_engine.queue_callback(_SHARED_GRADS.clear)
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass)
+    db = None
+    sk = _GRAD_SINKS.get(bias_like.data_ptr()) if bias_like is not None else None
+    if sk is not None and sk.shape == bias_like.shape:
+        if sk.grad is not None and sk.grad.shape == bias_like.shape and sk.grad.is_contiguous() and getattr(sk, "_nsky_sunk", False):
+            db = sk.grad  # the slab view, zeroed by zero_grad_all
+            _SUNK_BIAS.add(db.data_ptr())
+        else:
+            sk._nsky_sunk = True  # sinks from the next zero_grad_all on (which then keeps .grad as the slab view)
     nw = (like.numel() + 3) // 4 * 4
-    flat = zeros(nw + (bias_like.numel() if bias_like is not None else 0), device=like.device)
+    flat = zeros(nw + (bias_like.numel() if (bias_like is not None and db is None) else 0), device=like.device)
     dW = flat[:like.numel()].view_as(like)
-    db = flat[nw:].view_as(bias_like) if bias_like is not None else None
+    if db is None and bias_like is not None:
+        db = flat[nw:].view_as(bias_like)
     _SHARED_GRADS[key] = (like, dW, db)
     return dW, db, True
 
@@ -224,6 +254,13 @@ def join_weight_gradients() -> None:
         for side in _WGRAD_PENDING:
             cur.wait_stream(side)
         _WGRAD_PENDING.clear()
+
+
+def join_if_returned(*leaf_grads) -> None:
+    """a gradient handed to autograd for a LEAF (a bias that is not -- yet -- slab-resident: the first step, a caller without the
+    engine's slabs) is read by AccumulateGrad right away: the side stream's adds must have landed"""
+    if any(t is not None for t in leaf_grads):
+        join_weight_gradients()
 
 
 def grad_bias(dZ, M, n_out, like):
@@ -894,7 +931,7 @@ class SDFAlbedoFn(torch.autograd.Function):
         if dCIN is not None:  # x / PE columns of the colour-net input came straight from the encode row
             dET[:N, :39] += dCIN[:, GF + 4:GF + 4 + 39]
         flush_wgrad(wq)
-        k = lambda first, t: t if first else None  # noqa: E731  later nodes of the pass added in place
+        k = first_only  # later nodes of the pass added in place; slab-resident biases return nothing
         if colour is None:
             return (dET, k(f_0, dW0), k(f_0, db0), k(f_1, dW1), k(f_1, db1), k(f_2, dW2), k(f_2, db2), None, None, None, None, None, None,
                     None, None)
@@ -1015,9 +1052,10 @@ class FieldChainFn(torch.autograd.Function):
             hip.wgrad_native_batch([hip.wgrad_problem(d0q, 8, Eq, 4, R4, dW0, db0, gmax[5:6], 64.0, width_b=Kin, bias_row_mod=4, b_scale_max=qmax[0:1])], R4)
             hip.native_weighted_colsum(a1q, 8, R4, dW2[GF], db2[GF:GF + 1], g_sdf=g_sdf, g_grad=g_grad)
 
-        k = lambda first, t: t if first else None  # noqa: E731  later nodes of the pass added in place
+        k = first_only  # later nodes of the pass added in place; slab-resident biases return nothing
         if not colour:
             async_weight_gradients(launch_geo, [d1q, a0q, d0q, Eq, a1q, g_sdf, g_grad, gmax, qmax])
+            join_if_returned(k(f_0, db0), k(f_1, db1))
             return (dET, k(f_0, dW0), k(f_0, db0), k(f_1, dW1), k(f_1, db1), k(f_2, dW2), k(f_2, db2), *none6, None, None)
         dWc2, dbc2, f_c2 = shared_grad(Wc2, bc2)
         dWc1, dbc1, f_c1 = shared_grad(Wc1, bc1)
@@ -1032,6 +1070,7 @@ class FieldChainFn(torch.autograd.Function):
             hip.native_weighted_colsum(c1, 8, N, dWc2, dbc2, w4=dpc2, n_out=3)
 
         async_weight_gradients(launch_all, [d1q, a0q, d0q, Eq, a1q, g_sdf, g_grad, gmax, qmax, dfeat, a1v, dpc1, c0, dpc0, feat, xpe, c1, dpc2])
+        join_if_returned(k(f_0, db0), k(f_1, db1), k(f_c0, dbc0), k(f_c1, dbc1))
         return (dET, k(f_0, dW0), k(f_0, db0), k(f_1, dW1), k(f_1, db1), k(f_2, dW2), k(f_2, db2), k(f_c0, dWc0), k(f_c0, dbc0),
                 k(f_c1, dWc1), k(f_c1, dbc1), k(f_c2, dWc2), k(f_c2, dbc2), None, None)
 
@@ -1126,9 +1165,11 @@ class SDFValueFn(torch.autograd.Function):
                 grad_weight(dZ0, E, M, Hd, Kin, W0, b0, acc=(dW0, db0), a_native_nt=nt, b_native_nt=0, a_scale_max=gmax[1:2])
 
             async_weight_gradients(launch, [dZ1, A0, dZ0, E, gmax])
-            if not f2: dW2 = db2 = None
-            if not f1: dW1 = db1 = None
-            if not f0: dW0 = db0 = None
+            if not f2: dW2 = None
+            if not f1: dW1 = None
+            if not f0: dW0 = None
+            db0, db1, db2 = first_only(f0, db0), first_only(f1, db1), first_only(f2, db2)
+            join_if_returned(db0, db1)
         return dE, dW0, db0, dW1, db1, dW2, db2, None, None
 
     @staticmethod
@@ -1160,9 +1201,10 @@ class SDFValueFn(torch.autograd.Function):
             dW0, db0, f0 = shared_grad(W0, b0)
             grad_weight(dZ0, E, M, Hd, Kin, W0, b0, acc=(dW0, db0), batch=wq)
             flush_wgrad(wq)
-            if not f2: dW2 = db2 = None
-            if not f1: dW1 = db1 = None
-            if not f0: dW0 = db0 = None
+            if not f2: dW2 = None
+            if not f1: dW1 = None
+            if not f0: dW0 = None
+            db0, db1, db2 = first_only(f0, db0), first_only(f1, db1), first_only(f2, db2)
         return dE, dW0, db0, dW1, db1, dW2, db2, None, None
 
 
