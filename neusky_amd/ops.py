@@ -381,9 +381,15 @@ def ld(t):
     return hip.ld(t)
 
 
-def grad_input(dZ, W, M, k_in, n_red, out, **epi):
+# input gradients through FROZEN dense layers (the RENI++ attention decoder's 37 linear layers per step): three bf16 terms per operand,
+# six MFMAs per product (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi: ~2^-24, bf16 keeps fp32's exponent range so a gradient needs no
+# pre-scaling) instead of the exact-fp32 MFMA at 1/16 of the bf16 rate
+FROZEN_DX_PRECISION = hip.PREC_BF16X3 if os.environ.get("NSKY_FROZEN_DX", "bf16x3") == "bf16x3" else hip.PREC_F32
+
+
+def grad_input(dZ, W, M, k_in, n_red, out, precision=None, **epi):
     """dX[M, k_in] = dZ[M, n_red] @ W[n_red, k_in]   (W stored [out, in] = [n_red, k_in])."""
-    return hip.gemm(dZ, W, out, M, k_in, n_red, a_kcontig=True, b_kcontig=False, precision=BWD_PRECISION, **epi)
+    return hip.gemm(dZ, W, out, M, k_in, n_red, a_kcontig=True, b_kcontig=False, precision=BWD_PRECISION if precision is None else precision, **epi)
 
 
 # =============================================================================================
@@ -509,7 +515,8 @@ class DenseFn(torch.autograd.Function):
         dX = None
         if need_dx:
             dX = torch.empty(M, K, device=X.device)
-            grad_input(dZ, Wp, M, K, Wp.shape[0], dX)
+            frozen = not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+            grad_input(dZ, Wp, M, K, Wp.shape[0], dX, precision=FROZEN_DX_PRECISION if (frozen and _POLICY != "f32") else None)
         return dX, dW, db, None, None, None
 
 
@@ -1791,9 +1798,10 @@ class FrozenFeedForwardFn(torch.autograd.Function):
         h, W1, W2 = ctx.saved_tensors
         M = h.shape[0]
         dz = torch.empty_like(h)
-        grad_input(dy.contiguous(), W2, M, W2.shape[1], W2.shape[0], dz, epi=hip.EPI_BWD_RELU, aux0=h)
+        prec = FROZEN_DX_PRECISION if _POLICY != "f32" else None
+        grad_input(dy.contiguous(), W2, M, W2.shape[1], W2.shape[0], dz, precision=prec, epi=hip.EPI_BWD_RELU, aux0=h)
         dx = torch.empty(M, W1.shape[1], device=h.device)
-        grad_input(dz, W1, M, W1.shape[1], W1.shape[0], dx)
+        grad_input(dz, W1, M, W1.shape[1], W1.shape[0], dx, precision=prec)
         return dx, None, None, None, None
 
 
