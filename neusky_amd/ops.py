@@ -167,12 +167,26 @@ _SHARED_GRADS: dict = {}
 # and the nodes return None for it: no AccumulateGrad node ever touches the accumulator (which, while _SHARED_GRADS still refers to it,
 # AccumulateGrad would CLONE on the main stream -- under a captured graph in front of the side stream's last adds: found as two wrong bias
 # gradients under graph replay when the weight gradients first moved to the side stream).
-_GRAD_SINKS: dict = {}   # data_ptr of a slab parameter -> the parameter
+_GRAD_SINKS: dict = {}   # data_ptr of a slab parameter -> weak reference to the parameter (a dead pipeline's entries must not catch a new
+                         # pipeline's parameter that the allocator placed at the same address)
 _SUNK_BIAS: set = set()  # data_ptrs of the slab views handed out as bias accumulators in this backward pass
 
 
 def register_grad_sink(p) -> None:
-    _GRAD_SINKS[p.data_ptr()] = p
+    import weakref
+    _GRAD_SINKS[p.data_ptr()] = weakref.ref(p)
+
+
+def _grad_sink_of(t):
+    ref = _GRAD_SINKS.get(t.data_ptr())
+    if ref is None:
+        return None
+    sk = ref()
+    if sk is None or sk.data_ptr() != t.data_ptr() or sk.shape != t.shape:
+        if sk is None:
+            del _GRAD_SINKS[t.data_ptr()]
+        return None
+    return sk
 
 
 def _end_of_pass() -> None:
@@ -197,8 +211,8 @@ def shared_grad(like, bias_like):
     if not _SHARED_GRADS:  # first shared accumulator of this backward pass: forget them all when the pass ends
         torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass)
     db = None
-    sk = _GRAD_SINKS.get(bias_like.data_ptr()) if bias_like is not None else None
-    if sk is not None and sk.shape == bias_like.shape:
+    sk = _grad_sink_of(bias_like) if bias_like is not None else None
+    if sk is not None:
         if sk.grad is not None and sk.grad.shape == bias_like.shape and sk.grad.is_contiguous() and getattr(sk, "_nsky_sunk", False):
             db = sk.grad  # the slab view, zeroed by zero_grad_all
             _SUNK_BIAS.add(db.data_ptr())
@@ -516,7 +530,9 @@ class DenseFn(torch.autograd.Function):
         if need_dx:
             dX = torch.empty(M, K, device=X.device)
             frozen = not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-            grad_input(dZ, Wp, M, K, Wp.shape[0], dX, precision=FROZEN_DX_PRECISION if (frozen and _POLICY != "f32") else None)
+            # (the split kernels stage whole 32-deep k-tiles: a 3- or 4-row head keeps the exact kernel, whose loads are guarded)
+            split_ok = frozen and _POLICY != "f32" and Wp.shape[0] % 32 == 0 and K > 64
+            grad_input(dZ, Wp, M, K, Wp.shape[0], dX, precision=FROZEN_DX_PRECISION if split_ok else None)
         return dX, dW, db, None, None, None
 
 
