@@ -1069,7 +1069,9 @@ extern "C" int nsky_gemm_f32(const nsky_gemm_desc* d, nsky_stream_t stream) {
   auto ok = [](const void* p, int ld) { return p == nullptr || ((((uintptr_t)p) % 16 == 0) && (ld % 4 == 0)); };
   const int vec4 = (d->N % 4 == 0) && ok(d->C, d->ldc) && ok(d->bias, 4) && ok(d->aux0, d->ldaux0) && ok(d->aux1, d->ldaux1) &&
                    ok(d->aux2, d->ldaux2) && ok(d->out1, d->ldout1) && ok(d->out2, d->ldout2);
-  if (d->precision != NSKY_PREC_F32 && d->N > 64) {
+  // (a contraction shorter than one 32-deep k-tile -- the input gradient of a 3- or 4-row head -- keeps the exact kernel, whose loads are
+  // guarded element by element: the split kernels stage whole k-tiles)
+  if (d->precision != NSKY_PREC_F32 && d->N > 64 && (d->K >= 32 || d->a_scale_max)) {
     NSKY_CHECK_ARG(d->precision == NSKY_PREC_BF16X2 || d->precision == NSKY_PREC_BF16X3 || d->precision == NSKY_PREC_F16X2,
                    "nsky_gemm_f32: unknown precision %d", d->precision);
     if (d->precision == NSKY_PREC_F16X2) launch_split<2, true>(d, e, splits, k_split_len, vec4, s);

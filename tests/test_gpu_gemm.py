@@ -328,3 +328,19 @@ def test_planes_kernel_race_screen():
             if it % 4 == 3:
                 bad += sum(int(not torch.equal(x, ref)) for x in outs)
         assert bad == 0, (M, N, K, bad)
+
+
+def test_split_precisions_with_a_contraction_shorter_than_a_k_tile():
+    """the input gradient of a narrow head (dX = dZ[M, 4] W[4, 128]) under the split policies: the split kernels stage whole 32-deep
+    k-tiles, so a shorter contraction runs on the exact kernel (round 5: the 6-MFMA bf16 form on K = 4 read out of bounds)"""
+    from neusky_amd import hip
+    dev = "cuda:0"
+    torch.manual_seed(5)
+    for M, K in ((777, 4), (4096, 12), (64, 28)):
+        dZ = torch.randn(M, K, device=dev)
+        W = torch.randn(K, 128, device=dev)
+        ref = dZ.double() @ W.double()
+        for prec in (hip.PREC_BF16X3, hip.PREC_F16X2, hip.PREC_BF16X2):
+            out = torch.full((M, 128), float("nan"), device=dev)
+            hip.gemm(dZ, W, out, M, 128, K, a_kcontig=True, b_kcontig=False, precision=prec)
+            assert (out.double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item(), (M, K, prec)
