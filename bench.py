@@ -526,6 +526,75 @@ def _sources_sha(paths) -> str:
     return h.hexdigest()[:16]
 
 
+def pmc_traffic(fetch_dir: str, write_dir: str, iters: float = 0.0) -> dict:
+    """HBM traffic by kernel family from two rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) of an
+    eager bench run: bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE) -- the counters are KiB, and gfx950 reports half the bytes of wide
+    coalesced reads (MI355X_MICROARCH.md).  -> {whole_step_GB, iterations, bytes_per_launch{family}, GB_per_iteration{family}}"""
+    import collections
+    import csv
+    import glob
+    import re
+    tot = collections.defaultdict(lambda: [0.0, 0.0, 0])
+    for c, idx, d in (("FETCH_SIZE", 0, fetch_dir), ("WRITE_SIZE", 1, write_dir)):
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        for f in sorted(files, key=os.path.getmtime)[-1:]:  # the newest pass only
+            for row in csv.DictReader(open(f)):
+                if row["Counter_Name"] == c:
+                    k = re.sub(r"\(anonymous namespace\)::|^void ", "", row["Kernel_Name"])
+                    k = re.split(r"\((?![a-z])", k)[0][:90]
+                    tot[k][idx] += float(row["Counter_Value"]) * 1024.0
+                    if idx == 0:
+                        tot[k][2] += 1
+    if not tot:
+        raise RuntimeError("no counter records found")
+    if iters <= 0:  # one hemisphere-composite launch per training iteration
+        iters = float(max(v[2] for k, v in tot.items() if k.startswith("hemi_fwd_kernel")))
+    fam = collections.defaultdict(lambda: [0.0, 0])
+    for k, v in tot.items():
+        name = k.split("(")[0].strip()
+        key = re.sub(r"<(\d+)[^>]*>", r"<\1>", name) if name.startswith("film_") else name.split("<")[0]
+        fam[key][0] += 2 * v[0] + v[1]
+        fam[key][1] += v[2]
+    total = sum(v[0] for v in fam.values()) / iters
+    return {"whole_step_GB": total / 1e9, "iterations": iters,
+            "fetch_GB": sum(2 * v[0] for v in tot.values()) / iters / 1e9, "write_GB": sum(v[1] for v in tot.values()) / iters / 1e9,
+            "bytes_per_launch": {k: v[0] / max(v[1], 1) for k, v in fam.items() if v[1] > 0 and v[0] / iters > 5e7},
+            "launches_per_iteration": {k: v[1] / iters for k, v in fam.items() if v[1] > 0 and v[0] / iters > 5e7},
+            "GB_per_iteration": {k: v[0] / iters / 1e9 for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:20]}}
+
+
+def live_pmc_traffic(timeout_s: float = 240.0):
+    """the two --pmc passes collected IN THIS RUN: rank 0 (N = 1) starts `rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py
+    --no-spawn ...` (an eager two-step bench: one dispatch record per launch) as a child process, twice, and reads the counters back.
+    Counters only with --kernel-trace, as the pool's rules ask.  Any failure (no rocprofv3, a timeout, no records) returns (None, reason):
+    the line then falls back to the committed file and says so."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    base = tempfile.mkdtemp(prefix="nsky_pmc_")
+    dirs = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "NSKY_BENCH_LAUNCHER"):
+        env.pop(k, None)
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            dirs[c] = os.path.join(base, c)
+            cmd = [exe, "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", dirs[c], "--", sys.executable, os.path.abspath(__file__),
+                   "--no-spawn", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-graph", "--no-exact-f32", "--no-extra-configs",
+                   "--no-live-pmc"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {c} pass exited with code {r.returncode}"
+        return pmc_traffic(dirs["FETCH_SIZE"], dirs["WRITE_SIZE"]), "collected in this run (two rocprofv3 --kernel-trace --pmc passes of an eager two-step bench)"
+    except Exception as exc:  # noqa: BLE001
+        return None, f"{type(exc).__name__}: {str(exc)[:160]}"
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+
+
 def cpu_model() -> str:
     try:
         for line in open("/proc/cpuinfo"):
@@ -599,6 +668,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured HIP graph")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the three extra eager steps under the exact-fp32 policy")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the forward-only (configs[1]) and 1080p render (configs[4]) lines")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not collect the HBM counters in this run (roofline.traffic then comes from the committed file)")
     ap.add_argument("--no-spawn", action="store_true",
                     help="N = 1 only: run the rank in THIS process, without a process group (for rocprofv3 -- python3 bench.py ...: the "
                          "profiler's library initialises the GPU in the process it preloads into, which then must not start ranks)")
@@ -845,7 +915,15 @@ def main():
         traffic_src = {"file": "profiles/" + PMC_TRAFFIC_FILE, "collected": "committed rocprofv3 --pmc passes (tools/pmc_bench.sh), not this run"}
         dom = kernels[0]
         tj = json.load(open(tsrc)) if os.path.exists(tsrc) else None
-        if tj is not None:  # HBM bytes per launch from the committed rocprofv3 --pmc passes; the check that they describe THESE kernels is a field
+        live_note = "not attempted (--no-live-pmc / --no-extra-configs / N > 1)"
+        if world == 1 and not args.no_live_pmc and not args.no_extra_configs:
+            live, live_note = live_pmc_traffic()
+            if live is not None:
+                committed_gb = tj.get("whole_step_GB") if tj is not None else None
+                tj = dict(live, kernel_sources_sha=_sources_sha(step_kernel_sources()))
+                traffic_src = {"collected": live_note, "committed_file_whole_step_GB": committed_gb, "file": "profiles/" + PMC_TRAFFIC_FILE + " (for comparison)"}
+        traffic_src["live_collection"] = live_note
+        if tj is not None:  # HBM bytes per launch from the rocprofv3 --pmc passes; the check that they describe THESE kernels is a field
             traffic = tj.get("bytes_per_launch", {}).get(dom["kernel"].split(" ")[0])
             whole_step_gb = tj.get("whole_step_GB")
             sha = _sources_sha(step_kernel_sources())
