@@ -674,6 +674,209 @@ __global__ __launch_bounds__(512, 2) void film_bwd_kernel(const BwdFilmArgs a) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The FiLM backward with the gradient IN REGISTERS (round 5).  Four waves per workgroup, one per SIMD, 512 registers each -- the forward
+// kernel's shape -- so that a wave can hold, beside the 128 registers of h planes, the layer's incoming gradient dY as eight accumulator
+// tiles: pass 1 turns dY into dz IN PLACE (tile by tile, while dz, dF and dphase go out to memory for the weight gradients and the mapping
+// backward), the planes of W^T dz are split from those registers once the row maximum is known, and the W^T products write the next
+// layer's dY back into the same tiles.  What the eight-wave kernel moves through memory because 256 registers cannot hold two of the
+// three matrices -- the parked dY (1 KB per row and layer out and in) and the dz read-back (1 KB) -- never leaves the wave: 5 KB per row
+// and layer (h_last, z in; dz, dF, dphase out) instead of 8.  The price is the forward kernel's: the weight stream is walked once per
+// 128 rows instead of per 256, and one wave per SIMD hides nothing behind a second wave.
+template <int H, bool ACTIVE>
+__device__ __forceinline__ void film_bwd4_tile(const BwdFilmArgs& a, WStream& ws, const float* bl, const float* sl, const float* wo, long rt, int lane) {
+  constexpr int NT = H / 32, KS = H / 16, GH = (KS + GSLABS - 1) / GSLABS, PW = 4;
+  const nsky_film_net& net = a.net;
+  const int c = lane & 31, h = lane >> 5;
+  const long row = rt * 32 + c;
+  const bool live = ACTIVE && row < a.M;
+  const long rowc = row < a.M ? row : a.M - 1;
+  const int n_film = net.n_film;
+  f32x16 dY[NT];  // gradient w.r.t. the layer's sine outputs on entry to a layer, its dz after pass 1
+  float h_inv = 1.0f, h_scale = 1.0f;
+  if (ACTIVE) {
+    float m = 0.0f;
+    for (int t = 0; t < NT; ++t) {
+      float hv[16];
+      load_tile(a.h_last + (rt * NT + t) * 1024, lane, hv);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(hv[r]));
+    }
+    h_scale = row_scale(m, h_inv);
+    // head gradient -> dY of the last FiLM layer (register 4 g + q of tile t = feature 32 t + 8 g + 4 h + q)
+    const float4 dr = ldg4(a.d_res + rowc * a.ldres);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int fo = 32 * t + 8 * g + 4 * h;
+        const float4 w0 = *reinterpret_cast<const float4*>(wo + fo), w1 = *reinterpret_cast<const float4*>(wo + H + fo);
+        const float4 w2 = *reinterpret_cast<const float4*>(wo + 2 * H + fo), w3 = *reinterpret_cast<const float4*>(wo + 3 * H + fo);
+        dY[t][4 * g] = dr.x * w0.x + dr.y * w1.x + dr.z * w2.x + dr.w * w3.x;
+        dY[t][4 * g + 1] = dr.x * w0.y + dr.y * w1.y + dr.z * w2.y + dr.w * w3.y;
+        dY[t][4 * g + 2] = dr.x * w0.z + dr.y * w1.z + dr.z * w2.z + dr.w * w3.z;
+        dY[t][4 * g + 3] = dr.x * w0.w + dr.y * w1.w + dr.z * w2.w + dr.w * w3.w;
+      }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dY[t][r] = 0.0f;
+  }
+  const float* bias_mo = bl + net.n_map * H;
+  float fp_max = 0.0f;
+  int tile = 0;
+  for (int i = n_film - 1; i >= 0; --i) {
+    const float* bF = bias_mo + i * H;
+    const float* bP = bias_mo + (n_film + i) * H;
+    const float* zp = a.z_save[i] + rt * NT * 1024 + lane * 4;
+    float* dzp = a.dz_save[i] + rt * NT * 1024 + lane * 4;
+    float* dFp = a.dfp + (rt * (2 * n_film * NT) + (long)i * NT) * 1024 + lane * 4;
+    float* dPp = a.dfp + (rt * (2 * n_film * NT) + (long)(n_film + i) * NT) * 1024 + lane * 4;
+    float dz_max = 0.0f;
+    {
+      f16x8 hh[KS], hl[KS];
+      if (ACTIVE) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          float hv[16];
+          load_tile(a.h_last + (rt * NT + t) * 1024, lane, hv);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            float x8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x8[j] = hv[8 * u + j] * h_scale;
+            split8(x8, hh[2 * t + u], hl[2 * t + u]);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // compiler-visible loads: none pending when the hidden loads are counted
+      }
+      // ---- pass 1: dY -> dz in place, dF, dphase, tile by tile
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        f32x4 zq[4];
+        if (ACTIVE) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) zq[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int g = 0; g < 4; ++g) hidden_load4(zq[g], zp + t * 1024 + g * 256);
+        }
+        f32x16 aF, aP;
+        prodw<KS, PW, ACTIVE>(ws, hh, hl, aF);
+        prodw<KS, PW, ACTIVE>(ws, hh, hl, aP);
+        if (ACTIVE) {
+          hidden_wait<2 * GH * PW>(zq);  // requested just before the two products: only their 2 GH transitions x PW pieces are younger
+          const float iF = h_inv * sl[tile], iP = h_inv * sl[tile + 1];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int fo = 32 * t + 8 * g + 4 * h;
+            const float4 b4F = *reinterpret_cast<const float4*>(bF + fo);
+            const float4 b4P = *reinterpret_cast<const float4*>(bP + fo);
+            const float bf[4] = {b4F.x, b4F.y, b4F.z, b4F.w}, bp[4] = {b4P.x, b4P.y, b4P.z, b4P.w};
+            float dzv[4], dFv[4], dPv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int r = 4 * g + q;
+              const float F = fmaf(aF[r], iF, bf[q]), P = fmaf(aP[r], iP, bp[q]), z = zq[g][q];
+              const float f = fmaf(15.0f, F, 30.0f);
+              const float gc = dY[t][r] * cos_cw(fmaf(f, z, P));
+              dzv[q] = gc * f;
+              dFv[q] = 15.0f * gc * z;
+              dPv[q] = gc;
+              dY[t][r] = dzv[q];
+              dz_max = fmaxf(dz_max, fabsf(dzv[q]));
+              fp_max = fmaxf(fp_max, fmaxf(fabsf(dFv[q]), fabsf(gc)));
+            }
+            stg4(dzp + t * 1024 + g * 256, make_float4(dzv[0], dzv[1], dzv[2], dzv[3]));
+            stg4(dFp + t * 1024 + g * 256, make_float4(dFv[0], dFv[1], dFv[2], dFv[3]));
+            stg4(dPp + t * 1024 + g * 256, make_float4(dPv[0], dPv[1], dPv[2], dPv[3]));
+          }
+        }
+        tile += 2;
+      }
+    }
+    // ---- pass 2: dY of the layer below = W_i^T dz from the registers (i = 0: the gradient w.r.t. the input rows, one tile)
+    {
+      float dz_inv = 1.0f;
+      f16x8 dh_[KS], dl_[KS];
+      if (ACTIVE) {
+        publish_max(a.gmax + i, dz_max, live, true, lane);
+        const float s = row_scale(dz_max, dz_inv);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          float x8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x8[j] = dY[ks >> 1][8 * (ks & 1) + j] * s;
+          split8(x8, dh_[ks], dl_[ks]);
+        }
+      }
+      if (i > 0) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+          f32x16 acc;
+          prodw<KS, PW, ACTIVE>(ws, dh_, dl_, acc);
+          if (ACTIVE) {
+            const float inv = dz_inv * sl[tile];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dY[u][r] = acc[r] * inv;
+          }
+          ++tile;
+        }
+      } else {
+        f32x16 acc;
+        prodw<KS, PW, ACTIVE>(ws, dh_, dl_, acc);
+        if (ACTIVE && a.d_x && live) {
+          const float inv = dz_inv * sl[tile];
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+            if (8 * g + 4 * h < a.ldx)
+              stg4(a.d_x + row * a.ldx + 8 * g + 4 * h, make_float4(acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv, acc[4 * g + 3] * inv));
+        }
+        ++tile;
+      }
+    }
+  }
+  if (ACTIVE) {
+    fp_max = fmaxf(fp_max, __shfl_xor(fp_max, 32, 64));
+    if (h == 0) a.dfp_rowmax[row] = fp_max;
+    publish_max(a.gmax + n_film, fp_max, live, true, lane);
+  }
+}
+
+template <int H>
+__global__ __launch_bounds__(256, 1) void film_bwd4_kernel(const BwdFilmArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + (BIAS_FLOATS + SCALE_FLOATS) * 4 + 4 * H * 4];
+  float* bl = reinterpret_cast<float*>(smem + RING_BYTES);
+  float* sl = bl + BIAS_FLOATS;
+  float* wo = sl + SCALE_FLOATS;  // head weights [4][H] (rows >= out_dim zero)
+  const nsky_film_net& net = a.net;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    constexpr int N4 = (BIAS_FLOATS + SCALE_FLOATS) / 4;
+    float4 q[(N4 + 255) / 256];
+#pragma unroll
+    for (int i = 0; i < (N4 + 255) / 256; ++i)
+      if (i * 256 + tid < N4) q[i] = ldg4(a.table + 4 * (i * 256 + tid));
+#pragma unroll
+    for (int i = 0; i < (N4 + 255) / 256; ++i)
+      if (i * 256 + tid < N4) *reinterpret_cast<float4*>(bl + 4 * (i * 256 + tid)) = q[i];
+    for (int i = tid; i < 4 * H; i += 256) wo[i] = (i / H) < net.out_dim ? net.out_w[(long)(i / H) * net.out_ld + (i % H)] : 0.0f;
+  }
+  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every compiler-visible memory operation is done before the DMA stream starts
+  WStream ws;
+  ws.src = a.stream + wave * 4096 + lane * 16;
+  ws.dst = (uint32_t)(uintptr_t)smem + wave * 4096;
+  ws.lds_lane = (uint32_t)(uintptr_t)smem + lane * 16;
+  ws_begin(ws);
+  const long n_tiles = (a.M + 31) / 32;
+  const long rt = (long)blockIdx.x * 4 + wave;
+  if (rt < n_tiles) film_bwd4_tile<H, true>(a, ws, bl, sl, wo, rt, lane);
+  else film_bwd4_tile<H, false>(a, ws, bl, sl, wo, 0, lane);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
 // =====================================================================================================================
 // Backward, mapping network.  dh = sum over the 2 n_film H head rows of Wmo^T dfp (k-block outer: 64 head rows of dfp are
 // fetched tile-native one block ahead with hidden loads, pre-scaled by the row's maximum over ALL of dfp and split; dfp is read
@@ -1299,6 +1502,15 @@ extern "C" int nsky_film_chain_bwd_film(const nsky_film_net* net, const void* st
     a.z_save[l] = l < net->n_film ? z_save[l] : nullptr;
     a.dz_save[l] = l < net->n_film ? dz_save[l] : nullptr;
     if (l < net->n_film) NSKY_CHECK_ARG(a.z_save[l] && a.dz_save[l] && ((uintptr_t)a.z_save[l] % 16) == 0 && ((uintptr_t)a.dz_save[l] % 16) == 0, "nsky_film_chain_bwd_film: z_save / dz_save[%d]", l);
+  }
+  static const int form = [] { const char* e = getenv("NSKY_FILM_BWD"); return e ? atoi(e) : 4; }();  // lab switch for same-box A/B runs: 8 = the eight-wave kernel
+  if (form == 4) {
+    a.full_wgs = a.tail_wgs = a.tail_k = 0;
+    const dim3 grid(ceil_div(ceil_div(M, 32), 4));
+    if (net->hidden == 256) hipLaunchKernelGGL((film_bwd4_kernel<256>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((film_bwd4_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    NSKY_CHECK_LAUNCH("nsky_film_chain_bwd_film");
+    return NSKY_OK;
   }
   const TailPlan tp = tail_plan(ceil_div(M, 32), device_cus());
   a.full_wgs = tp.full_wgs; a.tail_wgs = tp.tail_wgs; a.tail_k = tp.tail_k;
