@@ -683,88 +683,10 @@ __global__ __launch_bounds__(512, 2) void film_bwd_kernel(const BwdFilmArgs a) {
 // three matrices -- the parked dY (1 KB per row and layer out and in) and the dz read-back (1 KB) -- never leaves the wave: 5 KB per row
 // and layer (h_last, z in; dz, dF, dphase out) instead of 8.  The price is the forward kernel's: the weight stream is walked once per
 // 128 rows instead of per 256, and one wave per SIMD hides nothing behind a second wave.
-// a value parked in an accumulation register (AGPR) by hand.  The eight gradient tiles are vector-unit data that live across the whole
-// layer loop; left to the allocator they compete with the products' fragments and accumulators for the 256 architectural VGPRs and 464
-// of them end up in scratch -- and a scratch reload is a vector-memory load the compiler waits for with every LDS-DMA piece in front of
-// it (measured: 3.8 ms against 2.3).  Pinned to the AGPR half of the file they cost one v_accvgpr_read / _write per use.
-__device__ __forceinline__ void agpr_set(float& a, float v) { asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v)); }
-__device__ __forceinline__ float agpr_get(const float& a) {
-  float v;
-  asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
-  return v;
-}
-struct APlane { float w[4]; };  // one f16x8 operand plane piece (a k-step's eight fp16 of a lane) parked in four AGPRs
-__device__ __forceinline__ void aplane_put(APlane& a, f16x8 x) {
-  typedef float f32x4_ __attribute__((ext_vector_type(4)));
-  const f32x4_ w = __builtin_bit_cast(f32x4_, x);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) agpr_set(a.w[k], w[k]);
-}
-// hi and lo planes of one k-step back into vector registers; the trailing wait state separates the moves from a matrix instruction
-// that reads them (the hazard recognizer does not look inside the statement)
-__device__ __forceinline__ void aplane_get2(const APlane& h, const APlane& l, f16x8& xh, f16x8& xl) {
-  typedef float f32x4_ __attribute__((ext_vector_type(4)));
-  float h0, h1, h2, h3, l0, l1, l2, l3;
-  asm volatile("v_accvgpr_read_b32 %0, %8\n\tv_accvgpr_read_b32 %1, %9\n\tv_accvgpr_read_b32 %2, %10\n\tv_accvgpr_read_b32 %3, %11\n\t"
-               "v_accvgpr_read_b32 %4, %12\n\tv_accvgpr_read_b32 %5, %13\n\tv_accvgpr_read_b32 %6, %14\n\tv_accvgpr_read_b32 %7, %15\n\ts_nop 1"
-               : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
-               : "a"(h.w[0]), "a"(h.w[1]), "a"(h.w[2]), "a"(h.w[3]), "a"(l.w[0]), "a"(l.w[1]), "a"(l.w[2]), "a"(l.w[3]));
-  xh = __builtin_bit_cast(f16x8, f32x4_{h0, h1, h2, h3});
-  xl = __builtin_bit_cast(f16x8, f32x4_{l0, l1, l2, l3});
-}
-
-__device__ __forceinline__ f16x8 aplane_get(const APlane& h) {
-  typedef float f32x4_ __attribute__((ext_vector_type(4)));
-  float h0, h1, h2, h3;
-  asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7\n\ts_nop 1"
-               : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3) : "a"(h.w[0]), "a"(h.w[1]), "a"(h.w[2]), "a"(h.w[3]));
-  return __builtin_bit_cast(f16x8, f32x4_{h0, h1, h2, h3});
-}
-
-// chain.h product<KS, 4> with the B planes parked in AGPRs: the planes of k-step ks + 1 are fetched into vector registers in the shadow
-// of k-step ks' matrix instructions
-template <int KS>
-__device__ __forceinline__ void product_ap(WStream& w, const APlane (&bhA)[KS], const f16x8 (&bl)[KS], f32x16& acc) {
-  constexpr int PW = 4, NB = 3, AHEAD = 2;
-  constexpr int NG = (KS + GSLABS - 1) / GSLABS;
-  f16x8 fh[NB], fl[NB];
-  fh[0] = w.ch;
-  fl[0] = w.cl;
-#pragma unroll
-  for (int b = 1; b < NB; ++b)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { fh[b][j] = (_Float16)0.0f; fl[b][j] = (_Float16)0.0f; }
-  const int g0 = w.g;
-  auto request = [&](int s) {  // s static
-    if (s < KS) frag_read(fh[s % NB], fl[s % NB], ws_addr(w, g0 + s / GSLABS, s % GSLABS));
-    else frag_read(fh[s % NB], fl[s % NB], ws_addr(w, g0 + NG, 0));
-  };
-  f16x8 bh[2];
-  bh[0] = aplane_get(bhA[0]);
-  if (1 <= KS) request(1);
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks % NB], bl[ks], acc, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (ks + AHEAD <= KS) request(ks + AHEAD);
-    if ((ks & (GSLABS - 1)) == GSLABS - 1 || ks == KS - 1) ws_transition<PW, false, RING_GROUPS>(w, g0 + ks / GSLABS);
-    __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks % NB], bh[ks & 1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks % NB], bh[ks & 1], acc, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (ks + 1 < KS) bh[(ks + 1) & 1] = aplane_get(bhA[ks + 1]);
-    if (ks < KS - 1) frag_wait<2>(fh[(ks + 1) % NB], fl[(ks + 1) % NB]);
-  }
-  frag_settle(w.ch, w.cl, fh[KS % NB], fl[KS % NB]);
-  w.g = g0 + NG;
-}
-template <int KS, bool ACTIVE>
-__device__ __forceinline__ void prodw_ap(WStream& ws, const APlane (&bhA)[KS], const f16x8 (&blA)[KS], f32x16& acc) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  if (ACTIVE) product_ap<KS>(ws, bhA, blA, acc);
-  else product_skip<KS, 4, false>(ws);
+// a hidden 16-byte load through a wave-uniform base (SGPR pair) and a per-lane byte offset: no 64-bit address per lane
+template <int OFF>
+__device__ __forceinline__ void hidden_load4_s(f32x4& q, const float* sbase, int voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(q) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
 
 template <int H, bool ACTIVE>
@@ -776,7 +698,7 @@ __device__ __forceinline__ void film_bwd4_tile(const BwdFilmArgs& a, WStream& ws
   const bool live = ACTIVE && row < a.M;
   const long rowc = row < a.M ? row : a.M - 1;
   const int n_film = net.n_film;
-  float dY[NT][16];  // (AGPR-resident: agpr_get / agpr_set) gradient w.r.t. the layer's sine outputs on entry to a layer, its dz after pass 1
+  f32x16 dY[NT];  // gradient w.r.t. the layer's sine outputs on entry to a layer, its dz after pass 1
   float h_inv = 1.0f, h_scale = 1.0f;
   if (ACTIVE) {
     float m = 0.0f;
@@ -796,17 +718,16 @@ __device__ __forceinline__ void film_bwd4_tile(const BwdFilmArgs& a, WStream& ws
         const int fo = 32 * t + 8 * g + 4 * h;
         const float4 w0 = *reinterpret_cast<const float4*>(wo + fo), w1 = *reinterpret_cast<const float4*>(wo + H + fo);
         const float4 w2 = *reinterpret_cast<const float4*>(wo + 2 * H + fo), w3 = *reinterpret_cast<const float4*>(wo + 3 * H + fo);
-        agpr_set(dY[t][4 * g], dr.x * w0.x + dr.y * w1.x + dr.z * w2.x + dr.w * w3.x);
-        agpr_set(dY[t][4 * g + 1], dr.x * w0.y + dr.y * w1.y + dr.z * w2.y + dr.w * w3.y);
-        agpr_set(dY[t][4 * g + 2], dr.x * w0.z + dr.y * w1.z + dr.z * w2.z + dr.w * w3.z);
-        agpr_set(dY[t][4 * g + 3], dr.x * w0.w + dr.y * w1.w + dr.z * w2.w + dr.w * w3.w);
-        __builtin_amdgcn_sched_barrier(0);  // (one 16-byte group at a time: the scheduler believes in 512 vector registers, the vector units see 256)
+        dY[t][4 * g] = dr.x * w0.x + dr.y * w1.x + dr.z * w2.x + dr.w * w3.x;
+        dY[t][4 * g + 1] = dr.x * w0.y + dr.y * w1.y + dr.z * w2.y + dr.w * w3.y;
+        dY[t][4 * g + 2] = dr.x * w0.z + dr.y * w1.z + dr.z * w2.z + dr.w * w3.z;
+        dY[t][4 * g + 3] = dr.x * w0.w + dr.y * w1.w + dr.z * w2.w + dr.w * w3.w;
       }
   } else {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) agpr_set(dY[t][r], 0.0f);
+      for (int r = 0; r < 16; ++r) dY[t][r] = 0.0f;
   }
   const float* bias_mo = bl + net.n_map * H;
   float fp_max = 0.0f;
@@ -814,29 +735,27 @@ __device__ __forceinline__ void film_bwd4_tile(const BwdFilmArgs& a, WStream& ws
   for (int i = n_film - 1; i >= 0; --i) {
     const float* bF = bias_mo + i * H;
     const float* bP = bias_mo + (n_film + i) * H;
-    const float* zp = a.z_save[i] + rt * NT * 1024 + lane * 4;
-    float* dzp = a.dz_save[i] + rt * NT * 1024 + lane * 4;
-    float* dFp = a.dfp + (rt * (2 * n_film * NT) + (long)i * NT) * 1024 + lane * 4;
-    float* dPp = a.dfp + (rt * (2 * n_film * NT) + (long)(n_film + i) * NT) * 1024 + lane * 4;
+    // wave-uniform bases (scalar registers) + ONE per-lane offset: eight 64-bit per-lane pointers were what the loop kept reloading from scratch
+    const float* zp = a.z_save[i] + rt * NT * 1024;
+    float* dzp = a.dz_save[i] + rt * NT * 1024;
+    float* dFp = a.dfp + (rt * (2 * n_film * NT) + (long)i * NT) * 1024;
+    float* dPp = a.dfp + (rt * (2 * n_film * NT) + (long)(n_film + i) * NT) * 1024;
     float dz_max = 0.0f;
     {
-      APlane hh[KS];
-      f16x8 hl[KS];  // (the hi planes parked in AGPRs by hand, the lo planes left to the allocator: 128 + 64 pinned, slack on both sides)
+      f16x8 hh[KS], hl[KS];
       if (ACTIVE) {
+        int hoff = 0;
+        asm volatile("" : "+s"(hoff));  // (the 32 tile addresses are the same in every layer: left visible, they are hoisted out of the layer loop and live in scratch)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           float hv[16];
-          load_tile(a.h_last + (rt * NT + t) * 1024, lane, hv);
+          load_tile(a.h_last + ((rt * NT + t) * 1024 + hoff), lane, hv);
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             float x8[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) x8[j] = hv[8 * u + j] * h_scale;
-            f16x8 ph, pl;
-            split8(x8, ph, pl);
-            aplane_put(hh[2 * t + u], ph);
-            hl[2 * t + u] = pl;
-            __builtin_amdgcn_sched_barrier(0);
+            split8(x8, hh[2 * t + u], hl[2 * t + u]);
           }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // compiler-visible loads: none pending when the hidden loads are counted
@@ -845,8 +764,6 @@ __device__ __forceinline__ void film_bwd4_tile(const BwdFilmArgs& a, WStream& ws
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         f32x4 zq[4];
-        // this tile's four addresses, formed HERE: unrolled, the compiler otherwise forms the 128 addresses of all eight tiles ahead
-        // of the loop (a tile is 4 KB apart: beyond the instruction's immediate offset) and spills them as 64-bit pairs
         int toff = t * 1024;
         asm volatile("" : "+s"(toff));  // (an opaque offset, not opaque pointers: those would lose their address space and turn into flat_* accesses)
         const float* zpt = zp + toff;
@@ -854,12 +771,14 @@ __device__ __forceinline__ void film_bwd4_tile(const BwdFilmArgs& a, WStream& ws
         if (ACTIVE) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) zq[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int g = 0; g < 4; ++g) hidden_load4(zq[g], zpt + g * 256);
+          hidden_load4_s<0>(zq[0], zpt, lane * 16);
+          hidden_load4_s<1024>(zq[1], zpt, lane * 16);
+          hidden_load4_s<2048>(zq[2], zpt, lane * 16);
+          hidden_load4_s<3072>(zq[3], zpt, lane * 16);
         }
         f32x16 aF, aP;
-        prodw_ap<KS, ACTIVE>(ws, hh, hl, aF);
-        prodw_ap<KS, ACTIVE>(ws, hh, hl, aP);
+        prodw<KS, PW, ACTIVE>(ws, hh, hl, aF);
+        prodw<KS, PW, ACTIVE>(ws, hh, hl, aP);
         if (ACTIVE) {
           hidden_wait<2 * GH * PW>(zq);  // requested just before the two products: only their 2 GH transitions x PW pieces are younger
           const float iF = h_inv * sl[tile], iP = h_inv * sl[tile + 1];
@@ -875,19 +794,18 @@ __device__ __forceinline__ void film_bwd4_tile(const BwdFilmArgs& a, WStream& ws
               const int r = 4 * g + q;
               const float F = fmaf(aF[r], iF, bf[q]), P = fmaf(aP[r], iP, bp[q]), z = zq[g][q];
               const float f = fmaf(15.0f, F, 30.0f);
-              const float gc = agpr_get(dY[t][r]) * cos_cw(fmaf(f, z, P));
+              const float gc = dY[t][r] * cos_cw(fmaf(f, z, P));
               dzv[q] = gc * f;
               dFv[q] = 15.0f * gc * z;
               dPv[q] = gc;
-              agpr_set(dY[t][r], dzv[q]);
+              dY[t][r] = dzv[q];
               dz_max = fmaxf(dz_max, fabsf(dzv[q]));
               fp_max = fmaxf(fp_max, fmaxf(fabsf(dFv[q]), fabsf(gc)));
             }
-            stg4(dzt + g * 256, make_float4(dzv[0], dzv[1], dzv[2], dzv[3]));
-            stg4(dFt + g * 256, make_float4(dFv[0], dFv[1], dFv[2], dFv[3]));
-            stg4(dPt + g * 256, make_float4(dPv[0], dPv[1], dPv[2], dPv[3]));
-            asm volatile("" : "+v"(dz_max), "+v"(fp_max));  // the running maxima are formed HERE (unrolled, the compiler otherwise keeps every term for one tree at the end)
-            __builtin_amdgcn_sched_barrier(0);
+            stg4(dzt + (g * 256 + lane * 4), make_float4(dzv[0], dzv[1], dzv[2], dzv[3]));
+            stg4(dFt + (g * 256 + lane * 4), make_float4(dFv[0], dFv[1], dFv[2], dFv[3]));
+            stg4(dPt + (g * 256 + lane * 4), make_float4(dPv[0], dPv[1], dPv[2], dPv[3]));
+            asm volatile("" : "+v"(dz_max), "+v"(fp_max));
           }
         }
         tile += 2;
@@ -896,8 +814,7 @@ __device__ __forceinline__ void film_bwd4_tile(const BwdFilmArgs& a, WStream& ws
     // ---- pass 2: dY of the layer below = W_i^T dz from the registers (i = 0: the gradient w.r.t. the input rows, one tile)
     {
       float dz_inv = 1.0f;
-      APlane dh_[KS];
-      f16x8 dl_[KS];
+      f16x8 dh_[KS], dl_[KS];
       if (ACTIVE) {
         publish_max(a.gmax + i, dz_max, live, true, lane);
         const float s = row_scale(dz_max, dz_inv);
@@ -905,30 +822,25 @@ __device__ __forceinline__ void film_bwd4_tile(const BwdFilmArgs& a, WStream& ws
         for (int ks = 0; ks < KS; ++ks) {
           float x8[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) x8[j] = agpr_get(dY[ks >> 1][8 * (ks & 1) + j]) * s;
-          f16x8 ph, pl;
-          split8(x8, ph, pl);
-          aplane_put(dh_[ks], ph);
-          dl_[ks] = pl;
-          __builtin_amdgcn_sched_barrier(0);
+          for (int j = 0; j < 8; ++j) x8[j] = dY[ks >> 1][8 * (ks & 1) + j] * s;
+          split8(x8, dh_[ks], dl_[ks]);
         }
       }
       if (i > 0) {
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
           f32x16 acc;
-          prodw_ap<KS, ACTIVE>(ws, dh_, dl_, acc);
+          prodw<KS, PW, ACTIVE>(ws, dh_, dl_, acc);
           if (ACTIVE) {
             const float inv = dz_inv * sl[tile];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) agpr_set(dY[u][r], acc[r] * inv);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int r = 0; r < 16; ++r) dY[u][r] = acc[r] * inv;
           }
           ++tile;
         }
       } else {
         f32x16 acc;
-        prodw_ap<KS, ACTIVE>(ws, dh_, dl_, acc);
+        prodw<KS, PW, ACTIVE>(ws, dh_, dl_, acc);
         if (ACTIVE && a.d_x && live) {
           const float inv = dz_inv * sl[tile];
 #pragma unroll
