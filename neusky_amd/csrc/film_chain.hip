@@ -732,6 +732,29 @@ __device__ __forceinline__ void film_bwd4_tile(const BwdFilmArgs& a, WStream& ws
   const float* bias_mo = bl + net.n_map * H;
   float fp_max = 0.0f;
   int tile = 0;
+  // the planes of the last mapping activation (every layer's F / phase products read them): at H = 128 formed ONCE and resident through
+  // all layers; at H = 256 they, the gradient tiles and pass 2's dz planes are 384 registers of 512 and the allocator gives up (357
+  // spills): re-formed per layer from h_last, dead during pass 2
+  constexpr bool H_RESIDENT = H <= 128;
+  f16x8 hh[KS], hl[KS];
+  auto load_h = [&]() {
+    int hoff = 0;
+    asm volatile("" : "+s"(hoff));  // (the 32 tile addresses are the same in every layer: left visible, they are hoisted out of the layer loop and live in scratch)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float hv[16];
+      load_tile(a.h_last + ((rt * NT + t) * 1024 + hoff), lane, hv);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float x8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x8[j] = hv[8 * u + j] * h_scale;
+        split8(x8, hh[2 * t + u], hl[2 * t + u]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // compiler-visible loads: none pending when the hidden loads are counted
+  };
+  if (ACTIVE && H_RESIDENT) load_h();
   for (int i = n_film - 1; i >= 0; --i) {
     const float* bF = bias_mo + i * H;
     const float* bP = bias_mo + (n_film + i) * H;
@@ -742,24 +765,7 @@ __device__ __forceinline__ void film_bwd4_tile(const BwdFilmArgs& a, WStream& ws
     float* dPp = a.dfp + (rt * (2 * n_film * NT) + (long)(n_film + i) * NT) * 1024;
     float dz_max = 0.0f;
     {
-      f16x8 hh[KS], hl[KS];
-      if (ACTIVE) {
-        int hoff = 0;
-        asm volatile("" : "+s"(hoff));  // (the 32 tile addresses are the same in every layer: left visible, they are hoisted out of the layer loop and live in scratch)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          float hv[16];
-          load_tile(a.h_last + ((rt * NT + t) * 1024 + hoff), lane, hv);
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            float x8[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x8[j] = hv[8 * u + j] * h_scale;
-            split8(x8, hh[2 * t + u], hl[2 * t + u]);
-          }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // compiler-visible loads: none pending when the hidden loads are counted
-      }
+      if (ACTIVE && !H_RESIDENT) load_h();
       // ---- pass 1: dY -> dz in place, dF, dphase, tile by tile
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
