@@ -414,6 +414,9 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(const FwdArgs a) {
 //   W^T dz on the transposed weight tiles.  Gradients therefore get the same fp32-grade products as the forward.
 // A vector-memory load the compiler knows about would make it wait for every LDS-DMA piece issued before it (one in-order
 // counter), so z is fetched with hidden loads one tile ahead and waited for with a counted vmcnt.
+// Rounds 2-4 ran this as an eight-wave kernel (256 registers per wave: the incoming gradient parked in the layer's dz buffer, dz read
+// back for the planes: 8 KB per row and layer, 12.3 GB per DDF launch); round 5's film_bwd4_kernel below keeps the gradient in the
+// registers of a four-wave workgroup (5 KB per row and layer) and replaced it: -0.5 ms per step on a same-box A/B.
 
 struct BwdFilmArgs {
   nsky_film_net net;
@@ -428,16 +431,12 @@ struct BwdFilmArgs {
   float* dfp_rowmax;               // [ceil32(M)] max |dfp| per batch row
   float* gmax;                     // zero-initialised by the caller: [i] = max |dz_save[i]|, [n_film] = max |dfp|
   float* d_x; int ldx;             // optional [M, ldx]: gradient w.r.t. the FiLM input rows (pad columns zeroed)
-  int full_wgs, tail_wgs, tail_k;  // tail_plan of the launch
+  int full_wgs, tail_wgs, tail_k;  // (unused by the four-wave kernel)
 };
 
 
-// Eight waves per workgroup (two per SIMD: the matrix pipe of one wave's products overlaps the epilogue arithmetic of the
-// other; 256 batch rows share one weight stream, half the L2 -> LDS traffic per row of the four-wave forward), 256 registers
-// each.  That budget is met by keeping NO per-layer matrix in registers across the tile loop: the incoming gradient dY of a
-// layer waits, tile-native, in that layer's dz buffer (written by the layer above, overwritten tile by tile with dz), and the
-// W^T products of the layer read the finished dz tiles back (the lane that stored a piece loads it).
-// Tail workgroups.  A launch of n wave tiles (32 rows each) on C CUs runs F = floor(n / (8 C)) C full workgroups of eight tiles; the
+// Tail workgroups of the EIGHT-wave kernels (the mapping backward, the sdf chain: two waves per SIMD, 256 batch rows share one weight
+// stream).  A launch of n wave tiles (32 rows each) on C CUs runs F = floor(n / (8 C)) C full workgroups of eight tiles; the
 // remaining R = n - 8 F tiles (less than one workgroup round) do not get a round of full workgroups on a few CUs: they are dealt k =
 // ceil(R / C) to a workgroup (T = ceil(R / k) "tail" workgroups, FIRST in the grid), whose other waves only take part in the ring's
 // hand-shakes (product_skip).  A tail workgroup is done sooner than a full one and the dispatcher hands its CU the next workgroup, so
@@ -471,207 +470,6 @@ __device__ __forceinline__ void prodw(WStream& ws, const f16x8 (&bh)[KSN], const
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   if (ACTIVE) product<KSN, PWN>(ws, bh, bl, acc);
   else product_skip<KSN, PWN, false>(ws);
-}
-
-template <int H, bool ACTIVE>
-__device__ __forceinline__ void film_bwd_tile(const BwdFilmArgs& a, WStream& ws, const float* bl, const float* sl, const float* wo, long rt, int lane) {
-  constexpr int NT = H / 32, KS = H / 16, GH = (KS + GSLABS - 1) / GSLABS, PW = 2;
-  const nsky_film_net& net = a.net;
-  const int c = lane & 31, h = lane >> 5;
-  const long row = rt * 32 + c;
-  const bool live = ACTIVE && row < a.M;
-  const long rowc = row < a.M ? row : a.M - 1;
-  const int n_film = net.n_film;
-  float h_inv = 1.0f, h_scale = 1.0f;
-  if (ACTIVE) {
-    // row scale of the last mapping activation
-    float m = 0.0f;
-    for (int t = 0; t < NT; ++t) {
-      float hv[16];
-      load_tile(a.h_last + (rt * NT + t) * 1024, lane, hv);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(hv[r]));
-    }
-    h_scale = row_scale(m, h_inv);
-    // head gradient -> dY of the last FiLM layer, parked in its dz buffer
-    const float4 dr = ldg4(a.d_res + rowc * a.ldres);
-    float* dst = a.dz_save[n_film - 1] + rt * NT * 1024 + lane * 4;
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int fo = 32 * t + 8 * g + 4 * h;
-        const float4 w0 = *reinterpret_cast<const float4*>(wo + fo), w1 = *reinterpret_cast<const float4*>(wo + H + fo);
-        const float4 w2 = *reinterpret_cast<const float4*>(wo + 2 * H + fo), w3 = *reinterpret_cast<const float4*>(wo + 3 * H + fo);
-        stg4(dst + t * 1024 + g * 256, make_float4(dr.x * w0.x + dr.y * w1.x + dr.z * w2.x + dr.w * w3.x, dr.x * w0.y + dr.y * w1.y + dr.z * w2.y + dr.w * w3.y,
-                                                    dr.x * w0.z + dr.y * w1.z + dr.z * w2.z + dr.w * w3.z, dr.x * w0.w + dr.y * w1.w + dr.z * w2.w + dr.w * w3.w));
-      }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's dY stores have left before it reads them back
-  }
-  const float* bias_mo = bl + net.n_map * H;
-  float fp_max = 0.0f;
-  int tile = 0;
-  for (int i = n_film - 1; i >= 0; --i) {
-    const float* bF = bias_mo + i * H;
-    const float* bP = bias_mo + (n_film + i) * H;
-    const float* zp = a.z_save[i] + rt * NT * 1024 + lane * 4;
-    float* dzp = a.dz_save[i] + rt * NT * 1024 + lane * 4;   // holds dY on entry
-    float* dFp = a.dfp + (rt * (2 * n_film * NT) + (long)i * NT) * 1024 + lane * 4;
-    float* dPp = a.dfp + (rt * (2 * n_film * NT) + (long)(n_film + i) * NT) * 1024 + lane * 4;
-    float dz_max = 0.0f;
-    f16x8 hh[KS], hl[KS];
-    if (ACTIVE) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        float hv[16];
-        load_tile(a.h_last + (rt * NT + t) * 1024, lane, hv);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          float x8[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) x8[j] = hv[8 * u + j] * h_scale;
-          split8(x8, hh[2 * t + u], hl[2 * t + u]);
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // compiler-visible loads: none pending when the hidden loads are counted
-    }
-    // ---- pass 1: dz, dF, dphase tile by tile
-    for (int t = 0; t < NT; ++t) {
-      f32x4 zq[4], yq[4];
-      if (ACTIVE) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { zq[g] = f32x4{0.f, 0.f, 0.f, 0.f}; yq[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) hidden_load4(zq[g], zp + t * 1024 + g * 256);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) hidden_load4_nt(yq[g], dzp + t * 1024 + g * 256);
-      }
-      f32x16 aF, aP;
-      prodw<KS, PW, ACTIVE>(ws, hh, hl, aF);
-      prodw<KS, PW, ACTIVE>(ws, hh, hl, aP);
-      if (ACTIVE) {
-        hidden_wait8<2 * GH * PW>(zq, yq);  // requested just before the two products: only their 2 GH transitions x PW pieces are younger
-        const float iF = h_inv * sl[tile], iP = h_inv * sl[tile + 1];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int fo = 32 * t + 8 * g + 4 * h;
-          const float4 b4F = *reinterpret_cast<const float4*>(bF + fo);
-          const float4 b4P = *reinterpret_cast<const float4*>(bP + fo);
-          const float bf[4] = {b4F.x, b4F.y, b4F.z, b4F.w}, bp[4] = {b4P.x, b4P.y, b4P.z, b4P.w};
-          float dzv[4], dFv[4], dPv[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int r = 4 * g + q;
-            const float F = fmaf(aF[r], iF, bf[q]), P = fmaf(aP[r], iP, bp[q]), z = zq[g][q];
-            const float f = fmaf(15.0f, F, 30.0f);
-            const float gc = yq[g][q] * cos_cw(fmaf(f, z, P));
-            dzv[q] = gc * f;
-            dFv[q] = 15.0f * gc * z;
-            dPv[q] = gc;
-            dz_max = fmaxf(dz_max, fabsf(dzv[q]));
-            fp_max = fmaxf(fp_max, fmaxf(fabsf(dFv[q]), fabsf(gc)));
-          }
-          // 1 KB-contiguous per wave instruction
-          stg4(dzp + t * 1024 + g * 256, make_float4(dzv[0], dzv[1], dzv[2], dzv[3]));
-          stg4(dFp + t * 1024 + g * 256, make_float4(dFv[0], dFv[1], dFv[2], dFv[3]));
-          stg4(dPp + t * 1024 + g * 256, make_float4(dPv[0], dPv[1], dPv[2], dPv[3]));
-        }
-      }
-      tile += 2;
-    }
-    // ---- pass 2: dY of the layer below = W_i^T dz (i = 0: the gradient w.r.t. the input rows, one tile)
-    {
-      float dz_inv = 1.0f;
-      f16x8 dh_[KS], dl_[KS];
-      if (ACTIVE) {
-        publish_max(a.gmax + i, dz_max, live, true, lane);
-        const float s = row_scale(dz_max, dz_inv);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's dz stores have left before it reads them back
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          float x8[8];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const float4 q = ldg4_nt(dzp + (ks >> 1) * 1024 + (2 * (ks & 1) + u) * 256);
-            x8[4 * u] = q.x * s; x8[4 * u + 1] = q.y * s; x8[4 * u + 2] = q.z * s; x8[4 * u + 3] = q.w * s;
-          }
-          split8(x8, dh_[ks], dl_[ks]);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      if (i > 0) {
-        float* nxt = a.dz_save[i - 1] + rt * NT * 1024 + lane * 4;
-        for (int u = 0; u < NT; ++u) {
-          f32x16 acc;
-          prodw<KS, PW, ACTIVE>(ws, dh_, dl_, acc);
-          if (ACTIVE) {
-            const float inv = dz_inv * sl[tile];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-              stg4(nxt + u * 1024 + g * 256, make_float4(acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv, acc[4 * g + 3] * inv));
-          }
-          ++tile;
-        }
-      } else {
-        f32x16 acc;
-        prodw<KS, PW, ACTIVE>(ws, dh_, dl_, acc);
-        if (ACTIVE && a.d_x && live) {
-          const float inv = dz_inv * sl[tile];
-#pragma unroll
-          for (int g = 0; g < 2; ++g)
-            if (8 * g + 4 * h < a.ldx)
-              stg4(a.d_x + row * a.ldx + 8 * g + 4 * h, make_float4(acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv, acc[4 * g + 3] * inv));
-        }
-        ++tile;
-      }
-      if (ACTIVE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next layer's hidden loads read what was just stored
-    }
-  }
-  if (ACTIVE) {
-    fp_max = fmaxf(fp_max, __shfl_xor(fp_max, 32, 64));
-    if (h == 0) a.dfp_rowmax[row] = fp_max;
-    publish_max(a.gmax + n_film, fp_max, live, true, lane);
-  }
-}
-
-// Eight waves per workgroup (two per SIMD: the matrix pipe of one wave's products overlaps the epilogue arithmetic of the
-// other; 256 batch rows share one weight stream, half the L2 -> LDS traffic per row of the four-wave forward), 256 registers
-// each.  That budget is met by keeping NO per-layer matrix in registers across the tile loop: the incoming gradient dY of a
-// layer waits, tile-native, in that layer's dz buffer (written by the layer above, overwritten tile by tile with dz), and the
-// W^T products of the layer read the finished dz tiles back (the lane that stored a piece loads it).
-// The remainder of the last round runs in tail workgroups (tail_plan above).
-template <int H>
-__global__ __launch_bounds__(512, 2) void film_bwd_kernel(const BwdFilmArgs a) {
-  constexpr int PW = 2;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES + (BIAS_FLOATS + SCALE_FLOATS) * 4 + 4 * H * 4];
-  float* bl = reinterpret_cast<float*>(smem + RING_BYTES);
-  float* sl = bl + BIAS_FLOATS;
-  float* wo = sl + SCALE_FLOATS;  // head weights [4][H] (rows >= out_dim zero)
-  const nsky_film_net& net = a.net;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  {
-    constexpr int N4 = (BIAS_FLOATS + SCALE_FLOATS) / 4;
-    float4 q[(N4 + 511) / 512];
-#pragma unroll
-    for (int i = 0; i < (N4 + 511) / 512; ++i)
-      if (i * 512 + tid < N4) q[i] = ldg4(a.table + 4 * (i * 512 + tid));
-#pragma unroll
-    for (int i = 0; i < (N4 + 511) / 512; ++i)
-      if (i * 512 + tid < N4) *reinterpret_cast<float4*>(bl + 4 * (i * 512 + tid)) = q[i];
-    for (int i = tid; i < 4 * H; i += 512) wo[i] = (i / H) < net.out_dim ? net.out_w[(long)(i / H) * net.out_ld + (i % H)] : 0.0f;
-  }
-  __syncthreads();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every compiler-visible memory operation is done before the DMA stream starts
-  WStream ws;
-  ws.src = a.stream + wave * (PW * 1024) + lane * 16;
-  ws.dst = (uint32_t)(uintptr_t)smem + wave * (PW * 1024);
-  ws.lds_lane = (uint32_t)(uintptr_t)smem + lane * 16;
-  ws_begin<PW>(ws);
-  const long n_tiles = (a.M + 31) / 32;
-  const long rt = tail_tile(a.full_wgs, a.tail_wgs, a.tail_k, n_tiles, wave);
-  if (rt >= 0 && rt < n_tiles) film_bwd_tile<H, true>(a, ws, bl, sl, wo, rt, lane);
-  else film_bwd_tile<H, false>(a, ws, bl, sl, wo, 0, lane);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1525,20 +1323,10 @@ extern "C" int nsky_film_chain_bwd_film(const nsky_film_net* net, const void* st
     a.dz_save[l] = l < net->n_film ? dz_save[l] : nullptr;
     if (l < net->n_film) NSKY_CHECK_ARG(a.z_save[l] && a.dz_save[l] && ((uintptr_t)a.z_save[l] % 16) == 0 && ((uintptr_t)a.dz_save[l] % 16) == 0, "nsky_film_chain_bwd_film: z_save / dz_save[%d]", l);
   }
-  static const int form = [] { const char* e = getenv("NSKY_FILM_BWD"); return e ? atoi(e) : 4; }();  // lab switch for same-box A/B runs: 8 = the eight-wave kernel
-  if (form == 4) {
-    a.full_wgs = a.tail_wgs = a.tail_k = 0;
-    const dim3 grid(ceil_div(ceil_div(M, 32), 4));
-    if (net->hidden == 256) hipLaunchKernelGGL((film_bwd4_kernel<256>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((film_bwd4_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    NSKY_CHECK_LAUNCH("nsky_film_chain_bwd_film");
-    return NSKY_OK;
-  }
-  const TailPlan tp = tail_plan(ceil_div(M, 32), device_cus());
-  a.full_wgs = tp.full_wgs; a.tail_wgs = tp.tail_wgs; a.tail_k = tp.tail_k;
-  const dim3 grid(tp.full_wgs + tp.tail_wgs);
-  if (net->hidden == 256) hipLaunchKernelGGL((film_bwd_kernel<256>), grid, dim3(512), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((film_bwd_kernel<128>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  a.full_wgs = a.tail_wgs = a.tail_k = 0;  // (four row tiles per workgroup, one per wave: no tail plan)
+  const dim3 grid(ceil_div(ceil_div(M, 32), 4));
+  if (net->hidden == 256) hipLaunchKernelGGL((film_bwd4_kernel<256>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((film_bwd4_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, a);
   NSKY_CHECK_LAUNCH("nsky_film_chain_bwd_film");
   return NSKY_OK;
 }
