@@ -233,11 +233,15 @@ def shared_grad(like, bias_like):
 # the very end of the pass read -- while the input gradients the same node returns are what the next nodes wait for (the hash-table
 # scatter, an LDS-atomic kernel that leaves the matrix pipes and most of the HBM bandwidth idle).  So a backward node may launch its
 # weight-gradient kernels on a SIDE stream: forked behind the node's own kernels, joined where their results are first read
-# (join_weight_gradients: the weight-norm / padding backward nodes, and a callback at the end of the backward pass).  Operands are
-# pinned to the side stream (record_stream) so the allocator does not hand their memory to a later kernel of the main stream.
+# (join_weight_gradients: the weight-norm / padding backward nodes, and a callback at the end of the backward pass).  The operands are
+# kept ALIVE until that join (references in _WGRAD_KEEP), so the allocator cannot hand their memory to a later kernel of the main stream;
+# after the join any reuse is ordered behind the side stream's work.  (Not Tensor.record_stream: with it the flaky-subset runs of
+# tools/flake.sh aborted one time in eight -- "free(): invalid pointer", host heap -- somewhere between the allocator's deferred events and
+# the captured graphs' private pools; the tree before the side stream: 0 of 8, with plain references: see DESIGN section 4.)
 ASYNC_WGRAD = os.environ.get("NSKY_ASYNC_WGRAD", "1") != "0"  # (lab switch for same-box A/B runs; arithmetic is identical either way)
 _WGRAD_SIDE: dict = {}     # device index -> side stream
 _WGRAD_PENDING: list = []  # side streams with unjoined work of THIS backward pass
+_WGRAD_KEEP: list = []     # operands of the unjoined launches
 
 
 def async_weight_gradients(launch, operands) -> None:
@@ -252,9 +256,7 @@ def async_weight_gradients(launch, operands) -> None:
     side.wait_stream(main)
     with torch.cuda.stream(side):
         launch()
-    for t in operands:
-        if t is not None:
-            t.record_stream(side)
+    _WGRAD_KEEP.append([t for t in operands if t is not None])
     if not _WGRAD_PENDING:
         torch.autograd.Variable._execution_engine.queue_callback(join_weight_gradients)
     if side not in _WGRAD_PENDING:
@@ -268,6 +270,7 @@ def join_weight_gradients() -> None:
         for side in _WGRAD_PENDING:
             cur.wait_stream(side)
         _WGRAD_PENDING.clear()
+        _WGRAD_KEEP.clear()
 
 
 def join_if_returned(*leaf_grads) -> None:
