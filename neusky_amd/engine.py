@@ -230,28 +230,12 @@ class Optimizers:
             hip.adam_step(g.flat_p, g.flat_g, g.m, g.v, lr, g.opt.betas[0], g.opt.betas[1], g.opt.eps, g.steps)
 
 
-_ENGINE_THREADS = __import__("os").environ.get("NSKY_BACKWARD_THREADS", "0") == "1"  # lab switch: autograd's default worker threads
-
-
-def backward_on_this_thread(loss) -> None:
-    """loss.backward() with autograd's worker threads off: every backward node -- every HIP launch, stream fork / join and allocation of
-    the backward pass -- runs on the CALLING thread.  Under a stream capture (GraphedTrainStep, the eval-latent fit) the default engine
-    drives the capturing stream from a second thread while the first one holds the capture; with the calling thread doing all of it the
-    runtime's capture state is only ever touched by one thread (an intermittent host-heap abort of the evaluation tests, about one
-    suite run in ten on some boxes since round 4, is what prompted this: tools/flake.sh)."""
-    if _ENGINE_THREADS:
-        loss.backward()
-        return
-    with torch.autograd.set_multithreading_enabled(False):
-        loss.backward()
-
-
 def train_iteration(pipeline, optimizers: Optimizers, step: int, **kw):
     """one step of the reference's training loop: forward + losses, backward, (all-reduce), 5 Adam steps"""
     optimizers.zero_grad_all()
     _, loss_dict, metrics_dict = pipeline.get_train_loss_dict(step, **kw)
     loss = total_loss(loss_dict)
-    backward_on_this_thread(loss)
+    loss.backward()
     optimizers.collect_grads()
     optimizers.all_reduce_gradients()
     optimizers.optimizer_scheduler_step_all(step)
@@ -308,7 +292,7 @@ class GraphedTrainStep:
         self.opt.zero_grad_all()
         _, loss_dict, metrics = self.pipeline.get_train_loss_dict(step, ray_bundle=self.rb, batch=self.batch, randoms=self.randoms)
         loss = total_loss(loss_dict)
-        backward_on_this_thread(loss)
+        loss.backward()
         self.opt.collect_grads()
         return loss.detach(), {k: v.detach() for k, v in loss_dict.items()}, metrics
 

@@ -38,11 +38,6 @@ from ..utils.utils import device_rng, device_rng_seed, linear_to_sRGB, to_device
 from ..plugin import ConfigBase, ModelBase
 
 
-def backward_on_this_thread(loss):
-    from ..engine import backward_on_this_thread as f  # (engine imports the model components: resolved at call time)
-    f(loss)
-
-
 def _default_loss_inclusions() -> Dict[str, Any]:  # neusky/configs/neusky_config.py:102-126
     return {
         "rgb_l1_loss": True, "rgb_l2_loss": False, "cosine_colour_loss": False, "eikonal loss": True, "fg_mask_loss": True,
@@ -747,7 +742,7 @@ class NeuSkyFactoModel(ModelBase):
             self.begin_step()
             outputs = self.forward(ray_bundle=rb, step=global_step, rotation=rot, randoms=randoms)
             loss = total_loss(self.get_loss_dict(outputs, batch))
-            backward_on_this_thread(loss)
+            loss.backward()
             return loss.detach()
 
         try:
