@@ -1,16 +1,31 @@
 """The evaluation half of the pipeline surface (neusky_pipeline.py:294-444, neusky_model.py:1079-1335): the methods run on the
-HIP path, keep the reference's return contracts and restore train mode."""
-import pytest
-import torch
+HIP path, keep the reference's return contracts and restore train mode.
 
-from util_step import randomise, small_pipeline_config
+Each parametrisation runs in a FRESH interpreter (this file as a script).  Round 5 chased an intermittent abort of exactly this test --
+SIGABRT / SIGSEGV / "free(): invalid pointer" at the first synchronisation behind the eval-latent fit, about one run in ten of the suite on
+some boxes, on the round-4 tree as much as on this one (tools/flake.sh, tools/flake_ab.sh) -- and only ever when
+the process had built and dropped other pipelines and captured graphs before; 400 fit / render / forward cycles in processes of their own
+never failed (tools/flake_eval2.py).  Not root-caused; the isolation keeps one test's host-heap state from deciding another's."""
+import os
+import subprocess
+import sys
+
+import pytest
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 @pytest.mark.parametrize("conditioning", ["FiLM", "Attention"])
 def test_eval_methods_run_and_keep_their_contracts(conditioning):
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), conditioning], cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "eval methods ok" in out.stdout, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
+
+
+def run_eval_methods(conditioning):
+    import torch
+    from util_step import randomise, small_pipeline_config
     torch.manual_seed(0)
     cfg = small_pipeline_config(R=64, num_prop=(32, 16), S=12, D=32, images=4)
     cfg.model.illumination_field.conditioning = conditioning  # (Attention: the decoder neusky_config.py:78-95 configures)
@@ -46,3 +61,11 @@ def test_eval_methods_run_and_keep_their_contracts(conditioning):
     feat = torch.randn(10, 256, device=DEV)
     alb = pipe.model.field.get_colors(torch.rand(10, 3, device=DEV) - 0.5, feat)
     assert alb.shape == (10, 3) and bool(((alb > 0) & (alb < 1)).all())
+
+
+if __name__ == "__main__":
+    for p_ in (os.path.dirname(HERE), HERE, os.path.join(HERE, "golden")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    run_eval_methods(sys.argv[1])
+    print("eval methods ok")
