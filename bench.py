@@ -97,10 +97,9 @@ class KernelTimer:
         def bwd_film(net, stream, table, M, *a, **kw):
             H, nm, nf, cd, xd, od = dims(net)
             fl = 2.0 * M * ((nf - 1) * H * H + H * xd)
-            # algorithmic bytes: d_res, h_last and the z saves in; dz and dF / dphase out (the parked dY and the read-back of dz are the
-            # kernel's own traffic, not counted)
+            # algorithmic bytes: d_res, h_last and the z saves in; dz and dF / dphase out
             by = 4.0 * M * (4 + H + nf * H + nf * H + 2 * nf * H + 16)
-            return t._timed(f"film_bwd_kernel<{H}>", o["film_chain_bwd_film"], fl, fl + 2.0 * M * 2 * nf * H * H, net, stream, table, M, *a,
+            return t._timed(f"film_bwd4_kernel<{H}>", o["film_chain_bwd_film"], fl, fl + 2.0 * M * 2 * nf * H * H, net, stream, table, M, *a,
                             nbytes=by, **kw)
 
         def bwd_map(net, stream, table, M, *a, **kw):
