@@ -668,6 +668,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the three extra eager steps under the exact-fp32 policy")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the forward-only (configs[1]) and 1080p render (configs[4]) lines")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not collect the HBM counters in this run (roofline.traffic then comes from the committed file)")
+    ap.add_argument("--launcher-selftest", choices=("ok", "fail"), default=None,
+                    help="CPU check of the launch path alone (tests/test_cpu_abi_and_host.py): the ranks started by spawn_ranks rendezvous over gloo, "
+                         "all-reduce a known answer on host tensors and rank 0 prints one line; 'fail': the last rank exits non-zero instead")
     ap.add_argument("--no-spawn", action="store_true",
                     help="N = 1 only: run the rank in THIS process, without a process group (for rocprofv3 -- python3 bench.py ...: the "
                          "profiler's library initialises the GPU in the process it preloads into, which then must not start ranks)")
@@ -771,6 +774,22 @@ def main():
     sys.stdout.flush()
     line_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
+    if args.launcher_selftest is not None:  # no GPU, no pipeline: the environment spawn_ranks hands a rank, a real (gloo) process group
+        world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+        assert int(os.environ["LOCAL_RANK"]) == rank and os.environ["MASTER_ADDR"] == "127.0.0.1" and world == args.gpus
+        if args.launcher_selftest == "fail" and rank == world - 1:
+            raise SystemExit(7)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        x = torch.full((8,), float(rank + 1))
+        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        if rank != 0:
+            print(f"(a line of rank {rank}: must not reach the parent's stdout)")
+        else:
+            line_out.write(json.dumps({"selftest": "ok", "ranks": world, "sum": float(x[0]), "launcher": os.environ.get("NSKY_BENCH_LAUNCHER")}) + "\n")
+            line_out.flush()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
     rank = int(os.environ.get("RANK", "0")) if launched else 0

@@ -135,3 +135,25 @@ def test_oracle_properties_of_unpinned_pieces():
     pp = p.detach().clone(); pp[:, 1] += eps
     fd = (O.hash_grid_encode(pp, tab, cfg)[:, 3] - f[:, 3].detach()) / eps
     assert torch.allclose(fd, gr[:, 1], atol=1e-4, rtol=1e-3)
+
+
+def test_bench_starts_its_own_ranks_cpu_selftest():
+    """bench.py's launch path without a GPU (`--launcher-selftest`): the parent starts one child per rank with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT, the ranks rendezvous over gloo and all-reduce a known answer, ONLY rank 0's one line reaches the
+    parent's stdout (library banners and the other ranks' output go to stderr), and a failing rank gives a non-zero exit and no line"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--launcher-selftest", "ok"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d == {"selftest": "ok", "ranks": 3, "sum": 6.0, "launcher": "self-spawned"}
+    assert "a line of rank 1" in out.stderr and "a line of rank 2" in out.stderr
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-selftest", "fail"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 7 and bad.stdout.strip() == "" and "rank 1 exited with code 7" in bad.stderr
