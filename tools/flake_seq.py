@@ -1,0 +1,16 @@
+"""python tools/flake_seq.py <comma-separated test files to run first> : run them through pytest IN THIS PROCESS, then the evaluation-method
+test body (tests/test_gpu_eval_methods.run_eval_methods) in the same process -- which preceding tests does the intermittent abort need?"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.chdir(ROOT)
+for p_ in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    sys.path.insert(0, p_)
+import pytest
+files = [f for f in sys.argv[1].split(",") if f]
+if files:
+    rc = pytest.main(["-m", "gpu", "-q", "-p", "no:cacheprovider"] + [os.path.join("tests", f) for f in files])
+    print("pytest rc", rc, flush=True)
+import test_gpu_eval_methods as t
+for c in ("FiLM", "Attention"):
+    t.run_eval_methods(c)
+    print("eval methods", c, "ok", flush=True)
