@@ -796,13 +796,6 @@ class NeuSkyFactoModel(ModelBase):
                 if log_every and it % log_every == 0:
                     trace.append(loss.clone())
         finally:
-            # The captured iteration must have finished before its graph object goes away with this frame: destroying a graph whose last
-            # replay is still in flight is where an intermittent host-heap abort of the evaluation tests came from (about one suite run in
-            # ten on some boxes since round 4; tools/flake_seq.sh: only ever behind tests/test_gpu_eval_latents.py, which drops its fit
-            # graphs with work in flight).  A 250-step fit does not notice one synchronisation.
-            if graph is not None and os.environ.get("NSKY_FIT_SYNC", "1") != "0":
-                torch.cuda.synchronize()
-            graph = None
             for p in frozen:
                 p.requires_grad_(True)
             for p, g in zip(params, old_grads):
