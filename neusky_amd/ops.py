@@ -273,10 +273,13 @@ def join_weight_gradients() -> None:
         _WGRAD_KEEP.clear()
 
 
-def join_if_returned(*leaf_grads) -> None:
-    """a gradient handed to autograd for a LEAF (a bias that is not -- yet -- slab-resident: the first step, a caller without the
-    engine's slabs) is read by AccumulateGrad right away: the side stream's adds must have landed"""
-    if any(t is not None for t in leaf_grads):
+def join_unless_sunk(*bias_grads) -> None:
+    """a bias accumulator that is not -- yet -- slab-resident (the first step, a caller without the engine's slabs) goes to autograd from
+    the node that allocated it and is read by the leaf's AccumulateGrad as soon as the LAST node sharing it has run, whichever that is:
+    EVERY node that added to one on the side stream joins before it returns, not only the one that hands the tensor over (round 5: the
+    first eager step of one pipeline in eight lost a later node's share of `glin0.bias`, tools/flake_graph.py).  Slab-resident biases
+    (every step after the first) are read by nothing before the end of the pass: no join, the launches stay off the critical path."""
+    if any(t is not None and t.data_ptr() not in _SUNK_BIAS for t in bias_grads):
         join_weight_gradients()
 
 
@@ -1081,7 +1084,7 @@ class FieldChainFn(torch.autograd.Function):
         k = first_only  # later nodes of the pass added in place; slab-resident biases return nothing
         if not colour:
             async_weight_gradients(launch_geo, [d1q, a0q, d0q, Eq, a1q, g_sdf, g_grad, gmax, qmax])
-            join_if_returned(k(f_0, db0), k(f_1, db1))
+            join_unless_sunk(db0, db1, db2)
             return (dET, k(f_0, dW0), k(f_0, db0), k(f_1, dW1), k(f_1, db1), k(f_2, dW2), k(f_2, db2), *none6, None, None)
         dWc2, dbc2, f_c2 = shared_grad(Wc2, bc2)
         dWc1, dbc1, f_c1 = shared_grad(Wc1, bc1)
@@ -1096,7 +1099,7 @@ class FieldChainFn(torch.autograd.Function):
             hip.native_weighted_colsum(c1, 8, N, dWc2, dbc2, w4=dpc2, n_out=3)
 
         async_weight_gradients(launch_all, [d1q, a0q, d0q, Eq, a1q, g_sdf, g_grad, gmax, qmax, dfeat, a1v, dpc1, c0, dpc0, feat, xpe, c1, dpc2])
-        join_if_returned(k(f_0, db0), k(f_1, db1), k(f_c0, dbc0), k(f_c1, dbc1))
+        join_unless_sunk(db0, db1, db2, dbc0, dbc1, dbc2)
         return (dET, k(f_0, dW0), k(f_0, db0), k(f_1, dW1), k(f_1, db1), k(f_2, dW2), k(f_2, db2), k(f_c0, dWc0), k(f_c0, dbc0),
                 k(f_c1, dWc1), k(f_c1, dbc1), k(f_c2, dWc2), k(f_c2, dbc2), None, None)
 
@@ -1191,11 +1194,11 @@ class SDFValueFn(torch.autograd.Function):
                 grad_weight(dZ0, E, M, Hd, Kin, W0, b0, acc=(dW0, db0), a_native_nt=nt, b_native_nt=0, a_scale_max=gmax[1:2])
 
             async_weight_gradients(launch, [dZ1, A0, dZ0, E, gmax])
+            join_unless_sunk(db0, db1)  # (db2's share came from the chain kernel above, on this stream)
             if not f2: dW2 = None
             if not f1: dW1 = None
             if not f0: dW0 = None
             db0, db1, db2 = first_only(f0, db0), first_only(f1, db1), first_only(f2, db2)
-            join_if_returned(db0, db1)
         return dE, dW0, db0, dW1, db1, dW2, db2, None, None
 
     @staticmethod

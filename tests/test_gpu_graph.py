@@ -82,6 +82,30 @@ def test_graph_replay_equals_eager_on_injected_randoms():
             off += g.numel
 
 
+def test_first_pass_gradients_wait_for_the_side_stream():
+    """the FIRST backward pass of a pipeline hands its bias accumulators to autograd (they are slab-resident only from the second pass on)
+    while the weight-gradient kernels that fill them run on the side stream (ops.async_weight_gradients): every node sharing such an
+    accumulator joins before it returns (ops.join_unless_sunk).  Round 5: one first pass in eight lost a node's share of `glin0.bias`.
+    Pass 0 against pass 1 (sunk biases, joined at the end of the pass) on the same injected inputs, on several fresh pipelines."""
+    from neusky_amd.model_components.losses import total_loss
+    for it in range(5):
+        pipe, opt, rb, batch, rnd = _setup()
+        passes = []
+        for _ in range(2):
+            opt.zero_grad_all()
+            outs, ld, _ = pipe.get_train_loss_dict(10_000, ray_bundle=rb, batch=batch, randoms=rnd)
+            total_loss(ld).backward()
+            passes.append(opt.flat_g.clone())
+            del outs, ld
+        torch.cuda.synchronize()
+        off = 0
+        for g in opt.groups:
+            a, b = passes[0][off:off + g.numel], passes[1][off:off + g.numel]
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12, (it, g.name, int((a - b).abs().argmax()))
+            off += g.numel
+        del pipe, opt
+
+
 def test_proposal_anneal_follows_the_step_under_graph_replay():
     """the proposal-weight anneal is a device scalar the graph READS; nothing inside the capture may write
     it.  Early steps must re-sample near-uniformly (anneal ~ 0.05), late steps with anneal 1, exactly as the eager step."""
