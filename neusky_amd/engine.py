@@ -284,7 +284,7 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: other host threads (e.g. the RCCL watchdog) may legally touch the runtime during the capture
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        with torch.cuda.graph(self.graph, capture_error_mode=ops.CAPTURE_MODE):
             self.loss, self.loss_dict, self.metrics = self._body(start_step + warmup)
         torch.cuda.synchronize()
 

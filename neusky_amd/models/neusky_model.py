@@ -767,7 +767,7 @@ class NeuSkyFactoModel(ModelBase):
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 try:
-                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    with torch.cuda.graph(graph, capture_error_mode=ops.CAPTURE_MODE):
                         gloss = iteration(srb, sbatch, None, srnd)
                 except RuntimeError as exc:  # a host-dependent op inside the iteration: run the fit with host launches instead
                     import warnings
@@ -885,7 +885,7 @@ class _ChunkRunner:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            with torch.cuda.graph(self.graph, capture_error_mode=ops.CAPTURE_MODE):
                 self.out = model.forward(self.rb)
 
     def _load(self, flat: RayBundle, a: int, b: int) -> None:
