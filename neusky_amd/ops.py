@@ -901,6 +901,7 @@ class SDFAlbedoFn(torch.autograd.Function):
         if g_alb is not None:
             alb = ALB[:, :3]
             dpc2[:, :3] = g_alb * alb * (1.0 - alb)
+        join_weight_gradients()  # this path adds on the current stream, to accumulators a fused node of the same pass may be filling on the side stream
         dWc2, dbc2, f_c2 = shared_grad(Wc2, bc2)
         wq: dict = {}  # the layers' weight gradients are queued and run as one launch per row count at the end
         grad_weight(dpc2, C1, N, 4, Hc, Wc2, bc2, acc=(dWc2, dbc2), batch=wq)
@@ -936,6 +937,7 @@ class SDFAlbedoFn(torch.autograd.Function):
             if g_sdf is not None:
                 dH[:, GF] = g_sdf
         # ---- geo net, last layer (value rows)
+        join_weight_gradients()  # (the geometry-only entry of this path: adds on the current stream, see backward)
         dW2, db2, f_2 = shared_grad(W2, b2)
         grad_weight(dH, A1[:N], N, GF + 4, Hd, W2, b2, acc=(dW2, db2), batch=wq)
         dA1v = torch.empty(N, Hd, device=dev)
@@ -1224,6 +1226,7 @@ class SDFValueFn(torch.autograd.Function):
         grad_input(dZ0, W0, M, Kin, Hd, dE)
         dW0 = db0 = dW1 = db1 = dW2 = db2 = None
         if train_w:
+            join_weight_gradients()  # (as in SDFAlbedoFn.backward: adds on the current stream)
             dW2, db2, f2 = shared_grad(W2, b2)
             hip.weighted_colsum(A1, M, Hd, g, 4, dW2[GF])
             db2[GF] += g_sdf.sum()
