@@ -238,8 +238,9 @@ def shared_grad(like, bias_like):
 # after the join any reuse is ordered behind the side stream's work.  (Not Tensor.record_stream: with it the flaky-subset runs of
 # tools/flake.sh aborted one time in eight -- "free(): invalid pointer", host heap -- somewhere between the allocator's deferred events and
 # the captured graphs' private pools; the tree before the side stream: 0 of 8, with plain references: see DESIGN section 4.)
-# capture mode of every HIP graph of this package (the train step, the eval-latent fit, the render chunk): autograd's worker thread launches
-# the backward's kernels into the capturing stream, which "global" mode forbids; (lab switch: "relaxed" for the flake hunt of DESIGN section 7)
+# capture mode of every HIP graph of this package (the train step, the eval-latent fit, the render chunk).  thread_local: only the capturing
+# thread is policed -- other host threads (the RCCL watchdog, a loader staging the next batch) may legally touch the runtime during a
+# capture.  The captures themselves make no unsafe call from any thread ("global" passes too).  (lab switch for the flake hunt of DESIGN section 7)
 CAPTURE_MODE = os.environ.get("NSKY_CAPTURE_MODE", "thread_local")
 ASYNC_WGRAD = os.environ.get("NSKY_ASYNC_WGRAD", "1") != "0"  # (lab switch for same-box A/B runs; arithmetic is identical either way)
 _WGRAD_SIDE: dict = {}     # device index -> side stream
