@@ -6,6 +6,10 @@ os.chdir(ROOT)
 for p_ in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
     sys.path.insert(0, p_)
 import pytest
+if os.environ.get("NSKY_FLAKE_PRELOAD"):  # every kernel of the evaluation-method body loaded while the heap is fresh: is the abort tied to FIRST use?
+    import test_gpu_eval_methods as t0
+    t0.run_eval_methods("FiLM")
+    print("preload: eval methods FiLM ok", flush=True)
 files = [f for f in sys.argv[1].split(",") if f]
 keep = ["-k", sys.argv[2]] if len(sys.argv) > 2 else []  # optional pytest -k expression
 if files:
