@@ -173,6 +173,9 @@ _SUNK_BIAS: set = set()  # data_ptrs of the slab views handed out as bias accumu
 
 
 def register_grad_sink(p) -> None:
+    """`p` (a parameter whose .grad is a view of the optimizer's gradient slab, zeroed by the optimizer before every pass) takes its bias
+    gradients IN PLACE from the second pass on: the backward nodes return None for it.  The contract of engine.Optimizers and of `.backward()`;
+    `torch.autograd.grad(loss, [p])` on a registered parameter sees no gradient -- read `p.grad` after `.backward()` instead."""
     import weakref
     _GRAD_SINKS[p.data_ptr()] = weakref.ref(p)
 
