@@ -1,0 +1,94 @@
+"""python tools/undefined_names.py [paths...] : names that are read but bound nowhere (module scope, enclosing functions, builtins) -- the
+image has no pyflakes, and a round that deletes whole alternatives (round 5: every CPU / torch branch of the product) can leave a reference
+behind in a branch no test reaches.  Scope rules simplified: a name bound ANYWHERE in a function counts as bound in it."""
+import ast
+import builtins
+import os
+import sys
+
+
+def bound_names(node):
+    """names bound directly in this scope (not in nested functions / classes / lambdas; comprehensions are folded into their scope)"""
+    out = set()
+
+    def visit(n, top=False):
+        if not top and isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+            out.add(n.name)
+            return
+        if not top and isinstance(n, ast.Lambda):
+            return
+        if isinstance(n, ast.Name) and isinstance(n.ctx, (ast.Store, ast.Del)):
+            out.add(n.id)
+        elif isinstance(n, (ast.Import, ast.ImportFrom)):
+            for a in n.names:
+                out.add((a.asname or a.name).split(".")[0])
+        elif isinstance(n, ast.ExceptHandler) and n.name:
+            out.add(n.name)
+        elif isinstance(n, (ast.Global, ast.Nonlocal)):
+            out.update(n.names)
+        elif isinstance(n, ast.arg):
+            out.add(n.arg)
+        elif isinstance(n, (ast.MatchAs, ast.MatchStar)) and getattr(n, "name", None):
+            out.add(n.name)
+        for c in ast.iter_child_nodes(n):
+            visit(c)
+
+    visit(node, top=True)
+    return out
+
+
+def check(path):
+    tree = ast.parse(open(path).read(), path)
+    problems = []
+    module_names = bound_names(tree) | set(dir(builtins)) | {"__file__", "__name__", "__doc__", "__package__", "__spec__", "__builtins__"}
+    star = any(isinstance(n, ast.ImportFrom) and any(a.name == "*" for a in n.names) for n in ast.walk(tree))
+
+    def walk(node, scopes):
+        for c in ast.iter_child_nodes(node):
+            if isinstance(c, (ast.FunctionDef, ast.AsyncFunctionDef, ast.Lambda)):
+                for d in getattr(c, "decorator_list", []):
+                    walk_expr(d, scopes)
+                args = c.args
+                for d in list(args.defaults) + [d for d in args.kw_defaults if d is not None]:
+                    walk_expr(d, scopes)
+                walk(c, scopes + [bound_names(c)])
+            elif isinstance(c, ast.ClassDef):
+                for d in c.decorator_list + c.bases + [k.value for k in c.keywords]:
+                    walk_expr(d, scopes)
+                # class bodies see their own names while executing, methods do not: approximate by checking the body against class + outer names
+                walk(c, scopes + [bound_names(c)])
+            else:
+                walk_expr(c, scopes, recurse=False)
+                walk(c, scopes)
+
+    def walk_expr(n, scopes, recurse=True):
+        nodes = ast.walk(n) if recurse else [n]
+        for m in nodes:
+            if isinstance(m, ast.Name) and isinstance(m.ctx, ast.Load):
+                if not any(m.id in s for s in scopes) and not star:
+                    problems.append((path, m.lineno, m.id))
+
+    walk(tree, [module_names])
+    return problems
+
+
+def main(argv):
+    roots = argv or ["neusky_amd", "bench.py", "__graft_entry__.py", "oracle", "tools", "tests"]
+    files = []
+    for r in roots:
+        if os.path.isdir(r):
+            for d, _, fs in os.walk(r):
+                files += [os.path.join(d, f) for f in fs if f.endswith(".py")]
+        elif r.endswith(".py"):
+            files.append(r)
+    problems = []
+    for f in sorted(files):
+        problems += check(f)
+    for p, line, name in problems:
+        print(f"{p}:{line}: undefined name {name!r}")
+    print(f"{len(files)} files, {len(problems)} undefined names")
+    return 1 if problems else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))
