@@ -1,4 +1,5 @@
-"""tools/undefined_names.py over the product, bench, oracle, tools and tests: no name is read that is bound nowhere (the image has no pyflakes;
+"""tools/undefined_names.py over the product, bench, oracle, tools and tests: no name is read that is bound nowhere, and every `module.name` /
+`from module import name` of this repository's own modules exists there -- which covers the GPU tests no CPU run executes (the image has no pyflakes;
 round 5 deleted every CPU / torch alternative of the product -- a reference left behind in an untested branch would show here)."""
 import os
 import subprocess
@@ -14,6 +15,8 @@ def test_no_undefined_names():
 
 def test_the_checker_sees_an_undefined_name(tmp_path):
     f = tmp_path / "bad.py"
-    f.write_text("import os\ndef f(a):\n    return a + missing_one + os.sep\n")
+    f.write_text("import os\nfrom neusky_amd import ops\nfrom neusky_amd.hip import no_such_entry\n"
+                 "def f(a):\n    return a + missing_one + os.sep + ops.no_such_function(a) + ops.zeros(1)\n")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "undefined_names.py"), str(f)], cwd=ROOT, capture_output=True, text=True, timeout=60)
-    assert out.returncode == 1 and "missing_one" in out.stdout
+    assert out.returncode == 1 and "missing_one" in out.stdout and "ops.no_such_function" in out.stdout and "no_such_entry" in out.stdout
+    assert "ops.zeros" not in out.stdout

@@ -72,6 +72,75 @@ def check(path):
     return problems
 
 
+# ---- attributes of this repository's own modules: `ops.join_if_returned`, `L._outer` ... must exist in the module they are read from
+PACKAGES = ("neusky_amd", "oracle")
+
+
+def module_file(dotted):
+    base = os.path.join(*dotted.split("."))
+    for cand in (base + ".py", os.path.join(base, "__init__.py")):
+        if os.path.isfile(cand):
+            return cand
+    return None
+
+
+_MODULE_NAMES: dict = {}
+
+
+def names_of_module(path):
+    if path not in _MODULE_NAMES:
+        tree = ast.parse(open(path).read(), path)
+        names = bound_names(tree)
+        if any(isinstance(n, ast.ImportFrom) and any(a.name == "*" for a in n.names) for n in ast.walk(tree)) or "__getattr__" in names:
+            names = None  # star imports / module __getattr__: anything goes
+        elif os.path.basename(path) == "__init__.py":  # submodules are attributes of a package
+            d = os.path.dirname(path)
+            names |= {f[:-3] for f in os.listdir(d) if f.endswith(".py")} | {f for f in os.listdir(d) if os.path.isdir(os.path.join(d, f))}
+        _MODULE_NAMES[path] = names
+    return _MODULE_NAMES[path]
+
+
+def check_attributes(path):
+    """aliases bound by an import of one of PACKAGES' modules (anywhere in the file; a name also assigned elsewhere is skipped)"""
+    tree = ast.parse(open(path).read(), path)
+    here = os.path.dirname(os.path.relpath(path)).replace(os.sep, ".")
+    alias, assigned, missing = {}, set(), []
+    for n in ast.walk(tree):
+        if isinstance(n, ast.ImportFrom):
+            if n.level:
+                parts = here.split(".") if here else []
+                parts = parts[:len(parts) - (n.level - 1)] if n.level > 1 else parts
+                mod = ".".join(parts + ([n.module] if n.module else []))
+            else:
+                mod = n.module or ""
+            if mod.split(".")[0] not in PACKAGES:
+                continue
+            src = module_file(mod)
+            for a in n.names:
+                f = module_file(mod + "." + a.name)
+                if f:  # `from pkg import module [as x]`
+                    alias[a.asname or a.name] = f
+                elif src and a.name != "*":  # `from pkg.module import name`: the name must be bound there
+                    names = names_of_module(src)
+                    if names is not None and a.name not in names:
+                        missing.append((path, n.lineno, f"from {mod} import {a.name} (no such name in {src})"))
+        elif isinstance(n, ast.Import):
+            for a in n.names:
+                if a.name.split(".")[0] in PACKAGES and a.asname and module_file(a.name):
+                    alias[a.asname] = module_file(a.name)
+        elif isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store):
+            assigned.add(n.id)
+        elif isinstance(n, ast.arg):
+            assigned.add(n.arg)
+    problems = missing
+    for n in ast.walk(tree):
+        if isinstance(n, ast.Attribute) and isinstance(n.value, ast.Name) and n.value.id in alias and n.value.id not in assigned:
+            names = names_of_module(alias[n.value.id])
+            if names is not None and n.attr not in names and not n.attr.startswith("__"):
+                problems.append((path, n.lineno, f"{n.value.id}.{n.attr} (no such name in {alias[n.value.id]})"))
+    return problems
+
+
 def main(argv):
     roots = argv or ["neusky_amd", "bench.py", "__graft_entry__.py", "oracle", "tools", "tests"]
     files = []
@@ -84,6 +153,7 @@ def main(argv):
     problems = []
     for f in sorted(files):
         problems += check(f)
+        problems += check_attributes(f)
     for p, line, name in problems:
         print(f"{p}:{line}: undefined name {name!r}")
     print(f"{len(files)} files, {len(problems)} undefined names")
