@@ -16,7 +16,7 @@ def test_no_undefined_names():
 def test_the_checker_sees_an_undefined_name(tmp_path):
     f = tmp_path / "bad.py"
     f.write_text("import os\nfrom neusky_amd import ops\nfrom neusky_amd.hip import no_such_entry\n"
-                 "def f(a):\n    return a + missing_one + os.sep + ops.no_such_function(a) + ops.zeros(1)\n")
+                 "def f(a):\n    return a + missing_one + os.sep + ops.no_such_function(a) + ops.zeros(1, device=a) + ops.zeros(1, where=a)\n")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "undefined_names.py"), str(f)], cwd=ROOT, capture_output=True, text=True, timeout=60)
     assert out.returncode == 1 and "missing_one" in out.stdout and "ops.no_such_function" in out.stdout and "no_such_entry" in out.stdout
-    assert "ops.zeros" not in out.stdout
+    assert "no parameter 'where'" in out.stdout and out.stdout.count("ops.zeros") == 1  # call shapes against the definition

@@ -1,6 +1,8 @@
 """python tools/undefined_names.py [paths...] : names that are read but bound nowhere (module scope, enclosing functions, builtins) -- the
 image has no pyflakes, and a round that deletes whole alternatives (round 5: every CPU / torch branch of the product) can leave a reference
-behind in a branch no test reaches.  Scope rules simplified: a name bound ANYWHERE in a function counts as bound in it."""
+behind in a branch no test reaches.  Scope rules simplified: a name bound ANYWHERE in a function counts as bound in it.  Also checked, for
+this repository's own modules: `module.name` and `from module import name` exist, and calls of plain module-level functions fit their
+definitions -- which covers the GPU tests and tools that no CPU run executes."""
 import ast
 import builtins
 import os
@@ -73,14 +75,15 @@ def check(path):
 
 
 # ---- attributes of this repository's own modules: `ops.join_if_returned`, `L._outer` ... must exist in the module they are read from
-PACKAGES = ("neusky_amd", "oracle")
+PACKAGES = ("neusky_amd", "oracle", "util_step", "bench", "__graft_entry__")
 
 
 def module_file(dotted):
     base = os.path.join(*dotted.split("."))
-    for cand in (base + ".py", os.path.join(base, "__init__.py")):
-        if os.path.isfile(cand):
-            return cand
+    for root in ("", "tests", "tools"):  # the tests and tools put their own directory on sys.path (util_step, bench helpers)
+        for cand in (os.path.join(root, base + ".py"), os.path.join(root, base, "__init__.py")):
+            if os.path.isfile(cand):
+                return cand
     return None
 
 
@@ -141,6 +144,96 @@ def check_attributes(path):
     return problems
 
 
+# ---- call shapes: a call of a plain module-level `def` of this repository (through a module alias, a from-import, or inside its own module)
+# must fit the definition: not too many positionals, no unknown keyword, no required parameter left out
+_MODULE_DEFS: dict = {}
+
+
+def defs_of_module(path):
+    if path not in _MODULE_DEFS:
+        tree = ast.parse(open(path).read(), path)
+        defs, rebound = {}, set()
+        for n in tree.body:
+            if isinstance(n, ast.FunctionDef) and not n.decorator_list:
+                if n.name in defs:
+                    rebound.add(n.name)
+                defs[n.name] = n.args
+        for n in ast.walk(tree):  # a name assigned anywhere else (monkeypatching, conditional definitions) is not checked
+            if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store) and n.id in defs:
+                rebound.add(n.id)
+        _MODULE_DEFS[path] = {k: v for k, v in defs.items() if k not in rebound}
+    return _MODULE_DEFS[path]
+
+
+def call_problem(call, a):
+    if any(isinstance(x, ast.Starred) for x in call.args) or any(k.arg is None for k in call.keywords):
+        return None  # *args / **kwargs at the call site: not decidable here
+    pos = [x.arg for x in a.posonlyargs + a.args]
+    kwonly = [x.arg for x in a.kwonlyargs]
+    if len(call.args) > len(pos) and a.vararg is None:
+        return f"{len(call.args)} positional arguments for {len(pos)}"
+    given = set(pos[:len(call.args)])
+    for k in call.keywords:
+        if k.arg in given:
+            return f"argument {k.arg!r} given twice"
+        if k.arg not in pos and k.arg not in kwonly and a.kwarg is None:
+            return f"no parameter {k.arg!r}"
+        given.add(k.arg)
+    required = pos[:len(pos) - len(a.defaults)] + [n for n, d in zip(kwonly, a.kw_defaults) if d is None]
+    left = [r for r in required if r not in given]
+    return f"missing {left}" if left else None
+
+
+def check_calls(path):
+    tree = ast.parse(open(path).read(), path)
+    here = os.path.dirname(os.path.relpath(path)).replace(os.sep, ".")
+    alias, direct, assigned = {}, {}, set()
+    for n in ast.walk(tree):
+        if isinstance(n, ast.ImportFrom):
+            if n.level:
+                parts = here.split(".") if here else []
+                parts = parts[:len(parts) - (n.level - 1)] if n.level > 1 else parts
+                mod = ".".join(parts + ([n.module] if n.module else []))
+            else:
+                mod = n.module or ""
+            if mod.split(".")[0] not in PACKAGES:
+                continue
+            src = module_file(mod)
+            for a in n.names:
+                f = module_file(mod + "." + a.name)
+                if f:
+                    alias[a.asname or a.name] = f
+                elif src and a.name in defs_of_module(src):
+                    direct[a.asname or a.name] = (src, a.name)
+        elif isinstance(n, ast.Import):
+            for a in n.names:
+                if a.name.split(".")[0] in PACKAGES and a.asname and module_file(a.name):
+                    alias[a.asname] = module_file(a.name)
+        elif isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store):
+            assigned.add(n.id)
+        elif isinstance(n, ast.arg):
+            assigned.add(n.arg)
+        elif isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n not in tree.body:
+            assigned.add(n.name)  # a nested def shadows
+    own = defs_of_module(path)
+    problems = []
+    for n in ast.walk(tree):
+        if not isinstance(n, ast.Call):
+            continue
+        f, target = n.func, None
+        if isinstance(f, ast.Attribute) and isinstance(f.value, ast.Name) and f.value.id in alias and f.value.id not in assigned:
+            target = (alias[f.value.id], f.attr, f"{f.value.id}.{f.attr}")
+        elif isinstance(f, ast.Name) and f.id in direct and f.id not in assigned:
+            target = (*direct[f.id], f.id)
+        elif isinstance(f, ast.Name) and f.id in own and f.id not in assigned:
+            target = (path, f.id, f.id)
+        if target and target[1] in defs_of_module(target[0]):
+            why = call_problem(n, defs_of_module(target[0])[target[1]])
+            if why:
+                problems.append((path, n.lineno, f"call {target[2]}(...): {why} (defined in {target[0]})"))
+    return problems
+
+
 def main(argv):
     roots = argv or ["neusky_amd", "bench.py", "__graft_entry__.py", "oracle", "tools", "tests"]
     files = []
@@ -154,6 +247,7 @@ def main(argv):
     for f in sorted(files):
         problems += check(f)
         problems += check_attributes(f)
+        problems += check_calls(f)
     for p, line, name in problems:
         print(f"{p}:{line}: undefined name {name!r}")
     print(f"{len(files)} files, {len(problems)} undefined names")
