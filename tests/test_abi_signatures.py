@@ -1,7 +1,7 @@
 """The ctypes bindings of neusky_amd/hip.py against the prototypes of include/neusky_hip.h: same parameter count and the same class of every
 parameter (pointer / 32-bit integer / 64-bit integer / float).  A binding that disagrees with its prototype is undefined behaviour on the
 host side of a GPU call -- nothing a CPU test executes, and nothing a GPU test is sure to notice.  Also: the ctypes mirrors of the
-header's structs have the C structs' sizes (compiled here with gcc)."""
+header's structs have the C structs' sizes and the same offset for every field (compiled here with gcc)."""
 import ctypes as C
 import os
 import re
@@ -97,3 +97,47 @@ def test_struct_mirrors_have_the_c_sizes(tmp_path):
     sizes = dict(line.split() for line in out.splitlines())
     wrong = {c: (int(sizes[c]), C.sizeof(getattr(hip, STRUCTS[c]))) for c in names if int(sizes[c]) != C.sizeof(getattr(hip, STRUCTS[c]))}
     assert not wrong, wrong
+
+
+def _c_struct_fields():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    out = {}
+    for m in re.finditer(r"typedef\s+struct\s*\w*\s*\{(.*?)\}\s*(nsky_\w+)\s*;", text, flags=re.S):
+        fields = []
+        for decl in m.group(1).split(";"):
+            for part in decl.strip().split(","):
+                mm = re.search(r"(\w+)\s*(\[[^\]]*\])?\s*$", part.strip())
+                if part.strip() and mm:
+                    fields.append(mm.group(1))
+        out[m.group(2)] = fields
+    return out
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc measures the C structs")
+def test_struct_mirrors_have_the_c_field_offsets(tmp_path):
+    from neusky_amd import hip
+    c_fields = _c_struct_fields()
+    lines, checked = [], 0
+    for c, py in STRUCTS.items():
+        assert c in c_fields, c
+        mirror = getattr(hip, py)
+        py_fields = [f[0] for f in mirror._fields_]
+        assert py_fields == c_fields[c], (c, py_fields, c_fields[c])  # same fields, same order, same names
+        for f in py_fields:
+            lines.append(f'  printf("{c}.{f} %zu\\n", offsetof({c}, {f}));\n')
+    src = tmp_path / "offsets.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "neusky_hip.h"\nint main(void) {\n' + "".join(lines) + "  return 0;\n}\n")
+    exe = tmp_path / "offsets"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True, capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    wrong = []
+    for line in out.splitlines():
+        key, off = line.split()
+        c, f = key.split(".")
+        checked += 1
+        if getattr(getattr(hip, STRUCTS[c]), f).offset != int(off):
+            wrong.append((key, int(off), getattr(getattr(hip, STRUCTS[c]), f).offset))
+    assert not wrong, wrong
+    assert checked >= 140, checked
