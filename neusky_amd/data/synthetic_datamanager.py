@@ -3,7 +3,7 @@
 Stands where `NeuSkyDataManager.next_train` / `get_sky_ray_bundle` stand in the reference
 (neusky/data/datamanagers/neusky_datamanager.py:277-288, called neusky/pipelines/neusky_pipeline.py:252,503):
 same output contract (RayBundle + batch{image [R,3], mask [R,4], indices}), data drawn from a seeded
-generator instead of the NeRF-OSR image stack (there is no dataset in the build environment).  Real
+generator instead of the NeRF-OSR image stack (there is no dataset in the build image).  Real
 data parsers are SURVEY.md section 8(f) items 1 and 4.
 """
 from __future__ import annotations

@@ -59,3 +59,190 @@ class ReplicaSync:
 
     def barrier(self) -> None:
         dist.barrier()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The gradient slab: what DDP's reducer is to the reference (neusky_pipeline.py:198-199), owned by the PIPELINE so that any trainer
+# that drives `get_train_loss_dict` -> `backward` (nerfstudio's Trainer with torch.optim.Adam, or neusky_amd.engine) sees synchronised
+# gradients in `p.grad`.
+GROUP_ORDER = ("proposal_networks", "fields", "illumination_field", "visibility_sigmoid", "ddf_field")  # neusky_config.py:216-237
+# buckets of the exchange, in the order the backward pass finishes them: the DDF group (its chain backward and hash-table scatter run
+# first) with the scalar / latent groups, then the field and proposal groups (last to finish).  Segments of one bucket are adjacent in
+# the slab when the groups are in GROUP_ORDER; otherwise the bucket falls back to per-group messages.
+COMM_BUCKETS = (("ddf_field", "visibility_sigmoid", "illumination_field"), ("fields", "proposal_networks"))
+
+
+def slab_of(params) -> "GradientSlab | None":
+    """the live GradientSlab the first of `params` belongs to (parameters carry a weak reference), or None"""
+    for p in params:
+        ref = getattr(p, "_nsky_slab", None)
+        slab = ref() if ref is not None else None
+        return slab
+    return None
+
+
+class GradientSlab:
+    """ONE flat fp32 buffer holding the gradient of every trainable parameter of the pipeline's groups, group after group, every
+    parameter on a 16-byte boundary.  `p.grad` of each parameter is a view of it, so
+      * the HIP backward kernels accumulate weight / bias / hash-table gradients straight into it (ops.register_grad_sink),
+      * the multi-GPU exchange is ONE all-reduce (mean) of ~110 MB over RCCL / xGMI instead of one message per tensor,
+      * an optimizer -- torch.optim.Adam on the parameters, or the fused `nsky_adam_step` of neusky_amd.engine -- reads it in place.
+    A parameter that received no gradient in a pass keeps its zero-filled slot, so every rank sends the same message whatever was used
+    (`find_unused_parameters=True`, neusky_pipeline.py:199)."""
+
+    def __init__(self, param_groups, world_size: int = 1, order=None):
+        import weakref
+        order = list(GROUP_ORDER if order is None else order)
+        names = [k for k in order if k in param_groups] + [k for k in param_groups if k not in order]
+        self.world_size = world_size
+        self.groups = []  # [(name, [params], numel)]
+        for k in names:
+            ps = [p for p in param_groups[k] if p.requires_grad]
+            if ps:
+                self.groups.append((k, ps, sum((p.numel() + 3) // 4 * 4 for p in ps)))
+        if not self.groups:
+            raise ValueError("no trainable parameter in any group")
+        dev = self.groups[0][1][0].device
+        self.flat = torch.zeros(sum(n for _, _, n in self.groups), device=dev)
+        self.group_views, self.views = {}, []  # name -> slab range; [(p, view)]
+        off = 0
+        me = weakref.ref(self)
+        for name, ps, n in self.groups:
+            self.group_views[name] = self.flat[off:off + n]
+            o = off
+            for p in ps:
+                k = p.numel()
+                view = self.flat[o:o + k].view_as(p)
+                p.grad = view
+                p._nsky_grad_sink = True  # custom backward passes may accumulate into p.grad directly (zeroed before every pass)
+                p._nsky_slab = me
+                self.views.append((p, view))
+                o += (k + 3) // 4 * 4
+            off += n
+        self.rebind()
+        self._backward_seen = False
+        self._clean = True  # every slot no gradient was written to since the last fill is zero
+        self.used = [True] * len(self.views)
+        self._pending = []
+        self.force_exchange = False  # run the collective with one rank too (a one-rank RCCL group: bench.py's self-check, tests)
+        self.exchanged = False  # the pipeline's end-of-pass hook has already exchanged this pass's gradients
+        # The ONE host seam: a slab in host memory exists only in the world-size-2 `gloo` tests of the exchange logic
+        # (tests/test_cpu_distributed.py: layout, buckets, zero-fill semantics, mean) -- there autograd accumulates into the slab views
+        # and nothing is gathered; every training path has the slab in HBM.
+        self.host = dev.type == "cpu"
+
+    def rebind(self) -> None:
+        """(again) after the parameters were re-homed (engine._Group moves `p.data` into its parameter slab): the sinks are keyed by address"""
+        from . import ops
+        for p, _ in self.views:
+            ops.register_grad_sink(p)
+
+    # ------------------------------------------------------------------ one pass
+    def zero_all(self) -> None:
+        """engine form (and the inside of a captured step): zero the slab; parameters whose gradient no kernel writes into the slab itself
+        (everything behind weight norm / padding / plain torch ops) start the backward with an undefined .grad: autograd's AccumulateGrad
+        then keeps the incoming tensor instead of launching one add kernel per parameter, and collect() moves all of them into the slab
+        with one launch.  Between this call and collect() the .grad of such a parameter is None or an autograd-owned temporary."""
+        self.flat.zero_()
+        self.exchanged, self._clean = False, True
+        if self._backward_seen and not self.host:
+            for p, _ in self.views:
+                if not getattr(p, "_nsky_sunk", False):
+                    p.grad = None
+
+    def begin_pass(self) -> None:
+        """trainer form: called by the pipeline at the top of get_train_loss_dict, i.e. after the trainer's own zero_grad (torch's sets
+        .grad = None; set_to_none=False zeroes the views in place and keeps them).  Only the parameters the kernels accumulate into IN
+        PLACE need anything here: a zeroed slot and their view back as .grad.  Every other slot is either overwritten by collect() or
+        zeroed there (no gradient this pass)."""
+        self.exchanged = False
+        if self.host:
+            return
+        none = [p.grad is None for p, _ in self.views]
+        if all(none):
+            self.flat.zero_()  # (the usual case: ONE fill)
+            self._clean = True
+        for (p, view), n in zip(self.views, none):
+            if n and getattr(p, "_nsky_sunk", False):
+                if not self._clean:
+                    view.zero_()
+                p.grad = view
+
+    def collect(self, attach_unused: bool = True) -> None:
+        """after backward: every gradient autograd left outside the slab is moved into its view (ONE launch) and .grad is the view again.
+        attach_unused=False (trainer form): a parameter that received no gradient keeps .grad = None, as under DDP when no rank used it
+        (torch optimizers then skip it) -- which parameters a step uses depends on the config and the step only, never on the rank's rays,
+        so ranks agree; its slot is zero in the message either way.  `self.used`: which parameters hold a gradient of this pass."""
+        self._backward_seen = True
+        if self.host:
+            return
+        from . import hip
+        pairs, used = [], []
+        for p, view in self.views:
+            g = p.grad
+            used.append(g is not None)
+            if g is None:
+                if not self._clean:
+                    view.zero_()
+                if attach_unused:
+                    p.grad = view
+                continue
+            if g.data_ptr() != view.data_ptr():
+                pairs.append((g if g.is_contiguous() else g.contiguous(), view))
+            p.grad = view
+        self.used = used
+        self._clean = False  # (until the next fill)
+        if pairs:
+            hip.gather_segments(pairs)
+
+    # ------------------------------------------------------------------ exchange
+    def buckets(self):
+        """[(group names, slab view)]: the contiguous slab range covered by the groups of each bucket that exist"""
+        out, offs, off = [], {}, 0
+        for name, _, n in self.groups:
+            offs[name] = (off, off + n)
+            off += n
+        done = set()
+        for names in COMM_BUCKETS:
+            gs = [name for name, _, _ in self.groups if name in names]
+            spans = sorted(offs[g] for g in gs)
+            if gs and all(a[1] == b[0] for a, b in zip(spans, spans[1:])):
+                out.append((gs, self.flat[spans[0][0]:spans[-1][1]]))
+            else:
+                out += [([g], self.group_views[g]) for g in gs]
+            done |= set(gs)
+        out += [([name], self.group_views[name]) for name, _, _ in self.groups if name not in done]
+        return out
+
+    def all_reduce(self, bucketed: bool = False) -> None:
+        """mean over ranks, over RCCL / xGMI: ONE all-reduce of the whole slab (~110 MB, 0.5-1.3 ms on 8 x MI355X against a 20 ms
+        step, DESIGN section 6), or -- bucketed -- one asynchronous all-reduce per bucket, issued back to back on RCCL's own stream;
+        wait(group) then makes the consumer of a group wait for its own bucket only, so the second bucket's exchange overlaps the first
+        bucket's optimizer launches."""
+        self._pending = []
+        if self.world_size <= 1 and not self.force_exchange:
+            return
+        backend = dist.get_backend()
+        if backend == "nccl":
+            if bucketed:
+                self._pending = [(gs, dist.all_reduce(view, op=dist.ReduceOp.AVG, async_op=True)) for gs, view in self.buckets()]
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
+        elif not self.host:  # gloo with device gradients (two ranks sharing one GPU in tests): staged through the host
+            host = self.flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            self.flat.copy_(host.div_(self.world_size))
+        elif bucketed:  # gloo (CPU tests) has no AVG: asynchronous SUMs, the division happens when the bucket is waited for
+            self._pending = [(gs, dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True), view) for gs, view in self.buckets()]
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(self.world_size)
+
+    def wait(self, group: "str | None" = None) -> None:
+        """the current stream (RCCL) / the host (gloo) waits for the bucket holding `group`; None: for all of them"""
+        for item in list(self._pending):
+            if group is None or group in item[0]:
+                item[1].wait()
+                if len(item) == 3:
+                    item[2].div_(self.world_size)
+                self._pending.remove(item)

@@ -80,12 +80,17 @@ class DirectionalDistanceField(FieldBase):
         row = torch.cat([local_dirs, nerf_encoding(local_dirs, 2, 2.0)], -1)
         return torch.nn.functional.pad(row, (0, 1)).contiguous()
 
-    def forward_rows(self, sphere_positions: torch.Tensor, xrow: torch.Tensor) -> torch.Tensor:
-        """fast path: xrow [M,16] already encoded (nsky_visibility_rays) -> expected termination distance [M]"""
-        cond = ops.HashEncodeFn.apply(sphere_positions, self.position_encoding.table, self.geom, hip.MODE_RAW, True, 0, 0.0,
-                                      False, False)  # [p | hash(p)] :267-268
+    def condition_rows(self, sphere_positions: torch.Tensor) -> torch.Tensor:
+        """[p | hash(p)] :267-268"""
+        return ops.HashEncodeFn.apply(sphere_positions, self.position_encoding.table, self.geom, hip.MODE_RAW, True, 0, 0.0, False, False)
+
+    def forward_encoded(self, xrow: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
         out = self.ddf(xrow, cond, padded_output=True)
         return ops.SigmoidColumnFn.apply(out, 2 * self.ddf_radius)  # :297-299
+
+    def forward_rows(self, sphere_positions: torch.Tensor, xrow: torch.Tensor) -> torch.Tensor:
+        """fast path: xrow [M,16] already encoded (nsky_visibility_rays) -> expected termination distance [M]"""
+        return self.forward_encoded(xrow, self.condition_rows(sphere_positions))
 
     def get_outputs(self, ray_samples: RaySamples) -> Dict:
         origins = ray_samples.frustums.origins.reshape(-1, 3).contiguous()

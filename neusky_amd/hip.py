@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("NSKY_LIB") or os.path.join(_HERE, "libneusky_hip.so")  # NSKY_LIB: experimental builds (tools/)
+LIB_PATH = os.path.join(_HERE, "libneusky_hip.so")
 
 
 class NeuSkyHipError(RuntimeError):

@@ -315,6 +315,35 @@ class NeuSkyFactoModel(ModelBase):
         with torch.cuda.stream(side):
             self._illumination_pending = self.sample_illumination_compact(cam, ray_bundle.directions, rotation, randoms)
 
+    def start_ddf_fit(self, prep: Dict[str, Any]) -> None:
+        """Evaluate the DDF on the step's fit rows (fit rays | multi-view | sky: DDFModel.prepare_queries) NOW, as a small chain launch
+        of its own on a third stream; compute_visibility_compact picks the result up.  In the same launch as the 262 144 visibility
+        rows (rounds 3-5) they were the 11 workgroups of a ninth round on 11 of 256 CUs; here they run beside the proposal sampler and
+        the field pass of the main rays, and their backward beside the model's.  The hash encode of their sphere points stays on the
+        CALLER's stream: its backward scatters into the DDF table, and the big scatter of the visibility rows writes its chunks back
+        without atomics -- the two must stay ordered."""
+        ddf = self.visibility_field
+        fork = self.second_stream and ops.ASYNC_WGRAD  # (in line: the small node's weight gradients share accumulators with the big one's)
+        pts, xrow, mv_points, sky_gt, dist_w = ops.DDFFitRowsFn.apply(prep["term_dist"], self.ddf_radius, prep)
+        cond = ddf.field.condition_rows(pts)
+        main = torch.cuda.current_stream()
+        side = self._ddf_fit_stream() if fork else main
+        if fork:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            t = ddf.field.forward_encoded(xrow, cond)
+        N, Ns = prep["positions"].shape[0], (prep["sky_o"].shape[0] if prep["sky_o"] is not None else 0)
+        t_main, t_mv, t_sky = torch.split(t, [N, mv_points.shape[0], Ns])
+        # (held until the next step replaces it: memory of the side stream's pool that this stream reads)
+        self._extra_ddf_eval = {"mv_points": mv_points, "t_main": t_main, "t_mv": t_mv, "t_sky": t_sky, "sky_gt": sky_gt,
+                                "distance_weight": dist_w, "stream": side if fork else None, "all": (t, cond, xrow, pts)}
+
+    def _ddf_fit_stream(self):
+        s = getattr(self, "_fit_stream", None)
+        if s is None:
+            s = self._fit_stream = torch.cuda.Stream()
+        return s
+
     # False: the illumination decode runs in line on the caller's stream (bench.py's per-kernel timing iteration, where a kernel
     # sharing the chip with the other stream's work would be timed with that work's share of the CUs missing)
     second_stream: bool = True
@@ -370,13 +399,23 @@ class NeuSkyFactoModel(ModelBase):
         M = R * Dv
         ddf = self.visibility_field
         extra = getattr(self, "_extra_ddf", None) if self.training else None
-        # the DDF-fit rows (rays | multi-view | sky, ddf_model.py:217,319,360) ride behind the visibility rows in the same
-        # buffers and the same chain launches; two kernels write all of them (ops.DDFQueryRowsFn)
+        # the DDF-fit rows (rays | multi-view | sky, ddf_model.py:217,319,360) were evaluated by start_ddf_fit (a small launch of their own
+        # on a third stream: the visibility rows are exactly 8 rounds of the chain kernels); without it they ride behind the visibility
+        # rows in the same buffers and launches (ops.DDFQueryRowsFn)
+        ev = getattr(self, "_extra_ddf_eval", None) if extra is not None else None
+        self._extra_ddf_eval = None
+        ride = extra if ev is None else None
         pts_all, xrow_all, surf_dist, term_dist, mv_points, sky_gt, dist_w = ops.DDFQueryRowsFn.apply(
-            None if extra is None else extra["term_dist"], origins.detach().contiguous(), ray_directions.detach().contiguous(),
-            depth.detach().reshape(-1).contiguous(), sel_dirs, self.ddf_radius, extra)
+            None if ride is None else ride["term_dist"], origins.detach().contiguous(), ray_directions.detach().contiguous(),
+            depth.detach().reshape(-1).contiguous(), sel_dirs, self.ddf_radius, ride)
         t_all = ddf.field.forward_rows(pts_all, xrow_all)  # :1716 -> ddf_model.py:217
-        if extra is not None:
+        if ev is not None:
+            if ev["stream"] is not None:
+                torch.cuda.current_stream().wait_stream(ev["stream"])
+            self._extra_ddf_keep = ev  # (the side stream's tensors stay referenced until the next step's replace them)
+            t_hat, t_main, t_mv, t_sky = t_all, ev["t_main"], ev["t_mv"], ev["t_sky"]
+            mv_points, sky_gt, dist_w = ev["mv_points"], ev["sky_gt"], ev["distance_weight"]
+        elif extra is not None:
             N, Ns = extra["positions"].shape[0], (extra["sky_o"].shape[0] if extra["sky_o"] is not None else 0)
             t_hat, t_main, t_mv, t_sky = torch.split(t_all, [M, N, mv_points.shape[0], Ns])
         else:

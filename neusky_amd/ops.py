@@ -12,8 +12,6 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence
 
-import os
-
 import torch
 import torch.nn.functional as F
 
@@ -30,7 +28,7 @@ from . import hip
 #                    (bench.py's `fp32_exact` line; tests/test_gpu_full_size.py compares the two kernel sets).
 _POLICIES = ("f32", "splith")
 _FWD = {"splith": hip.PREC_F16X2}
-_POLICY = "splith"  # the product runs ONE policy; no environment variable or config key selects another
+_POLICY = "splith"  # the product runs ONE policy; no process variable or config key selects another
 FWD_PRECISION = _FWD.get(_POLICY, hip.PREC_F32)
 BWD_PRECISION = hip.PREC_F32  # per-layer backward GEMMs: exact fp32 MFMA under either policy
 
@@ -57,9 +55,18 @@ def pad4(n: int) -> int:
     return (n + 3) // 4 * 4
 
 
+def _slab_resident(sk) -> bool:
+    """`sk` (a registered slab parameter) holds its pre-zeroed slab view as .grad and takes gradients in place (from its second pass on)"""
+    g = sk.grad
+    return g is not None and getattr(sk, "_nsky_sunk", False) and g.shape == sk.shape and g.is_contiguous()
+
+
 class _PadFn(torch.autograd.Function):
     """zero padding of a small weight / bias to multiples of 4: one copy into a zero-filled (arena) buffer forward, a VIEW of the
-    incoming gradient backward (torch's F.pad costs a pad kernel each way)"""
+    incoming gradient backward (torch's F.pad costs a pad kernel each way).  When the padded tensor is a slab parameter, the backward
+    DEFERS: the view is added to the parameter's slab slot at the end of the pass (finish_pass, behind the final join), so the node
+    neither returns a gradient nor waits for the side stream that may still be accumulating `g` -- the FiLM chains' weight gradients
+    (2 ms for the DDF network) then really run beside the rest of the backward pass instead of being joined by the next node."""
 
     @staticmethod
     def forward(ctx, w, shape, persistent=False):
@@ -69,13 +76,31 @@ class _PadFn(torch.autograd.Function):
         else:
             out[:w.shape[0]].copy_(w)
         ctx.orig = tuple(w.shape)
+        ctx.sink = w if getattr(w, "_nsky_grad_sink", False) else None
+        ctx.set_materialize_grads(False)  # (a consumer that deferred its share itself sends nothing: FilmSirenFn)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        join_weight_gradients()  # (g may be a weight-gradient accumulator of the side stream)
+        if g is None:
+            return None, None, None
         o = ctx.orig
-        return (g[:o[0], :o[1]] if len(o) == 2 else g[:o[0]]), None, None
+        gs = g[:o[0], :o[1]] if len(o) == 2 else g[:o[0]]
+        sk = ctx.sink
+        if sk is not None:
+            if _slab_resident(sk):
+                _DEFERRED_PADS.append((gs, sk.grad))
+                _queue_end_of_pass()
+                return None, None, None
+            sk._nsky_sunk = True  # (slab-resident from the next zero fill on)
+        join_weight_gradients()  # (g may be a weight-gradient accumulator of the side stream)
+        return gs, None, None
+
+
+def _padded(w, shape, persistent):
+    out = _PadFn.apply(w, shape, persistent)
+    out._nsky_pad_of = w if getattr(w, "_nsky_grad_sink", False) else None  # (read by the consumer's forward: FilmSirenFn)
+    return out
 
 
 def pad_weight(w: torch.Tensor, persistent: bool = False) -> torch.Tensor:
@@ -84,13 +109,13 @@ def pad_weight(w: torch.Tensor, persistent: bool = False) -> torch.Tensor:
     o, i = w.shape
     if o % 4 == 0 and i % 4 == 0:
         return w if w.is_contiguous() else w.contiguous()
-    return _PadFn.apply(w, (pad4(o), pad4(i)), persistent)
+    return _padded(w, (pad4(o), pad4(i)), persistent)
 
 
 def pad_bias(b: torch.Tensor, persistent: bool = False) -> torch.Tensor:
     if b.shape[0] % 4 == 0:
         return b if b.is_contiguous() else b.contiguous()
-    return _PadFn.apply(b, (pad4(b.shape[0]),), persistent)
+    return _padded(b, (pad4(b.shape[0]),), persistent)
 
 
 WGRAD_STREAM_MIN_ROWS = 32768
@@ -192,9 +217,39 @@ def _grad_sink_of(t):
     return sk
 
 
-def _end_of_pass() -> None:
+_PASS = {"queued": False}  # the end-of-pass callback of the running backward pass has been queued
+
+
+def _queue_end_of_pass() -> None:
+    if not _PASS["queued"]:
+        _PASS["queued"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass)
+
+
+def finish_pass() -> None:
+    """the end of a backward pass, on the stream `backward()` was called on: the last join of the side streams, the padded parameters'
+    deferred gradients into their slab slots, then everything this pass shared or kept alive is released.  Idempotent: autograd runs it
+    as a final callback, and whoever reads the slab first (the pipeline's exchange hook, queued in front of it) calls it itself."""
+    join_weight_gradients()
+    for gs, view in _DEFERRED_PADS:
+        view.add_(gs)
+    reset_pass_state()
+
+
+_end_of_pass = finish_pass
+
+
+def reset_pass_state() -> None:
+    """forget the per-pass state.  Runs at the end of every backward pass AND at every step boundary (begin_step, the pipeline's
+    get_train_loss_dict): autograd skips the final callbacks of a backward pass that raised (out of memory, a failed capture), and
+    stale entries would make the next pass skip its join, return None for gradients that were never accumulated, and re-wait a side
+    stream of an aborted capture."""
     _SHARED_GRADS.clear()
     _SUNK_BIAS.clear()
+    _WGRAD_PENDING.clear()
+    _WGRAD_KEEP.clear()
+    _DEFERRED_PADS.clear()
+    _PASS["queued"] = False
 
 
 def first_only(first, t):
@@ -211,8 +266,7 @@ def shared_grad(like, bias_like):
     hit = _SHARED_GRADS.get(key)
     if hit is not None:
         return hit[1], hit[2], False
-    if not _SHARED_GRADS:  # first shared accumulator of this backward pass: forget them all when the pass ends
-        torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass)
+    _queue_end_of_pass()  # forget the shared accumulators when the pass ends
     db = None
     sk = _grad_sink_of(bias_like) if bias_like is not None else None
     if sk is not None:
@@ -243,12 +297,13 @@ def shared_grad(like, bias_like):
 # the captured graphs' private pools; the tree before the side stream: 0 of 8, with plain references: see DESIGN section 4.)
 # capture mode of every HIP graph of this package (the train step, the eval-latent fit, the render chunk).  thread_local: only the capturing
 # thread is policed -- other host threads (the RCCL watchdog, a loader staging the next batch) may legally touch the runtime during a
-# capture.  The captures themselves make no unsafe call from any thread ("global" passes too).  (lab switch for the flake hunt of DESIGN section 7)
-CAPTURE_MODE = os.environ.get("NSKY_CAPTURE_MODE", "thread_local")
-ASYNC_WGRAD = os.environ.get("NSKY_ASYNC_WGRAD", "1") != "0"  # (lab switch for same-box A/B runs; arithmetic is identical either way)
+# capture.  The captures themselves make no unsafe call from any thread ("global" passes too).  (tools/lab.py sets another for the flake hunt of DESIGN section 7; nothing in the package does)
+CAPTURE_MODE = "thread_local"
+ASYNC_WGRAD = True  # (tools/lab.py clears it for same-box A/B runs; nothing in the package does; arithmetic is identical either way)
 _WGRAD_SIDE: dict = {}     # device index -> side stream
 _WGRAD_PENDING: list = []  # side streams with unjoined work of THIS backward pass
 _WGRAD_KEEP: list = []     # operands of the unjoined launches
+_DEFERRED_PADS: list = []  # (gradient view, slab view) of padded slab parameters: added by finish_pass
 
 
 def async_weight_gradients(launch, operands) -> None:
@@ -264,20 +319,21 @@ def async_weight_gradients(launch, operands) -> None:
     with torch.cuda.stream(side):
         launch()
     _WGRAD_KEEP.append([t for t in operands if t is not None])
-    if not _WGRAD_PENDING:
-        torch.autograd.Variable._execution_engine.queue_callback(join_weight_gradients)
+    _queue_end_of_pass()
     if side not in _WGRAD_PENDING:
         _WGRAD_PENDING.append(side)
 
 
 def join_weight_gradients() -> None:
-    """the current stream waits for every weight-gradient launch made so far in this backward pass"""
+    """the current stream waits for every weight-gradient launch made so far in this backward pass.  A join never forgets anything: the
+    model runs on two streams and a mid-pass join on one of them (a weight-norm / padding node) must leave the side streams pending for
+    the other and for the end-of-pass callback, and the operands stay referenced until that callback (_end_of_pass) -- dropping them at
+    a mid-pass join would let the joining stream's allocator hand out memory the side stream may still read for another consumer.
+    A redundant wait costs an event."""
     if _WGRAD_PENDING:
         cur = torch.cuda.current_stream()
         for side in _WGRAD_PENDING:
             cur.wait_stream(side)
-        _WGRAD_PENDING.clear()
-        _WGRAD_KEEP.clear()
 
 
 def join_unless_sunk(*bias_grads) -> None:
@@ -383,6 +439,7 @@ def _order_after(hit_stream, hit_seq) -> None:
 
 def begin_step(device=None) -> None:
     _STEP_SEQ[0] += 1
+    reset_pass_state()
     _PLANES.clear()
     _SDF_STREAMS.clear()
     _FIELD_STREAMS.clear()
@@ -411,7 +468,7 @@ def ld(t):
 # input gradients through FROZEN dense layers (the RENI++ attention decoder's 37 linear layers per step): three bf16 terms per operand,
 # six MFMAs per product (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi: ~2^-24, bf16 keeps fp32's exponent range so a gradient needs no
 # pre-scaling) instead of the exact-fp32 MFMA at 1/16 of the bf16 rate
-FROZEN_DX_PRECISION = hip.PREC_BF16X3 if os.environ.get("NSKY_FROZEN_DX", "bf16x3") == "bf16x3" else hip.PREC_F32
+FROZEN_DX_PRECISION = hip.PREC_BF16X3
 
 
 def grad_input(dZ, W, M, k_in, n_red, out, precision=None, **epi):
@@ -628,6 +685,7 @@ class FilmSirenFn(torch.autograd.Function):
             ctx.save_for_backward(x, cond, x.new_empty(0), *hs, *ys, *zs, *wb)
             ctx.cfg = (n_map, n_film, train_weights, need_dcond, M, H, Hm)
             ctx.sinks = [w if getattr(w, "_nsky_grad_sink", False) else None for w in wb]
+            ctx.pad_sinks = [getattr(w, "_nsky_pad_of", None) for w in wb]  # slab parameters behind a padding copy (_PadFn defers)
             return res
         if save:
             hs = [torch.empty(M, Hm, device=dev) for _ in range(n_map)]
@@ -736,8 +794,19 @@ class FilmSirenFn(torch.autograd.Function):
                 if native:
                     hip.wgrad_native_batch(native, M)
 
-            if all(sunk):  # every gradient lands in the optimizer slab: nothing this node returns depends on the launches
-                async_weight_gradients(launch, [d_res, x, cond, dfp, gmax, *ys, *hs, *dzs, *dpres])
+            # every gradient lands in the optimizer slab -- directly, or (a padded copy of a slab parameter) as an add of this node's
+            # accumulator deferred to the end of the pass -- so nothing the backward pass runs before its end depends on the launches: they
+            # go to the side stream.  (The deferred share is NOT handed to autograd: the padding node may have a second producer -- the
+            # DDF-fit rows are a node of their own -- and autograd would sum the two accumulators while this one is still being written.)
+            pad = [(not sunk[i]) and ctx.pad_sinks[i] is not None and _slab_resident(ctx.pad_sinks[i]) for i in range(len(wb))]
+            if all(sunk[i] or pad[i] for i in range(len(wb))):
+                async_weight_gradients(launch, [d_res, x, cond, dfp, gmax, *ys, *hs, *dzs, *(dpres or [])])
+                for i, t in enumerate(wb):
+                    if pad[i]:
+                        o = ctx.pad_sinks[i].shape
+                        _DEFERRED_PADS.append((grads[i][:o[0], :o[1]] if len(o) == 2 else grads[i][:o[0]], ctx.pad_sinks[i].grad))
+                        sunk[i] = True
+                _queue_end_of_pass()
             else:
                 launch()
         return (d_x, d_cond, None, None, None, None, *[None if sunk[i] else g for i, g in enumerate(grads)])
@@ -1586,6 +1655,49 @@ class DDFQueryRowsFn(torch.autograd.Function):
         d_t = torch.empty(N, device=positions.device)
         hip.ddf_fit_rows_bwd(positions, directions, t, mv_points, d_xrow[M + N:M + 2 * N], d_t)
         return (d_t.view(tshape),) + (None,) * 6
+
+
+class DDFFitRowsFn(torch.autograd.Function):
+    """The DDF-fit rows ALONE (fit rays | multi-view | sky; hip.ddf_fit_rows_fwd, ddf_model.py:193-360) in buffers of their own, for
+    NeuSkyFactoModel.start_ddf_fit: 263 456 rows are 8 full rounds of the four-wave chain kernels plus 11 workgroups, i.e. a ninth
+    round on 11 of 256 CUs (8 % of the DDF forward and of its FiLM backward), so the 1 312 fit rows run as a small launch of their
+    own, early, on a third stream, beside kernels that leave most of the chip idle, and the visibility rows are exactly 8 rounds.
+    Differentiable input: the fit rays' ground-truth termination distance, through the multi-view rows' directions.
+    -> pts [E,3], xrow [E,16], mv_points [N,3], sky_gt [Ns], distance_weight [N]"""
+
+    @staticmethod
+    def forward(ctx, term_dist_fit, radius, fit):
+        dev = fit["positions"].device
+        N = fit["positions"].shape[0]
+        n_mv = N if fit["want_mv"] else 0
+        sky_o = fit["sky_o"]
+        Ns = sky_o.shape[0] if sky_o is not None else 0
+        E = N + n_mv + Ns
+        pts = torch.empty(E, 3, device=dev)
+        xrow = torch.empty(E, 16, device=dev)
+        mv_points = torch.empty(n_mv, 3, device=dev)
+        sky_gt = torch.empty(Ns, device=dev)
+        dist_w = torch.empty(N, device=dev) if fit["want_weight"] else None
+        t = term_dist_fit.detach().reshape(-1).contiguous()
+        hip.ddf_fit_rows_fwd(fit["positions"], fit["directions"], t, fit["mv_points_in"], fit["seed"], fit["counter"], sky_o, fit["sky_d"],
+                             radius, bool(n_mv), fit["weight_exp"], fit["weight_include_z"], pts, xrow,
+                             mv_points if n_mv else None, sky_gt if Ns else None, dist_w)
+        ctx.save_for_backward(fit["positions"], fit["directions"], t, mv_points)
+        ctx.cfg = (N, n_mv, tuple(term_dist_fit.shape))
+        ctx.set_materialize_grads(False)
+        outs = (pts, xrow, mv_points, sky_gt, dist_w if dist_w is not None else torch.empty(0, device=dev))
+        ctx.mark_non_differentiable(outs[0], *outs[2:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, _dp, d_xrow, *_):
+        N, n_mv, tshape = ctx.cfg
+        if n_mv == 0 or d_xrow is None or not ctx.needs_input_grad[0]:
+            return None, None, None
+        positions, directions, t, mv_points = ctx.saved_tensors
+        d_t = torch.empty(N, device=positions.device)
+        hip.ddf_fit_rows_bwd(positions, directions, t, mv_points, d_xrow[N:2 * N], d_t)
+        return d_t.view(tshape), None, None
 
 
 class VisibilityFinishFn(torch.autograd.Function):

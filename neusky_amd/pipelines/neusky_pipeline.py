@@ -2,14 +2,22 @@
 (neusky/pipelines/neusky_pipeline.py:99-515) for `__init__` (:117-202), `get_param_groups` (:227-238),
 `get_train_loss_dict` (:241-291), `generate_ddf_samples` (:493-515), `_setup_visibility_field` (:446-491).
 
-Multi-GPU: one process per GPU; parameters are replicated and the flat gradient is all-reduced (mean) over
-RCCL once per step (`neusky_amd.engine.Optimizers.all_reduce_gradients`, on the slab every group's gradients live in).  The reference wraps the model in DDP and
-then dereferences `.visibility_field` on the wrapper (:249-250, :278), which does not work (SURVEY.md F6);
-here the model is never wrapped, so the same call sites work at any world size.
+Multi-GPU: one process per GPU; parameters are replicated and the gradients are all-reduced (mean) over RCCL once per step, BY THE
+PIPELINE: at world_size > 1 every gradient lives in one flat slab (`neusky_amd.distributed.GradientSlab`, `p.grad` are views of it)
+and the loss dict `get_train_loss_dict` returns carries an autograd node whose backward queues an end-of-pass callback that collects
+the gradients into the slab and all-reduces it -- what DDP's reducer does for the reference (:198-199).  So nerfstudio's trainer loop
+(`zero_grad_all -> get_train_loss_dict -> sum -> backward -> optimizer.step`) sees synchronised `p.grad` with torch optimizers, and
+`neusky_amd.engine` (fused Adam over the same slab) is one more client.  The reference wraps the model in DDP and then dereferences
+`.visibility_field` on the wrapper (:249-250, :278), which does not work; here the model is never wrapped, so the same
+call sites work at any world size.
+
+`graph_replay` (config, off by default like every non-reference key): after `graph_replay_warmup` eager calls, `get_train_loss_dict`
+captures forward + losses + backward in a HIP graph (pipelines/train_graph.py) and from then on loads the datamanager's next batch
+into the graph's static buffers, replays, exchanges, and returns a loss whose `.backward()` only hands the slab views to `p.grad`.
 """
 from __future__ import annotations
 
-import os
+import weakref
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Type
 
@@ -40,9 +48,28 @@ class NeuSkyPipelineConfig(ConfigBase):
     test_mode: Optional[str] = None
     stop_sdf_gradients: bool = False
     least_squares_global_scale: bool = False
+    graph_replay: bool = False  # (not a reference key) the train step as a HIP-graph replay behind get_train_loss_dict
+    graph_replay_warmup: int = 3  # eager calls before the capture
+    bucketed_exchange: bool = False  # (not a reference key) the all-reduce as two asynchronous buckets instead of one message
 
     def setup(self, **kwargs):
         return self._target(self, **kwargs)
+
+
+class _ExchangeFn(torch.autograd.Function):
+    """identity; its backward -- the first node of the trainer's backward pass -- queues the pipeline's end-of-pass exchange"""
+
+    @staticmethod
+    def forward(ctx, x, pipe_ref):
+        ctx.pipe_ref = pipe_ref
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        pipe = ctx.pipe_ref()
+        if pipe is not None:
+            pipe._queue_exchange()
+        return g, None
 
 
 class NeuSkyPipeline(PipelineBase):
@@ -73,11 +100,20 @@ class NeuSkyPipeline(PipelineBase):
         self.step_of_last_latent_optimisation = 0  # neusky_pipeline.py:202
         self.eval_image_num = 0
         self.max_eval_num = max(int(self.num_val_data if self.test_mode == "val" else self.num_test_data), 1)
+        self.grad_scaler = grad_scaler
         self.grad_sync = None
+        self._slab = None          # distributed.GradientSlab: built here at world_size > 1, else on first use (graph replay, engine)
+        self._train_graph = None   # train_graph.TrainGraph once captured (config.graph_replay)
+        self._train_calls = 0
+        self._exchange_queued = False
+        # True at world_size > 1.  (A one-rank process group -- the RCCL self-check of bench.py and tests -- may set it to run the
+        # exchange with one rank: an AVG all-reduce over one rank is the identity.)
+        self.exchange_gradients = world_size > 1
         if world_size > 1:
             from ..distributed import ReplicaSync
             self.grad_sync = ReplicaSync(self, world_size)
             self.grad_sync.broadcast_parameters()  # identical replicas (all parameters, frozen ones too, and buffers), then the :200 barrier
+            self.gradient_slab()  # the reducer of :198-199
             self.grad_sync.barrier()
 
     @property
@@ -119,8 +155,90 @@ class NeuSkyPipeline(PipelineBase):
                 data[k] = data[k].detach()
         return data
 
+    # ------------------------------------------------------------------ gradients (the DDP wrapper's job, :198-199)
+    def gradient_slab(self):
+        """the flat gradient slab over every trainable parameter of get_param_groups() (groups in the optimizer-config order)"""
+        if self._slab is None:
+            from ..distributed import GradientSlab, slab_of
+            groups = self.get_param_groups()
+            self._slab = slab_of([p for ps in groups.values() for p in ps if p.requires_grad]) or GradientSlab(groups, self.world_size)
+            self._slab.world_size = self.world_size
+        return self._slab
+
+    def exchange_with_one_rank(self) -> None:
+        """run the exchange although world_size = 1 (a one-rank RCCL process group: bench.py's self-check and
+        tests/test_gpu_trainer_surface.py -- the collective path on hardware when one GPU is all there is)"""
+        self.exchange_gradients = True
+        self.gradient_slab().force_exchange = True
+
+    def _queue_exchange(self) -> None:
+        if not self._exchange_queued:
+            self._exchange_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_pass)
+
+    def _end_of_pass(self) -> None:
+        """end of the trainer's backward pass (autograd final callback, on the stream `backward()` was called on, after the leaf
+        streams were joined): collect -> all-reduce(mean); `p.grad` are the slab views when the trainer's optimizer runs"""
+        from .. import ops
+        self._exchange_queued = False
+        slab = self.gradient_slab()
+        ops.finish_pass()  # (its own callback may be queued behind this one)
+        slab.collect(attach_unused=False)
+        slab.all_reduce(self.config.bucketed_exchange)
+        slab.wait()
+        slab.exchanged = True
+
+    def _with_gradient_exchange(self, loss_dict):
+        """every differentiable scalar of the loss dict behind an identity node whose backward queues _end_of_pass (once per pass)"""
+        from ..model_components.losses import LossDict
+        ref = weakref.ref(self)
+        wrap = lambda t: _ExchangeFn.apply(t, ref) if torch.is_tensor(t) and t.requires_grad else t  # noqa: E731
+        out = LossDict({k: wrap(v) for k, v in loss_dict.items()})
+        parts, total = getattr(loss_dict, "parts", None), getattr(loss_dict, "total", None)
+        if parts:
+            out.parts = [(wrap(x), c, sc) for x, c, sc in parts]
+        if total is not None:
+            out.total = wrap(total)
+        return out
+
     def get_train_loss_dict(self, step: int, ray_bundle=None, batch=None, randoms: Optional[Dict] = None):
-        """:241-291.  ray_bundle/batch/randoms may be injected (tests, bench); otherwise they come from the datamanager."""
+        """:241-291 -> (model_outputs, loss_dict, metrics_dict).  ray_bundle/batch/randoms may be injected (tests, bench); otherwise
+        they come from the datamanager.  At world_size > 1 the backward pass of the returned losses ends with the gradient exchange;
+        with config.graph_replay the step (and its backward) is a graph replay from call graph_replay_warmup + 1 on."""
+        from .. import ops
+        ops.reset_pass_state()  # (a backward pass that raised leaves its end-of-pass callbacks unrun)
+        self._exchange_queued = False
+        self._train_calls += 1
+        if self.config.graph_replay and self.model.training and torch.is_grad_enabled() \
+                and (self._train_graph is not None or self._train_calls > self.config.graph_replay_warmup):
+            return self._replayed_train_loss_dict(step, ray_bundle, batch, randoms)
+        exchange = self.exchange_gradients and self.model.training and torch.is_grad_enabled()
+        if exchange:
+            self.gradient_slab().begin_pass()
+        model_outputs, loss_dict, metrics_dict = self._train_loss_dict(step, ray_bundle, batch, randoms)
+        if exchange:
+            loss_dict = self._with_gradient_exchange(loss_dict)
+        return model_outputs, loss_dict, metrics_dict
+
+    def _replayed_train_loss_dict(self, step: int, ray_bundle=None, batch=None, randoms: Optional[Dict] = None):
+        sky = None
+        if ray_bundle is None:
+            ray_bundle, batch = self.datamanager.next_train(step)
+        if randoms is None or "sky_ray_bundle" not in randoms:
+            sky = self.datamanager.get_sky_ray_bundle(self.config.num_sky_rays)
+        if self._train_graph is None:
+            from .train_graph import TrainGraph
+            self._train_graph = TrainGraph(self, self.gradient_slab(), ray_bundle, batch, warmup=1, start_step=step, randoms=randoms)
+        tg = self._train_graph
+        tg.replay(step, ray_bundle, batch, sky, randoms)
+        if self.exchange_gradients:
+            tg.slab.all_reduce(self.config.bucketed_exchange)
+            tg.slab.wait()
+            tg.slab.exchanged = True
+        return tg.outputs, tg.trainer_loss_dict(), tg.metrics
+
+    def _train_loss_dict(self, step: int, ray_bundle=None, batch=None, randoms: Optional[Dict] = None):
+        """the step itself (:241-291), eager: what get_train_loss_dict runs and what TrainGraph captures"""
         model = self.model
         if model.visibility_field is not None and not model.config.fit_visibility_field:
             model.visibility_field.eval()
@@ -141,6 +259,7 @@ class NeuSkyPipeline(PipelineBase):
                                                           None if randoms is None else randoms.get("mv_points"))
             prep["stop_gradients"] = self.config.stop_sdf_gradients
             model._extra_ddf, model._extra_ddf_out = prep, None
+            model.start_ddf_fit(prep)  # a small chain launch of its own, third stream; picked up inside the model's forward
         try:
             model_outputs = model(ray_bundle, batch=batch, step=step, randoms=randoms)
         finally:

@@ -3,6 +3,7 @@ one stream, HIP events: python tools/bench_film_kernels.py [ddf|illum] [reps]   
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import lab; lab.apply()  # NSKY_* lab switches (tools/lab.py)
 import torch
 from neusky_amd import hip
 from test_gpu_film_chain import _net, _inputs

@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
 for p_ in (ROOT, os.path.join(ROOT, "tests")):
     sys.path.insert(0, p_)
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import lab; lab.apply()  # NSKY_* lab switches (tools/lab.py)
 import torch
 import test_gpu_graph as T
 from neusky_amd.engine import GraphedTrainStep

@@ -1,0 +1,40 @@
+"""Lab switches for the scripts under tools/ -- the package itself reads no process variable.
+
+    import lab; lab.apply()          # before anything imports neusky_amd.hip
+
+NSKY_LIB=<path>            an experimental build of the library instead of neusky_amd/libneusky_hip.so
+NSKY_ASYNC_WGRAD=0         weight gradients on the launching stream (same arithmetic; same-box A/B runs)
+NSKY_CAPTURE_MODE=global   capture mode of every HIP graph (flake hunt)
+NSKY_FROZEN_DX=f32         input gradients through frozen dense layers on the exact-fp32 MFMA (attention decoder A/B)
+"""
+import importlib.util
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def use_library(path: str) -> None:
+    """load neusky_amd.hip against another shared library (must run before the first import of neusky_amd.hip)"""
+    import neusky_amd
+    assert "neusky_amd.hip" not in sys.modules, "neusky_amd.hip is already bound to the in-tree library"
+    spec = importlib.util.find_spec("neusky_amd.hip")
+    src = open(spec.origin).read()
+    marker = 'LIB_PATH = os.path.join(_HERE, "libneusky_hip.so")'
+    assert marker in src
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["neusky_amd.hip"] = mod
+    exec(compile(src.replace(marker, f"LIB_PATH = {os.path.abspath(path)!r}"), spec.origin, "exec"), mod.__dict__)
+    neusky_amd.hip = mod
+
+
+def apply() -> None:
+    if os.environ.get("NSKY_LIB"):
+        use_library(os.environ["NSKY_LIB"])
+    from neusky_amd import hip, ops
+    if os.environ.get("NSKY_ASYNC_WGRAD", "1") == "0":
+        ops.ASYNC_WGRAD = False
+    if os.environ.get("NSKY_CAPTURE_MODE"):
+        ops.CAPTURE_MODE = os.environ["NSKY_CAPTURE_MODE"]
+    if os.environ.get("NSKY_FROZEN_DX", "bf16x3") != "bf16x3":
+        ops.FROZEN_DX_PRECISION = hip.PREC_F32

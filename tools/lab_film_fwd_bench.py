@@ -4,6 +4,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CODE = r'''
 import sys, os, ctypes
 sys.path.insert(0, "%s"); sys.path.insert(0, "%s/tests"); sys.path.insert(0, "%s/tools")
+import lab; lab.apply()
 import torch
 from neusky_amd import hip
 from test_gpu_film_chain import _net, _inputs
