@@ -573,6 +573,39 @@ def render_1080p_line(pipe, device, chunk=4096):
     return res
 
 
+def render_pmc_traffic(timeout_s: float = 200.0):
+    """HBM traffic of the render pass from two rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE) of ONE eagerly launched
+    480 x 270 frame (tools/bench_render.py 270 480 eager: same chunk size and kernels as the 1080p frame, 1/16 of its rays, one dispatch
+    record per launch) -> (dict, note) or (None, reason)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    base = tempfile.mkdtemp(prefix="nsky_pmc_render_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "NSKY_BENCH_LAUNCHER"):
+        env.pop(k, None)
+    try:
+        dirs = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            dirs[c] = os.path.join(base, c)
+            cmd = [exe, "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", dirs[c], "--", sys.executable,
+                   os.path.join(ROOT, "tools", "bench_render.py"), "270", "480", "eager"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {c} pass of the render exited with code {r.returncode}"
+        t = pmc_traffic(dirs["FETCH_SIZE"], dirs["WRITE_SIZE"], iters=1.0)
+        return {"frame": "480x270, eager launches, chunk 4096", "GB_per_480x270_frame": t["whole_step_GB"],
+                "GB_per_1080p_frame_scaled_x16": 16.0 * t["whole_step_GB"], "bytes_per_launch": t["bytes_per_launch"],
+                "GB_per_frame_by_kernel": t["GB_per_iteration"]}, "collected in this run"
+    except Exception as exc:  # noqa: BLE001
+        return None, f"{type(exc).__name__}: {str(exc)[:160]}"
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+
+
 STEP_KERNEL_SOURCES_EXCLUDE = ("attention.hip",)  # kernels of the attention-decoder key only: not in the headline step the counters describe
 
 
@@ -626,6 +659,114 @@ def pmc_traffic(fetch_dir: str, write_dir: str, iters: float = 0.0) -> dict:
             "GB_per_iteration": {k: v[0] / iters / 1e9 for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:20]}}
 
 
+def _family_of(kernel_name: str) -> str:
+    import re
+    k = re.sub(r"\(anonymous namespace\)::|^void ", "", kernel_name)
+    k = re.split(r"\((?![a-z])", k)[0][:90]
+    name = k.split("(")[0].strip()
+    return re.sub(r"<(\d+)[^>]*>", r"<\1>", name) if name.startswith("film_") else name.split("<")[0]
+
+
+def pmc_mfma(sq_dir: str) -> dict:
+    """matrix-pipe occupancy and effective shader clock by kernel family from ONE rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES
+    GRBM_GUI_ACTIVE pass of an eager bench run.  MI355X_MICROARCH.md: SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD (32 per
+    32x32x16 MFMA), summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs, so a dispatch lasts GUI_ACTIVE / 8
+    cycles:  mfma_busy = MFMA_BUSY / (1024 * GUI_ACTIVE / 8),  clock = GUI_ACTIVE / 8 / duration (reads high below ~0.3 ms)."""
+    import collections
+    import csv
+    import glob
+    acc = collections.defaultdict(lambda: {"SQ_VALU_MFMA_BUSY_CYCLES": 0.0, "GRBM_GUI_ACTIVE": 0.0, "n": 0, "dur_ns": 0.0})
+    cfiles = sorted(glob.glob(os.path.join(sq_dir, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]
+    for f in cfiles:
+        for row in csv.DictReader(open(f)):
+            c = row["Counter_Name"]
+            if c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
+                a = acc[_family_of(row["Kernel_Name"])]
+                a[c] += float(row["Counter_Value"])
+                if c == "GRBM_GUI_ACTIVE":
+                    a["n"] += 1
+                    if "Start_Timestamp" in row and "End_Timestamp" in row:
+                        a["dur_ns"] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+    if not any(a["dur_ns"] for a in acc.values()):  # older layouts: the durations sit in the kernel trace of the same pass
+        for f in sorted(glob.glob(os.path.join(sq_dir, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1:]:
+            for row in csv.DictReader(open(f)):
+                fam = _family_of(row["Kernel_Name"])
+                if fam in acc:
+                    acc[fam]["dur_ns"] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+    out = {}
+    for fam, a in acc.items():
+        if a["GRBM_GUI_ACTIVE"] > 0 and a["n"] > 0:
+            cyc = a["GRBM_GUI_ACTIVE"] / 8.0
+            out[fam] = {"mfma_busy": a["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc), "launches": a["n"],
+                        "avg_launch_us_under_counters": a["dur_ns"] / a["n"] * 1e-3 if a["dur_ns"] else None,
+                        "clock_mhz": cyc / (a["dur_ns"] * 1e-9) * 1e-6 if a["dur_ns"] else None}
+    if not out:
+        raise RuntimeError("no SQ counter records found")
+    return out
+
+
+class PowerSampler:
+    """package power (and the shader clock level, where the driver exposes it) of the GPU during the timed region, from sysfs
+    (hwmon power1_average / power1_input in microwatts, pp_dpm_sclk's starred level), ~50 samples per second on a host thread; an
+    ordinary user may read them.  Anything missing -> the fields stay None."""
+
+    def __init__(self, index: int = 0):
+        import glob
+        self.samples, self.clocks, self._stop, self._th = [], [], False, None
+        self.power_files, self.sclk_files = [], []
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk")) or glob.glob(os.path.join(c, "hwmon/hwmon*/power1_*"))]
+        # the box may expose more cards in sysfs than the one this process was given: match the PCI address of torch's device
+        self.card = None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+            for c in cards:
+                if os.path.basename(os.path.realpath(c)).lower().startswith(want):
+                    self.card = c
+        except Exception:  # noqa: BLE001  (an older torch without the PCI fields)
+            pass
+        if self.card is None and len(cards) == 1:
+            self.card = cards[0]
+        if self.card is not None:
+            c = self.card
+            self.power_files = [f for f in (glob.glob(os.path.join(c, "hwmon/hwmon*/power1_average")) + glob.glob(os.path.join(c, "hwmon/hwmon*/power1_input")))][:1]
+            self.sclk_files = [os.path.join(c, "pp_dpm_sclk")] if os.path.exists(os.path.join(c, "pp_dpm_sclk")) else []
+
+    def _run(self):
+        import re
+        while not self._stop:
+            try:
+                for f in self.power_files:
+                    self.samples.append(float(open(f).read().strip()) * 1e-6)
+                for f in self.sclk_files:
+                    m = re.search(r"(\d+)\s*Mhz\s*\*", open(f).read(), re.I)
+                    if m:
+                        self.clocks.append(float(m.group(1)))
+            except (OSError, ValueError):
+                pass
+            time.sleep(0.02)
+
+    def __enter__(self):
+        import threading
+        if self.power_files or self.sclk_files:
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._th is not None:
+            self._th.join(timeout=1.0)
+
+    def summary(self):
+        avg = lambda v: (sum(v) / len(v)) if v else None  # noqa: E731
+        return {"power_w": avg(self.samples), "power_w_max": max(self.samples) if self.samples else None, "sclk_level_mhz": avg(self.clocks),
+                "samples": max(len(self.samples), len(self.clocks)), "card": self.card,
+                "source": "sysfs hwmon power1_average / pp_dpm_sclk of the card with this device's PCI address, during the timed region"
+                if (self.samples or self.clocks) else "not exposed to this user on this box"}
+
+
 def live_pmc_traffic(timeout_s: float = 240.0):
     """the two --pmc passes collected IN THIS RUN: rank 0 (N = 1) starts `rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py
     --no-spawn ...` (an eager two-step bench: one dispatch record per launch) as a child process, twice, and reads the counters back.
@@ -651,7 +792,17 @@ def live_pmc_traffic(timeout_s: float = 240.0):
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
             if r.returncode != 0:
                 return None, f"rocprofv3 --pmc {c} pass exited with code {r.returncode}"
-        return pmc_traffic(dirs["FETCH_SIZE"], dirs["WRITE_SIZE"]), "collected in this run (two rocprofv3 --kernel-trace --pmc passes of an eager two-step bench)"
+        out = pmc_traffic(dirs["FETCH_SIZE"], dirs["WRITE_SIZE"])
+        try:  # third pass: matrix-pipe busy cycles and the effective clock per kernel family
+            dirs["SQ"] = os.path.join(base, "SQ")
+            cmd = [exe, "--kernel-trace", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "--output-format", "csv", "-d", dirs["SQ"], "--",
+                   sys.executable, os.path.abspath(__file__), "--no-spawn", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-graph",
+                   "--no-exact-f32", "--no-extra-configs", "--no-live-pmc"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            out["mfma"] = pmc_mfma(dirs["SQ"]) if r.returncode == 0 else {"error": f"SQ pass exited with code {r.returncode}"}
+        except Exception as exc:  # noqa: BLE001
+            out["mfma"] = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
+        return out, "collected in this run (rocprofv3 --kernel-trace --pmc passes of an eager two-step bench: FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE)"
     except Exception as exc:  # noqa: BLE001
         return None, f"{type(exc).__name__}: {str(exc)[:160]}"
     finally:
@@ -920,12 +1071,14 @@ def main():
         for i in range(args.warmup):
             stepper.step(1000 + i, batches[i][0], batches[i][1], skies[i])
         barrier()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            j = args.warmup + i
-            loss, _, _ = stepper.step(2000 + i, batches[j][0], batches[j][1], skies[j])
-        barrier()
-        dt = time.perf_counter() - t0
+        power = PowerSampler(dev_index)
+        with power:
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                j = args.warmup + i
+                loss, _, _ = stepper.step(2000 + i, batches[j][0], batches[j][1], skies[j])
+            barrier()
+            dt = time.perf_counter() - t0
         # HIP events cannot be read back from inside a replayed graph: the heavy kernels' launches are timed with events on
         # one extra EAGER iteration of the same step (same kernels, shapes and stream) right after the timed region
         timer.install()
@@ -942,12 +1095,14 @@ def main():
             rb, b = batches[i]
             train_iteration(pipe, opt, 1000 + i, ray_bundle=rb, batch=b)
         barrier()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            rb, b = batches[args.warmup + i]
-            loss, _, _ = train_iteration(pipe, opt, 2000 + i, ray_bundle=rb, batch=b)
-        barrier()
-        dt = time.perf_counter() - t0
+        power = PowerSampler(dev_index)
+        with power:
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                rb, b = batches[args.warmup + i]
+                loss, _, _ = train_iteration(pipe, opt, 2000 + i, ray_bundle=rb, batch=b)
+            barrier()
+            dt = time.perf_counter() - t0
         timer.install()
         pipe.model.second_stream = False
         ops.ASYNC_WGRAD = False
@@ -1013,6 +1168,8 @@ def main():
                                 "describes_these_kernels": tj.get("kernel_sources_sha") == sha})
             for k in kernels:
                 k["pmc_bytes_per_launch"] = tj.get("bytes_per_launch", {}).get(k["kernel"].split(" ")[0])
+                m = (tj.get("mfma") or {}).get(k["kernel"].split(" ")[0]) or {}
+                k["mfma_busy"], k["clock_mhz_under_counters"] = m.get("mfma_busy"), m.get("clock_mhz")
 
         def bound_of(k):
             hb = k.get("algorithmic_bytes_per_launch")
@@ -1025,7 +1182,8 @@ def main():
             roof = {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["achieved_GBs"] / HBM_PEAK_GBS}
         top3 = [{"kernel": k["kernel"], "ms_per_step": k["ms_per_step"], "launches_per_step": k["launches"] / iters, "bound": bound_of(k),
                  "mfma_frac_of_833_tflops": k["frac_of_833_tflops"], "hbm_frac_of_8000_GBs": k["frac_of_8000_GBs"],
-                 "pmc_bytes_per_launch": k.get("pmc_bytes_per_launch")} for k in kernels[:3]]
+                 "pmc_bytes_per_launch": k.get("pmc_bytes_per_launch"),
+                 "mfma_busy": k.get("mfma_busy"), "clock_mhz": k.get("clock_mhz_under_counters")} for k in kernels[:3]]
         ms_step = 1e3 * dt / args.steps
         step_roof = {"algorithmic_tflop": STEP_ALGORITHMIC_TFLOP, "tf_s": STEP_ALGORITHMIC_TFLOP / (ms_step * 1e-3),
                      "frac_of_833": STEP_ALGORITHMIC_TFLOP / (ms_step * 1e-3) / peak,
@@ -1060,6 +1218,7 @@ def main():
                          "algorithmic_flops_per_launch": dom["algorithmic_flops_per_launch"],
                          "executed_flops_per_launch": dom["executed_flops_per_launch"]},
             "kernels": kernels[:8],
+            "device_state": power.summary(),  # package power / shader clock level sampled during the timed region
             "fp32_exact": exact,
             # the process group the step's gradient exchange runs on (0 ranks: --no-spawn, no group) and its collectives exercised
             # before the timed region (rccl_selfcheck)
@@ -1074,6 +1233,13 @@ def main():
             line["trainer_surface"] = trainer_surface_line(device)
             line["forward_only"] = forward_only_line(pipe, device)
             line["render_1080p"] = render_1080p_line(pipe, device)
+            if not args.no_live_pmc:  # the saves-free forward's HBM traffic, from counters
+                rp, note = render_pmc_traffic()
+                line["render_1080p"]["pmc_traffic"] = rp if rp is not None else {"error": note}
+                if rp is not None:
+                    gb = rp["GB_per_1080p_frame_scaled_x16"]
+                    line["render_1080p"]["hbm"] = {"GB_per_frame": gb, "tb_s": gb / line["render_1080p"]["ms_per_frame"],
+                                                   "frac_of_8": gb / line["render_1080p"]["ms_per_frame"] / (HBM_PEAK_GBS * 1e-3)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         line_out.write(json.dumps(line) + "\n")

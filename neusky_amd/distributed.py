@@ -246,3 +246,64 @@ class GradientSlab:
                 if len(item) == 3:
                     item[2].div_(self.world_size)
                 self._pending.remove(item)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Camera-sharded illumination decode (the one place the path shards beyond rays; neusky_model.py:445-551).  In a training step EVERY
+# training camera's environment light is decoded at the step's D directions (static shapes: U x D rows whatever the batch holds) --
+# 153 600 rows, ~3 ms of the 20 ms step that every rank would repeat.  With `NeuSkyPipelineConfig.shard_illumination_decode` rank r
+# decodes cameras r::N and the [U, D, 3] colours are all-gathered (1.8 MB); backward, each rank's gradient w.r.t. ALL cameras' colours
+# (from its own rays) is reduce-scattered (sum) to the owners, which backpropagate it through their share of the decode.  The owner's
+# latent gradient is then the SUM over ranks of what plain data parallelism would have spread over them, every other rank's is zero,
+# and the slab's all-reduce(mean) gives sum / N on every rank: exactly the mean the unsharded replicas get.  All ranks must use the same
+# direction set in a step (the sampler's generator is seeded rank-free in this mode).
+def _all_gather_rows(local: torch.Tensor) -> torch.Tensor:
+    """[n, ...] (same shape on every rank) -> [N, n, ...]"""
+    n = dist.get_world_size()
+    if dist.get_backend() == "nccl" or not local.is_cuda:
+        if dist.get_backend() == "nccl":
+            out = torch.empty((n,) + tuple(local.shape), device=local.device, dtype=local.dtype)
+            dist.all_gather_into_tensor(out, local.contiguous())
+            return out
+        outs = [torch.empty_like(local) for _ in range(n)]
+        dist.all_gather(outs, local.contiguous())
+        return torch.stack(outs)
+    host = local.detach().cpu()  # gloo with device tensors (two ranks sharing one GPU in tests): staged through the host
+    outs = [torch.empty_like(host) for _ in range(n)]
+    dist.all_gather(outs, host)
+    return torch.stack(outs).to(local.device)
+
+
+def _reduce_scatter_rows(full: torch.Tensor) -> torch.Tensor:
+    """[N, n, ...] on every rank -> sum over ranks of full[this rank]: [n, ...]"""
+    if dist.get_backend() == "nccl":
+        out = torch.empty(tuple(full.shape[1:]), device=full.device, dtype=full.dtype)
+        dist.reduce_scatter_tensor(out, full.contiguous(), op=dist.ReduceOp.SUM)
+        return out
+    host = full.detach().cpu().contiguous()  # gloo has no reduce-scatter: all-reduce, keep the own block
+    dist.all_reduce(host, op=dist.ReduceOp.SUM)
+    return host[dist.get_rank()].to(full.device)
+
+
+class CameraAllGather(torch.autograd.Function):
+    """colours of the cameras rank r decoded (cameras r, r + N, r + 2N, ...: [ceil((U - r) / N), D, 3]) -> colours of all U cameras
+    on every rank; backward: reduce-scatter(sum) of the gradient w.r.t. all cameras' colours"""
+
+    @staticmethod
+    def forward(ctx, local, U, rank, world):
+        n_pad = (U + world - 1) // world
+        n_loc = local.shape[0]
+        if n_loc < n_pad:
+            local = torch.cat([local, local.new_zeros((n_pad - n_loc,) + tuple(local.shape[1:]))])
+        g = _all_gather_rows(local)  # [N, n_pad, D, 3]: camera i N + r sits at g[r, i]
+        ctx.cfg = (U, n_loc, n_pad, world)
+        return g.transpose(0, 1).reshape((n_pad * world,) + tuple(local.shape[1:]))[:U].contiguous()
+
+    @staticmethod
+    def backward(ctx, d_cols):
+        U, n_loc, n_pad, world = ctx.cfg
+        tail = tuple(d_cols.shape[1:])
+        if U < n_pad * world:
+            d_cols = torch.cat([d_cols, d_cols.new_zeros((n_pad * world - U,) + tail)])
+        full = d_cols.reshape((n_pad, world) + tail).transpose(0, 1).contiguous()  # [N, n_pad, ...]
+        return _reduce_scatter_rows(full)[:n_loc], None, None, None

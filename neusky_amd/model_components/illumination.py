@@ -163,6 +163,9 @@ class IcosahedronSampler:
             from .. import hip
             from ..utils.utils import device_rng
             seed, counter = device_rng(self, "illumination_directions", 2, base.device)
+            if getattr(self, "shared_across_ranks", False):  # camera-sharded decode: every rank draws the SAME rotation in a step
+                from ..utils.utils import _rank
+                seed = (int(seed) - 7919 * _rank()) & (2**63 - 1)
             dirs = torch.empty(D, 3, device=base.device)
             sel = torch.empty(D // 2, dtype=torch.int32, device=base.device)
             self.last_rotation = torch.empty(3, 3, device=base.device)

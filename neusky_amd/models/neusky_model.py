@@ -279,6 +279,16 @@ class NeuSkyFactoModel(ModelBase):
             # are being fitted: static shape, no torch.unique host sync, hipGraph-safe); rows of cameras absent from the
             # batch are never read by the renderer and receive zero gradient
             inverse = camera_indices
+            shard = getattr(self, "illumination_shard", None) if self.training else None
+            if shard is not None and rotation is None:
+                # camera-sharded decode (distributed.CameraAllGather): this rank decodes cameras r::N, the colours are all-gathered,
+                # the gradient w.r.t. them reduce-scattered; the rays' own background rows are this rank's rays: decoded here
+                from ..distributed import CameraAllGather
+                r, n = shard
+                own = self.illumination_field.forward_grid(dirs, latents[r::n].contiguous(), scales[r::n].contiguous())
+                cols = CameraAllGather.apply(own, latents.shape[0], r, n)
+                bg = self.illumination_field(ray_directions, latents[camera_indices], scales[camera_indices], None)
+                return dirs, cols, inverse.to(torch.int32), bg
             if rotation is None:  # the rays' own background rows (:535-549) ride in the same decoder pass
                 cols, bg = self.illumination_field.forward_grid_and_rays(dirs, latents, scales, ray_directions, camera_indices)
                 return dirs, cols, inverse.to(torch.int32), bg
@@ -330,10 +340,12 @@ class NeuSkyFactoModel(ModelBase):
         side = self._ddf_fit_stream() if fork else main
         if fork:
             side.wait_stream(main)
+        N, Ns = prep["positions"].shape[0], (prep["sky_o"].shape[0] if prep["sky_o"] is not None else 0)
         with torch.cuda.stream(side):
             t = ddf.field.forward_encoded(xrow, cond)
-        N, Ns = prep["positions"].shape[0], (prep["sky_o"].shape[0] if prep["sky_o"] is not None else 0)
-        t_main, t_mv, t_sky = torch.split(t, [N, mv_points.shape[0], Ns])
+            # (the split too: autograd runs a node's backward on its forward's stream, and the split's backward -- enqueued late, it is
+            # one of the first nodes of the step -- would otherwise sit at the end of the MAIN stream's queue in front of the small chain)
+            t_main, t_mv, t_sky = torch.split(t, [N, mv_points.shape[0], Ns])
         # (held until the next step replaces it: memory of the side stream's pool that this stream reads)
         self._extra_ddf_eval = {"mv_points": mv_points, "t_main": t_main, "t_mv": t_mv, "t_sky": t_sky, "sky_gt": sky_gt,
                                 "distance_weight": dist_w, "stream": side if fork else None, "all": (t, cond, xrow, pts)}
@@ -412,7 +424,9 @@ class NeuSkyFactoModel(ModelBase):
         if ev is not None:
             if ev["stream"] is not None:
                 torch.cuda.current_stream().wait_stream(ev["stream"])
-            self._extra_ddf_keep = ev  # (the side stream's tensors stay referenced until the next step's replace them)
+            # the side stream's tensors stay referenced until the next step's replace them -- their MEMORY, not their autograd graph:
+            # a graph kept past its step keeps the parameters' AccumulateGrad nodes, which remember the stream they were made on
+            self._extra_ddf_keep = [t.detach() for t in ev["all"]]
             t_hat, t_main, t_mv, t_sky = t_all, ev["t_main"], ev["t_mv"], ev["t_sky"]
             mv_points, sky_gt, dist_w = ev["mv_points"], ev["sky_gt"], ev["distance_weight"]
         elif extra is not None:
@@ -840,6 +854,7 @@ class NeuSkyFactoModel(ModelBase):
             for p, g in zip(params, old_grads):
                 p.grad = g
             self.fitting_eval_latents = False  # :1588
+            ops.retire_graph(locals().get("graph"))  # never destroyed next to its last replay (ops.retire_graph: a runtime use-after-free)
         return trace
 
     def begin_frame(self, camera_index: int, rotation: Optional[torch.Tensor] = None) -> None:
@@ -860,6 +875,8 @@ class NeuSkyFactoModel(ModelBase):
         if st is None or st[0].shape != dirs.shape or st[0].device != dirs.device:
             st = (torch.empty_like(dirs), torch.empty_like(cols), torch.empty_like(sel))
             self._frame_static = st
+            for old in getattr(self, "_chunk_runners", {}).values():
+                ops.retire_graph(old.graph)
             self._chunk_runners = {}
         st[0].copy_(dirs); st[1].copy_(cols); st[2].copy_(sel)
         self._frame_illumination = (st[0], st[1], st[2], cam, rotation)
@@ -893,6 +910,8 @@ class NeuSkyFactoModel(ModelBase):
             if runner is None:
                 runner = _ChunkRunner(self, chunk, flat, use_graph)
                 if len(self._chunk_runners) >= 4:
+                    for old in self._chunk_runners.values():
+                        ops.retire_graph(old.graph)
                     self._chunk_runners.clear()
                 self._chunk_runners[key] = runner
             for i in range(0, num_rays, chunk):
@@ -926,6 +945,12 @@ class _ChunkRunner:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, capture_error_mode=ops.CAPTURE_MODE):
                 self.out = model.forward(self.rb)
+
+    def __del__(self):
+        try:  # (dropped with its model, possibly right behind its last replay: retired, not destroyed here -- ops.retire_graph)
+            ops.retire_graph(self.__dict__.pop("graph", None))
+        except Exception:  # noqa: BLE001
+            pass
 
     def _load(self, flat: RayBundle, a: int, b: int) -> None:
         n = b - a

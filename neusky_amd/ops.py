@@ -306,6 +306,36 @@ _WGRAD_KEEP: list = []     # operands of the unjoined launches
 _DEFERRED_PADS: list = []  # (gradient view, slab view) of padded slab parameters: added by finish_pass
 
 
+# ---- retiring a captured graph -------------------------------------------------------------------------------------------------
+# Round 6 root-caused the host-heap damage that rounds 4-5 chased behind the eval-latent fits: a use-after-free in the
+# HIP runtime (libamdhip64 7.0.51831).  hipGraphLaunch holds a reference to the executable graph until the launch's last command
+# completes; if the caller's handle is destroyed first (torch.cuda.CUDAGraph dropped right after its last replay) that reference is the
+# LAST one and is released by the completion callback on ROCr's async-events thread -- HsaAmdSignalHandler -> VirtualGPU::
+# updateCommandsState -> Event::processCallbacks -> GraphExec::~GraphExec -> Stream::terminate -> HostQueue::terminate frees the graph's
+# internal streams' roc::VirtualGPU objects, and HsaAmdSignalHandler then touches the VirtualGPU it was called for: freed memory whenever
+# the completing command ran on one of the graph's own streams (tools/heap_guard.c with HEAP_GUARD_FENCE_SIZE=920 faults at that
+# instruction; tools/hip_graph_destroy_uaf.py reproduces it with torch alone).  A synchronize in front of the destruction is not enough:
+# the callback runs on another thread, some time after the signal the synchronize waited for.  So no captured graph of this package is
+# destroyed near its last launch: it is RETIRED -- kept alive here -- and destroyed by a later call, on the caller's thread, once it has
+# been idle for seconds (the destructor then holds the last reference and runs outside the signal handler).
+_RETIRED_GRAPHS: list = []  # [(graph or object holding graphs, time.monotonic() at retirement)]
+RETIRE_SECONDS = 2.0
+
+
+def retire_graph(obj) -> None:
+    """keep `obj` (a torch.cuda.CUDAGraph, or anything whose destruction destroys captured graphs) alive past its last launch; destroy
+    what was retired more than RETIRE_SECONDS ago, after a device synchronize"""
+    import time
+    now = time.monotonic()
+    if obj is not None:
+        _RETIRED_GRAPHS.append((obj, now))
+    if any(now - t > RETIRE_SECONDS for _, t in _RETIRED_GRAPHS) and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize()
+        keep = [(o, t) for o, t in _RETIRED_GRAPHS if now - t <= RETIRE_SECONDS]
+        del _RETIRED_GRAPHS[:]
+        _RETIRED_GRAPHS.extend(keep)  # (the dropped entries' destructors run here, on this thread)
+
+
 def async_weight_gradients(launch, operands) -> None:
     """run `launch()` (weight-gradient kernels only: nothing the caller returns may depend on them) on the side stream"""
     if not ASYNC_WGRAD:
@@ -428,13 +458,23 @@ def _stream_buffers(key, nbytes, n_table, device):
     return hit[0], hit[1]
 
 
-def _order_after(hit_stream, hit_seq) -> None:
-    """a cached weight preparation (planes / packed stream) made on another stream of THIS step: order the current stream after it.
+def _ready_mark():
+    """(stream, event recorded behind what the caller has just launched on it): what a cache entry keeps of its preparation"""
+    s = torch.cuda.current_stream()
+    e = torch.cuda.Event()
+    e.record(s)
+    return s, e
+
+
+def _order_after(mark, hit_seq) -> None:
+    """a cached weight preparation (planes / packed stream) made on another stream of THIS step: order the current stream after it --
+    after the PREPARATION (an event recorded behind it), not after everything the other stream was handed since: a wait for the whole
+    stream made the small DDF-fit backward, enqueued late by autograd, wait for the main stream's entire backward (round 6).
     An entry that survives from an earlier step (a frozen network's stream) needs no edge -- steps are ordered by their caller --
     and must not get one: the stream it was made on may be the legacy stream, which a capturing stream cannot wait for."""
     cur = torch.cuda.current_stream()
-    if hit_seq == _STEP_SEQ[0] and hit_stream != cur:
-        cur.wait_stream(hit_stream)
+    if hit_seq == _STEP_SEQ[0] and mark[0] != cur:
+        cur.wait_event(mark[1])
 
 
 def begin_step(device=None) -> None:
@@ -455,7 +495,7 @@ def _planes(W, n_rows, n_k, transpose, precision):
     key = (W.data_ptr(), W._version, ld(W), n_rows, n_k, transpose, precision)
     hit = _PLANES.get(key)
     if hit is None:
-        hit = _PLANES[key] = (W, hip.split_planes(W, n_rows, n_k, transpose, precision), torch.cuda.current_stream(), _STEP_SEQ[0])
+        hit = _PLANES[key] = (W, hip.split_planes(W, n_rows, n_k, transpose, precision), _ready_mark(), _STEP_SEQ[0])
     else:  # split on another stream (parallel passes of one step share the weights): order this stream after it
         _order_after(hit[2], hit[3])
     return hit[1]
@@ -635,7 +675,7 @@ def _film_stream(wb, n_map, n_film, mw, mb, mwo, mbo, fw, fb, ow, ob, direction=
         # zero-filled once: the pad slabs of partial groups are streamed through LDS but never multiplied
         stream, table = _stream_buffers(("film", stable_id(wb[0]), n_map, n_film, direction), nbytes, hip.FILM_TABLE_FLOATS, wb[0].device)
         hip.film_pack(net, stream, table, direction)
-        hit = _FILM_STREAMS[key] = (list(wb), net, stream, table, torch.cuda.current_stream(), _STEP_SEQ[0])
+        hit = _FILM_STREAMS[key] = (list(wb), net, stream, table, _ready_mark(), _STEP_SEQ[0])
     else:  # packed on another stream of the same step: order this stream after it
         _order_after(hit[4], hit[5])
     return hit[1], hit[2], hit[3]
@@ -1059,7 +1099,7 @@ def _field_pack(kind, weights, layers_fn):
     if hit is None:
         dev = weights[0].device
         pk = hip.chain_pack(layers_fn(), dev, lambda nb, nt: _stream_buffers((kind,) + tuple(stable_id(w) for w in weights), nb, nt, dev))
-        hit = _FIELD_STREAMS[key] = (weights, pk, torch.cuda.current_stream(), _STEP_SEQ[0])
+        hit = _FIELD_STREAMS[key] = (weights, pk, _ready_mark(), _STEP_SEQ[0])
     else:
         _order_after(hit[2], hit[3])
     return hit[1]
@@ -1203,7 +1243,7 @@ def _sdf_stream(W0, b0, W1, b1, W2, b2, GF, beta, direction):
         nbytes, _ = hip.sdf_stream_layout(net, direction)
         stream, table = _stream_buffers(("sdf", stable_id(W0), stable_id(W1), GF, direction), nbytes, hip.FILM_TABLE_FLOATS, W0.device)
         hip.sdf_pack(net, stream, table, direction)
-        hit = _SDF_STREAMS[key] = (keep, net, stream, table, torch.cuda.current_stream(), _STEP_SEQ[0])
+        hit = _SDF_STREAMS[key] = (keep, net, stream, table, _ready_mark(), _STEP_SEQ[0])
     else:
         _order_after(hit[4], hit[5])
     return hit[1], hit[2], hit[3]

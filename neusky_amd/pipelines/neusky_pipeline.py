@@ -51,6 +51,7 @@ class NeuSkyPipelineConfig(ConfigBase):
     graph_replay: bool = False  # (not a reference key) the train step as a HIP-graph replay behind get_train_loss_dict
     graph_replay_warmup: int = 3  # eager calls before the capture
     bucketed_exchange: bool = False  # (not a reference key) the all-reduce as two asynchronous buckets instead of one message
+    shard_illumination_decode: bool = False  # (not a reference key) world_size > 1: rank r decodes cameras r::N (distributed.CameraAllGather)
 
     def setup(self, **kwargs):
         return self._target(self, **kwargs)
@@ -114,6 +115,10 @@ class NeuSkyPipeline(PipelineBase):
             self.grad_sync = ReplicaSync(self, world_size)
             self.grad_sync.broadcast_parameters()  # identical replicas (all parameters, frozen ones too, and buffers), then the :200 barrier
             self.gradient_slab()  # the reducer of :198-199
+            if config.shard_illumination_decode:
+                import torch.distributed as dist
+                self._model.illumination_shard = (dist.get_rank(), world_size)
+                self._model.illumination_sampler.shared_across_ranks = True  # one direction set per step on all ranks
             self.grad_sync.barrier()
 
     @property
@@ -228,6 +233,10 @@ class NeuSkyPipeline(PipelineBase):
             sky = self.datamanager.get_sky_ray_bundle(self.config.num_sky_rays)
         if self._train_graph is None:
             from .train_graph import TrainGraph
+            if getattr(self.model, "illumination_shard", None) is not None:
+                import torch.distributed as dist
+                if dist.get_backend() != "nccl":
+                    raise RuntimeError("graph_replay with shard_illumination_decode needs the RCCL backend: the colours' all-gather is part of the captured step")
             self._train_graph = TrainGraph(self, self.gradient_slab(), ray_bundle, batch, warmup=1, start_step=step, randoms=randoms)
         tg = self._train_graph
         tg.replay(step, ray_bundle, batch, sky, randoms)

@@ -85,6 +85,13 @@ class TrainGraph:
         self.used = list(slab.used)  # which parameters the captured pass gives a gradient
         torch.cuda.synchronize()
 
+    def __del__(self):
+        # a pipeline dropped right behind its last replay: the graph is retired, not destroyed here (ops.retire_graph)
+        try:
+            ops.retire_graph(self.__dict__.pop("graph", None))
+        except Exception:  # noqa: BLE001  (interpreter shutdown: modules may be gone; the process is ending anyway)
+            pass
+
     def _body(self, step):
         self.slab.zero_all()
         outputs, loss_dict, metrics = self.pipeline._train_loss_dict(step, ray_bundle=self.rb, batch=self.batch, randoms=self.randoms)

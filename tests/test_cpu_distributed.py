@@ -254,3 +254,41 @@ def test_nccl_branch_of_the_gradient_exchange(monkeypatch):
     solo = E.Optimizers(E.neusky_optimizers(), {k: [torch.nn.Parameter(torch.randn(4))] for k in params}, world_size=1)
     solo.all_reduce_gradients()
     assert calls == []
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# camera-sharded illumination decode: the all-gather of the colours and the reduce-scatter of their gradient (distributed.CameraAllGather)
+def _camera_gather_worker(rank, world, port, out_q):
+    if not _init(rank, world, port, out_q):
+        return
+    from neusky_amd.distributed import CameraAllGather
+    U, D = 5, 4  # cameras 0, 2, 4 on rank 0 (three rows), 1, 3 on rank 1 (two rows + one row of padding in the message)
+    own = torch.arange(rank, U, world)
+    f = lambda cams: (cams[:, None, None] * 100 + torch.arange(D)[None, :, None] * 10 + torch.arange(3)[None, None, :]).double()  # noqa: E731
+    local = f(own).clone().requires_grad_(True)
+    cols = CameraAllGather.apply(local, U, rank, world)
+    fwd_ok = bool(torch.equal(cols, f(torch.arange(U))))
+    w = torch.randn(U, D, 3, generator=torch.Generator().manual_seed(5 + rank), dtype=torch.float64)  # this rank's rays' gradient w.r.t. ALL cameras
+    (cols * w).sum().backward()
+    w_all = sum(torch.randn(U, D, 3, generator=torch.Generator().manual_seed(5 + r), dtype=torch.float64) for r in range(world))
+    bwd_ok = bool(torch.allclose(local.grad, w_all[own])) and local.grad.shape == local.shape
+    out_q.put((rank, fwd_ok, bwd_ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_camera_gather():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_camera_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    return _collect(q, procs, 120)
+
+
+def test_camera_all_gather_and_reduce_scatter_two_ranks():
+    os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+    res = _run_with_one_rendezvous_retry(_run_camera_gather)
+    assert all(r[1] for r in res), "all-gathered colours are not in camera order"
+    assert all(r[2] for r in res), "the owner's gradient is not the sum over ranks of the gradient w.r.t. its cameras' colours"

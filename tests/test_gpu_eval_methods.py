@@ -1,13 +1,12 @@
 """The evaluation half of the pipeline surface (neusky_pipeline.py:294-444, neusky_model.py:1079-1335): the methods run on the
 HIP path, keep the reference's return contracts and restore train mode.
 
-Each parametrisation runs in a FRESH interpreter (this file as a script).  Round 5 chased an intermittent abort of exactly this test --
-SIGABRT / SIGSEGV / "free(): invalid pointer" at the first synchronisation behind the eval-latent fit, about one run in ten of the suite on
-some boxes, on the round-4 tree as much as on this one (tools/flake.sh, tools/flake_ab.sh) -- and only ever when
-the process had built and dropped other pipelines and captured graphs before; 400 fit / render / forward cycles in processes of their own
-never failed (tools/flake_eval2.py).  Not root-caused; the isolation keeps one test's host-heap state from deciding another's."""
+IN-PROCESS again (round 6).  Rounds 4-5 saw this test abort now and then (SIGABRT / SIGSEGV / "free(): invalid pointer" behind the
+eval-latent fit) and round 5 hid it behind fresh interpreters.  Root cause, found with tools/heap_guard.c (HEAP_GUARD_FENCE_SIZE=920): a
+use-after-free in the HIP runtime when a captured graph is destroyed while its last launch's completion callback is still pending
+(ops.retire_graph has the call chain; tools/hip_graph_destroy_uaf.py reproduces it with torch alone).  Every captured graph of the
+package is now retired instead of destroyed next to its last launch; tests/test_gpu_soak.py runs the sequence that used to abort."""
 import os
-import subprocess
 import sys
 
 import pytest
@@ -19,8 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.mark.parametrize("conditioning", ["FiLM", "Attention"])
 def test_eval_methods_run_and_keep_their_contracts(conditioning):
-    out = subprocess.run([sys.executable, os.path.abspath(__file__), conditioning], cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0 and "eval methods ok" in out.stdout, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
+    run_eval_methods(conditioning)
 
 
 def run_eval_methods(conditioning):

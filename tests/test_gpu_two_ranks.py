@@ -20,10 +20,12 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _launch(world, tmp):
+def _launch(world, tmp, shard=False):
     port = _free_port()
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    outs = [os.path.join(tmp, f"w{world}_r{r}.npz") for r in range(world)]
+    if shard:
+        env["NSKY_TEST_SHARD_ILLUMINATION"] = "1"
+    outs = [os.path.join(tmp, f"w{world}_r{r}{'_shard' if shard else ''}.npz") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "two_rank_worker.py"), str(r), str(world), str(port), outs[r]],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = []
@@ -66,3 +68,23 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path):
         assert np.isfinite(sg).all() and np.abs(se - sg).max() <= 2e-3 * np.abs(se).max(), np.abs(se - sg).max()
         assert int(w["moved"]) > 40, "the Adam step behind the graph replay moved too few parameters"
         assert abs(float(w["loss"]) - float(w["graph_loss"])) < 1e-4 * abs(float(w["loss"]))
+
+
+def test_camera_sharded_illumination_decode_equals_one_rank(tmp_path):
+    """VERDICT r5 item 5 (neusky_model.py:445-551): with `shard_illumination_decode` rank r decodes the environment light of cameras r::2
+    only, the [U, D, 3] colours are all-gathered and their gradient reduce-scattered (distributed.CameraAllGather); the all-reduced
+    gradient of every parameter -- the illumination latents and scales above all -- equals the one-rank gradient of the concatenated
+    batch within the same bar as the unsharded two-rank run.  (gloo, both ranks on cuda:0; unmeasured on hardware.)"""
+    two = _launch(2, str(tmp_path), shard=True)
+    one = _launch(1, str(tmp_path))
+    keys = sorted(k for k in one.files if k.startswith("g:"))
+    assert keys == sorted(k for k in two.files if k.startswith("g:")) and len(keys) > 40
+    bad = []
+    for k in keys:
+        a, b = two[k].astype(np.float64), one[k].astype(np.float64)
+        scale = np.abs(b).max()
+        if np.abs(a - b).max() > 2e-3 * scale + 1e-9:
+            bad.append((k, float(np.abs(a - b).max()), float(scale)))
+    assert not bad, bad
+    lat = [k for k in keys if "illumination_latents" in k or k.endswith("train_scale")]
+    assert lat and all(np.abs(one[k]).max() > 0 for k in lat), "the probe batch must reach the latents"

@@ -22,6 +22,7 @@ def build(dev, world, rank):
     from util_step import make_randoms, randomise, small_pipeline_config
     torch.manual_seed(0)
     cfg = small_pipeline_config(R=R_TOTAL // world, num_prop=(24, 12), S=8, D=24, images=5, vmf=(2, 8), sky=8)
+    cfg.shard_illumination_decode = bool(os.environ.get("NSKY_TEST_SHARD_ILLUMINATION")) and world > 1  # (tests/test_gpu_two_ranks.py)
     pipe = cfg.setup(device=dev, world_size=world, local_rank=rank)
     pipe.train()
     randomise(pipe)
@@ -81,6 +82,12 @@ def main():
     # which remember the (legacy) stream they were made on and would run on it inside the capture below
     loss_eager = float(loss)
     del loss, ld
+    if getattr(pipe.model, "illumination_shard", None) is not None:  # (the colours' all-gather cannot be captured under gloo: eager only)
+        if rank == 0:
+            np.savez(out, loss=loss_eager, slab_eager=slab_eager, **{"g:" + k: v for k, v in eager.items()})
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # ---- the same iteration captured in a HIP graph, replayed, all-reduced, Adam-stepped
     before = {n: p.detach().clone() for n, p in pipe.named_parameters() if p.requires_grad}
     stepper = GraphedTrainStep(pipe, opt, rbs, bs, warmup=1, start_step=10_000, randoms=rs)

@@ -21,7 +21,8 @@ d = torch.einsum("ij,hwj->hwi", cR, d_cam)
 d = d / d.norm(dim=-1, keepdim=True)
 rb = RayBundle(origins=cp.expand(H, W, 3).contiguous().to(dev), directions=d.to(dev), pixel_area=torch.ones(H, W, 1, device=dev),
                camera_indices=torch.zeros(H, W, 1, dtype=torch.long, device=dev), metadata={"directions_norm": torch.ones(H, W, 1, device=dev)})
-for use_graph in (True, False):
+modes = {"graph": (True,), "eager": (False,)}.get(sys.argv[3] if len(sys.argv) > 3 else "", (True, False))  # (eager: one dispatch record per launch for --pmc passes)
+for use_graph in modes:
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out = pipe.model.get_outputs_for_camera_ray_bundle(rb, camera_index=0, chunk=chunk, use_graph=use_graph)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0

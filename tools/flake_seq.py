@@ -61,7 +61,8 @@ if os.environ.get("NSKY_FLAKE_PRELOAD"):  # every kernel of the evaluation-metho
 files = [f for f in sys.argv[1].split(",") if f]
 keep = ["-k", sys.argv[2]] if len(sys.argv) > 2 else []  # optional pytest -k expression
 if files:
-    rc = pytest.main(["-m", "gpu", "-q", "-p", "no:cacheprovider"] + keep + [os.path.join("tests", f) for f in files], plugins=[SweepPlugin()])
+    # (-s: the guard reports on fd 2, which pytest's capture would swallow)
+    rc = pytest.main(["-m", "gpu", "-q", "-s", "-p", "no:cacheprovider", "-p", "no:faulthandler"] + keep + [os.path.join("tests", f) for f in files], plugins=[SweepPlugin()])
     print("pytest rc", rc, flush=True)
     sweep("after the preceding tests")
 if os.environ.get("NSKY_FLAKE_COLLECT"):  # destroy what the preceding tests left (dead pipelines, their graphs and pools) HERE, step by step

@@ -172,9 +172,61 @@ static void violation(void) {
   if (!getenv("HEAP_GUARD_CONTINUE")) abort();
 }
 
+/* ---- fenced blocks: HEAP_GUARD_FENCE_SIZE=<n> gives every allocation of exactly n bytes a page of its own (mmap); free() makes the page
+   inaccessible for good instead of parking the block in the quarantine, so a write -- or read -- through a stale pointer FAULTS at the
+   instruction that does it: the SIGSEGV handler prints the faulting address and the native backtrace.  free() of a fenced block prints
+   who frees it.  (Found with it in round 6: the 920-byte roc::VirtualGPU of a destroyed stream, decremented at offset 152 after its free.) */
+#include <signal.h>
+#include <sys/mman.h>
+#define FENCE_MAGIC 0x46454e4345444221ull /* "FENCEDB!" */
+static size_t g_fence_size = 0;
+static long g_fence_n = 0;
+
+static void fence_segv(int sig, siginfo_t* si, void* uc) {
+  (void)uc;
+  say("heap_guard: signal %d at address %p -- an access to a FREED fenced block if the address lies in one of the pages listed at their free; native backtrace:\n", sig, si ? si->si_addr : 0);
+  backtrace_here();
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+
+static void* fence_alloc(size_t n, void* caller) {
+  size_t len = (HDR + n + TAIL + 4095) & ~(size_t)4095;
+  char* page = (char*)mmap(0, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (page == MAP_FAILED) return 0;
+  char* user = page + HDR;
+  Block* b = (Block*)page;
+  b->magic = FENCE_MAGIC ^ (uint64_t)(uintptr_t)user;
+  b->size = n;
+  b->caller = caller;
+  b->base = page;
+  memset(user + n, TAIL_BYTE, TAIL);
+  __atomic_add_fetch(&g_fence_n, 1, __ATOMIC_RELAXED);
+  return user;
+}
+
+static int fence_is(void* user) {
+  if (!g_fence_size || ((uintptr_t)user & 4095) != HDR) return 0;
+  Block* b = (Block*)((char*)user - HDR);
+  return b->magic == (FENCE_MAGIC ^ (uint64_t)(uintptr_t)user);
+}
+
+static void fence_free(void* user, void* caller) {
+  Block* b = (Block*)((char*)user - HDR);
+  char who[256], by[256];
+  name_of(b->caller, who, sizeof who);
+  name_of(caller, by, sizeof by);
+  size_t len = (HDR + b->size + TAIL + 4095) & ~(size_t)4095;
+  say("heap_guard: fenced block %p (%lu bytes, allocated by %s) FREED by %s; page %p..%p is now inaccessible; backtrace of the free:\n", user,
+      (unsigned long)b->size, who, by, (void*)b->base, (void*)((char*)b->base + len));
+  backtrace_here();
+  mprotect(b->base, len, PROT_NONE);
+}
+
 /* ---- allocation ---- */
 static void* guard_alloc(size_t align, size_t n, void* caller) {
   if (n > (SIZE_MAX >> 1)) { errno = ENOMEM; return 0; }
+  if (g_fence_size && n == g_fence_size && align <= 16 && !g_inside) return fence_alloc(n, caller);
   size_t lead = align > HDR ? align : HDR;
   char* base = (char*)(align > 16 ? __libc_memalign(lead, lead + n + TAIL) : __libc_malloc(lead + n + TAIL));
   if (!base) return 0;
@@ -193,6 +245,7 @@ static void* guard_alloc(size_t align, size_t n, void* caller) {
 
 static void guard_free(void* user, void* caller) {
   if (!user) return;
+  if (fence_is(user)) { fence_free(user, caller); return; }
   lock();
   int known = live_remove(user);
   unlock();
@@ -240,23 +293,56 @@ __attribute__((constructor)) static void heap_guard_init(void) {
   g_inside++;
   backtrace(warm, 4); /* loads libgcc's unwinder now */
   g_inside--;
+  const char* f = getenv("HEAP_GUARD_FENCE_SIZE");
+  if (f && strtoul(f, 0, 10) > 0) {
+    g_fence_size = (size_t)strtoul(f, 0, 10);
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_sigaction = fence_segv;
+    sa.sa_flags = SA_SIGINFO | SA_RESETHAND;
+    sigaction(SIGSEGV, &sa, 0);
+    sigaction(SIGBUS, &sa, 0);
+  }
 }
 
-/* every live block and every quarantined block; -> violations found (printed); never aborts.  Call it at a quiet point: the blocks are
-   checked from a snapshot of the registry, outside the lock (the report itself allocates) */
+/* quiet forms of the two checks (no report, no allocation): usable under the lock */
+static int live_ok(void* user) {
+  Block* b = (Block*)((char*)user - HDR);
+  if (b->magic != (MAGIC ^ (uint64_t)(uintptr_t)user)) return 0;
+  const unsigned char* t = (const unsigned char*)user + b->size;
+  for (int i = 0; i < TAIL; ++i)
+    if (t[i] != TAIL_BYTE) return 0;
+  return 1;
+}
+static int dead_ok(void* user) {
+  Block* b = (Block*)((char*)user - HDR);
+  if (b->magic != ~(MAGIC ^ (uint64_t)(uintptr_t)user)) return 0;
+  const unsigned char* u = (const unsigned char*)user;
+  for (size_t i = 0; i < b->size + TAIL; ++i)
+    if (u[i] != (i < b->size ? DEAD_BYTE : TAIL_BYTE)) return 0;
+  return 1;
+}
+
+/* every live block and every quarantined block; -> violations found (printed); never aborts.  The checks run UNDER the lock (other
+   threads -- the GPU runtime's, torch's -- allocate and free all the time: a block freed between a snapshot and its check looks
+   damaged); a free() of another thread waits at its registry update meanwhile.  The reports (which allocate) come after the unlock. */
 long heap_guard_sweep(const char* tag) {
-  long bad = 0;
+  enum { MAXBAD = 16 };
+  void* bad_live[MAXBAD];
+  void* bad_dead[MAXBAD];
+  long n_bad_live = 0, n_bad_dead = 0;
   lock();
-  size_t n_live = g_live_n, n_quar = g_quar_n, k = 0;
-  void** snap = (void**)__libc_malloc((n_live + n_quar + 1) * sizeof(void*));
-  for (size_t i = 0; i < g_live_cap && k < n_live; ++i)
-    if ((uintptr_t)g_live[i] > 1) snap[k++] = g_live[i];
-  n_live = k;
-  for (size_t i = 0; i < n_quar; ++i) snap[k++] = g_quar[(g_quar_head + i) % g_quar_cap];
+  size_t n_live = g_live_n, n_quar = g_quar_n;
+  for (size_t i = 0; i < g_live_cap; ++i)
+    if ((uintptr_t)g_live[i] > 1 && !live_ok(g_live[i])) { if (n_bad_live < MAXBAD) bad_live[n_bad_live] = g_live[i]; n_bad_live++; }
+  for (size_t i = 0; i < n_quar; ++i) {
+    void* u = g_quar[(g_quar_head + i) % g_quar_cap];
+    if (!dead_ok(u)) { if (n_bad_dead < MAXBAD) bad_dead[n_bad_dead] = u; n_bad_dead++; }
+  }
   unlock();
-  for (size_t i = 0; i < n_live; ++i) bad += check_live(snap[i], tag ? tag : "sweep");
-  for (size_t i = n_live; i < k; ++i) bad += check_dead(snap[i], tag ? tag : "sweep");
-  __libc_free(snap);
+  long bad = n_bad_live + n_bad_dead;
+  for (long i = 0; i < n_bad_live && i < MAXBAD; ++i) check_live(bad_live[i], tag ? tag : "sweep");
+  for (long i = 0; i < n_bad_dead && i < MAXBAD; ++i) check_dead(bad_dead[i], tag ? tag : "sweep");
   if (bad || getenv("HEAP_GUARD_VERBOSE")) say("heap_guard: sweep '%s': %lu live blocks, %lu quarantined, %ld damaged\n", tag ? tag : "", (unsigned long)n_live, (unsigned long)n_quar, bad);
   g_violations += bad;
   return bad;
@@ -282,6 +368,13 @@ void* realloc(void* p, size_t n) {
   if (!p) return guard_alloc(16, n, caller);
   if (n == 0) { guard_free(p, caller); return 0; }
   Block* b = (Block*)((char*)p - HDR);
+  if (fence_is(p)) {
+    void* q2 = guard_alloc(16, n, caller);
+    if (!q2) return 0;
+    memcpy(q2, p, b->size < n ? b->size : n);
+    fence_free(p, caller);
+    return q2;
+  }
   if (b->magic != (MAGIC ^ (uint64_t)(uintptr_t)p)) { /* not ours or damaged: let free() say which */
     guard_free(p, caller);
     return guard_alloc(16, n, caller);
@@ -310,5 +403,6 @@ int posix_memalign(void** out, size_t align, size_t n) {
 size_t malloc_usable_size(void* p) {
   if (!p) return 0;
   Block* b = (Block*)((char*)p - HDR);
+  if (fence_is(p)) return b->size;
   return b->magic == (MAGIC ^ (uint64_t)(uintptr_t)p) ? b->size : 0;
 }

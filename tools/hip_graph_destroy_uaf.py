@@ -1,0 +1,51 @@
+"""Repro WITHOUT this package (torch only) of the host-heap damage behind the eval-latent fits:
+    gcc -O1 -g -shared -fPIC -o /tmp/heap_guard.so tools/heap_guard.c -ldl
+    HEAP_GUARD_FENCE_SIZE=920 LD_PRELOAD="/tmp/heap_guard.so${LD_PRELOAD:+:$LD_PRELOAD}" python tools/hip_graph_destroy_uaf.py [fork|line] [inflight|idle] [cycles]
+A HIP graph whose capture FORKED a second stream is instantiated with internal streams of its own.  hipGraphLaunch keeps a reference to
+the executable graph until the launch's last command completes; when the user's handle is destroyed while a launch is in flight, that
+reference is the LAST one and it is dropped by the completion callback, on ROCr's async-events thread:
+    amd::roc::HsaAmdSignalHandler -> VirtualGPU::updateCommandsState -> amd::Event::setStatus -> Event::processCallbacks
+      -> hip::GraphExec::~GraphExec -> hip::Stream::terminate -> amd::HostQueue::terminate -> free(roc::VirtualGPU, 920 bytes)
+and HsaAmdSignalHandler then goes on using the VirtualGPU it was called for -- the one just freed when the completing command ran on one
+of the graph's own streams (a decrement at offset 152: glibc's "free(): invalid pointer" / "corrupted size vs. prev_size" much later,
+in whoever owns that memory by then).  libamdhip64.so 7.0.51831 (torch 2.10.0+rocm7.0 wheel).  `idle` (synchronize, wait, then destroy:
+the destructor runs on the caller's thread) is clean; so is `line` (no fork: the executable graph owns no stream)."""
+import ctypes, sys, time
+import torch
+mode = sys.argv[1] if len(sys.argv) > 1 else "fork"
+when = sys.argv[2] if len(sys.argv) > 2 else "inflight"
+cycles = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+libc = ctypes.CDLL(None)
+sweep = getattr(libc, "heap_guard_sweep", None)
+if sweep is not None:
+    sweep.restype, sweep.argtypes = ctypes.c_long, [ctypes.c_char_p]
+x = torch.zeros(1 << 26, device="cuda")
+side = torch.cuda.Stream()
+def body():
+    y = x * 2
+    if mode == "fork":  # a second branch on another stream, joined before the capture ends
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            z = x + 1
+            for _ in range(8):
+                z = z * 1.0001
+        torch.cuda.current_stream().wait_stream(side)
+        return y + z
+    return y + (x + 1)
+print("torch", torch.__version__, "hip", torch.version.hip, "guard", sweep is not None, mode, when, flush=True)
+for i in range(cycles):
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = body()
+    for _ in range(3):
+        graph.replay()
+    if when == "idle":
+        torch.cuda.synchronize()
+        time.sleep(0.05)
+    del graph, out  # hipGraphExecDestroy (+ hipGraphDestroy): in flight -> the launch's reference is the last one
+    torch.cuda.synchronize()
+    time.sleep(0.01)
+    if sweep is not None and sweep(b"after destroying graph %d" % i):
+        print("HEAP DAMAGE first seen after destroying graph", i, flush=True)
+        sys.exit(77)
+print("clean:", cycles, "capture / replay / destroy cycles", flush=True)

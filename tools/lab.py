@@ -6,6 +6,8 @@ NSKY_LIB=<path>            an experimental build of the library instead of neusk
 NSKY_ASYNC_WGRAD=0         weight gradients on the launching stream (same arithmetic; same-box A/B runs)
 NSKY_CAPTURE_MODE=global   capture mode of every HIP graph (flake hunt)
 NSKY_FROZEN_DX=f32         input gradients through frozen dense layers on the exact-fp32 MFMA (attention decoder A/B)
+NSKY_FIT_STREAM=0          the DDF-fit rows ride in the visibility rows' launches (rounds 3-5) instead of a launch of their own
+NSKY_FILM_ASYNC=0          the FiLM chains' weight gradients on the launching stream (implies NSKY_FIT_STREAM=0: timing only)
 """
 import importlib.util
 import os
@@ -38,3 +40,16 @@ def apply() -> None:
         ops.CAPTURE_MODE = os.environ["NSKY_CAPTURE_MODE"]
     if os.environ.get("NSKY_FROZEN_DX", "bf16x3") != "bf16x3":
         ops.FROZEN_DX_PRECISION = hip.PREC_F32
+    if os.environ.get("NSKY_FIT_STREAM", "1") == "0" or os.environ.get("NSKY_FILM_ASYNC", "1") == "0":
+        from neusky_amd.models.neusky_model import NeuSkyFactoModel
+        NeuSkyFactoModel.start_ddf_fit = lambda self, prep: None
+    if os.environ.get("NSKY_FILM_ASYNC", "1") == "0":
+        orig = ops.FilmSirenFn._backward_fused
+
+        def in_line(*a, **k):
+            keep, ops.ASYNC_WGRAD = ops.ASYNC_WGRAD, False
+            try:
+                return orig(*a, **k)
+            finally:
+                ops.ASYNC_WGRAD = keep
+        ops.FilmSirenFn._backward_fused = staticmethod(in_line)
