@@ -31,7 +31,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
 RAYS, SAMPLES, DIRECTIONS, PROPOSAL = 1024, 96, 512, (256, 96)
 STEP_ALGORITHMIC_TFLOP = 2.3  # BASELINE.md section 4 / SURVEY 8(d): forward 762 GFLOP, forward + backward ~ 3 x
-PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"  # rocprofv3 --pmc passes of this round's kernels (tools/pmc_bench.sh + tools/pmc_step_traffic.py)
+PMC_TRAFFIC_FILE = "r06_pmc_traffic.json"  # rocprofv3 --pmc passes of this round's kernels (tools/pmc_bench.sh + tools/pmc_step_traffic.py)
 
 
 def build_pipeline(device, world_size, local_rank, rays=RAYS, samples=SAMPLES, directions=DIRECTIONS, proposal=PROPOSAL):

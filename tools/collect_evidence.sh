@@ -15,5 +15,5 @@ cp $O/timeline_$TAG.txt $P/${TAG}_step_timeline.txt
 cp $O/prof_bench/*/*_kernel_stats.csv $P/${TAG}_bench_graph_kernel_stats.csv
 cp $O/prof_bench/*/*_domain_stats.csv $P/${TAG}_bench_graph_domain_stats.csv
 cp $O/prof_render/*/*_kernel_stats.csv $P/${TAG}_render_480x270_kernel_stats.csv
-cp $O/r05_pmc_traffic.json $P/r05_pmc_traffic.json
-ls $P | grep "^${TAG}_\|r05_pmc"
+cp $O/r06_pmc_traffic.json $P/r06_pmc_traffic.json
+ls $P | grep "^${TAG}_\|r06_pmc"

@@ -6,12 +6,12 @@ TAG=${1:-r02x}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/ev_$TAG
 mkdir -p $O
-# the two --pmc passes come first: bench.py reads profiles/r05_pmc_traffic.json for roofline.traffic (and checks it against the kernel
+# the two --pmc passes come first: bench.py reads profiles/r06_pmc_traffic.json for roofline.traffic (and checks it against the kernel
 # sources), so the committed bench line and the counters describe the same binaries
 (cd /tmp && export TMPDIR=/tmp && for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_bench_$c -- python3 $R/bench.py --no-spawn --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-exact-f32 --no-extra-configs --no-live-pmc > $R/gpurun_out/pmc_bench_$c.log 2>&1
 done)
-python3 $R/tools/pmc_step_traffic.py 0 r05_pmc_traffic.json > $O/pmc_traffic.txt 2>&1; cp $R/profiles/r05_pmc_traffic.json $O/ 2>/dev/null
+python3 $R/tools/pmc_step_traffic.py 0 r06_pmc_traffic.json > $O/pmc_traffic.txt 2>&1; cp $R/profiles/r06_pmc_traffic.json $O/ 2>/dev/null
 cd $R
 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 python bench.py > $O/bench_line.json 2> $O/bench.err

@@ -15,24 +15,32 @@ import torch
 mode = sys.argv[1] if len(sys.argv) > 1 else "fork"
 when = sys.argv[2] if len(sys.argv) > 2 else "inflight"
 cycles = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+wide = int(sys.argv[4]) if len(sys.argv) > 4 else 1    # forked side streams
+depth = int(sys.argv[5]) if len(sys.argv) > 5 else 8   # kernels per branch
 libc = ctypes.CDLL(None)
 sweep = getattr(libc, "heap_guard_sweep", None)
 if sweep is not None:
     sweep.restype, sweep.argtypes = ctypes.c_long, [ctypes.c_char_p]
 x = torch.zeros(1 << 26, device="cuda")
-side = torch.cuda.Stream()
+sides = [torch.cuda.Stream() for _ in range(wide)]
 def body():
     y = x * 2
-    if mode == "fork":  # a second branch on another stream, joined before the capture ends
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            z = x + 1
-            for _ in range(8):
-                z = z * 1.0001
-        torch.cuda.current_stream().wait_stream(side)
-        return y + z
+    if mode == "fork":  # `wide` more branches on other streams, forked and joined twice before the capture ends
+        for rnd in range(2):
+            zs = []
+            for s_ in sides:
+                s_.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s_):
+                    z = y + 1
+                    for _ in range(depth):
+                        z = z * 1.0001
+                zs.append(z)
+            for s_ in sides:
+                torch.cuda.current_stream().wait_stream(s_)
+            y = y + sum(zs)
+        return y
     return y + (x + 1)
-print("torch", torch.__version__, "hip", torch.version.hip, "guard", sweep is not None, mode, when, flush=True)
+print("torch", torch.__version__, "hip", torch.version.hip, "guard", sweep is not None, mode, when, "wide", wide, "depth", depth, flush=True)
 for i in range(cycles):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
