@@ -987,7 +987,8 @@ extern "C" int nsky_density_weights_bwd(const float* raw, int32_t ld_raw, const 
 extern "C" int nsky_interlevel_fwd(const float* c, const float* w, const float* sb, const float* wp, int32_t R, int32_t S, int32_t n,
                                    float* per_ray, nsky_stream_t stream) {
   if (R == 0) return NSKY_OK;
-  NSKY_CHECK_ARG(c && w && sb && wp && per_ray && R > 0 && S > 0 && n > 0 && n <= 4096, "nsky_interlevel_fwd: bad argument");
+  NSKY_CHECK_ARG(c && w && sb && wp && per_ray && R > 0 && S > 0 && n > 0, "nsky_interlevel_fwd: bad argument");
+  NSKY_CHECK_ARG(n <= 1023, "nsky_interlevel_fwd: %d proposal samples per ray: at most 1023 (four rays x four (n + 1)-float arrays = 64 (n + 1) bytes of LDS per workgroup, 64 KB)", n);
   const size_t smem = 4 * 4 * (size_t)(n + 1) * sizeof(float);
   hipLaunchKernelGGL((interlevel_kernel<false>), dim3(ceil_div(R, 4)), dim3(256), smem, (hipStream_t)stream, c, w, sb, wp, nullptr, R,
                      S, n, per_ray, nullptr);
@@ -998,7 +999,8 @@ extern "C" int nsky_interlevel_fwd(const float* c, const float* w, const float* 
 extern "C" int nsky_interlevel_bwd(const float* c, const float* w, const float* sb, const float* wp, const float* d_per_ray,
                                    int32_t R, int32_t S, int32_t n, float* d_wp, nsky_stream_t stream) {
   if (R == 0) return NSKY_OK;
-  NSKY_CHECK_ARG(c && w && sb && wp && d_per_ray && d_wp && R > 0 && S > 0 && n > 0 && n <= 4096, "nsky_interlevel_bwd: bad argument");
+  NSKY_CHECK_ARG(c && w && sb && wp && d_per_ray && d_wp && R > 0 && S > 0 && n > 0, "nsky_interlevel_bwd: bad argument");
+  NSKY_CHECK_ARG(n <= 1023, "nsky_interlevel_bwd: %d proposal samples per ray: at most 1023 (four rays x four (n + 1)-float arrays = 64 (n + 1) bytes of LDS per workgroup, 64 KB)", n);
   const size_t smem = 4 * 4 * (size_t)(n + 1) * sizeof(float);
   hipLaunchKernelGGL((interlevel_kernel<true>), dim3(ceil_div(R, 4)), dim3(256), smem, (hipStream_t)stream, c, w, sb, wp, d_per_ray, R,
                      S, n, nullptr, d_wp);

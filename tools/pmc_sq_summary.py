@@ -33,9 +33,12 @@ for k in rows:
         us = sum(dur[k]) / len(dur[k])
         print(f"    {'duration under the counter pass (us)':44s} {us:10.1f}")
         if "GRBM_GUI_ACTIVE" in a:
-            print(f"    {'clock = GRBM_GUI_ACTIVE / duration (GHz)':44s} {a['GRBM_GUI_ACTIVE'] / us * 1e-3:8.3f}")
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md): a dispatch lasts GUI_ACTIVE / 8 cycles.  (Round 3's file divided
+            # by GUI_ACTIVE itself: "clock 14.9 GHz", "matrix pipe busy 0.046" -- both off by the 8 XCDs)
+            cyc = a["GRBM_GUI_ACTIVE"] / 8.0
+            print(f"    {'clock = GRBM_GUI_ACTIVE / 8 / duration (GHz)':44s} {cyc / us * 1e-3:8.3f}")
             if "SQ_VALU_MFMA_BUSY_CYCLES" in a:
-                print(f"    {'matrix pipe busy = MFMA_BUSY / (1024 SIMDs x GUI_ACTIVE)':44s} {a['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / a['GRBM_GUI_ACTIVE']:8.3f}")
+                print(f"    {'matrix pipe busy = MFMA_BUSY / (1024 SIMDs x GUI_ACTIVE / 8)':44s} {a['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc:8.3f}")
     w = a.get("SQ_WAVE_CYCLES")
     if w:
         # WAVE_CYCLES, WAIT_*, ACTIVE_INST_* count quad-cycles summed over waves; VALU_MFMA_BUSY_CYCLES counts cycles per SIMD (guide, constants table)
