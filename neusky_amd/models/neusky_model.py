@@ -321,6 +321,8 @@ class NeuSkyFactoModel(ModelBase):
             return
         main = torch.cuda.current_stream()
         side = self._illumination_stream()
+        if side == main:  # (the caller's stream IS this pool stream: sample_and_forward_field decodes in line)
+            return
         side.wait_stream(main)
         with torch.cuda.stream(side):
             self._illumination_pending = self.sample_illumination_compact(cam, ray_bundle.directions, rotation, randoms)
@@ -338,6 +340,7 @@ class NeuSkyFactoModel(ModelBase):
         cond = ddf.field.condition_rows(pts)
         main = torch.cuda.current_stream()
         side = self._ddf_fit_stream() if fork else main
+        fork = fork and side != main
         if fork:
             side.wait_stream(main)
         N, Ns = prep["positions"].shape[0], (prep["sky_o"].shape[0] if prep["sky_o"] is not None else 0)
@@ -353,7 +356,7 @@ class NeuSkyFactoModel(ModelBase):
     def _ddf_fit_stream(self):
         s = getattr(self, "_fit_stream", None)
         if s is None:
-            s = self._fit_stream = torch.cuda.Stream()
+            s = self._fit_stream = ops.role_stream("ddf_fit", self.device)  # (one per process and device: ops.role_stream)
         return s
 
     # False: the illumination decode runs in line on the caller's stream (bench.py's per-kernel timing iteration, where a kernel
@@ -363,7 +366,7 @@ class NeuSkyFactoModel(ModelBase):
     def _illumination_stream(self):
         s = getattr(self, "_illum_stream", None)
         if s is None:
-            s = self._illum_stream = torch.cuda.Stream()
+            s = self._illum_stream = ops.role_stream("illumination", self.device)  # (one per process and device: ops.role_stream)
         return s
 
     def render_depth(self, weights: torch.Tensor, ray_samples: RaySamples) -> torch.Tensor:
@@ -479,6 +482,8 @@ class NeuSkyFactoModel(ModelBase):
         if fork and pending is not None:  # started by start_illumination (the pipeline, before the DDF-fit ground truth pass)
             main, side = torch.cuda.current_stream(), self._illumination_stream()
             dirs, cam_colours, cam_of_ray, hdr_bg = pending
+        elif fork and self._illumination_stream() == torch.cuda.current_stream():
+            fork = False  # (the caller's stream IS the illumination pool stream: in line, below)
         elif fork:
             main = torch.cuda.current_stream()
             side = self._illumination_stream()
@@ -812,7 +817,7 @@ class NeuSkyFactoModel(ModelBase):
                 if randoms_per_step is not None:  # injected draws live in static buffers the graph reads
                     keys = ("jitters", "light_rotation", "grid_perturb", "grid_dirs")
                     srnd = {k: ([c(t) for t in v] if isinstance(v, (list, tuple)) else c(v)) for k, v in randoms_per_step[0].items() if k in keys}
-                side = torch.cuda.Stream()
+                side = ops.role_stream("capture", self.device)  # warm-up and capture on the package's capture stream (ops.role_stream)
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):  # eager warm-up (allocator pools, per-step caches); no parameter is updated by it
                     iteration(srb, sbatch, None, srnd)
@@ -820,7 +825,7 @@ class NeuSkyFactoModel(ModelBase):
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 try:
-                    with torch.cuda.graph(graph, capture_error_mode=ops.CAPTURE_MODE):
+                    with torch.cuda.graph(graph, stream=side, capture_error_mode=ops.CAPTURE_MODE):
                         gloss = iteration(srb, sbatch, None, srnd)
                 except RuntimeError as exc:  # a host-dependent op inside the iteration: run the fit with host launches instead
                     import warnings
@@ -935,7 +940,7 @@ class _ChunkRunner:
         self.rb.directions[:, 2] = 1.0
         if use_graph:
             self._load(flat, 0, min(chunk, flat.origins.shape[0]))
-            side = torch.cuda.Stream()
+            side = ops.role_stream("capture", dev)  # warm-up and capture on the package's capture stream (ops.role_stream)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):
@@ -943,7 +948,7 @@ class _ChunkRunner:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, capture_error_mode=ops.CAPTURE_MODE):
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode=ops.CAPTURE_MODE):
                 self.out = model.forward(self.rb)
 
     def __del__(self):

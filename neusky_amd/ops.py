@@ -300,7 +300,29 @@ def shared_grad(like, bias_like):
 # capture.  The captures themselves make no unsafe call from any thread ("global" passes too).  (tools/lab.py sets another for the flake hunt of DESIGN section 7; nothing in the package does)
 CAPTURE_MODE = "thread_local"
 ASYNC_WGRAD = True  # (tools/lab.py clears it for same-box A/B runs; nothing in the package does; arithmetic is identical either way)
-_WGRAD_SIDE: dict = {}     # device index -> side stream
+# ---- one stream per ROLE and device for the life of the process -------------------------------------------------------------------
+# torch.cuda.Stream() hands out 32 pool streams per priority round-robin: the 33rd object IS the 1st stream again.  Rounds 2-5 created
+# streams per model / per capture (illumination stream, warm-up side stream, torch.cuda.graph's own capture stream), so in a process that
+# builds many pipelines two "different" streams of one captured step end up the same pool stream -- a capturing stream then waits on an
+# event recorded on itself, or forks into itself -- and round 6's extra stream moved the coincidences onto a case in which
+# hipStreamEndCapture segfaults (deterministic, in the 80th test of the GPU suite).  The package's streams are therefore created ONCE,
+# together (consecutive pool slots: distinct), and every capture runs on the package's own capture stream.
+ROLES = ("capture", "illumination", "ddf_fit", "wgrad")
+_ROLE_STREAMS: dict = {}  # device index -> {role: stream}
+
+
+def role_stream(role: str, device=None) -> "torch.cuda.Stream":
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    streams = _ROLE_STREAMS.get(idx)
+    if streams is None:
+        with torch.cuda.device(idx):
+            streams = _ROLE_STREAMS[idx] = {r: torch.cuda.Stream() for r in ROLES}
+        assert len({s.stream_id for s in streams.values()}) == len(ROLES)
+    return streams[role]
+
+
 _WGRAD_PENDING: list = []  # side streams with unjoined work of THIS backward pass
 _WGRAD_KEEP: list = []     # operands of the unjoined launches
 _DEFERRED_PADS: list = []  # (gradient view, slab view) of padded slab parameters: added by finish_pass
@@ -342,9 +364,10 @@ def async_weight_gradients(launch, operands) -> None:
         launch()
         return
     main = torch.cuda.current_stream()
-    side = _WGRAD_SIDE.get(main.device_index)
-    if side is None:
-        side = _WGRAD_SIDE[main.device_index] = torch.cuda.Stream()
+    side = role_stream("wgrad", main.device)
+    if side == main:  # (a caller running the step on a stream of its own that IS this pool stream: in line)
+        launch()
+        return
     side.wait_stream(main)
     with torch.cuda.stream(side):
         launch()

@@ -71,7 +71,7 @@ class TrainGraph:
             self.randoms.update({k: static(v) for k, v in randoms.items() if k != "sky_ray_bundle"})
         self._anchor = torch.zeros((), device=dev, requires_grad=True)
         self._attached = True
-        side = torch.cuda.Stream()
+        side = ops.role_stream("capture", dev)  # warm-up and capture on the package's capture stream (ops.role_stream: never an alias of a role stream)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # eager warm-up on the side stream: caches, autotuned paths, allocator pools
             for i in range(warmup):
@@ -80,7 +80,7 @@ class TrainGraph:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: other host threads (e.g. the RCCL watchdog) may legally touch the runtime during the capture
-        with torch.cuda.graph(self.graph, capture_error_mode=ops.CAPTURE_MODE):
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode=ops.CAPTURE_MODE):
             self.outputs, self.loss, self.loss_dict, self.metrics = self._body(start_step + warmup)
         self.used = list(slab.used)  # which parameters the captured pass gives a gradient
         torch.cuda.synchronize()

@@ -4,7 +4,7 @@
 # Exit code 77 of a run = the guard saw the damage; its log names the block's allocator and the step it was first seen after.
 mkdir -p gpurun_out/flake
 gcc -O1 -g -shared -fPIC -o /tmp/heap_guard.so tools/heap_guard.c -ldl || exit 1
-for i in 1 2 3 4 5 6 7 8 9 10 11 12; do
+for i in $(seq 1 ${FLAKE_RUNS:-12}); do
   LD_PRELOAD="/tmp/heap_guard.so${LD_PRELOAD:+:$LD_PRELOAD}" NSKY_FLAKE_SWEEP_STEPS=1 python tools/flake_seq.py test_gpu_eval_latents.py > /tmp/fs.log 2>&1; rc=$?
   echo "[guard] rc=$rc $(grep -c 'eval methods' /tmp/fs.log) $(grep -a -m1 'heap_guard:' /tmp/fs.log | cut -c1-200)"
   [ $rc -ne 0 ] && { grep -a -B2 -A40 -m1 'heap_guard:' /tmp/fs.log > gpurun_out/flake/guard_$i.log; tail -c 4000 /tmp/fs.log >> gpurun_out/flake/guard_$i.log; }
