@@ -426,66 +426,76 @@ def attention_decoder_line(device, steps=5):
 
 def trainer_surface_line(device, steps=10):
     """The same step driven the way nerfstudio's Trainer drives the plugin surface (neusky_pipeline.py:198-200,
-    241-291) -- zero_grad -> pipeline.get_train_loss_dict -> sum the loss dict -> backward -> torch.optim.Adam(eps=1e-15).step per
-    group -> scheduler.step -- with nothing from neusky_amd.engine: `ms_per_step` with the pipeline's graph replay
-    (NeuSkyPipelineConfig.graph_replay), `eager_ms_per_step` without it (host launches of every kernel); inputs resident in HBM like the
+    241-291) -- zero_grad -> pipeline.get_train_loss_dict -> sum the loss dict -> backward -> optimizer.step per group ->
+    scheduler.step -- with nothing from neusky_amd.engine.  Two optimizers: `neusky_amd.optimizers.SlabAdam`, what the plugin's
+    `SlabAdamOptimizerConfig` hands the trainer (torch.optim.Adam's update, one fused launch per group: `ms_per_step`), and
+    torch.optim.Adam(eps=1e-15) itself (`torch_adam_ms_per_step`); each with the pipeline's graph replay
+    (NeuSkyPipelineConfig.graph_replay) and without it (`eager_*`: host launches of every kernel); inputs resident in HBM like the
     headline's; `with_datamanager_ms_per_step`: get_train_loss_dict(step) drawing its own batch and sky rays each step, as the Trainer
-    calls it.  A fresh pipeline at full size."""
+    calls it.  Fresh pipelines at full size."""
     import functools
     from neusky_amd.engine import ExponentialDecaySchedulerConfig, neusky_optimizers
+    from neusky_amd.optimizers import SlabAdam
     from neusky_amd.utils.randomise import randomise
-    torch.manual_seed(0)
-    pipe = build_pipeline(device, 1, 0)
-    randomise(pipe)
-    cfg = neusky_optimizers()
-    opts, scheds = {}, {}
-    for name, params in pipe.get_param_groups().items():
-        oc, sc = cfg[name]["optimizer"], cfg[name]["scheduler"]
-        opts[name] = torch.optim.Adam([p for p in params if p.requires_grad], lr=oc.lr, eps=oc.eps, betas=oc.betas)
-        if isinstance(sc, ExponentialDecaySchedulerConfig):
-            sc.lr_init = oc.lr
-        scheds[name] = torch.optim.lr_scheduler.LambdaLR(opts[name], lr_lambda=lambda e, f=sc.factor: f(1000 + e))
-    batches = [pipe.datamanager.next_train(i) for i in range(3)]
-    skies = [pipe.datamanager.get_sky_ray_bundle(pipe.config.num_sky_rays) for _ in range(3)]
 
-    def iteration(step, resident=True):
-        for o in opts.values():
-            o.zero_grad()
-        j = step % 3
-        kw = dict(ray_bundle=batches[j][0], batch=batches[j][1], randoms={"sky_ray_bundle": skies[j]}) if resident else {}
-        _, loss_dict, _ = pipe.get_train_loss_dict(step, **kw)
-        loss = functools.reduce(torch.add, loss_dict.values())
-        loss.backward()
-        for o in opts.values():
-            o.step()
-        for s_ in scheds.values():
-            s_.step()
-        return loss
+    def run(fused):
+        torch.manual_seed(0)
+        pipe = build_pipeline(device, 1, 0)
+        randomise(pipe)
+        cfg = neusky_optimizers()
+        opts, scheds = {}, {}
+        Adam = SlabAdam if fused else torch.optim.Adam
+        for name, params in pipe.get_param_groups().items():
+            oc, sc = cfg[name]["optimizer"], cfg[name]["scheduler"]
+            opts[name] = Adam([p for p in params if p.requires_grad], lr=oc.lr, eps=oc.eps, betas=oc.betas)
+            if isinstance(sc, ExponentialDecaySchedulerConfig):
+                sc.lr_init = oc.lr
+            scheds[name] = torch.optim.lr_scheduler.LambdaLR(opts[name], lr_lambda=lambda e, f=sc.factor: f(1000 + e))
+        batches = [pipe.datamanager.next_train(i) for i in range(3)]
+        skies = [pipe.datamanager.get_sky_ray_bundle(pipe.config.num_sky_rays) for _ in range(3)]
 
-    def timed(n, resident=True):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(n):
-            loss = iteration(2000 + i, resident)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n * 1e3, float(loss)
+        def iteration(step, resident=True):
+            for o in opts.values():
+                o.zero_grad()
+            j = step % 3
+            kw = dict(ray_bundle=batches[j][0], batch=batches[j][1], randoms={"sky_ray_bundle": skies[j]}) if resident else {}
+            _, loss_dict, _ = pipe.get_train_loss_dict(step, **kw)
+            loss = functools.reduce(torch.add, loss_dict.values())
+            loss.backward()
+            for o in opts.values():
+                o.step()
+            for s_ in scheds.values():
+                s_.step()
+            return loss
 
-    for i in range(3):  # eager: also the warm-up in front of the capture
-        iteration(1000 + i)
-    eager_ms, _ = timed(max(steps // 2, 3))
-    pipe.config.graph_replay, pipe.config.graph_replay_warmup = True, 0
-    for i in range(3):  # the first call captures
-        iteration(1500 + i)
-    assert pipe._train_graph is not None
-    ms, final = timed(steps)
-    dm_ms, _ = timed(steps, resident=False)
-    out = {"loop": "zero_grad -> get_train_loss_dict -> reduce(add, loss_dict.values()) -> backward -> torch.optim.Adam(eps=1e-15).step x 5 groups -> LambdaLR.step",
-           "ms_per_step": ms, "rays_per_s": RAYS / (ms * 1e-3), "eager_ms_per_step": eager_ms, "with_datamanager_ms_per_step": dm_ms,
-           "final_loss": final, "optimizer": "torch.optim.Adam (foreach) on the parameters; p.grad = views of the pipeline's gradient slab",
-           "launch": "pipeline graph replay (NeuSkyPipelineConfig.graph_replay) + torch's Adam launches"}
-    del pipe, opts, scheds
-    torch.cuda.empty_cache()
-    return out
+        def timed(n, resident=True):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                loss = iteration(2000 + i, resident)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3, float(loss)
+
+        for i in range(3):  # eager: also the warm-up in front of the capture
+            iteration(1000 + i)
+        eager_ms, _ = timed(max(steps // 2, 3))
+        pipe.config.graph_replay, pipe.config.graph_replay_warmup = True, 0
+        for i in range(3):  # the first call captures
+            iteration(1500 + i)
+        assert pipe._train_graph is not None
+        ms, final = timed(steps)
+        dm_ms, _ = timed(steps, resident=False)
+        del pipe, opts, scheds
+        torch.cuda.empty_cache()
+        return ms, eager_ms, dm_ms, final
+
+    ms, eager_ms, dm_ms, final = run(True)
+    t_ms, t_eager_ms, _, _ = run(False)
+    return {"loop": "zero_grad -> get_train_loss_dict -> reduce(add, loss_dict.values()) -> backward -> optimizer.step x 5 groups -> LambdaLR.step",
+            "optimizer": "neusky_amd.optimizers.SlabAdam (plugin.SlabAdamOptimizerConfig: torch.optim.Adam's update, one nsky_adam_step launch per group, gradients read in place from the pipeline's slab)",
+            "ms_per_step": ms, "rays_per_s": RAYS / (ms * 1e-3), "eager_ms_per_step": eager_ms, "with_datamanager_ms_per_step": dm_ms,
+            "torch_adam_ms_per_step": t_ms, "torch_adam_eager_ms_per_step": t_eager_ms, "final_loss": final,
+            "launch": "pipeline graph replay (NeuSkyPipelineConfig.graph_replay) + the optimizers' own launches"}
 
 
 def global_batch_line(device, rays=8192, steps=5):

@@ -27,7 +27,7 @@ extern "C" {
 typedef void* nsky_stream_t; /* hipStream_t */
 
 const char* nsky_last_error(void);
-int nsky_abi_version(void); /* 15 (bumped when a struct layout or an entry point's signature changes) */
+int nsky_abi_version(void); /* 16 (bumped when a struct layout or an entry point's signature changes) */
 
 /* ------------------------------------------------------------------------------------------
  * Dense layer on the matrix cores: C[M,N] = epilogue( sum_k A(m,k) * B(n,k) + bias[n] )
@@ -591,9 +591,11 @@ int nsky_gather_segments(const nsky_segment* segments, int32_t n_segments, nsky_
 int nsky_copy_segments(const void* const* src, void* const* dst, const int64_t* nbytes, int32_t n_segments, nsky_stream_t stream);
 
 /* Adam update (torch.optim.Adam semantics, no weight decay / amsgrad) over a flat slab of n floats;
- * the five optimizer groups of neusky/configs/neusky_config.py:216-237.  grad_scale multiplies g first. */
-int nsky_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                   float eps, int32_t step, float grad_scale, nsky_stream_t stream);
+ * the five optimizer groups of neusky/configs/neusky_config.py:216-237.  grad_scale multiplies g first.  The hyper-parameters are
+ * DOUBLES (ABI 16): torch forms 1 - beta, lr / (1 - beta1^t) and sqrt(1 - beta2^t) in double from the Python scalars and rounds each to
+ * float once; a float beta2 = 0.999 already puts 1 - beta2 off by 1.3e-5 relative. */
+int nsky_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                   double eps, int32_t step, float grad_scale, nsky_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Closed-form loss terms, one launch each way per model (instead of ~300 small torch launches per step).

@@ -15,4 +15,4 @@ void nsky_set_error(const char* fmt, ...) {
 
 extern "C" const char* nsky_last_error(void) { return g_err; }
 // 2: nsky_gemm_desc gained rowsum_k_limit; nsky_split_planes / nsky_gemm_f32_planes, nsky_main_losses_*, nsky_ddf_losses_* added
-extern "C" int nsky_abi_version(void) { return 15; }
+extern "C" int nsky_abi_version(void) { return 16; }

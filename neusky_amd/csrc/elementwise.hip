@@ -94,16 +94,19 @@ __global__ __launch_bounds__(256) void pdf_sample_kernel(const float* __restrict
   }
 }
 
+// torch.optim.Adam's update with torch's own scalar handling: every scalar is formed in double on the host (1 - beta, lr / (1 - beta1^t),
+// sqrt(1 - beta2^t)) and rounded to float once, as torch rounds a Python scalar where it meets a float tensor:
+//   m.lerp_(g, 1 - beta1);  v.mul_(beta2).addcmul_(g, g, value = 1 - beta2);  p.addcdiv_(m, v.sqrt() / sqrt(bc2) + eps, value = -lr / bc1)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            long n, float lr, float b1, float b2, float eps, float bc1, float bc2, float grad_scale) {
+                            long n, float b2, float om1, float om2, float eps, float step_size, float bc2_sqrt, float grad_scale) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float gi = g[i] * grad_scale;
-  const float mi = b1 * m[i] + (1.0f - b1) * gi;
-  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  const float m0 = m[i];
+  const float mi = m0 + om1 * (gi - m0);          // lerp, weight 1 - beta1 < 0.5
+  const float vi = b2 * v[i] + om2 * (gi * gi);
   m[i] = mi; v[i] = vi;
-  // torch.optim.Adam: p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps)
-  p[i] -= (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+  p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
 }
 
 
@@ -380,13 +383,14 @@ extern "C" int nsky_pdf_sample(const float* weights, const float* bins, const fl
   return NSKY_OK;
 }
 
-extern "C" int nsky_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                              float eps, int32_t step, float grad_scale, nsky_stream_t stream) {
+extern "C" int nsky_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                              double eps, int32_t step, float grad_scale, nsky_stream_t stream) {
   if (n == 0) return NSKY_OK;
   NSKY_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "nsky_adam_step: bad argument");
-  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(adam_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2,
-                     eps, bc1, bc2, grad_scale);
+  NSKY_CHECK_ARG(beta1 >= 0.5 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0, "nsky_adam_step: betas (%g, %g): beta1 in [0.5, 1) (torch's lerp form), beta2 in [0, 1)", beta1, beta2);
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, (float)beta2,
+                     (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)(lr / bc1), (float)sqrt(bc2), grad_scale);
   NSKY_CHECK_LAUNCH("nsky_adam_step");
   return NSKY_OK;
 }

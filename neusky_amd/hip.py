@@ -52,7 +52,7 @@ class GemmDesc(C.Structure):
 
 _lib.nsky_last_error.restype = C.c_char_p
 _lib.nsky_abi_version.restype = C.c_int
-ABI_VERSION = 15  # the ctypes structures below mirror this version of include/neusky_hip.h
+ABI_VERSION = 16  # the ctypes structures below mirror this version of include/neusky_hip.h
 if _lib.nsky_abi_version() != ABI_VERSION:
     raise NeuSkyHipError(f"libneusky_hip.so has ABI version {_lib.nsky_abi_version()}, this package binds version {ABI_VERSION}: rebuild (build.sh)")
 
@@ -432,7 +432,7 @@ def visibility_finish_bwd(t_hat, surf_dist, threshold, scale, sel_index, R, Dv, 
 # ------------------------------------------------------------------------------------------ elementwise helpers
 _sp_tan_bwd = _sig("nsky_softplus_tangent_bwd", _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P)
 _pdf_sample = _sig("nsky_pdf_sample", _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P)
-_adam = _sig("nsky_adam_step", _P, _P, _P, _P, C.c_int64, _F, _F, _F, _F, _I, _F, _P)
+_adam = _sig("nsky_adam_step", _P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, _I, _F, _P)
 _wn_fwd = _sig("nsky_weight_norm_fwd", _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P)
 _wn_bwd = _sig("nsky_weight_norm_bwd", _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P)
 

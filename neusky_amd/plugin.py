@@ -58,20 +58,30 @@ except ImportError:
         description: str
 
 
-def neusky_trainer_optimizers() -> Dict[str, Dict[str, Any]]:
-    """neusky/configs/neusky_config.py:216-237 in the types of the trainer that will consume them"""
+if HAVE_NERFSTUDIO:
+    @dataclass
+    class SlabAdamOptimizerConfig(NSAdamOptimizerConfig):  # pragma: no cover - needs nerfstudio; tests/test_plugin_seam.py runs it on the stand-in
+        """nerfstudio's AdamOptimizerConfig with `_target = neusky_amd.optimizers.SlabAdam`: the same update as ONE launch per group
+        (OptimizerConfig.setup passes lr / eps / weight_decay to the target; max_norm is handled by the trainer)"""
+        _target: Any = field(default_factory=lambda: __import__("neusky_amd.optimizers", fromlist=["SlabAdam"]).SlabAdam)
+
+
+def neusky_trainer_optimizers(fused: bool = True) -> Dict[str, Dict[str, Any]]:
+    """neusky/configs/neusky_config.py:216-237 in the types of the trainer that will consume them.  fused (default): the Adam groups are
+    `SlabAdamOptimizerConfig` -- torch.optim.Adam's update on the fused kernel; False: nerfstudio's own AdamOptimizerConfig."""
     if not HAVE_NERFSTUDIO:
         from .engine import neusky_optimizers
         return neusky_optimizers()
+    Adam = SlabAdamOptimizerConfig if fused else NSAdamOptimizerConfig
     cos = lambda: NSCosineDecaySchedulerConfig(warm_up_end=500, learning_rate_alpha=0.05, max_steps=100001)  # noqa: E731
     return {
-        "proposal_networks": {"optimizer": NSAdamOptimizerConfig(lr=1e-2, eps=1e-15), "scheduler": cos()},
-        "fields": {"optimizer": NSAdamOptimizerConfig(lr=1e-3, eps=1e-15), "scheduler": cos()},
-        "illumination_field": {"optimizer": NSAdamOptimizerConfig(lr=1e-2, eps=1e-15),
+        "proposal_networks": {"optimizer": Adam(lr=1e-2, eps=1e-15), "scheduler": cos()},
+        "fields": {"optimizer": Adam(lr=1e-3, eps=1e-15), "scheduler": cos()},
+        "illumination_field": {"optimizer": Adam(lr=1e-2, eps=1e-15),
                                "scheduler": NSExponentialDecaySchedulerConfig(lr_final=1e-5, max_steps=100001)},
-        "visibility_sigmoid": {"optimizer": NSAdamOptimizerConfig(lr=1e-3, eps=1e-15),
+        "visibility_sigmoid": {"optimizer": Adam(lr=1e-3, eps=1e-15),
                                "scheduler": NSExponentialDecaySchedulerConfig(warmup_steps=4000, lr_final=1e-4, max_steps=100001)},
-        "ddf_field": {"optimizer": NSAdamOptimizerConfig(lr=1e-4, eps=1e-15), "scheduler": cos()},
+        "ddf_field": {"optimizer": Adam(lr=1e-4, eps=1e-15), "scheduler": cos()},
     }
 
 

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, f"declared in the header but not exported: {missing}"
     lib.nsky_abi_version.restype = ctypes.c_int
-    assert lib.nsky_abi_version() == 15
+    assert lib.nsky_abi_version() == 16
     lib.nsky_last_error.restype = ctypes.c_char_p
     assert isinstance(lib.nsky_last_error(), bytes)
 

@@ -130,14 +130,14 @@ def test_trainer_loop_with_graph_replay_lands_where_the_engine_lands():
     from neusky_amd.engine import GraphedTrainStep, Optimizers, neusky_optimizers
     dev = "cuda:0"
     runs = {}
-    for mode in ("trainer", "engine"):
+    for mode in ("trainer", "trainer_slab_adam", "engine"):
         pipe, rb, batch, rnd = build(dev, 1, 0)
         rbs, bs, rs = shard(rb, batch, rnd, 1, 0, dev)
         before = {n: p.detach().clone() for n, p in pipe.named_parameters() if p.requires_grad}
         losses = []
-        if mode == "trainer":
+        if mode.startswith("trainer"):
             pipe.config.graph_replay, pipe.config.graph_replay_warmup = True, 0
-            opts, scheds = torch_optimizers(pipe)
+            opts, scheds = torch_optimizers(pipe, fused=mode.endswith("slab_adam"))  # (SlabAdam: what plugin.SlabAdamOptimizerConfig gives ns-train)
             for i in range(8):
                 losses.append(float(nerfstudio_train_iteration(pipe, opts, scheds, STEP0 + i, ray_bundle=rbs, batch=bs, randoms=rs)))
             assert pipe._train_graph is not None
@@ -149,11 +149,16 @@ def test_trainer_loop_with_graph_replay_lands_where_the_engine_lands():
         torch.cuda.synchronize()
         runs[mode] = (losses, {n: (p.detach() - before[n]).double().cpu() for n, p in pipe.named_parameters() if p.requires_grad})
         del pipe
-    lt, le = runs["trainer"][0], runs["engine"][0]
-    assert np.allclose(lt, le, rtol=2e-4), (lt, le)
+    for which in ("trainer", "trainer_slab_adam"):
+        _lands_where(runs[which], runs["engine"], which)
+
+
+def _lands_where(trainer_run, engine_run, which):
+    lt, le = trainer_run[0], engine_run[0]
+    assert np.allclose(lt, le, rtol=2e-4), (which, lt, le)
     bad, moved = [], 0
-    for n, d_e in runs["engine"][1].items():
-        d_t = runs["trainer"][1][n]
+    for n, d_e in engine_run[1].items():
+        d_t = trainer_run[1][n]
         if float(d_e.norm()) == 0.0:
             assert float(d_t.norm()) == 0.0, n
             continue
@@ -163,4 +168,4 @@ def test_trainer_loop_with_graph_replay_lands_where_the_engine_lands():
         off = float(((d_t - d_e).abs() > 0.05 * travel).double().mean())
         if rel > _rel_bar(n) or off > 1e-3:
             bad.append((n, rel, off))
-    assert moved > 40 and not bad, bad
+    assert moved > 40 and not bad, (which, bad)

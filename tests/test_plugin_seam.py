@@ -116,6 +116,15 @@ def test_with_nerfstudio_importable_the_seam_uses_its_types(tmp_path):
         assert isinstance(NeuSky, T.MethodSpecification) and isinstance(NeuSky.config, TR.TrainerConfig)
         assert NeuSky.config.method_name == "neusky" and NeuSky.config.viewer.num_rays_per_chunk == 1 << 15
         assert all(isinstance(v["optimizer"], OP.AdamOptimizerConfig) and v["optimizer"].eps == 1e-15 for v in NeuSky.config.optimizers.values())
+        # the Adam groups are nerfstudio AdamOptimizerConfigs whose target is the fused SlabAdam (torch.optim.Optimizer interface)
+        import torch
+        from neusky_amd.optimizers import SlabAdam
+        oc = NeuSky.config.optimizers["fields"]["optimizer"]
+        assert oc._target is SlabAdam and issubclass(SlabAdam, torch.optim.Optimizer)
+        opt = oc._target([torch.nn.Parameter(torch.zeros(3))], lr=oc.lr, eps=oc.eps)   # what OptimizerConfig.setup(params) does
+        assert opt.param_groups[0]["eps"] == 1e-15 and set(opt.state_dict()["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+        assert all(isinstance(v["optimizer"], OP.AdamOptimizerConfig) and not hasattr(v["optimizer"], "_target")
+                   for v in plugin.neusky_trainer_optimizers(fused=False).values())
         from neusky_amd.pipelines.neusky_pipeline import NeuSkyPipeline
         from neusky_amd.models.neusky_model import NeuSkyFactoModel
         from neusky_amd.models.ddf_model import DDFModel

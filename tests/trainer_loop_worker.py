@@ -26,15 +26,18 @@ for p in (os.path.dirname(HERE), HERE, os.path.join(HERE, "golden")):
 STEP0 = 10_000
 
 
-def torch_optimizers(pipe, step0=STEP0):
-    """what nerfstudio's Optimizers builds from neusky_config.py:216-237: one Adam per parameter group + its scheduler as a LambdaLR"""
+def torch_optimizers(pipe, step0=STEP0, fused=False):
+    """what nerfstudio's Optimizers builds from neusky_config.py:216-237: one Adam per parameter group + its scheduler as a LambdaLR
+    (fused: neusky_amd.optimizers.SlabAdam, what plugin.SlabAdamOptimizerConfig hands the trainer; else torch.optim.Adam)"""
     import torch
     from neusky_amd.engine import ExponentialDecaySchedulerConfig, neusky_optimizers
+    from neusky_amd.optimizers import SlabAdam
     cfg = neusky_optimizers()
     opts, scheds = {}, {}
+    Adam = SlabAdam if fused else torch.optim.Adam
     for name, params in pipe.get_param_groups().items():
         oc, sc = cfg[name]["optimizer"], cfg[name]["scheduler"]
-        opts[name] = torch.optim.Adam([p for p in params if p.requires_grad], lr=oc.lr, eps=oc.eps, betas=oc.betas)
+        opts[name] = Adam([p for p in params if p.requires_grad], lr=oc.lr, eps=oc.eps, betas=oc.betas)
         if isinstance(sc, ExponentialDecaySchedulerConfig):
             sc.lr_init = oc.lr
         scheds[name] = torch.optim.lr_scheduler.LambdaLR(opts[name], lr_lambda=lambda e, f=sc.factor: f(step0 + e))  # (the trainer resumes at step0)
@@ -73,7 +76,7 @@ def main():
     pipe.config.graph_replay, pipe.config.graph_replay_warmup = True, eager_steps
     if backend == "nccl" and world == 1:
         pipe.exchange_with_one_rank()  # the RCCL exchange on the hardware there is: one rank
-    opts, scheds = torch_optimizers(pipe)
+    opts, scheds = torch_optimizers(pipe, fused=bool(os.environ.get("NSKY_TEST_SLAB_ADAM")))
     before = {n: p.detach().clone() for n, p in pipe.named_parameters() if p.requires_grad}
     losses, grads_eager = [], None
     for i in range(steps):
