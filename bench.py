@@ -723,6 +723,7 @@ class PowerSampler:
     def __init__(self, index: int = 0):
         import glob
         self.samples, self.clocks, self._stop, self._th = [], [], False, None
+        self.power_cap_w = None
         self.power_files, self.sclk_files = [], []
         cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
         cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk")) or glob.glob(os.path.join(c, "hwmon/hwmon*/power1_*"))]
@@ -742,6 +743,11 @@ class PowerSampler:
             c = self.card
             self.power_files = [f for f in (glob.glob(os.path.join(c, "hwmon/hwmon*/power1_average")) + glob.glob(os.path.join(c, "hwmon/hwmon*/power1_input")))][:1]
             self.sclk_files = [os.path.join(c, "pp_dpm_sclk")] if os.path.exists(os.path.join(c, "pp_dpm_sclk")) else []
+            for f in glob.glob(os.path.join(c, "hwmon/hwmon*/power1_cap")):  # the package power limit in force on this box (microwatts)
+                try:
+                    self.power_cap_w = float(open(f).read().strip()) * 1e-6
+                except (OSError, ValueError):
+                    pass
 
     def _run(self):
         import re
@@ -772,7 +778,7 @@ class PowerSampler:
     def summary(self):
         avg = lambda v: (sum(v) / len(v)) if v else None  # noqa: E731
         return {"power_w": avg(self.samples), "power_w_max": max(self.samples) if self.samples else None, "sclk_level_mhz": avg(self.clocks),
-                "samples": max(len(self.samples), len(self.clocks)), "card": self.card,
+                "power_cap_w": self.power_cap_w, "samples": max(len(self.samples), len(self.clocks)), "card": self.card,
                 "source": "sysfs hwmon power1_average / pp_dpm_sclk of the card with this device's PCI address, during the timed region"
                 if (self.samples or self.clocks) else "not exposed to this user on this box"}
 

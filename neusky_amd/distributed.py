@@ -2,7 +2,9 @@
 all-reduce (mean) per step over RCCL/xGMI (`torch.distributed` backend "nccl"; "gloo" in CPU tests).
 
 Replaces `DDP(self._model, device_ids=[local_rank], find_unused_parameters=True)` + `dist.barrier`
-at neusky/pipelines/neusky_pipeline.py:198-200.  `find_unused_parameters=True` semantics are kept by
+at neusky/pipelines/neusky_pipeline.py:198-200: `ReplicaSync` (state broadcast, barrier), `GradientSlab` (the reducer: layout, zero
+fill, collection, all-reduce, owned by NeuSkyPipeline and exchanged at the end of the trainer's backward pass), `CameraAllGather`
+(the opt-in camera-sharded illumination decode).  `find_unused_parameters=True` semantics are kept by
 zero-filling the slots of parameters that received no gradient (frozen RENI decoder, unused heads), so
 ranks never disagree on the message.  The payload is dominated by the two 2^19 x 16 hash tables
 (2 x 48.8 MB fp32); xGMI ring all-reduce of ~110 MB costs about a millisecond against a >15 ms step,
@@ -47,8 +49,8 @@ def _broadcast(t: torch.Tensor, src: int) -> None:
 
 
 class ReplicaSync:
-    """What is left of the DDP wrapper once the gradients live in `engine.Optimizers`' slab (which all-reduces itself,
-    `Optimizers.all_reduce_gradients`): the initial state broadcast and the barrier of neusky_pipeline.py:198-200."""
+    """The DDP wrapper's start-up half: the initial state broadcast and the barrier of neusky_pipeline.py:198-200.  (Its per-step
+    half -- the gradient reducer -- is `GradientSlab` below, owned by the pipeline.)"""
 
     def __init__(self, module: torch.nn.Module, world_size: int):
         self.module = module
