@@ -1188,6 +1188,12 @@ extern "C" int nsky_attn_core_bwd(const float* Q, const float* dirs, const float
   return NSKY_OK;
 }
 
+// workgroups per (head, camera) of the ray kernels: a workgroup walks 32-ray slices z, z + Z, ... of its camera's rays.  Z = what the
+// rays need when they spread evenly over the cameras, at most 32: a training batch (1 024 rays over 300 cameras: a few rays each) gets
+// ONE workgroup per (head, camera) -- rounds 4-5 launched 32 and 31 of them left at once: 76 800 workgroups whose dispatch was the
+// kernel's time --; a batch drawn from one image (the eval-latent fit) still gets its 32 slices side by side.
+static inline int ray_slices(int R, int U) { return max(1, min(32, ceil_div(R, 32 * max(U, 1)))); }
+
 extern "C" int nsky_attn_core_rays_fwd(const float* Q, const float* dirs, const int32_t* perm, const int32_t* seg, const float* Kt, const float* Vt,
                                        int32_t U, int32_t R, int32_t L, int32_t n_heads, float scale, float* O, float* row_max, float* row_sum,
                                        nsky_stream_t stream) {
@@ -1197,7 +1203,7 @@ extern "C" int nsky_attn_core_rays_fwd(const float* Q, const float* dirs, const 
   RayArgs a{};
   a.Q = Q; a.dirs = dirs; a.Kt = Kt; a.Vt = Vt; a.perm = perm; a.seg = seg; a.O = O; a.rmax = row_max; a.rsum = row_sum;
   a.U = U; a.R = R; a.L = L; a.nh = n_heads; a.scale = scale;
-  hipLaunchKernelGGL(attn_rays_kernel<false>, dim3(n_heads, U, min(32, ceil_div(R, 32))), dim3(ATT_THREADS), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(attn_rays_kernel<false>, dim3(n_heads, U, ray_slices(R, U)), dim3(ATT_THREADS), 0, (hipStream_t)stream, a);
   NSKY_CHECK_LAUNCH("nsky_attn_core_rays_fwd");
   return NSKY_OK;
 }
@@ -1212,7 +1218,7 @@ extern "C" int nsky_attn_core_rays_bwd(const float* Q, const float* dirs, const 
   a.Q = Q; a.dirs = dirs; a.Kt = Kt; a.Vt = Vt; a.perm = perm; a.seg = seg; a.O = const_cast<float*>(O); a.rmax = const_cast<float*>(row_max);
   a.rsum = const_cast<float*>(row_sum); a.dO = dO; a.dQ = dQ; a.dKt = dKt; a.dVt = dVt;
   a.U = U; a.R = R; a.L = L; a.nh = n_heads; a.scale = scale;
-  hipLaunchKernelGGL(attn_rays_kernel<true>, dim3(n_heads, U, min(32, ceil_div(R, 32))), dim3(ATT_THREADS), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(attn_rays_kernel<true>, dim3(n_heads, U, ray_slices(R, U)), dim3(ATT_THREADS), 0, (hipStream_t)stream, a);
   NSKY_CHECK_LAUNCH("nsky_attn_core_rays_bwd");
   return NSKY_OK;
 }
