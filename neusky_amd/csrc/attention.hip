@@ -920,6 +920,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_rays_kernel(const RayArgs a)
   __shared__ float red[2];
   __shared__ float sP[ATT_LMAX];   // p_n (forward) / ds_n (backward)
   __shared__ float sO[E];          // the 48-wide sums before the (d_x, d_y, 1) combination
+  __shared__ float sT[ATT_LMAX * E];  // this (camera, head)'s V~ (forward) / K~ (backward), [token][48]: every ray's 48 token sums read it (round 6:
+                                      // they walked it in global memory, 100 dependent-latency loads per ray, the kernel's time)
   // blockIdx.z: the 32-ray slice of the camera's rays this workgroup walks (a batch drawn from ONE image -- the eval-latent fit -- puts
   // all its rays on one camera: its slices run side by side; a camera with up to 32 rays has one workgroup and the rest leave at once)
   const int tid = threadIdx.x, h = blockIdx.x, u = blockIdx.y;
@@ -943,6 +945,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_rays_kernel(const RayArgs a)
       dV[4 * k] = dV[4 * k + 1] = dV[4 * k + 2] = dV[4 * k + 3] = 0.0f;
     }
   }
+  {
+    const float* src = (BWD ? a.Kt : a.Vt) + kv0;
+    for (int i = tid; i < a.L * E / 4; i += ATT_THREADS) reinterpret_cast<float4*>(sT)[i] = reinterpret_cast<const float4*>(src)[i];
+  }
+  __syncthreads();
   for (int s0 = seg_beg + 32 * blockIdx.z; s0 < seg_end; s0 += 32 * gridDim.z)  // (slices z, z + Z, ..: more than 32 Z rays on one camera)
   for (int i = s0; i < min(seg_end, s0 + 32); ++i) {
     const int r = a.perm[i];                       // block-uniform
@@ -971,7 +978,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_rays_kernel(const RayArgs a)
       __syncthreads();
       if (tid < E) {  // thread e: sum over the tokens, V~ read along e
         float acc = 0.0f;
-        for (int t2 = 0; t2 < a.L; ++t2) acc = fmaf(sP[t2], a.Vt[kv0 + (long)t2 * E + tid], acc);
+        for (int t2 = 0; t2 < a.L; ++t2) acc = fmaf(sP[t2], sT[t2 * E + tid], acc);
         sO[tid] = acc;
       }
       __syncthreads();
@@ -995,7 +1002,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_rays_kernel(const RayArgs a)
       __syncthreads();
       if (tid < E) {
         float acc = 0.0f;
-        for (int t2 = 0; t2 < a.L; ++t2) acc = fmaf(sP[t2], a.Kt[kv0 + (long)t2 * E + tid], acc);
+        for (int t2 = 0; t2 < a.L; ++t2) acc = fmaf(sP[t2], sT[t2 * E + tid], acc);
         sO[tid] = acc;
       }
       __syncthreads();
