@@ -1,6 +1,7 @@
 """Micro-benchmark of the streaming weight-gradient kernel at the DDF chain's sizes (run on the GPU box)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import lab; lab.apply()  # NSKY_* lab switches (tools/lab.py)
 import torch
 from neusky_amd import hip, ops
 dev = "cuda:0"
