@@ -88,3 +88,15 @@ def test_camera_sharded_illumination_decode_equals_one_rank(tmp_path):
     assert not bad, bad
     lat = [k for k in keys if "illumination_latents" in k or k.endswith("train_scale")]
     assert lat and all(np.abs(one[k]).max() > 0 for k in lat), "the probe batch must reach the latents"
+
+
+def test_sharded_decode_collectives_are_captured_under_rccl():
+    """with `graph_replay` the sharded decode's all-gather and reduce-scatter are part of the captured step: RCCL collectives inside a HIP
+    graph.  One rank is all one GPU gives, and it answers the question that could not be answered on paper -- the capture and its replays
+    work on this stack (RCCL 2.26, HIP 7.0): nerfstudio's loop with graph replay, SlabAdam and the shard forced on over a one-rank
+    communicator trains (tests/shard_capture_worker.py)."""
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(HERE, "shard_capture_worker.py"), str(_free_port())], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "captured: True" in out.stdout, (out.returncode, out.stdout[-1500:], out.stderr[-2500:])
+    losses = eval(out.stdout.split("losses", 1)[1].strip().splitlines()[0])
+    assert len(losses) == 4 and all(l == l and l < 1e4 for l in losses) and losses[-1] < losses[0]
