@@ -3,8 +3,9 @@
     for optimizer: optimizer.zero_grad()            # Optimizers.zero_grad_all (torch: .grad = None)
     _, loss_dict, _ = pipeline.get_train_loss_dict(step)
     loss = functools.reduce(torch.add, loss_dict.values())
-    loss.backward()                                 # grad_scaler.scale(loss) with a disabled scaler
-    for optimizer: optimizer.step()                 # torch.optim.Adam(eps=1e-15) per group, neusky_config.py:216-237
+    grad_scaler.scale(loss).backward()              # GradScaler(enabled=mixed_precision): disabled for `neusky` (neusky_config.py:38)
+    for optimizer: grad_scaler.step(optimizer)      # Optimizers.optimizer_scaler_step_all: torch.optim.Adam(eps=1e-15) per group, :216-237
+    grad_scaler.update()
     for scheduler: scheduler.step()
 
 -- driving NeuSkyPipeline with nothing from neusky_amd.engine.  The gradient exchange (world_size 2, gloo, both ranks on cuda:0; or a
@@ -44,15 +45,23 @@ def torch_optimizers(pipe, step0=STEP0, fused=False):
     return opts, scheds
 
 
+_SCALER = []
+
+
 def nerfstudio_train_iteration(pipe, opts, scheds, step, **inject):
+    """nerfstudio Trainer.train_iteration, statement for statement (its GradScaler is disabled unless mixed_precision is set)"""
     import torch
+    if not _SCALER:
+        _SCALER.append(torch.amp.GradScaler("cuda", enabled=False))
+    grad_scaler = _SCALER[0]
     for o in opts.values():
         o.zero_grad()
     _, loss_dict, _ = pipe.get_train_loss_dict(step, **inject)
     loss = functools.reduce(torch.add, loss_dict.values())
-    loss.backward()
+    grad_scaler.scale(loss).backward()
     for o in opts.values():
-        o.step()
+        grad_scaler.step(o)
+    grad_scaler.update()
     for s in scheds.values():
         s.step()
     return loss.detach()
