@@ -331,11 +331,15 @@ class AttentionDecoder(nn.Module):
             ray_perm = ray_perm.to(torch.int32)
 
         resid = None  # the block's pending residual: added inside the next layer norm's pass (ops.add_layer_norm)
+        mask = None
         for blk in self.layers:
             K3, V3 = self._linear(T3, blk.wk), self._linear(T3, blk.wv)  # [U, 3 L, H]
-            # the bias of K / V belongs to the constant part only: remove it from the d_x and d_y thirds
-            mask = torch.cat([torch.ones(2 * L, device=T3.device), torch.zeros(L, device=T3.device)]).reshape(1, -1, 1)
-            Kt, Vt = parts(K3 - blk.wk.bias * mask), parts(V3 - blk.wv.bias * mask)
+            # the bias of K / V belongs to the constant part only.  V: removed from the d_x and d_y thirds.  K: left where the linear
+            # layer put it -- in the scores it adds (d_x + d_y) (q . b_k), the same number for every token of a row, and a softmax
+            # does not see a per-row shift (nor does any gradient: the shift depends on no key) -- one [U, 3 L, H] pass less per layer
+            if mask is None:
+                mask = torch.cat([torch.ones(2 * L, device=T3.device), torch.zeros(L, device=T3.device)]).reshape(1, -1, 1)
+            Kt, Vt = parts(K3), parts(V3 - blk.wv.bias * mask)
             q, n1 = ops.add_layer_norm(q, resid, blk.ln1)
             Qp = self._linear(n1, blk.wq)  # [N + R, H]
             # the attention core as HIP kernels (csrc/attention.hip: matrix-core forms from 32 directions per camera on, vector-unit forms
